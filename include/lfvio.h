@@ -1,0 +1,233 @@
+/*
+ * lfvio.h — C-ABI boundary of the MI355X sliding-window solver.
+ *
+ * This is the single host -> device seam of the drop-in.  The reference has no
+ * FFI: its seam is the C++ member `void Estimator::optimization()`
+ * (vins_estimator/src/estimator.h:47, body estimator.cpp:676-1009), which talks
+ * to Ceres through flat `para_*` arrays (estimator.h:107-113) filled by
+ * `vector2double()` (estimator.cpp:488-530).  A re-implemented
+ * `optimization()` body packs exactly those arrays, the feature-per-frame
+ * observations (feature_manager.h:18-71), the ten `IntegrationBase` results
+ * (factor/integration_base.h:188-203) and the marginalization prior
+ * (factor/marginalization_factor.h:47-72) into the PODs below and calls the
+ * entry points declared here.  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - everything is FP64; matrices are ROW-major; quaternions inside pose
+ *     blocks are stored [x y z w] exactly like para_Pose (estimator.cpp:492-499);
+ *     preintegration delta_q is [x y z w] (Eigen coeffs() order).
+ *   - pose block  = [px py pz qx qy qz qw]                  (SIZE_POSE = 7)
+ *     speed/bias  = [vx vy vz bax bay baz bgx bgy bgz]      (SIZE_SPEEDBIAS = 9)
+ *   - caller owns every buffer; the context owns device memory, streams and
+ *     graphs; no pointer is retained across calls.
+ *   - every function returns LFVIO_OK (0) or a negative error; on error the
+ *     outputs are untouched so the caller can fall back (the reference itself
+ *     has no error channel: optimization() is void, estimator.cpp:676).
+ *   - one caller at a time per context (the reference holds m_estimator across
+ *     processImage(), estimator_node.cpp:215-332).
+ */
+#ifndef LFVIO_H
+#define LFVIO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFVIO_WINDOW_SIZE 10                      /* parameters.h:12 */
+#define LFVIO_NUM_FRAMES (LFVIO_WINDOW_SIZE + 1)  /* estimator.h:107 */
+#define LFVIO_SIZE_POSE 7                         /* parameters.h:45 */
+#define LFVIO_SIZE_SPEEDBIAS 9                    /* parameters.h:46 */
+#define LFVIO_MAX_PRIOR_BLOCKS 24                 /* 11 poses + 11 speed/bias + ex + td */
+#define LFVIO_MAX_PRIOR_DIM 172                   /* 11*6 + 11*9 + 6 + 1 tangent dims */
+#define LFVIO_MAX_TRACE 64
+
+/* error codes */
+#define LFVIO_OK 0
+#define LFVIO_ERR_ARG (-1)         /* malformed window (bad CSR, NULL, sizes)  */
+#define LFVIO_ERR_DEVICE (-2)      /* HIP runtime error                         */
+#define LFVIO_ERR_NONFINITE (-3)   /* non-finite cost / state                   */
+#define LFVIO_ERR_NOT_PD (-4)      /* reduced system never became PD            */
+
+/* marginalization flags: Estimator::MarginalizationFlag, estimator.h:58-62 */
+#define LFVIO_MARGIN_OLD 0
+#define LFVIO_MARGIN_SECOND_NEW 1
+
+/* termination: ceres::TerminationType subset used by TrustRegionMinimizer */
+#define LFVIO_CONVERGENCE 0
+#define LFVIO_NO_CONVERGENCE 1
+#define LFVIO_FAILURE 2
+
+/* parameter-block identity.  The reference identifies prior blocks by the
+ * ADDRESS of para_* rows (addr_shift, estimator.cpp:921-933); the ABI uses
+ * (kind, frame) tags instead. */
+#define LFVIO_BLOCK_POSE 0       /* para_Pose[frame],       global 7 / local 6 */
+#define LFVIO_BLOCK_SPEEDBIAS 1  /* para_SpeedBias[frame],  9 / 9              */
+#define LFVIO_BLOCK_EX_POSE 2    /* para_Ex_Pose[0],        7 / 6              */
+#define LFVIO_BLOCK_TD 3         /* para_Td[0],             1 / 1              */
+
+typedef struct LfvioBlockId {
+  int kind;
+  int frame;
+} LfvioBlockId;
+
+/* One IntegrationBase (factor/integration_base.h:188-203) as consumed by
+ * IMUFactor::Evaluate (factor/imu_factor.h:19-200). */
+typedef struct LfvioPreintegration {
+  double sum_dt;
+  double delta_p[3];
+  double delta_q[4]; /* x y z w */
+  double delta_v[3];
+  double linearized_ba[3];
+  double linearized_bg[3];
+  double jacobian[225];   /* 15x15 row-major, order O_P O_R O_V O_BA O_BG */
+  double covariance[225]; /* 15x15 row-major */
+} LfvioPreintegration;
+
+/* MarginalizationInfo after marginalize()+getParameterBlocks()
+ * (factor/marginalization_factor.cpp:174-319): the kept blocks in order,
+ * their linearization points, and linearized_jacobians / linearized_residuals. */
+typedef struct LfvioPrior {
+  int valid;      /* 0 => no prior (last_marginalization_info == nullptr) */
+  int m;          /* marginalized tangent dim (informational)             */
+  int n;          /* kept tangent dim = rows = cols of linearized_jacobians */
+  int num_blocks; /* kept parameter blocks                                 */
+  LfvioBlockId blocks[LFVIO_MAX_PRIOR_BLOCKS]; /* AFTER addr_shift          */
+  int block_idx[LFVIO_MAX_PRIOR_BLOCKS];       /* column offset (keep_block_idx - m) */
+  double block_x0[LFVIO_MAX_PRIOR_BLOCKS][9];  /* keep_block_data (global size) */
+  double linearized_jacobians[LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM]; /* n x n row-major, leading dim n */
+  double linearized_residuals[LFVIO_MAX_PRIOR_DIM];
+} LfvioPrior;
+
+/* The whole input of one optimization() call. */
+typedef struct LfvioWindow {
+  /* state, as written by vector2double() (estimator.cpp:488-530) */
+  double para_pose[LFVIO_NUM_FRAMES][LFVIO_SIZE_POSE];
+  double para_speed_bias[LFVIO_NUM_FRAMES][LFVIO_SIZE_SPEEDBIAS];
+  double para_ex_pose[LFVIO_SIZE_POSE];
+  double para_td;
+
+  /* flags / solver options (estimator.cpp:690-703, 810-822) */
+  int estimate_extrinsic;            /* ESTIMATE_EXTRINSIC != 0                */
+  int estimate_td;                   /* ESTIMATE_TD: ProjectionTdFactor vs ProjectionFactor */
+  int max_num_iterations;            /* NUM_ITERATIONS                          */
+  double max_solver_time_in_seconds; /* <= 0: disabled (parity / bench runs)    */
+
+  /* globals read by the factors (parameters.h:17-41) */
+  double g[3];      /* G                                      */
+  double tr;        /* TR (rolling-shutter read-out time)     */
+  double row;       /* ROW (image height)                     */
+  double sqrt_info; /* FOCAL_LENGTH / 1.5, estimator.cpp:18-19 */
+
+  /* landmarks that pass `used_num >= 2 && start_frame < WINDOW_SIZE - 2`
+   * (feature_manager.cpp:36), in f_manager.feature list order, CSR over
+   * their feature_per_frame vectors.  Observation o of landmark l is seen in
+   * frame start_frame[l] + (o - obs_offset[l]); the first one is the anchor
+   * (estimator.cpp:737-745). */
+  int num_landmarks;
+  int num_observations;            /* obs_offset[num_landmarks]              */
+  const int *start_frame;          /* [N]                                    */
+  const int *obs_offset;           /* [N+1]                                  */
+  const double *inv_depth;         /* [N] para_Feature = 1/estimated_depth   */
+  const double *obs_point;         /* [M][3] FeaturePerFrame::point (unit bearing) */
+  const double *obs_velocity;      /* [M][3] FeaturePerFrame::velocity       */
+  const double *obs_cur_td;        /* [M]    FeaturePerFrame::cur_td         */
+  const double *obs_uv_y;          /* [M]    FeaturePerFrame::uv.y()         */
+
+  /* pre_integrations[1..10] (estimator.cpp:717-724); imu[i] links frame i -> i+1 */
+  LfvioPreintegration imu[LFVIO_WINDOW_SIZE];
+
+  /* last_marginalization_info (+ parameter blocks); prior->valid==0 or NULL => none */
+  const LfvioPrior *prior;
+} LfvioWindow;
+
+typedef struct LfvioIterationSummary { /* ceres::IterationSummary subset */
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+  int step_is_valid;
+  int step_is_successful;
+} LfvioIterationSummary;
+
+/* Output of the solve: the para_* arrays as Ceres leaves them (BEFORE
+ * double2vector(), estimator.cpp:830, which stays on the host). */
+typedef struct LfvioSolution {
+  double para_pose[LFVIO_NUM_FRAMES][LFVIO_SIZE_POSE];
+  double para_speed_bias[LFVIO_NUM_FRAMES][LFVIO_SIZE_SPEEDBIAS];
+  double para_ex_pose[LFVIO_SIZE_POSE];
+  double para_td;
+  double *inv_depth; /* [N] caller-allocated */
+  int num_iterations; /* summary.iterations.size() (iteration 0 included) */
+  int num_successful_steps;
+  int num_unsuccessful_steps;
+  int termination;
+  double initial_cost;
+  double final_cost;
+  LfvioIterationSummary trace[LFVIO_MAX_TRACE];
+} LfvioSolution;
+
+typedef struct lfvio_ctx lfvio_ctx;
+
+/* Create a context on HIP device `device`.  Fails (returns NULL) when no
+ * gfx950 device / HIP runtime is usable: there is no CPU fallback. */
+lfvio_ctx *lfvio_create(int device);
+void lfvio_destroy(lfvio_ctx *ctx);
+const char *lfvio_last_error(const lfvio_ctx *ctx);
+const char *lfvio_version(void);
+
+/* ceres::Solve replacement for the problem built at estimator.cpp:678-825:
+ * upload, run the trust-region loop on the device, download. */
+int lfvio_solve(lfvio_ctx *ctx, const LfvioWindow *in, LfvioSolution *out);
+
+/* MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks}
+ * replacement for the factor sets built at estimator.cpp:833-1005.  `in` holds
+ * the state AFTER double2vector()+vector2double().  For MARGIN_SECOND_NEW with
+ * no prior touching Pose[WINDOW_SIZE-1] the reference does nothing
+ * (estimator.cpp:942-943): out->valid is copied from the input prior. */
+int lfvio_marginalize(lfvio_ctx *ctx, const LfvioWindow *in, int flag, LfvioPrior *out);
+
+/* ---- device-resident API (throughput / bench; same kernels) -------------
+ * upload once, then run the whole optimization() — solve, the gauge fix of
+ * double2vector() (estimator.cpp:532-600) and marginalization — without
+ * leaving the device.  `batch` independent windows can be resident at once
+ * (BASELINE config "512 independent windows"). */
+int lfvio_batch_reserve(lfvio_ctx *ctx, int batch, int max_landmarks, int max_observations);
+int lfvio_batch_upload(lfvio_ctx *ctx, int slot, const LfvioWindow *in);
+/* run optimization() for slots [0, count): flag per call (same for all slots) */
+int lfvio_batch_optimize(lfvio_ctx *ctx, int count, int marg_flag);
+/* enqueue only (no host sync); stream is the context's stream */
+int lfvio_batch_optimize_async(lfvio_ctx *ctx, int count, int marg_flag);
+int lfvio_batch_sync(lfvio_ctx *ctx);
+/* state returned here is AFTER the gauge fix (what Ps/Rs/Vs... hold after
+ * double2vector()), re-expressed through vector2double(). */
+int lfvio_batch_download(lfvio_ctx *ctx, int slot, LfvioSolution *sol, LfvioPrior *prior);
+/* the context's HIP stream (hipStream_t) for event timing by the caller */
+void *lfvio_stream(lfvio_ctx *ctx);
+
+/* ---- landmark-sharded API (multi-GPU) ------------------------
+ * Every rank uploads the same window but linearizes only landmarks
+ * [lm_begin, lm_end).  Between the phases the caller sum-all-reduces the
+ * exchange buffer (device pointer, `lfvio_shard_exchange_len()` doubles) over
+ * RCCL.  Pose-side factors (IMU, prior) are added on the rank with
+ * add_pose_side != 0 only. */
+int lfvio_shard_begin(lfvio_ctx *ctx, const LfvioWindow *in, int lm_begin, int lm_end, int add_pose_side);
+int lfvio_shard_exchange_len(void);
+double *lfvio_shard_exchange_ptr(lfvio_ctx *ctx);
+/* phase A: linearize local landmarks at the current point -> partial [S|g|cost|sums] */
+int lfvio_shard_linearize(lfvio_ctx *ctx);
+/* phase B (after all-reduce): solve reduced system, back-substitute local
+ * landmarks, write partial step norms into the exchange buffer */
+int lfvio_shard_solve(lfvio_ctx *ctx);
+/* phase C (after all-reduce): dogleg step, candidate, partial candidate cost */
+int lfvio_shard_candidate(lfvio_ctx *ctx);
+/* phase D (after all-reduce): accept/reject, radius update.  *state: 0 = need
+ * linearize, 1 = retry candidate (step rejected, reuse), 2 = terminated */
+int lfvio_shard_decide(lfvio_ctx *ctx, int *state);
+int lfvio_shard_finish(lfvio_ctx *ctx, LfvioSolution *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFVIO_H */
