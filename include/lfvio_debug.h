@@ -1,0 +1,22 @@
+/*
+ * lfvio_debug.h — parity / inspection hooks of liblfvio_hip.so used by tests/ only.
+ * Not part of the drop-in boundary (include/lfvio.h).
+ */
+#ifndef LFVIO_DEBUG_H
+#define LFVIO_DEBUG_H
+#include "lfvio.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Gauss-Newton blocks at the window's state, caller landmark order:
+ * Hpp 172x172 row-major, gp 172, a/b N, W N x 73, cost. */
+int lfvio_debug_linearize(lfvio_ctx *ctx, const LfvioWindow *in, double *Hpp, double *gp, double *a, double *b,
+                          double *W, double *cost);
+/* Post-Schur system (A' n x n, b' n) of the last marginalization run on slot 0. */
+int lfvio_debug_marg_system(lfvio_ctx *ctx, int n, double *A, double *b);
+/* 0: launch kernels directly, 1: replay the captured hipGraph (default). */
+int lfvio_debug_set_graph(lfvio_ctx *ctx, int on);
+#ifdef __cplusplus
+}
+#endif
+#endif

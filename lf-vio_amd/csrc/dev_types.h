@@ -1,0 +1,145 @@
+// dev_types.h — HBM layout of one resident sliding window ("slot") and the
+// trust-region state that lives on the device.  Shared by host packing code and kernels.
+//
+// One slot = one contiguous device blob:  [Slot header | input arrays | work arrays].
+// The host builds header + inputs in pinned memory and uploads them with ONE copy;
+// every pointer inside the header is a device address into the same blob.
+//
+// Landmark order on the device is NOT the caller's: landmarks are bucket-sorted by
+// (start_frame, track length) so that (a) landmarks anchored at frame 0 — the ones
+// marginalization drops — form a prefix, (b) neighbouring lanes take the same trip
+// count in the per-landmark loops, (c) the MFMA Schur SYRK sees runs of rows with the
+// same zero pattern.  `lm_perm` maps device order -> caller order.
+// Observations are SoA, landmark-major in device order (coalesced 8-byte lanes); a second
+// index list orders the non-anchor observations by frame pair (i, j) for the Gram sweep.
+#pragma once
+#include "../../include/lfvio.h"
+
+constexpr int KC = 73;     // camera-side tangent dim: 11 poses * 6 + ex 6 + td 1
+constexpr int KP = 172;    // + 11 speed/bias * 9
+constexpr int WLD = 80;    // leading dimension of W rows (5 MFMA column tiles of 16)
+constexpr int COL_B = 73;  // W pad column holding b_l
+constexpr int COL_K = 74;  // W pad column holding b_l * kappa_l (Cauchy-point cross term)
+constexpr int NQ = 105;    // 14x14 upper triangle (basis Gram)
+constexpr int NG = 210;    // 20x20 upper triangle (expanded pair Gram incl. residual column)
+constexpr int NGP = 212;   // + cost, padded
+constexpr int NPAIR = 121; // pair slot = i * 11 + j
+constexpr int NT = 15;     // upper tiles of the 5x5 tiling of the 80x80 Schur accumulator
+constexpr int SCHUR_LEN = NT * 256;
+constexpr int PACKED = KP * (KP + 1) / 2;
+constexpr int HPP_CAP = 16384;   // packed H_pp (14878), reused as dense scratch by the marginalization
+constexpr int LM_BLOCK = 64;     // landmarks per workgroup (one wave) in the landmark sweep
+constexpr int CHUNK_LANES = 64;
+constexpr int CHUNK_MAX = 512;   // observations per Gram chunk (8 per lane)
+constexpr int SCHUR_LM = 256;    // landmarks per wave in the Schur SYRK
+constexpr int LMS = 16;          // per-block landmark scalar partials
+constexpr int IMU_OUT = 900 + 30 + 2;
+
+__host__ __device__ inline int off_pose(int f) { return 6 * f; }
+__host__ __device__ inline int off_ex() { return 66; }
+__host__ __device__ inline int off_td() { return 72; }
+__host__ __device__ inline int off_sb(int f) { return 73 + 9 * f; }
+__host__ __device__ inline int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+struct FrameState {
+  double pose[LFVIO_NUM_FRAMES][7];
+  double sb[LFVIO_NUM_FRAMES][9];
+  double ex[7];
+  double td;
+};
+
+// Quantities that are uniform per frame / per frame pair at one linearization point.
+struct Tab {
+  double R[11][9], P[11][3];
+  double ric[9], ricT[9], tic[3];
+  double M1[11][9];     // ric^T Rj^T
+  double M2[NPAIR][9];  // ric^T Rj^T Ri
+  double T[NPAIR][9];   // ric^T Rj^T Ri ric
+  double c[NPAIR][3];   // ric^T (Rj^T (Ri tic + Pi - Pj) - tic)
+};
+
+// indices into TRState::q (pose-side scalars produced by k_solve / k_dogleg)
+enum {
+  Q_GG = 0,    // G^T H_pp G   (G = unscaled Cauchy direction, pose side)
+  Q_GN,        // G^T H_pp N   (N = unscaled Gauss-Newton direction)
+  Q_NN,        // N^T H_pp N
+  Q_gG,        // g_p . G
+  Q_gN,        // g_p . N
+  Q_GRAD_SQ,   // ||gradient_||^2, pose side (D-scaled space)
+  Q_GN_SQ,     // ||gauss_newton_step_||^2, pose side
+  Q_GRAD_GN,   // gradient_ . gauss_newton_step_, pose side
+  Q_ZG,        // z-cross terms: sum_l G_l (w_l . G_c) is carried per landmark (d1/d2), unused slot
+  Q_COUNT = 16
+};
+
+struct TRState {
+  double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha;
+  double cg, cn;        // dogleg step = cg * gradient_ + cn * gauss_newton_step_ (D-scaled space)
+  double gn_sq_total, grad_sq_total, grad_gn_total;
+  double step_sq_pose;  // ||x - candidate||^2, pose side (ambient)
+  double xn2_pose_cand; // ||candidate||^2, pose side (ambient)
+  double gmax_pose;
+  double initial_cost;
+  double q[Q_COUNT];
+  int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled;
+  int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, pad0;
+  LfvioIterationSummary it;
+  LfvioIterationSummary trace[LFVIO_MAX_TRACE];
+};
+
+struct MargPlan {  // structure of the marginalization, computed on the host at upload
+  int valid;       // 0: nothing to do (MARGIN_SECOND_NEW without a prior touching Pose[9])
+  int m15;         // dropped pose-side dims (15 for MARGIN_OLD, 6 for SECOND_NEW)
+  int n;           // kept dims
+  int nb;          // kept blocks
+  int N0;          // landmarks to eliminate (device-order prefix)
+  int nChunks0;    // Gram chunks to sweep (pairs (0, j))
+  int use_imu0, use_visual;
+  int col[KP];     // tangent column -> column of A ([0,m15) dropped, [m15, m15+n) kept, -1 absent)
+  int kind[LFVIO_MAX_PRIOR_BLOCKS], frame[LFVIO_MAX_PRIOR_BLOCKS], shifted_frame[LFVIO_MAX_PRIOR_BLOCKS];
+  int idx[LFVIO_MAX_PRIOR_BLOCKS];
+};
+
+struct Slot {
+  // ---------------- header: sizes, flags, constants
+  int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
+  int max_iter, prior_valid, prior_n, prior_nb;
+  double g[3], tr_over_row, half_row, sqrt_info;
+  FrameState x0;
+  LfvioPreintegration imu[LFVIO_WINDOW_SIZE];
+  int imu_active[LFVIO_WINDOW_SIZE];
+  int prior_kind[LFVIO_MAX_PRIOR_BLOCKS], prior_frame[LFVIO_MAX_PRIOR_BLOCKS], prior_idx[LFVIO_MAX_PRIOR_BLOCKS];
+  double prior_x0[LFVIO_MAX_PRIOR_BLOCKS][9];
+  int prior_cmap[KP];            // prior column -> tangent column
+  int pair_chunk0[NPAIR + 1];    // chunk range per pair slot
+  MargPlan marg[2];              // [MARGIN_OLD, MARGIN_SECOND_NEW]
+  // ---------------- input arrays (device pointers into the blob)
+  int *lm_start, *lm_cnt, *lm_obs0, *lm_perm;
+  double *lam0;
+  double *obs[8];                // px py pz vx vy vz cur_td uv_y, each [M]
+  int *pm_obs, *pm_lm;           // [NV] pair-major: observation index, landmark index
+  int *chunk_pair, *chunk_begin, *chunk_end;
+  double *prior_J, *prior_r;     // n*n, n
+  // ---------------- work arrays
+  FrameState x[2];
+  TRState tr;                    // directly after x[]: one small D2H copy fetches state + trace
+  Tab tab[2];
+  double *lam[2];
+  double imu_sqrt[LFVIO_WINDOW_SIZE][225];
+  double *prior_A;               // n*n  (J0^T J0)
+  double prior_b0[KP];           // J0^T r0
+  double *a, *b, *W, *scale_l, *grad_l, *gn_l, *diag_l, *einv_l, *d1, *d2;
+  double *gram_part, *pairG, *schur_part, *schur_sum;
+  double *lm_part;               // nLmBlocks * LMS
+  double lm_sum[LMS];
+  double *cost_part;             // nLmBlocks * LMS (candidate sweep)
+  double *imu_out;               // 10 * IMU_OUT
+  double prior_g[KP + 4];        // prior gradient (tangent cols) + cost
+  double pose_cost[16];          // candidate costs of imu[0..9], prior [10]
+  double *Hpp;                   // packed lower KP
+  double gp[KP], scale_p[KP], diag_p[KP], grad_p[KP], gn_p[KP], step_p[KP];
+  double uc_grad[WLD], uc_gn[WLD], uc_y[WLD];
+  double z1[WLD], z2[WLD];
+  // marginalization outputs
+  LfvioPrior prior_out;
+};

@@ -1,0 +1,816 @@
+// kernels_solve.h — reduced pose system (assembly, Jacobi scaling, Cauchy point, Schur
+// complement, dense Cholesky, back-substitution), landmark back-substitution, dogleg,
+// candidate cost sweep and the Ceres accept/reject bookkeeping.
+//
+// Semantics follow Ceres 1.12 (trust_region_minimizer.cc, dogleg_strategy.cc,
+// schur_complement_solver.cc); see oracle/oracle_solver.cpp for the step-by-step CPU
+// statement these kernels are checked against.
+#pragma once
+#include "kernels_lin.h"
+
+constexpr int SOLVE_THREADS = 256;
+constexpr int NROW = KP + 1;                       // + rhs row (forward substitution fused)
+constexpr int LPACK = NROW * (NROW + 1) / 2;       // 15051
+constexpr size_t SOLVE_LDS = (size_t)(LPACK + 2 * 176 + 8 * KP + 64) * sizeof(double);
+
+DEV bool col_active(const Slot *S, int c, int mode) {
+  if (mode >= MODE_MARG) return true;
+  if (!S->est_ex && c >= off_ex() && c < off_ex() + 6) return false;
+  if (!S->est_td && c == off_td()) return false;
+  return true;
+}
+
+// frame block of a camera-side column: 0..10 pose, 11 ex, 12 td; lc = index inside the block
+DEV void cam_block(int c, int &f, int &lc) {
+  if (c < 66) {
+    f = c / 6;
+    lc = c - 6 * f;
+  } else if (c < 72) {
+    f = 11;
+    lc = c - 66;
+  } else {
+    f = 12;
+    lc = 0;
+  }
+}
+// local column (0..19) of camera-side block (f, lc) inside pair (i, j), or -1
+DEV int pair_local(int f, int lc, int i, int j) {
+  if (f == i) return lc;
+  if (f == j) return 6 + lc;
+  if (f == 11) return 12 + lc;
+  if (f == 12) return 18;
+  return -1;
+}
+
+DEV double block_sum(double v, double *scratch, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  double s = 0;
+  for (int w = 0; w < SOLVE_THREADS / 64; w++) s += scratch[w];
+  return s;
+}
+DEV double block_max(double v, double *scratch, int tid) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = v;
+  __syncthreads();
+  double s = 0;
+  for (int w = 0; w < SOLVE_THREADS / 64; w++) s = fmax(s, scratch[w]);
+  return s;
+}
+
+// Assemble the unscaled pose-side Gauss-Newton Hessian (packed lower, LDS) and gradient.
+DEV void assemble_Hpp(Slot *S, double *Hs, double *g, int tid, int mode) {
+  for (int e = tid; e < PACKED; e += SOLVE_THREADS) Hs[e] = 0.0;
+  for (int c = tid; c < KP; c += SOLVE_THREADS) g[c] = 0.0;
+  __syncthreads();
+  // ---- visual: owner-computes over the pair Grams (fixed order => deterministic)
+  const double *PG = S->pairG;
+  for (int e = tid; e < KC * (KC + 1) / 2; e += SOLVE_THREADS) {
+    int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= e) r++;
+    while (r * (r + 1) / 2 > e) r--;
+    const int c = e - r * (r + 1) / 2;
+    int fr, lr, fc, lc;
+    cam_block(r, fr, lr);
+    cam_block(c, fc, lc);
+    double s = 0;
+    for (int i = 0; i < 10; i++)
+      for (int j = i + 1; j < 11; j++) {
+        const int pr = pair_local(fr, lr, i, j);
+        if (pr < 0) continue;
+        const int pc = pair_local(fc, lc, i, j);
+        if (pc < 0) continue;
+        const int lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
+        s += PG[(size_t)(i * 11 + j) * NGP + gidx20(lo, hi)];
+      }
+    Hs[e] = s;
+  }
+  for (int r = tid; r < KC; r += SOLVE_THREADS) {
+    int fr, lr;
+    cam_block(r, fr, lr);
+    double s = 0;
+    for (int i = 0; i < 10; i++)
+      for (int j = i + 1; j < 11; j++) {
+        const int pr = pair_local(fr, lr, i, j);
+        if (pr >= 0) s += PG[(size_t)(i * 11 + j) * NGP + gidx20(pr, 19)];
+      }
+    g[r] = s;
+  }
+  __syncthreads();
+  // ---- IMU factors, one after the other (neighbouring factors share blocks)
+  for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) {
+    const double *out = S->imu_out + (size_t)f * IMU_OUT;
+    for (int e = tid; e < 930; e += SOLVE_THREADS) {
+      if (e < 900) {
+        const int p = e / 30, q = e % 30;
+        const int tp = p < 6 ? off_pose(f) + p : p < 15 ? off_sb(f) + p - 6 : p < 21 ? off_pose(f + 1) + p - 15 : off_sb(f + 1) + p - 21;
+        const int tq = q < 6 ? off_pose(f) + q : q < 15 ? off_sb(f) + q - 6 : q < 21 ? off_pose(f + 1) + q - 15 : off_sb(f + 1) + q - 21;
+        if (tp >= tq) Hs[pidx(tp, tq)] += out[e];
+      } else {
+        const int p = e - 900;
+        const int tp = p < 6 ? off_pose(f) + p : p < 15 ? off_sb(f) + p - 6 : p < 21 ? off_pose(f + 1) + p - 15 : off_sb(f + 1) + p - 21;
+        g[tp] += out[e];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- prior: A' = J0^T J0 in prior column order -> tangent columns (one-to-one)
+  if (S->prior_valid) {
+    const int n = S->prior_n;
+    for (int e = tid; e < n * n; e += SOLVE_THREADS) {
+      const int tp = S->prior_cmap[e / n], tq = S->prior_cmap[e % n];
+      if (tp >= tq) Hs[pidx(tp, tq)] += S->prior_A[e];
+    }
+    for (int c = tid; c < KP; c += SOLVE_THREADS) g[c] += S->prior_g[c];
+  }
+  __syncthreads();
+  // ---- constant blocks leave the program (SetParameterBlockConstant / block never added)
+  if (mode == MODE_SOLVE && (!S->est_ex || !S->est_td)) {
+    for (int e = tid; e < KP * KP; e += SOLVE_THREADS) {
+      const int r = e / KP, c = e % KP;
+      if (r >= c && (!col_active(S, r, mode) || !col_active(S, c, mode))) Hs[pidx(r, c)] = 0.0;
+    }
+    for (int c = tid; c < KP; c += SOLVE_THREADS)
+      if (!col_active(S, c, mode)) g[c] = 0.0;
+    __syncthreads();
+  }
+}
+
+// y = H x with H packed-lower symmetric (LDS or global)
+DEV double sym_row_dot(const double *H, const double *x, int i) {
+  double s = 0;
+  const int base = i * (i + 1) / 2;
+  for (int j = 0; j <= i; j++) s = fma(H[base + j], x[j], s);
+  for (int j = i + 1; j < KP; j++) s = fma(H[j * (j + 1) / 2 + i], x[j], s);
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// k_solve: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stride) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  Slot *S = SLOT(base, stride);
+  TRState *tr = &S->tr;
+  if (tr->done || !tr->do_schur) return;
+  const int tid = threadIdx.x;
+  double *Hs = smem;                 // LPACK (H_pp packed, later L packed incl. rhs row)
+  double *colbuf = Hs + LPACK;       // 2 x 176
+  double *g = colbuf + 2 * 176;      // KP
+  double *sc = g + KP;               // scale
+  double *dg = sc + KP;              // diagonal_
+  double *gr = dg + KP;              // gradient_
+  double *Gd = gr + KP;              // unscaled Cauchy direction  S gr / dg
+  double *yv = Gd + KP;              // y, then N direction
+  double *hv = yv + KP;              // H N
+  double *invd = hv + KP;            // 1 / L_ii
+  double *scratch = invd + KP;       // 64
+
+  if (tr->do_lin) {
+    assemble_Hpp(S, Hs, g, tid, MODE_SOLVE);
+    for (int e = tid; e < PACKED; e += SOLVE_THREADS) S->Hpp[e] = Hs[e];
+    for (int c = tid; c < KP; c += SOLVE_THREADS) S->gp[c] = g[c];
+    if (tid == 0) {
+      double cost = S->lm_sum[0] + S->prior_g[KP];
+      for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += S->imu_out[(size_t)f * IMU_OUT + 930];
+      tr->x_cost = cost;
+    }
+  } else {
+    for (int e = tid; e < PACKED; e += SOLVE_THREADS) Hs[e] = S->Hpp[e];
+    for (int c = tid; c < KP; c += SOLVE_THREADS) g[c] = S->gp[c];
+  }
+  __syncthreads();
+
+  // ---- Jacobi scaling (iteration 0 only), diagonal_, gradient_  (dogleg_strategy.cc ComputeStep)
+  const double mu = tr->mu;
+  for (int i = tid; i < KP; i += SOLVE_THREADS) {
+    const double hii = Hs[pidx(i, i)];
+    double s;
+    if (!tr->scaled) {
+      s = 1.0 / (1.0 + sqrt(hii));
+      S->scale_p[i] = s;
+    } else {
+      s = S->scale_p[i];
+    }
+    const double d = sqrt(fmin(fmax(s * s * hii, 1e-6), 1e32));
+    const bool act = col_active(S, i, MODE_SOLVE);
+    const double gi = act ? s * g[i] / d : 0.0;
+    sc[i] = s, dg[i] = d, gr[i] = gi;
+    Gd[i] = s * gi / d;
+    S->diag_p[i] = d;
+    S->grad_p[i] = gi;
+  }
+  __syncthreads();
+  // gradient_max_norm: x - Plus(x, -g) over the pose-side blocks (EvaluateGradientAndJacobian)
+  if (tr->do_lin) {
+    const FrameState *x = &S->x[tr->cur];
+    double mx = 0;
+    if (tid < 12) {
+      const double *xb = tid < 11 ? x->pose[tid] : x->ex;
+      const int o = tid < 11 ? off_pose(tid) : off_ex();
+      if (tid < 11 || S->est_ex) {
+        double d[6], xo[7];
+        for (int k = 0; k < 6; k++) d[k] = -g[o + k];
+        pose_plus(xb, d, xo);
+        for (int k = 0; k < 7; k++) mx = fmax(mx, fabs(xb[k] - xo[k]));
+      }
+    } else if (tid >= 64 && tid < 64 + 99) {
+      mx = fabs(g[off_sb(0) + tid - 64]);
+    } else if (tid == 200 && S->est_td) {
+      mx = fabs(g[off_td()]);
+    }
+    mx = block_max(mx, scratch, tid);
+    if (tid == 0) tr->gmax_pose = fmax(mx, S->lm_sum[4]);
+  }
+  // ---- Cauchy point: alpha = ||gradient_||^2 / ||J (gradient_/diagonal_)||^2
+  const double *Sc = S->schur_sum;
+  {
+    double part = 0, gs = 0, cross = 0;
+    if (tid < KP) {
+      part = Gd[tid] * sym_row_dot(Hs, Gd, tid);
+      gs = gr[tid] * gr[tid];
+      if (tid < KC) cross = Sc[schur_index(tid, COL_K)] * Gd[tid];  // z2 . G_c
+    }
+    const double q_gg = block_sum(part, scratch, tid);
+    const double gsq = block_sum(gs, scratch, tid);
+    const double cr = block_sum(cross, scratch, tid);
+    if (tid == 0) {
+      const double Jg2 = q_gg + 2.0 * cr + S->lm_sum[2];
+      const double gtot = gsq + S->lm_sum[1];
+      tr->alpha = gtot / Jg2;
+      tr->grad_sq_total = gtot;
+      tr->q[Q_GG] = q_gg;
+      tr->q[Q_GRAD_SQ] = gsq;
+    }
+  }
+  __syncthreads();
+
+  // ---- reduced system in registers: thread (trow, tcol) owns (i, j) = (trow + 16 a, tcol + 16 b)
+  const int trow = tid & 15, tcol = tid >> 4;
+  double m[11][11];
+#pragma unroll
+  for (int a = 0; a < 11; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      const int i = trow + 16 * a, j = tcol + 16 * b;
+      double v = 0.0;
+      if (i < KP && j <= i) {
+        const bool ai = col_active(S, i, MODE_SOLVE), aj = col_active(S, j, MODE_SOLVE);
+        if (ai && aj) {
+          double h = Hs[pidx(i, j)];
+          if (i < KC) h -= schur_get(Sc, j, i);  // j <= i < 73
+          v = sc[i] * sc[j] * h;
+          if (i == j) v += mu * dg[i] * dg[i];
+        } else {
+          v = (i == j) ? 1.0 : 0.0;
+        }
+      } else if (i == KP && j < KP) {
+        if (col_active(S, j, MODE_SOLVE)) {
+          double r = g[j];
+          if (j < KC) r -= Sc[schur_index(j, COL_B)];  // z1
+          v = sc[j] * r;
+        }
+      }
+      m[a][b] = v;
+    }
+  __syncthreads();  // Hs may now be overwritten
+
+  // ---- right-looking Cholesky, one barrier per pivot (column owners live in one 16-lane group)
+  bool bad = !(mu < 1.0);  // ComputeGaussNewtonStep: `while (mu_ < max_mu_)` — no attempt at mu >= 1
+#pragma unroll
+  for (int kb = 0; kb < 11; kb++) {
+    for (int kk = 0; kk < 16; kk++) {
+      const int k = kb * 16 + kk;
+      if (k >= KP) break;
+      double *cb = colbuf + (k & 1) * 176;
+      if (tcol == kk) {
+        const double d = __shfl(m[kb][kb], ((kk & 3) << 4) | kk, 64);
+        if (!(d > 0.0)) bad = true;
+        const double dinv = rsqrt(d);
+#pragma unroll
+        for (int a = kb; a < 11; a++) {
+          const int i = trow + 16 * a;
+          if (i > k && i <= KP) {
+            m[a][kb] *= dinv;
+            cb[i] = m[a][kb];
+          } else if (i == k) {
+            m[a][kb] = d * dinv;
+            invd[k] = dinv;
+          }
+        }
+      }
+      __syncthreads();
+      double li[11], lj[11];
+#pragma unroll
+      for (int a = kb; a < 11; a++) {
+        const int i = trow + 16 * a, j = tcol + 16 * a;
+        li[a] = (i > k && i <= KP) ? cb[i] : 0.0;
+        lj[a] = (j > k && j < KP) ? cb[j] : 0.0;
+      }
+#pragma unroll
+      for (int a = kb; a < 11; a++)
+#pragma unroll
+        for (int b = kb; b <= a; b++) m[a][b] = fma(-li[a], lj[b], m[a][b]);
+    }
+  }
+  // failure detection: any non-positive pivot or non-finite entry in the solution row
+  {
+    double f = bad ? 1.0 : 0.0;
+    f = block_max(f, scratch, tid);
+    bad = f > 0.0;
+  }
+  // ---- L (and z = row KP) to LDS, packed
+#pragma unroll
+  for (int a = 0; a < 11; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      const int i = trow + 16 * a, j = tcol + 16 * b;
+      if (i <= KP && j <= i && j < KP) Hs[pidx(i, j)] = m[a][b];
+    }
+  __syncthreads();
+  // ---- back-substitution L^T y = z by wave 0 (readlane broadcast, no barriers)
+  if (tid < 64) {
+    const int lane = tid;
+    double s0 = 0, s1 = 0, s2 = 0, y0 = 0, y1 = 0, y2 = 0;
+    const int zbase = KP * (KP + 1) / 2;
+    for (int i = KP - 1; i >= 0; i--) {
+      const int owner = i & 63, slot = i >> 6;
+      const double ssel = slot == 0 ? s0 : (slot == 1 ? s1 : s2);
+      const int lo = __builtin_amdgcn_readlane(__double2loint(ssel), owner);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(ssel), owner);
+      const double sown = __hiloint2double(hi, lo);
+      const double yi = (Hs[zbase + i] - sown) * invd[i];
+      if (lane == owner) {
+        if (slot == 0) y0 = yi;
+        else if (slot == 1) y1 = yi;
+        else y2 = yi;
+      }
+      const int rb = i * (i + 1) / 2;
+      if (lane < i) s0 = fma(Hs[rb + lane], yi, s0);
+      if (lane + 64 < i) s1 = fma(Hs[rb + lane + 64], yi, s1);
+      if (lane + 128 < i) s2 = fma(Hs[rb + lane + 128], yi, s2);
+    }
+    yv[lane] = y0;
+    yv[lane + 64] = y1;
+    if (lane + 128 < KP) yv[lane + 128] = y2;
+  }
+  __syncthreads();
+  {
+    double f = 0.0;
+    if (tid < KP && !isfinite(yv[tid])) f = 1.0;
+    f = block_max(f, scratch, tid);
+    if (f > 0.0) bad = true;
+  }
+  if (bad) {
+    // LINEAR_SOLVER_FAILURE inside ComputeGaussNewtonStep: mu *= 10 and retry (same Jacobian)
+    if (tid == 0) {
+      tr->chol_fail = 1;
+      if (mu < 1.0) tr->mu = mu * 10.0;
+    }
+    return;
+  }
+  // ---- Gauss-Newton step, directions and pose-side quadratic forms
+  if (tid < KP) {
+    const double y = yv[tid];
+    const double gn = -dg[tid] * y;  // gauss_newton_step_ = -diagonal_ * y
+    S->gn_p[tid] = gn;
+    const double Nd = -sc[tid] * y;  // unscaled GN direction
+    yv[tid] = Nd;
+    if (tid < KC) {
+      S->uc_grad[tid] = Gd[tid];
+      S->uc_gn[tid] = Nd;
+    }
+  }
+  if (tid >= KC && tid < WLD) S->uc_grad[tid] = S->uc_gn[tid] = 0.0;
+  __syncthreads();
+  {
+    double hn = 0, gn2 = 0, ggn = 0, gG = 0, gN = 0, qgn = 0, qnn = 0;
+    if (tid < KP) {
+      hn = sym_row_dot(S->Hpp, yv, tid);  // H_pp N from the global copy (LDS now holds L)
+      const double gn = S->gn_p[tid];
+      gn2 = gn * gn;
+      ggn = gr[tid] * gn;
+      gG = g[tid] * Gd[tid];
+      gN = g[tid] * yv[tid];
+      qgn = Gd[tid] * hn;
+      qnn = yv[tid] * hn;
+    }
+    gn2 = block_sum(gn2, scratch, tid);
+    ggn = block_sum(ggn, scratch, tid);
+    gG = block_sum(gG, scratch, tid);
+    gN = block_sum(gN, scratch, tid);
+    qgn = block_sum(qgn, scratch, tid);
+    qnn = block_sum(qnn, scratch, tid);
+    if (tid == 0) {
+      tr->q[Q_GN_SQ] = gn2;
+      tr->q[Q_GRAD_GN] = ggn;
+      tr->q[Q_gG] = gG;
+      tr->q[Q_gN] = gN;
+      tr->q[Q_GN] = qgn;
+      tr->q[Q_NN] = qnn;
+      tr->chol_fail = 0;
+      if (tr->iteration > 0 && tr->do_lin && tr->trace_len > 0) {
+        // HandleSuccessfulStep -> EvaluateGradientAndJacobian at the accepted point
+        LfvioIterationSummary *last = &tr->trace[tr->trace_len - 1];
+        last->cost = tr->x_cost;
+        last->gradient_max_norm = tr->gmax_pose;
+        if (last->step_is_successful && tr->gmax_pose <= 1e-10) {  // GradientToleranceReached
+          tr->termination = LFVIO_CONVERGENCE;
+          tr->done = 1;
+        }
+      }
+      if (tr->iteration == 0) {
+        {
+          const FrameState *x0 = &S->x[tr->cur];
+          double xn = S->lm_sum[3];
+          for (int f = 0; f < LFVIO_NUM_FRAMES; f++) {
+            for (int k = 0; k < 7; k++) xn += x0->pose[f][k] * x0->pose[f][k];
+            for (int k = 0; k < 9; k++) xn += x0->sb[f][k] * x0->sb[f][k];
+          }
+          if (S->est_ex)
+            for (int k = 0; k < 7; k++) xn += x0->ex[k] * x0->ex[k];
+          if (S->est_td) xn += x0->td * x0->td;
+          tr->x_norm = sqrt(xn);
+        }
+        // IterationZero + first FinalizeIterationAndCheckIfMinimizerCanContinue
+        LfvioIterationSummary it;
+        it.cost = tr->x_cost;
+        it.cost_change = 0;
+        it.gradient_max_norm = tr->gmax_pose;
+        it.step_norm = 0;
+        it.relative_decrease = 0;
+        it.trust_region_radius = tr->radius;
+        it.step_is_valid = 0;
+        it.step_is_successful = 0;
+        tr->trace[0] = it;
+        tr->trace_len = 1;
+        tr->num_unsucc = 1;
+        tr->initial_cost = tr->x_cost;
+        tr->iteration = 1;
+        tr->scaled = 1;
+        if (S->max_iter <= 0) tr->done = 1;
+        if (!isfinite(tr->x_cost)) {
+          tr->done = 1;
+          tr->error = LFVIO_ERR_NONFINITE;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_backsub: grid (nLmBlocks, batch) x 64 — landmark part of the Gauss-Newton step
+//   y_l = (s_l b_l - s_l w_l . (S_c y_c)) / e_l ;  gauss_newton_l = -diagonal_l y_l
+// plus the two dot products w_l . G_c, w_l . N_c every dogleg interpolant needs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_backsub(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  const TRState *tr = &S->tr;
+  if (tr->done || !tr->do_schur || tr->chol_fail) return;
+  __shared__ double ug[WLD], un[WLD];
+  const int lane = threadIdx.x;
+  for (int c = lane; c < WLD; c += 64) ug[c] = S->uc_grad[c], un[c] = S->uc_gn[c];
+  __syncthreads();
+  const int l = blockIdx.x * LM_BLOCK + lane;
+  double gn2 = 0, ggn = 0;
+  if (l < S->N) {
+    const double *w = S->W + (size_t)l * WLD;
+    const int lo = 6 * S->lm_start[l], hi = lo + 6 * S->lm_cnt[l];
+    double d1 = 0, d2 = 0;
+    for (int c = lo; c < hi; c++) {
+      const double wc = w[c];
+      d1 = fma(wc, ug[c], d1);
+      d2 = fma(wc, un[c], d2);
+    }
+#pragma unroll
+    for (int c = 66; c < KC; c++) {
+      const double wc = w[c];
+      d1 = fma(wc, ug[c], d1);
+      d2 = fma(wc, un[c], d2);
+    }
+    const double s = S->scale_l[l];
+    // s_l w_l . (S_c y_c) = -s_l d2   (N_c = -S_c y_c)
+    const double y = (s * S->b[l] + s * d2) * S->einv_l[l];
+    const double gn = -S->diag_l[l] * y;
+    S->gn_l[l] = gn;
+    S->d1[l] = d1;
+    S->d2[l] = d2;
+    gn2 = gn * gn;
+    ggn = S->grad_l[l] * gn;
+  }
+  gn2 = wave_sum(gn2);
+  ggn = wave_sum(ggn);
+  if (lane == 0) {
+    double *p = S->lm_part + (size_t)blockIdx.x * LMS;
+    p[8] = gn2, p[9] = ggn;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_dogleg: grid (1, batch) x 128 — ComputeTraditionalDoglegStep, candidate pose-side state,
+// per-pair table of the candidate.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  TRState *tr = &S->tr;
+  if (tr->done || tr->chol_fail) return;
+  const int tid = threadIdx.x;
+  __shared__ double sh[4];
+  __shared__ double delta[KP];
+  if (tr->do_schur) {
+    // total norms: pose side (k_solve) + landmark partials (k_backsub)
+    double a = 0, b = 0;
+    for (int k = tid; k < S->nLmBlocks; k += 128) {
+      a += S->lm_part[(size_t)k * LMS + 8];
+      b += S->lm_part[(size_t)k * LMS + 9];
+    }
+    a = wave_sum(a), b = wave_sum(b);
+    if ((tid & 63) == 0) sh[(tid >> 6) * 2] = a, sh[(tid >> 6) * 2 + 1] = b;
+    __syncthreads();
+    if (tid == 0) {
+      tr->gn_sq_total = tr->q[Q_GN_SQ] + sh[0] + sh[2];
+      tr->grad_gn_total = tr->q[Q_GRAD_GN] + sh[1] + sh[3];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double radius = tr->radius, alpha = tr->alpha;
+    const double gradient_norm = sqrt(tr->grad_sq_total), gauss_newton_norm = sqrt(tr->gn_sq_total);
+    double cg, cn, sn;
+    if (gauss_newton_norm <= radius) {  // Case 1
+      cg = 0.0, cn = 1.0, sn = gauss_newton_norm;
+    } else if (gradient_norm * alpha >= radius) {  // Case 2
+      cg = -(radius / gradient_norm), cn = 0.0, sn = radius;
+    } else {  // Case 3
+      const double b_dot_a = -alpha * tr->grad_gn_total;
+      const double a_squared_norm = (alpha * gradient_norm) * (alpha * gradient_norm);
+      const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gauss_newton_norm * gauss_newton_norm;
+      const double c = b_dot_a - a_squared_norm;
+      const double d = sqrt(c * c + b_minus_a_squared_norm * (radius * radius - a_squared_norm));
+      const double beta = (c <= 0) ? (d - c) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d + c);
+      cg = -alpha * (1.0 - beta), cn = beta;
+      // ||cg g + cn n||
+      sn = sqrt(cg * cg * tr->grad_sq_total + 2.0 * cg * cn * tr->grad_gn_total + cn * cn * tr->gn_sq_total);
+    }
+    tr->cg = cg, tr->cn = cn, tr->dogleg_step_norm = sn;
+  }
+  __syncthreads();
+  const double cg = tr->cg, cn = tr->cn;
+  const int cur = tr->cur;
+  const FrameState *x = &S->x[cur];
+  FrameState *xc = &S->x[cur ^ 1];
+  // delta = (step / diagonal_) * scale, step = cg gradient_ + cn gauss_newton_
+  for (int i = tid; i < KP; i += 128) {
+    const double st = (cg * S->grad_p[i] + cn * S->gn_p[i]) / S->diag_p[i];
+    double d = st * S->scale_p[i];
+    if (!col_active(S, i, MODE_SOLVE)) d = 0.0;
+    delta[i] = d;
+    S->step_p[i] = d;
+  }
+  __syncthreads();
+  // candidate = Plus(x, delta); ambient step norm and candidate norm, pose side
+  double dn = 0, xn = 0;
+  if (tid < 12) {
+    const double *xb = tid < 11 ? x->pose[tid] : x->ex;
+    double *xo = tid < 11 ? xc->pose[tid] : xc->ex;
+    const int o = tid < 11 ? off_pose(tid) : off_ex();
+    if (tid < 11 || S->est_ex) {
+      pose_plus(xb, delta + o, xo);
+      for (int k = 0; k < 7; k++) dn += (xb[k] - xo[k]) * (xb[k] - xo[k]), xn += xo[k] * xo[k];
+    } else {
+      for (int k = 0; k < 7; k++) xo[k] = xb[k];
+    }
+  } else if (tid >= 16 && tid < 16 + 99) {
+    const int e = tid - 16, f = e / 9, k = e % 9;
+    const double v = x->sb[f][k] + delta[off_sb(f) + k];
+    xc->sb[f][k] = v;
+    dn = (v - x->sb[f][k]) * (v - x->sb[f][k]);
+    xn = v * v;
+  } else if (tid == 120) {
+    double v = x->td;
+    if (S->est_td) {
+      v = x->td + delta[off_td()];
+      dn = (v - x->td) * (v - x->td);
+      xn = v * v;
+    }
+    xc->td = v;
+  }
+  dn = wave_sum(dn), xn = wave_sum(xn);
+  __syncthreads();
+  if ((tid & 63) == 0) sh[(tid >> 6) * 2] = dn, sh[(tid >> 6) * 2 + 1] = xn;
+  __syncthreads();
+  if (tid == 0) {
+    tr->step_sq_pose = sh[0] + sh[2];
+    tr->xn2_pose_cand = sh[1] + sh[3];
+  }
+  build_tab(xc, &S->tab[cur ^ 1], tid);
+}
+
+// ---------------------------------------------------------------------------
+// k_cost: grid (nLmBlocks + 10 + 1, batch) x 64 — candidate point:
+//   landmark blocks: lambda_c = lambda + delta_l, cost of every observation at the candidate,
+//                    landmark part of the model cost change and of the norms
+//   IMU / prior blocks: residual-only evaluation at the candidate
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cost(char *base, size_t stride, int gLm) {
+  Slot *S = SLOT(base, stride);
+  const TRState *tr = &S->tr;
+  if (tr->done || tr->chol_fail) return;
+  const int lane = threadIdx.x;
+  const int cur = tr->cur, nxt = cur ^ 1;
+  int b = blockIdx.x;
+  if (b < gLm) {
+    if (b >= S->nLmBlocks) return;
+    const Tab *T = &S->tab[nxt];
+    const double cg = tr->cg, cn = tr->cn;
+    const double td = S->x[nxt].td;
+    const int l = b * LM_BLOCK + lane;
+    double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
+    if (l < S->N) {
+      const double s = S->scale_l[l];
+      const double dl = (cg * S->grad_l[l] + cn * S->gn_l[l]) / S->diag_l[l] * s;
+      const double lam = S->lam[cur][l];
+      const double lc = lam + dl;
+      S->lam[nxt][l] = lc;
+      dn = dl * dl;
+      xn = lc * lc;
+      // model: -(delta.g) - 1/2 delta^T H delta, landmark rows/cols
+      const double wd = cg * S->d1[l] + cn * S->d2[l];  // w_l . delta_c
+      mlin = dl * S->b[l];
+      mquad = 2.0 * dl * wd + S->a[l] * dl * dl;
+      const int i = S->lm_start[l], k = S->lm_cnt[l], o0 = S->lm_obs0[l];
+      ObsPair ob;
+      load_obs(S, o0, ob.pi, ob.vi, ob.tdi, ob.rowi);
+      for (int o = 1; o < k; o++) {
+        const int pair = i * 11 + i + o;
+        load_obs(S, o0 + o, ob.pj, ob.vj, ob.tdj, ob.rowj);
+        cost += 0.5 * visual_cost(ob, lc, td, S->est_td, S->tr_over_row, S->half_row, S->sqrt_info, ldm(T->T[pair]),
+                                  ld3(T->c[pair]));
+      }
+    }
+    cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn);
+    if (lane == 0) {
+      double *p = S->cost_part + (size_t)b * LMS;
+      p[0] = cost, p[1] = mlin, p[2] = mquad, p[3] = dn, p[4] = xn;
+    }
+    return;
+  }
+  b -= gLm;
+  const FrameState *x = &S->x[nxt];
+  if (b < LFVIO_WINDOW_SIZE) {
+    __shared__ double rr[15];
+    double c = 0.0;
+    if (S->imu_active[b]) {
+      if (lane == 0) imu_raw_residual(&S->imu[b], S->g, x->pose[b], x->sb[b], x->pose[b + 1], x->sb[b + 1], rr);
+      __syncthreads();
+      double v = 0;
+      if (lane < 15) {
+        const double *Sq = S->imu_sqrt[b];
+        for (int k = lane; k < 15; k++) v = fma(Sq[lane * 15 + k], rr[k], v);
+        v = v * v;
+      }
+      c = 0.5 * wave_sum(v);
+    }
+    if (lane == 0) S->pose_cost[b] = c;
+    return;
+  }
+  {
+    __shared__ double dx[KP];
+    double c = 0.0;
+    if (S->prior_valid) {
+      const int n = S->prior_n;
+      if (lane < S->prior_nb) prior_block_dx(S, x, lane, dx);
+      __syncthreads();
+      const double *J = S->prior_J;
+      for (int row = lane; row < n; row += 64) {
+        double s = S->prior_r[row];
+        for (int cc = 0; cc < n; cc++) s = fma(J[row * n + cc], dx[cc], s);
+        c += s * s;
+      }
+      c = 0.5 * wave_sum(c);
+    }
+    if (lane == 0) S->pose_cost[10] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_decide: grid (1, batch) x 64 — TrustRegionMinimizer bookkeeping for one iteration.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  TRState *tr = &S->tr;
+  if (tr->done) return;
+  const int lane = threadIdx.x;
+  if (tr->chol_fail) {
+    // retry the Gauss-Newton solve with the larger mu; LINEAR_SOLVER_FAILURE once mu >= max_mu
+    if (lane == 0) {
+      if (tr->mu < 1.0) {
+        tr->do_lin = 0;
+        tr->do_schur = 1;
+        tr->chol_fail = 0;
+        tr->skip_step = 1;
+      }
+    }
+    if (tr->mu < 1.0) return;
+  }
+  double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
+  if (!tr->chol_fail) {
+    for (int k = lane; k < S->nLmBlocks; k += 64) {
+      const double *p = S->cost_part + (size_t)k * LMS;
+      cost += p[0], mlin += p[1], mquad += p[2], dn += p[3], xn += p[4];
+    }
+    if (lane < 11) cost += S->pose_cost[lane];
+    cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn);
+  }
+  if (lane != 0) return;
+  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
+  LfvioIterationSummary it;
+  it.cost = tr->x_cost, it.cost_change = 0, it.gradient_max_norm = 0, it.step_norm = 0, it.relative_decrease = 0;
+  it.step_is_valid = 0, it.step_is_successful = 0;
+  bool finished = false;
+  bool step_valid = false;
+  double model_cost_change = 0;
+  if (!tr->chol_fail) {
+    // model_cost_change = -(J step)^T (r + J step / 2) = -delta.g - 1/2 delta^T H delta
+    const double cg = tr->cg, cn = tr->cn;
+    // unscaled pose direction delta_p = cg' G + cn' N where gradient_/diagonal_*scale = G, gn/diag*scale = N
+    const double lin = cg * tr->q[Q_gG] + cn * tr->q[Q_gN] + mlin;
+    const double quad = cg * cg * tr->q[Q_GG] + 2.0 * cg * cn * tr->q[Q_GN] + cn * cn * tr->q[Q_NN] + mquad;
+    model_cost_change = -lin - 0.5 * quad;
+    step_valid = model_cost_change > 0.0;
+  }
+  tr->model_cost_change = model_cost_change;
+  it.step_is_valid = step_valid ? 1 : 0;
+  if (!step_valid) {
+    // HandleInvalidStep
+    if (++tr->consec_invalid >= 5) {
+      tr->termination = LFVIO_FAILURE;
+      tr->done = 1;
+      finished = true;
+    } else {
+      tr->mu *= 10.0;  // StepIsInvalid
+      tr->chol_fail = 0;
+      tr->do_lin = 0;
+      tr->do_schur = 1;
+    }
+  } else {
+    tr->consec_invalid = 0;
+    const double candidate_cost = isfinite(cost) ? cost : 1.79769313486231570815e+308;
+    tr->cand_cost = candidate_cost;
+    it.step_norm = sqrt(tr->step_sq_pose + dn);
+    if (it.step_norm <= parameter_tolerance * (tr->x_norm + parameter_tolerance)) {
+      tr->termination = LFVIO_CONVERGENCE;
+      tr->done = 1;
+      finished = true;
+    } else {
+      it.cost_change = tr->x_cost - candidate_cost;
+      if (fabs(it.cost_change) <= function_tolerance * tr->x_cost) {
+        tr->termination = LFVIO_CONVERGENCE;
+        tr->done = 1;
+        finished = true;
+      } else {
+        it.relative_decrease = it.cost_change / model_cost_change;
+        if (it.relative_decrease > min_relative_decrease) {
+          // HandleSuccessfulStep: x <- candidate; the next k_lin re-evaluates cost/gradient there
+          tr->cur ^= 1;
+          tr->x_norm = sqrt(tr->xn2_pose_cand + xn);
+          it.step_is_successful = 1;
+          it.cost = candidate_cost;  // replaced by the re-evaluated x_cost when the trace is read
+          if (it.relative_decrease < 0.25) tr->radius *= 0.5;
+          if (it.relative_decrease > 0.75) tr->radius = fmax(tr->radius, 3.0 * tr->dogleg_step_norm);
+          tr->mu = fmax(1e-8, 2.0 * tr->mu / 10.0);
+          tr->do_lin = 1;
+          tr->do_schur = 1;
+          tr->x_cost = candidate_cost;
+        } else {
+          // HandleUnsuccessfulStep / StepRejected
+          tr->radius *= 0.5;
+          tr->do_lin = 0;
+          tr->do_schur = 0;
+          it.cost = candidate_cost;
+        }
+      }
+    }
+  }
+  if (finished) return;  // the converged iteration is not pushed (Minimize() returns before Finalize)
+  // FinalizeIterationAndCheckIfMinimizerCanContinue
+  if (it.step_is_successful)
+    tr->num_succ++;
+  else
+    tr->num_unsucc++;
+  it.trust_region_radius = tr->radius;
+  if (tr->trace_len < LFVIO_MAX_TRACE) tr->trace[tr->trace_len++] = it;
+  if (tr->iteration >= S->max_iter) {
+    tr->termination = LFVIO_NO_CONVERGENCE;
+    tr->done = 1;
+  } else if (tr->radius <= min_trust_region_radius) {
+    tr->termination = LFVIO_CONVERGENCE;
+    tr->done = 1;
+  }
+  (void)gradient_tolerance;
+  tr->iteration++;
+}

@@ -1,0 +1,709 @@
+// lfvio_hip.hip — C-ABI implementation (include/lfvio.h) on HIP for gfx950 (MI355X).
+//
+// Host side of the hot path of LF-VIO's Estimator::optimization()
+// (vins_estimator/src/estimator.cpp:676-1009): packs one LfvioWindow into the device
+// layout of dev_types.h, launches the kernel pipeline and unpacks the result.
+// There is NO CPU fallback: without a usable HIP device lfvio_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lfvio.h"
+#include "../../include/lfvio_debug.h"
+#include "kernels_marg.h"
+
+#define HIPCHK(ctx, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return LFVIO_ERR_DEVICE;                                                                 \
+    }                                                                                          \
+  } while (0)
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Layout {  // byte offsets inside one slot blob, by capacity
+  int maxN = 0, maxM = 0;
+  int capLmBlocks = 0, capChunks = 0, capSchurParts = 0;
+  size_t in_begin = 0, in_end = 0, total = 0;
+  size_t lm_start, lm_cnt, lm_obs0, lm_perm, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, prior_J,
+      prior_r;
+  size_t lam[2], prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
+      schur_sum, lm_part, cost_part, imu_out, Hpp;
+};
+
+Layout make_layout(int maxN, int maxM) {
+  Layout L;
+  L.maxN = maxN;
+  L.maxM = maxM;
+  L.capLmBlocks = std::max(1, (maxN + LM_BLOCK - 1) / LM_BLOCK);
+  L.capChunks = 64 + maxM / CHUNK_MAX;
+  L.capSchurParts = std::max(1, (maxN + SCHUR_LM - 1) / SCHUR_LM);
+  size_t o = align_up(sizeof(Slot), 256);
+  auto take = [&](size_t bytes) {
+    size_t r = o;
+    o = align_up(o + bytes, 256);
+    return r;
+  };
+  const size_t N = std::max(maxN, 1), M = std::max(maxM, 1), LB = (size_t)L.capLmBlocks * LM_BLOCK;
+  L.in_begin = o;
+  L.lm_start = take(N * 4), L.lm_cnt = take(N * 4), L.lm_obs0 = take(N * 4), L.lm_perm = take(N * 4);
+  L.lam0 = take(N * 8);
+  for (int k = 0; k < 8; k++) L.obs[k] = take(M * 8);
+  L.pm_obs = take(M * 4), L.pm_lm = take(M * 4);
+  L.chunk_pair = take((size_t)L.capChunks * 4), L.chunk_begin = take((size_t)L.capChunks * 4),
+  L.chunk_end = take((size_t)L.capChunks * 4);
+  L.prior_J = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
+  L.prior_r = take(LFVIO_MAX_PRIOR_DIM * 8);
+  L.in_end = o;
+  L.lam[0] = take(LB * 8), L.lam[1] = take(LB * 8);
+  L.prior_A = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
+  L.a = take(LB * 8), L.b = take(LB * 8), L.W = take(LB * WLD * 8);
+  L.scale_l = take(LB * 8), L.grad_l = take(LB * 8), L.gn_l = take(LB * 8), L.diag_l = take(LB * 8);
+  L.einv_l = take(LB * 8), L.d1 = take(LB * 8), L.d2 = take(LB * 8);
+  L.gram_part = take((size_t)L.capChunks * NGP * 8);
+  L.pairG = take((size_t)NPAIR * NGP * 8);
+  L.schur_part = take((size_t)L.capSchurParts * SCHUR_LEN * 8);
+  L.schur_sum = take((size_t)SCHUR_LEN * 8);
+  L.lm_part = take((size_t)L.capLmBlocks * LMS * 8);
+  L.cost_part = take((size_t)L.capLmBlocks * LMS * 8);
+  L.imu_out = take((size_t)LFVIO_WINDOW_SIZE * IMU_OUT * 8);
+  L.Hpp = take((size_t)HPP_CAP * 8);
+  L.total = align_up(o, 4096);
+  return L;
+}
+
+struct SlotHostInfo {
+  int N = 0, M = 0, gLm = 0, gCh = 0, gSc = 0;
+  std::vector<int> perm;  // device order -> caller order
+  bool uploaded = false;
+  LfvioPrior in_prior;    // kept for the "prior passes through" case of MARGIN_SECOND_NEW
+  bool has_in_prior = false;
+};
+
+}  // namespace
+
+struct lfvio_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int batch = 0;
+  Layout L;
+  char *d_base = nullptr;
+  char *h_stage = nullptr;  // pinned, one slot's header + inputs
+  char *h_down = nullptr;   // pinned download buffer
+  size_t h_down_bytes = 0;
+  std::vector<SlotHostInfo> info;
+  // cached graph of the solve loop
+  hipGraphExec_t graph = nullptr;
+  int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0;
+  bool use_graph = true;
+};
+
+namespace {
+
+void destroy_graph(lfvio_ctx *c) {
+  if (c->graph) {
+    (void)hipGraphExecDestroy(c->graph);
+    c->graph = nullptr;
+  }
+}
+
+int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
+  if (c->d_base && batch <= c->batch && maxN <= c->L.maxN && maxM <= c->L.maxM) return LFVIO_OK;
+  batch = std::max(batch, c->batch);
+  maxN = std::max(maxN, c->L.maxN);
+  maxM = std::max(maxM, c->L.maxM);
+  destroy_graph(c);
+  if (c->d_base) HIPCHK(c, hipFree(c->d_base));
+  if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+  if (c->h_down) HIPCHK(c, hipHostFree(c->h_down));
+  c->d_base = nullptr, c->h_stage = nullptr, c->h_down = nullptr;
+  // grow with headroom so a slowly growing window does not re-allocate every frame
+  Layout L = make_layout(maxN + maxN / 4 + 64, maxM + maxM / 4 + 256);
+  HIPCHK(c, hipMalloc((void **)&c->d_base, L.total * (size_t)batch));
+  HIPCHK(c, hipMemsetAsync(c->d_base, 0, L.total * (size_t)batch, c->stream));
+  HIPCHK(c, hipHostMalloc((void **)&c->h_stage, L.in_end, hipHostMallocDefault));
+  c->h_down_bytes = sizeof(FrameState) * 2 + sizeof(TRState) + (size_t)L.maxN * 8 + sizeof(LfvioPrior) + 4096;
+  HIPCHK(c, hipHostMalloc((void **)&c->h_down, c->h_down_bytes, hipHostMallocDefault));
+  c->L = L;
+  c->batch = batch;
+  c->info.assign(batch, SlotHostInfo());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LFVIO_OK;
+}
+
+inline int local_size(int kind) {
+  return (kind == LFVIO_BLOCK_POSE || kind == LFVIO_BLOCK_EX_POSE) ? 6 : (kind == LFVIO_BLOCK_SPEEDBIAS ? 9 : 1);
+}
+inline int tangent_off(int kind, int frame) {
+  return kind == LFVIO_BLOCK_POSE ? off_pose(frame)
+         : kind == LFVIO_BLOCK_SPEEDBIAS ? off_sb(frame)
+         : kind == LFVIO_BLOCK_EX_POSE ? off_ex()
+                                       : off_td();
+}
+
+// Structure of MarginalizationInfo for this window (estimator.cpp:833-1005): which blocks
+// take part, which are dropped, canonical column order (dropped first, then poses / speed-bias
+// by frame, ex pose, td) and the addr_shift of the kept blocks.
+void plan_marg(const LfvioWindow *w, int flag, int N0, int kmax0, int nChunks0, bool imu0_ok, MargPlan *mp) {
+  std::memset(mp, 0, sizeof *mp);
+  for (int c = 0; c < KP; c++) mp->col[c] = -1;
+  const LfvioPrior *pr = (w->prior && w->prior->valid) ? w->prior : nullptr;
+  bool present[4][LFVIO_NUM_FRAMES] = {}, dropped[4][LFVIO_NUM_FRAMES] = {};
+  auto touch = [&](int kind, int frame, bool drop) {
+    present[kind][frame] = true;
+    if (drop) dropped[kind][frame] = true;
+  };
+  if (flag == LFVIO_MARGIN_OLD) {
+    if (pr)
+      for (int i = 0; i < pr->num_blocks; i++) {
+        const int k = pr->blocks[i].kind, f = pr->blocks[i].frame;
+        touch(k, f, (k == LFVIO_BLOCK_POSE || k == LFVIO_BLOCK_SPEEDBIAS) && f == 0);
+      }
+    mp->use_imu0 = (w->imu[0].sum_dt < 10.0) && imu0_ok;
+    if (w->imu[0].sum_dt < 10.0) {
+      touch(LFVIO_BLOCK_POSE, 0, true), touch(LFVIO_BLOCK_SPEEDBIAS, 0, true);
+      touch(LFVIO_BLOCK_POSE, 1, false), touch(LFVIO_BLOCK_SPEEDBIAS, 1, false);
+    }
+    if (N0 > 0) {
+      touch(LFVIO_BLOCK_POSE, 0, true);
+      for (int j = 1; j < kmax0; j++) touch(LFVIO_BLOCK_POSE, j, false);
+      touch(LFVIO_BLOCK_EX_POSE, 0, false);
+      if (w->estimate_td) touch(LFVIO_BLOCK_TD, 0, false);
+    }
+    mp->N0 = N0;
+    mp->nChunks0 = nChunks0;
+    mp->use_visual = N0 > 0;
+    mp->valid = 1;
+  } else {
+    bool touches = false;
+    if (pr)
+      for (int i = 0; i < pr->num_blocks; i++)
+        if (pr->blocks[i].kind == LFVIO_BLOCK_POSE && pr->blocks[i].frame == LFVIO_WINDOW_SIZE - 1) touches = true;
+    if (!touches) return;  // valid = 0
+    for (int i = 0; i < pr->num_blocks; i++) {
+      const int k = pr->blocks[i].kind, f = pr->blocks[i].frame;
+      touch(k, f, k == LFVIO_BLOCK_POSE && f == LFVIO_WINDOW_SIZE - 1);
+    }
+    mp->valid = 1;
+  }
+  int pos = 0;
+  for (int k = 0; k < 4; k++)
+    for (int f = 0; f < LFVIO_NUM_FRAMES; f++)
+      if (present[k][f] && dropped[k][f]) {
+        const int o = tangent_off(k, f);
+        for (int e = 0; e < local_size(k); e++) mp->col[o + e] = pos++;
+      }
+  mp->m15 = pos;
+  int nb = 0;
+  for (int k = 0; k < 4; k++)
+    for (int f = 0; f < LFVIO_NUM_FRAMES; f++)
+      if (present[k][f] && !dropped[k][f]) {
+        const int o = tangent_off(k, f);
+        mp->kind[nb] = k, mp->frame[nb] = f, mp->idx[nb] = pos - mp->m15;
+        int sf = f;
+        if (k == LFVIO_BLOCK_POSE || k == LFVIO_BLOCK_SPEEDBIAS) {
+          if (flag == LFVIO_MARGIN_OLD) sf = f - 1;
+          else if (f == LFVIO_WINDOW_SIZE) sf = LFVIO_WINDOW_SIZE - 1;
+        }
+        mp->shifted_frame[nb] = sf;
+        nb++;
+        for (int e = 0; e < local_size(k); e++) mp->col[o + e] = pos++;
+      }
+  mp->nb = nb;
+  mp->n = pos - mp->m15;
+}
+
+// Pack one window into the pinned staging blob and upload it to slot `slot`.
+int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w) {
+  if (!w || w->num_landmarks < 0 || w->num_observations < 0) {
+    c->err = "null window / negative sizes";
+    return LFVIO_ERR_ARG;
+  }
+  const int N = w->num_landmarks, M = w->num_observations;
+  if (N > 0 && (!w->start_frame || !w->obs_offset || !w->inv_depth || !w->obs_point || !w->obs_velocity ||
+                !w->obs_cur_td || !w->obs_uv_y)) {
+    c->err = "null landmark / observation arrays";
+    return LFVIO_ERR_ARG;
+  }
+  if (N > 0 && (w->obs_offset[0] != 0 || w->obs_offset[N] != M)) {
+    c->err = "obs_offset is not a CSR over num_observations";
+    return LFVIO_ERR_ARG;
+  }
+  for (int l = 0; l < N; l++) {
+    const int k = w->obs_offset[l + 1] - w->obs_offset[l], s = w->start_frame[l];
+    if (k < 2 || s < 0 || s + k > LFVIO_NUM_FRAMES) {  // used_num >= 2, track inside the window
+      c->err = "landmark with fewer than 2 observations or a track leaving the window";
+      return LFVIO_ERR_ARG;
+    }
+  }
+  const LfvioPrior *pr = (w->prior && w->prior->valid) ? w->prior : nullptr;
+  if (pr && (pr->n <= 0 || pr->n > LFVIO_MAX_PRIOR_DIM || pr->num_blocks <= 0 || pr->num_blocks > LFVIO_MAX_PRIOR_BLOCKS)) {
+    c->err = "malformed prior";
+    return LFVIO_ERR_ARG;
+  }
+  const Layout &L = c->L;
+  char *h = c->h_stage;
+  char *d = c->d_base + (size_t)slot * L.total;
+  Slot *S = (Slot *)h;
+  std::memset(S, 0, offsetof(Slot, x));
+  S->N = N, S->M = M, S->NV = M - N;
+  S->est_ex = w->estimate_extrinsic != 0, S->est_td = w->estimate_td != 0;
+  S->max_iter = w->max_num_iterations;
+  for (int k = 0; k < 3; k++) S->g[k] = w->g[k];
+  S->tr_over_row = w->tr / w->row;
+  S->half_row = w->row / 2;
+  S->sqrt_info = w->sqrt_info;
+  std::memcpy(S->x0.pose, w->para_pose, sizeof S->x0.pose);
+  std::memcpy(S->x0.sb, w->para_speed_bias, sizeof S->x0.sb);
+  std::memcpy(S->x0.ex, w->para_ex_pose, sizeof S->x0.ex);
+  S->x0.td = w->para_td;
+  for (int i = 0; i < LFVIO_WINDOW_SIZE; i++) {
+    S->imu[i] = w->imu[i];
+    S->imu_active[i] = !(w->imu[i].sum_dt > 10.0);  // estimator.cpp:720
+  }
+  // ---- landmarks: stable bucket sort by (start_frame, track length)
+  SlotHostInfo &info = c->info[slot];
+  info.N = N, info.M = M;
+  info.perm.resize(N);
+  {
+    int count[16 * 16 + 1] = {0};
+    for (int l = 0; l < N; l++) count[w->start_frame[l] * 16 + (w->obs_offset[l + 1] - w->obs_offset[l]) + 1]++;
+    for (int k = 0; k < 256; k++) count[k + 1] += count[k];
+    for (int l = 0; l < N; l++) info.perm[count[w->start_frame[l] * 16 + (w->obs_offset[l + 1] - w->obs_offset[l])]++] = l;
+  }
+  int *lm_start = (int *)(h + L.lm_start), *lm_cnt = (int *)(h + L.lm_cnt), *lm_obs0 = (int *)(h + L.lm_obs0);
+  int *lm_perm = (int *)(h + L.lm_perm);
+  double *lam0 = (double *)(h + L.lam0);
+  double *obs[8];
+  for (int k = 0; k < 8; k++) obs[k] = (double *)(h + L.obs[k]);
+  int o = 0, N0 = 0, kmax0 = 0;
+  int pair_count[NPAIR + 1] = {0};
+  for (int dl = 0; dl < N; dl++) {
+    const int l = info.perm[dl];
+    const int s = w->start_frame[l], k = w->obs_offset[l + 1] - w->obs_offset[l], o0 = w->obs_offset[l];
+    lm_start[dl] = s, lm_cnt[dl] = k, lm_obs0[dl] = o, lm_perm[dl] = l;
+    lam0[dl] = w->inv_depth[l];
+    if (s == 0) N0++, kmax0 = std::max(kmax0, k);
+    for (int q = 0; q < k; q++, o++) {
+      const int src = o0 + q;
+      obs[0][o] = w->obs_point[3 * src], obs[1][o] = w->obs_point[3 * src + 1], obs[2][o] = w->obs_point[3 * src + 2];
+      obs[3][o] = w->obs_velocity[3 * src], obs[4][o] = w->obs_velocity[3 * src + 1], obs[5][o] = w->obs_velocity[3 * src + 2];
+      obs[6][o] = w->obs_cur_td[src];
+      obs[7][o] = w->obs_uv_y[src];
+      if (q > 0) pair_count[s * 11 + s + q + 1]++;
+    }
+  }
+  // ---- pair-major list of the non-anchor observations + chunk table
+  for (int p = 0; p < NPAIR; p++) pair_count[p + 1] += pair_count[p];
+  int *pm_obs = (int *)(h + L.pm_obs), *pm_lm = (int *)(h + L.pm_lm);
+  {
+    int cursor[NPAIR];
+    for (int p = 0; p < NPAIR; p++) cursor[p] = pair_count[p];
+    for (int dl = 0; dl < N; dl++) {
+      const int s = lm_start[dl], k = lm_cnt[dl];
+      for (int q = 1; q < k; q++) {
+        const int p = s * 11 + s + q;
+        pm_obs[cursor[p]] = lm_obs0[dl] + q;
+        pm_lm[cursor[p]] = dl;
+        cursor[p]++;
+      }
+    }
+  }
+  int *chunk_pair = (int *)(h + L.chunk_pair), *chunk_begin = (int *)(h + L.chunk_begin), *chunk_end = (int *)(h + L.chunk_end);
+  int nChunks = 0;
+  for (int p = 0; p < NPAIR; p++) {
+    S->pair_chunk0[p] = nChunks;
+    for (int b = pair_count[p]; b < pair_count[p + 1]; b += CHUNK_MAX) {
+      if (nChunks >= L.capChunks) {
+        c->err = "chunk table overflow";
+        return LFVIO_ERR_ARG;
+      }
+      chunk_pair[nChunks] = p, chunk_begin[nChunks] = b, chunk_end[nChunks] = std::min(b + CHUNK_MAX, pair_count[p + 1]);
+      nChunks++;
+    }
+  }
+  S->pair_chunk0[NPAIR] = nChunks;
+  S->nChunks = nChunks;
+  S->nLmBlocks = (N + LM_BLOCK - 1) / LM_BLOCK;
+  S->nSchurParts = (N + SCHUR_LM - 1) / SCHUR_LM;
+  info.gLm = S->nLmBlocks, info.gCh = nChunks, info.gSc = S->nSchurParts;
+  // ---- prior
+  info.has_in_prior = pr != nullptr;
+  if (pr) {
+    info.in_prior = *pr;
+    S->prior_valid = 1, S->prior_n = pr->n, S->prior_nb = pr->num_blocks;
+    for (int i = 0; i < pr->num_blocks; i++) {
+      S->prior_kind[i] = pr->blocks[i].kind, S->prior_frame[i] = pr->blocks[i].frame, S->prior_idx[i] = pr->block_idx[i];
+      std::memcpy(S->prior_x0[i], pr->block_x0[i], sizeof(double) * 9);
+      const int to = tangent_off(pr->blocks[i].kind, pr->blocks[i].frame);
+      for (int e = 0; e < local_size(pr->blocks[i].kind); e++) S->prior_cmap[pr->block_idx[i] + e] = to + e;
+    }
+    std::memcpy(h + L.prior_J, pr->linearized_jacobians, sizeof(double) * pr->n * pr->n);
+    std::memcpy(h + L.prior_r, pr->linearized_residuals, sizeof(double) * pr->n);
+  }
+  plan_marg(w, LFVIO_MARGIN_OLD, N0, kmax0, S->pair_chunk0[11], true, &S->marg[0]);
+  plan_marg(w, LFVIO_MARGIN_SECOND_NEW, 0, 0, 0, true, &S->marg[1]);
+  // ---- device pointers
+  S->lm_start = (int *)(d + L.lm_start), S->lm_cnt = (int *)(d + L.lm_cnt), S->lm_obs0 = (int *)(d + L.lm_obs0);
+  S->lm_perm = (int *)(d + L.lm_perm), S->lam0 = (double *)(d + L.lam0);
+  for (int k = 0; k < 8; k++) S->obs[k] = (double *)(d + L.obs[k]);
+  S->pm_obs = (int *)(d + L.pm_obs), S->pm_lm = (int *)(d + L.pm_lm);
+  S->chunk_pair = (int *)(d + L.chunk_pair), S->chunk_begin = (int *)(d + L.chunk_begin), S->chunk_end = (int *)(d + L.chunk_end);
+  S->prior_J = (double *)(d + L.prior_J), S->prior_r = (double *)(d + L.prior_r);
+  // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
+  HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, L.in_end - L.in_begin, hipMemcpyHostToDevice, c->stream));
+  if (!info.uploaded) {
+    // work-array pointers: fixed per slot until the next reserve()
+    Slot W;
+    std::memset(&W, 0, sizeof W);
+    W.lam[0] = (double *)(d + L.lam[0]), W.lam[1] = (double *)(d + L.lam[1]);
+    W.prior_A = (double *)(d + L.prior_A);
+    W.a = (double *)(d + L.a), W.b = (double *)(d + L.b), W.W = (double *)(d + L.W);
+    W.scale_l = (double *)(d + L.scale_l), W.grad_l = (double *)(d + L.grad_l), W.gn_l = (double *)(d + L.gn_l);
+    W.diag_l = (double *)(d + L.diag_l), W.einv_l = (double *)(d + L.einv_l), W.d1 = (double *)(d + L.d1), W.d2 = (double *)(d + L.d2);
+    W.gram_part = (double *)(d + L.gram_part), W.pairG = (double *)(d + L.pairG);
+    W.schur_part = (double *)(d + L.schur_part), W.schur_sum = (double *)(d + L.schur_sum);
+    W.lm_part = (double *)(d + L.lm_part), W.cost_part = (double *)(d + L.cost_part), W.imu_out = (double *)(d + L.imu_out);
+    W.Hpp = (double *)(d + L.Hpp);
+    // field-by-field so that only pointer members are touched
+#define PUTP(field) HIPCHK(c, hipMemcpyAsync(d + offsetof(Slot, field), &W.field, sizeof W.field, hipMemcpyHostToDevice, c->stream))
+    PUTP(lam);
+    PUTP(prior_A);
+    PUTP(a); PUTP(b); PUTP(W); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
+    PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out);
+    PUTP(Hpp);
+#undef PUTP
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // W is on the stack
+    info.uploaded = true;
+  }
+  // the staging buffer is reused by the next upload
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LFVIO_OK;
+}
+
+struct Grid {
+  int lm, ch, sc;
+};
+
+Grid grid_for(lfvio_ctx *c, int count) {
+  Grid g{1, 1, 1};
+  for (int s = 0; s < count; s++) {
+    g.lm = std::max(g.lm, c->info[s].gLm);
+    g.ch = std::max(g.ch, c->info[s].gCh);
+    g.sc = std::max(g.sc, c->info[s].gSc);
+  }
+  return g;
+}
+
+void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
+  const size_t st = c->L.total;
+  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, mode, g.lm, g.ch);
+  hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, mode);
+  hipLaunchKernelGGL(k_sum, dim3(NPAIR + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode);
+  if (mode == MODE_SOLVE) {
+    hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
+    hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
+    hipLaunchKernelGGL(k_dogleg, dim3(1, count), dim3(128), 0, c->stream, c->d_base, st);
+    hipLaunchKernelGGL(k_cost, dim3(g.lm + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, g.lm);
+    hipLaunchKernelGGL(k_decide, dim3(1, count), dim3(64), 0, c->stream, c->d_base, st);
+  }
+}
+
+// Enqueue the trust-region loop for slots [0, count): max_iter Ceres iterations plus spare
+// passes for mu-retries (a failed Cholesky consumes a pass but not an iteration).
+int enqueue_solve(lfvio_ctx *c, int count, int max_iter) {
+  const Grid g = grid_for(c, count);
+  const int passes = std::max(max_iter, 0) + 4;
+  hipLaunchKernelGGL(k_setup, dim3(3, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  if (c->use_graph) {
+    if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes) {
+      destroy_graph(c);
+      hipGraph_t graph;
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE);
+      HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
+      HIPCHK(c, hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0));
+      HIPCHK(c, hipGraphDestroy(graph));
+      c->g_batch = count, c->g_lm = g.lm, c->g_ch = g.ch, c->g_sc = g.sc, c->g_iters = passes;
+    }
+    HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
+  } else {
+    for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE);
+  }
+  HIPCHK(c, hipGetLastError());
+  return LFVIO_OK;
+}
+
+int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone) {
+  const Grid g = grid_for(c, count);
+  const int mode = MODE_MARG + flag;
+  if (standalone)
+    hipLaunchKernelGGL(k_setup, dim3(3, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
+  launch_iteration(c, count, g, mode);
+  hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag);
+  HIPCHK(c, hipGetLastError());
+  return LFVIO_OK;
+}
+
+int download_solution(lfvio_ctx *c, int slot, LfvioSolution *out) {
+  const Layout &L = c->L;
+  char *d = c->d_base + (size_t)slot * L.total;
+  const SlotHostInfo &info = c->info[slot];
+  char *hd = c->h_down;
+  const size_t hdr = sizeof(FrameState) * 2 + sizeof(TRState);
+  HIPCHK(c, hipMemcpyAsync(hd, d + offsetof(Slot, x), hdr, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const FrameState *xs = (const FrameState *)hd;
+  const TRState *tr = (const TRState *)(hd + sizeof(FrameState) * 2);
+  if (tr->error) {
+    c->err = "non-finite cost";
+    return tr->error;
+  }
+  const int cur = tr->cur;
+  if (info.N > 0) {
+    HIPCHK(c, hipMemcpyAsync(hd + hdr, d + L.lam[cur], (size_t)info.N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  const FrameState &x = xs[cur];
+  std::memcpy(out->para_pose, x.pose, sizeof x.pose);
+  std::memcpy(out->para_speed_bias, x.sb, sizeof x.sb);
+  std::memcpy(out->para_ex_pose, x.ex, sizeof x.ex);
+  out->para_td = x.td;
+  const double *lam = (const double *)(hd + hdr);
+  if (out->inv_depth)
+    for (int dl = 0; dl < info.N; dl++) out->inv_depth[info.perm[dl]] = lam[dl];
+  out->num_iterations = tr->trace_len;
+  out->num_successful_steps = tr->num_succ;
+  out->num_unsuccessful_steps = tr->num_unsucc;
+  out->termination = tr->termination;
+  out->initial_cost = tr->initial_cost;
+  out->final_cost = tr->x_cost;
+  std::memset(out->trace, 0, sizeof out->trace);
+  for (int k = 0; k < tr->trace_len && k < LFVIO_MAX_TRACE; k++) out->trace[k] = tr->trace[k];
+  for (int k = 0; k < (int)(sizeof(FrameState) / 8); k++)
+    if (!std::isfinite(((const double *)&x)[k])) {
+      c->err = "non-finite state";
+      return LFVIO_ERR_NONFINITE;
+    }
+  return LFVIO_OK;
+}
+
+int download_prior(lfvio_ctx *c, int slot, LfvioPrior *out) {
+  const Layout &L = c->L;
+  char *d = c->d_base + (size_t)slot * L.total;
+  const SlotHostInfo &info = c->info[slot];
+  // header of LfvioPrior up to the Jacobian, then only the n*n / n used entries
+  LfvioPrior *hp = (LfvioPrior *)c->h_down;
+  const size_t head = offsetof(LfvioPrior, linearized_jacobians);
+  HIPCHK(c, hipMemcpyAsync(hp, d + offsetof(Slot, prior_out), head, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (hp->valid == -1) {  // nothing was marginalized: the input prior stays
+    if (info.has_in_prior) *out = info.in_prior;
+    else out->valid = 0;
+    return LFVIO_OK;
+  }
+  const int n = hp->n;
+  if (hp->valid != 1 || n <= 0 || n > LFVIO_MAX_PRIOR_DIM) {
+    c->err = "marginalization produced no prior";
+    return LFVIO_ERR_DEVICE;
+  }
+  HIPCHK(c, hipMemcpyAsync(hp->linearized_jacobians, d + offsetof(Slot, prior_out) + head, sizeof(double) * n * n,
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(hp->linearized_residuals, d + offsetof(Slot, prior_out) + offsetof(LfvioPrior, linearized_residuals),
+                           sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out, hp, head);
+  std::memcpy(out->linearized_jacobians, hp->linearized_jacobians, sizeof(double) * n * n);
+  std::memcpy(out->linearized_residuals, hp->linearized_residuals, sizeof(double) * n);
+  for (int k = 0; k < n * n; k++)
+    if (!std::isfinite(out->linearized_jacobians[k])) {
+      c->err = "non-finite prior";
+      return LFVIO_ERR_NONFINITE;
+    }
+  return LFVIO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *lfvio_version(void) { return "lfvio-hip 0.1 (gfx950, FP64)"; }
+
+lfvio_ctx *lfvio_create(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  lfvio_ctx *c = new lfvio_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  // kernels that need more than the default 64 KiB of LDS
+  (void)hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
+  (void)hipFuncSetAttribute((const void *)k_marg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
+  const char *env = getenv("LFVIO_NO_GRAPH");
+  if (env && env[0] == '1') c->use_graph = false;
+  return c;
+}
+
+void lfvio_destroy(lfvio_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  destroy_graph(c);
+  if (c->d_base) (void)hipFree(c->d_base);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_down) (void)hipHostFree(c->h_down);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *lfvio_last_error(const lfvio_ctx *c) { return c ? c->err.c_str() : "null context"; }
+void *lfvio_stream(lfvio_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int lfvio_solve(lfvio_ctx *c, const LfvioWindow *in, LfvioSolution *out) {
+  if (!c || !in || !out) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = reserve(c, 1, in->num_landmarks, in->num_observations);
+  if (rc) return rc;
+  if ((rc = upload_window(c, 0, in))) return rc;
+  if ((rc = enqueue_solve(c, 1, in->max_num_iterations))) return rc;
+  return download_solution(c, 0, out);
+}
+
+int lfvio_marginalize(lfvio_ctx *c, const LfvioWindow *in, int flag, LfvioPrior *out) {
+  if (!c || !in || !out || (flag != LFVIO_MARGIN_OLD && flag != LFVIO_MARGIN_SECOND_NEW)) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = reserve(c, 1, in->num_landmarks, in->num_observations);
+  if (rc) return rc;
+  if ((rc = upload_window(c, 0, in))) return rc;
+  if ((rc = enqueue_marg(c, 1, flag, true))) return rc;
+  return download_prior(c, 0, out);
+}
+
+int lfvio_batch_reserve(lfvio_ctx *c, int batch, int max_landmarks, int max_observations) {
+  if (!c || batch <= 0) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  return reserve(c, batch, max_landmarks, max_observations);
+}
+
+int lfvio_batch_upload(lfvio_ctx *c, int slot, const LfvioWindow *in) {
+  if (!c || slot < 0 || slot >= c->batch) return LFVIO_ERR_ARG;
+  if (in->num_landmarks > c->L.maxN || in->num_observations > c->L.maxM) {
+    c->err = "window larger than the reserved capacity";
+    return LFVIO_ERR_ARG;
+  }
+  (void)hipSetDevice(c->device);
+  return upload_window(c, slot, in);
+}
+
+int lfvio_batch_optimize_async(lfvio_ctx *c, int count, int marg_flag) {
+  if (!c || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int max_iter = 0;
+  // every slot carries its own max_iter on the device; the pass count follows the largest
+  max_iter = 8;
+  for (int s = 0; s < count; s++)
+    if (!c->info[s].uploaded) {
+      c->err = "slot not uploaded";
+      return LFVIO_ERR_ARG;
+    }
+  int rc = enqueue_solve(c, count, max_iter);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gauge, dim3(1, count), dim3(128), 0, c->stream, c->d_base, c->L.total);
+  return enqueue_marg(c, count, marg_flag, false);
+}
+
+int lfvio_batch_sync(lfvio_ctx *c) {
+  if (!c) return LFVIO_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LFVIO_OK;
+}
+
+int lfvio_batch_optimize(lfvio_ctx *c, int count, int marg_flag) {
+  int rc = lfvio_batch_optimize_async(c, count, marg_flag);
+  if (rc) return rc;
+  return lfvio_batch_sync(c);
+}
+
+int lfvio_batch_download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior *prior) {
+  if (!c || slot < 0 || slot >= c->batch) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = LFVIO_OK;
+  if (sol && (rc = download_solution(c, slot, sol))) return rc;
+  if (prior && (rc = download_prior(c, slot, prior))) return rc;
+  return rc;
+}
+
+// ---- debug / parity hooks (include/lfvio_debug.h)
+int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, double *gp, double *a, double *b, double *W,
+                          double *cost) {
+  if (!c || !in) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = reserve(c, 1, in->num_landmarks, in->num_observations);
+  if (rc) return rc;
+  if ((rc = upload_window(c, 0, in))) return rc;
+  const Grid g = grid_for(c, 1);
+  hipLaunchKernelGGL(k_setup, dim3(3, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, 1), dim3(64), 0, c->stream, c->d_base, c->L.total,
+                     MODE_SOLVE, g.lm, g.ch);
+  hipLaunchKernelGGL(k_schur, dim3(g.sc, 1), dim3(64), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_sum, dim3(NPAIR + SCHUR_LEN / 256 + 1, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const Layout &L = c->L;
+  char *d = c->d_base;
+  const int N = in->num_landmarks;
+  std::vector<double> packed(PACKED), av(N), bv(N), Wv((size_t)N * WLD);
+  HIPCHK(c, hipMemcpy(packed.data(), d + L.Hpp, sizeof(double) * PACKED, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(gp, d + offsetof(Slot, gp), sizeof(double) * KP, hipMemcpyDeviceToHost));
+  if (N) {
+    HIPCHK(c, hipMemcpy(av.data(), d + L.a, sizeof(double) * N, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(bv.data(), d + L.b, sizeof(double) * N, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(Wv.data(), d + L.W, sizeof(double) * N * WLD, hipMemcpyDeviceToHost));
+  }
+  TRState tr;
+  HIPCHK(c, hipMemcpy(&tr, d + offsetof(Slot, tr), sizeof tr, hipMemcpyDeviceToHost));
+  for (int i = 0; i < KP; i++)
+    for (int j = 0; j < KP; j++) Hpp[i * KP + j] = packed[pidx(i, j)];
+  const std::vector<int> &perm = c->info[0].perm;
+  for (int dl = 0; dl < N; dl++) {
+    a[perm[dl]] = av[dl], b[perm[dl]] = bv[dl];
+    for (int k = 0; k < KC; k++) W[(size_t)perm[dl] * KC + k] = Wv[(size_t)dl * WLD + k];
+  }
+  *cost = tr.x_cost;
+  return LFVIO_OK;
+}
+
+// Post-Schur system A', b' of the last marginalization of slot 0 (n x n, n).
+int lfvio_debug_marg_system(lfvio_ctx *c, int n, double *A, double *b) {
+  if (!c || !c->d_base) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  char *d = c->d_base + c->L.Hpp;
+  HIPCHK(c, hipMemcpy(A, d + sizeof(double) * (92 * 92 + 96), sizeof(double) * n * n, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(b, d + sizeof(double) * (92 * 92 + 96 + n * n), sizeof(double) * n, hipMemcpyDeviceToHost));
+  return LFVIO_OK;
+}
+
+int lfvio_debug_set_graph(lfvio_ctx *c, int on) {
+  if (!c) return LFVIO_ERR_ARG;
+  c->use_graph = on != 0;
+  return LFVIO_OK;
+}
+
+// ---- landmark-sharded API: declared in lfvio.h, implemented in shard.inc
+#include "shard.inc"
+
+}  // extern "C"

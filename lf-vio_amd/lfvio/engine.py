@@ -1,0 +1,99 @@
+"""Thin object wrapper over the C-ABI of liblfvio_hip.so (no compute, no fallback)."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Engine:
+    def __init__(self, device=0, lib_path=None):
+        self.lib = abi.load_hip_library(lib_path)
+        self.lib.lfvio_debug_linearize.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), _dp, _dp, _dp, _dp, _dp, _dp]
+        self.lib.lfvio_debug_marg_system.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        self.lib.lfvio_debug_set_graph.argtypes = [C.c_void_p, C.c_int]
+        self.ctx = self.lib.lfvio_create(device)
+        if not self.ctx:
+            raise RuntimeError("lfvio_create failed: no usable HIP device (there is no CPU fallback)")
+
+    def close(self):
+        if self.ctx:
+            self.lib.lfvio_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed rc={rc}: {self.lib.lfvio_last_error(self.ctx).decode()}")
+
+    def set_graph(self, on):
+        self.lib.lfvio_debug_set_graph(self.ctx, int(on))
+
+    def solve(self, win):
+        sol = abi.Solution(win.N)
+        self._check(self.lib.lfvio_solve(self.ctx, C.byref(win.c()), C.byref(sol.c)), "lfvio_solve")
+        return sol
+
+    def marginalize(self, win, flag):
+        prior = abi.Prior()
+        self._check(self.lib.lfvio_marginalize(self.ctx, C.byref(win.c()), flag, C.byref(prior)), "lfvio_marginalize")
+        return prior
+
+    def marg_system(self, n):
+        A = np.zeros((n, n))
+        b = np.zeros(n)
+        self._check(self.lib.lfvio_debug_marg_system(self.ctx, n, _p(A), _p(b)), "lfvio_debug_marg_system")
+        return A, b
+
+    def linearize(self, win):
+        N = win.N
+        H = np.zeros((abi.KP, abi.KP))
+        g = np.zeros(abi.KP)
+        a, b = np.zeros(max(N, 1)), np.zeros(max(N, 1))
+        W = np.zeros((max(N, 1), abi.KC))
+        cost = np.zeros(1)
+        self._check(self.lib.lfvio_debug_linearize(self.ctx, C.byref(win.c()), _p(H), _p(g), _p(a), _p(b), _p(W),
+                                                   _p(cost)), "lfvio_debug_linearize")
+        return dict(H=H, g=g, a=a[:N], b=b[:N], W=W[:N], cost=float(cost[0]))
+
+    # ---- device-resident batch API
+    def batch_reserve(self, batch, max_landmarks, max_observations):
+        self._check(self.lib.lfvio_batch_reserve(self.ctx, batch, max_landmarks, max_observations), "batch_reserve")
+
+    def batch_upload(self, slot, win):
+        self._check(self.lib.lfvio_batch_upload(self.ctx, slot, C.byref(win.c())), "batch_upload")
+
+    def batch_optimize(self, count, flag, sync=True):
+        fn = self.lib.lfvio_batch_optimize if sync else self.lib.lfvio_batch_optimize_async
+        self._check(fn(self.ctx, count, flag), "batch_optimize")
+
+    def batch_sync(self):
+        self._check(self.lib.lfvio_batch_sync(self.ctx), "batch_sync")
+
+    def batch_download(self, slot, n_landmarks, want_prior=True):
+        sol = abi.Solution(n_landmarks)
+        prior = abi.Prior() if want_prior else None
+        self._check(self.lib.lfvio_batch_download(self.ctx, slot, C.byref(sol.c), C.byref(prior) if want_prior else None),
+                    "batch_download")
+        return sol, prior
+
+    def optimize(self, win, flag):
+        """Whole optimization() of one window on slot 0: solve -> gauge fix -> marginalization."""
+        self.batch_reserve(1, win.N, win.M)
+        self.batch_upload(0, win)
+        self.batch_optimize(1, flag)
+        return self.batch_download(0, win.N)
+
+    def stream(self):
+        return self.lib.lfvio_stream(self.ctx)
