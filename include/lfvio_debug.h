@@ -14,6 +14,11 @@ int lfvio_debug_linearize(lfvio_ctx *ctx, const LfvioWindow *in, double *Hpp, do
                           double *W, double *cost);
 /* Post-Schur system (A' n x n, b' n) of the last marginalization run on slot 0. */
 int lfvio_debug_marg_system(lfvio_ctx *ctx, int n, double *A, double *b);
+/* shader-clock stamps written by the last k_solve of slot 0 (bring-up instrumentation) */
+int lfvio_debug_read_clocks(lfvio_ctx *ctx, long long *out32);
+/* Average ms of `reps` launches of one pipeline kernel over slots [0,count) (HIP events on the context stream).
+ * which: 0 k_lin (residual/Jacobian sweep), 1 k_schur (MFMA SYRK), 2 k_sum, 3 k_solve. */
+int lfvio_debug_time_kernel(lfvio_ctx *ctx, int which, int count, int reps, double *avg_ms);
 /* 0: launch kernels directly, 1: replay the captured hipGraph (default). */
 int lfvio_debug_set_graph(lfvio_ctx *ctx, int on);
 #ifdef __cplusplus

@@ -31,7 +31,8 @@ constexpr int HPP_CAP = 16384;   // packed H_pp (14878), reused as dense scratch
 constexpr int LM_BLOCK = 64;     // landmarks per workgroup (one wave) in the landmark sweep
 constexpr int CHUNK_LANES = 64;
 constexpr int CHUNK_MAX = 512;   // observations per Gram chunk (8 per lane)
-constexpr int SCHUR_LM = 256;    // landmarks per wave in the Schur SYRK
+constexpr int SCHUR_LM_MIN = 16;  // landmarks per wave in the Schur SYRK: >= 16, grown so that parts <= SCHUR_PARTS_MAX
+constexpr int SCHUR_PARTS_MAX = 1024;
 constexpr int LMS = 16;          // per-block landmark scalar partials
 constexpr int IMU_OUT = 900 + 30 + 2;
 
@@ -82,7 +83,7 @@ struct TRState {
   double initial_cost;
   double q[Q_COUNT];
   int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled;
-  int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, pad0;
+  int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, new_point;
   LfvioIterationSummary it;
   LfvioIterationSummary trace[LFVIO_MAX_TRACE];
 };
@@ -104,6 +105,7 @@ struct Slot {
   // ---------------- header: sizes, flags, constants
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
   int max_iter, prior_valid, prior_n, prior_nb;
+  int schur_lm, pad1;
   double g[3], tr_over_row, half_row, sqrt_info;
   FrameState x0;
   LfvioPreintegration imu[LFVIO_WINDOW_SIZE];
@@ -111,6 +113,7 @@ struct Slot {
   int prior_kind[LFVIO_MAX_PRIOR_BLOCKS], prior_frame[LFVIO_MAX_PRIOR_BLOCKS], prior_idx[LFVIO_MAX_PRIOR_BLOCKS];
   double prior_x0[LFVIO_MAX_PRIOR_BLOCKS][9];
   int prior_cmap[KP];            // prior column -> tangent column
+  int prior_inv[KP];             // tangent column -> prior column (-1: not in the prior)
   int pair_chunk0[NPAIR + 1];    // chunk range per pair slot
   MargPlan marg[2];              // [MARGIN_OLD, MARGIN_SECOND_NEW]
   // ---------------- input arrays (device pointers into the blob)
@@ -136,10 +139,12 @@ struct Slot {
   double *imu_out;               // 10 * IMU_OUT
   double prior_g[KP + 4];        // prior gradient (tangent cols) + cost
   double pose_cost[16];          // candidate costs of imu[0..9], prior [10]
-  double *Hpp;                   // packed lower KP
+  double *Hpp;                   // packed lower KP (assembled by k_sum)
+  double *mscr;                  // dense scratch of the marginalization (HPP_CAP)
   double gp[KP], scale_p[KP], diag_p[KP], grad_p[KP], gn_p[KP], step_p[KP];
   double uc_grad[WLD], uc_gn[WLD], uc_y[WLD];
   double z1[WLD], z2[WLD];
+  long long dbg[32];             // shader-clock stamps (bring-up instrumentation)
   // marginalization outputs
   LfvioPrior prior_out;
 };

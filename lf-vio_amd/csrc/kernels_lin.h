@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       t->step_valid = 0;
       t->skip_step = 0;
       t->error = 0;
+      t->new_point = 0;
       if (mode >= MODE_MARG) t->mu = 0.0;
     }
     __syncthreads();
@@ -475,8 +476,9 @@ __global__ __launch_bounds__(64) void k_schur(char *base, size_t stride, int mod
   double4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) acc[t] = double4_t{0, 0, 0, 0};
-  const int l0 = part * SCHUR_LM;
-  for (int s = 0; s < SCHUR_LM / 4; s++) {
+  const int lm = S->schur_lm;
+  const int l0 = part * lm;
+  for (int s = 0; s < lm / 4; s++) {
     if (l0 + 4 * s >= Nlim) break;
     const int l = l0 + 4 * s + kk;
     double coef = 0.0, e = 0.0;
@@ -531,39 +533,162 @@ DEV int schur_index(int R, int Cc) {
 DEV double schur_get(const double *Sc, int r, int c) { return r <= c ? Sc[schur_index(r, c)] : Sc[schur_index(c, r)]; }
 
 // ---------------------------------------------------------------------------
-// k_sum: grid (NPAIR + SCHUR_LEN/256 + 1, batch) x 256
+// k_sum: grid (HPP_BLOCKS + SCHUR_LEN/256 + 1, batch) x 256
+//   role 1: every packed entry of the pose-side Gauss-Newton Hessian H_pp (and of g_p) is
+//           produced by exactly ONE thread that adds its contributions in a fixed order —
+//           Gram chunks of the frame pairs touching it, the (at most two) IMU factors, the
+//           prior — so the result is deterministic and needs no atomics
+//   role 2: fixed-order sum of the Schur SYRK partials
+//   role 3: landmark scalar partials
 // ---------------------------------------------------------------------------
+constexpr int HPP_ITEMS = PACKED + KP;
+constexpr int HPP_BLOCKS = (HPP_ITEMS + 255) / 256;
+
+// frame block of a camera-side column: 0..10 pose, 11 ex, 12 td; lc = index inside the block
+DEV void cam_block(int c, int &f, int &lc) {
+  if (c < 66) {
+    f = c / 6;
+    lc = c - 6 * f;
+  } else if (c < 72) {
+    f = 11;
+    lc = c - 66;
+  } else {
+    f = 12;
+    lc = 0;
+  }
+}
+// IMU factor f sees tangent column c as local column (0..29) or -1
+DEV int imu_local(int c, int f) {
+  if (c < 66) {
+    const int fr = c / 6, l = c - 6 * fr;
+    if (fr == f) return l;
+    if (fr == f + 1) return 15 + l;
+    return -1;
+  }
+  if (c < KC) return -1;
+  const int fr = (c - KC) / 9, l = (c - KC) - 9 * fr;
+  if (fr == f) return 6 + l;
+  if (fr == f + 1) return 21 + l;
+  return -1;
+}
+DEV int col_frame(int c) { return c < 66 ? c / 6 : (c < KC ? -10 : (c - KC) / 9); }
+
+DEV bool col_active(const Slot *S, int c, int mode) {
+  if (mode >= MODE_MARG) return true;
+  if (!S->est_ex && c >= off_ex() && c < off_ex() + 6) return false;
+  if (!S->est_td && c == off_td()) return false;
+  return true;
+}
+
+DEV double gram_pair_sum(const Slot *S, int i, int j, int idx, int chunk_limit) {
+  const int p = i * 11 + j;
+  const int c0 = S->pair_chunk0[p];
+  int c1 = S->pair_chunk0[p + 1];
+  if (c1 > chunk_limit) c1 = chunk_limit;
+  double s = 0;
+  for (int c = c0; c < c1; c++) s += S->gram_part[(size_t)c * NGP + idx];
+  return s;
+}
+
 __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   if (tr->done) return;
   const int tid = threadIdx.x;
   int b = blockIdx.x;
-  if (b < NPAIR) {
+  if (b < HPP_BLOCKS) {
     if (!tr->do_lin) return;
-    const int c0 = S->pair_chunk0[b];
-    int c1 = S->pair_chunk0[b + 1];
-    if (is_marg(mode) && c1 > marg_plan(S, mode)->nChunks0) c1 = marg_plan(S, mode)->nChunks0;
-    if (tid < NGP) {
-      double s = 0;
-      for (int c = c0; c < c1; c++) s += S->gram_part[(size_t)c * NGP + tid];
-      S->pairG[(size_t)b * NGP + tid] = s;
+    const int e = b * 256 + tid;
+    if (e >= HPP_ITEMS) return;
+    const int chunk_limit = is_marg(mode) ? marg_plan(S, mode)->nChunks0 : S->nChunks;
+    double val = 0.0;
+    if (e < PACKED) {
+      int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= e) r++;
+      while (r * (r + 1) / 2 > e) r--;
+      const int c = e - r * (r + 1) / 2;
+      if (col_active(S, r, mode) && col_active(S, c, mode)) {
+        // ---- visual: Gram blocks of the frame pairs that contain both columns
+        if (r < KC) {
+          int fr, lr, fc, lc;
+          cam_block(r, fr, lr);
+          cam_block(c, fc, lc);
+          if (fr < 11) {  // both pose blocks (c <= r => fc <= fr)
+            if (fr == fc) {
+              for (int j = fr + 1; j < 11; j++) val += gram_pair_sum(S, fr, j, gidx20(lc, lr), chunk_limit);
+              for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lc, 6 + lr), chunk_limit);
+            } else {
+              val += gram_pair_sum(S, fc, fr, gidx20(lc, 6 + lr), chunk_limit);
+            }
+          } else {
+            const int hi = fr == 11 ? 12 + lr : 18;
+            if (fc < 11) {
+              for (int j = fc + 1; j < 11; j++) val += gram_pair_sum(S, fc, j, gidx20(lc, hi), chunk_limit);
+              for (int i = 0; i < fc; i++) val += gram_pair_sum(S, i, fc, gidx20(6 + lc, hi), chunk_limit);
+            } else {
+              const int lo = fc == 11 ? 12 + lc : 18;
+              for (int i = 0; i < 10; i++)
+                for (int j = i + 1; j < 11; j++) val += gram_pair_sum(S, i, j, gidx20(lo, hi), chunk_limit);
+            }
+          }
+        }
+        // ---- IMU factors covering both columns (at most two)
+        const int f0 = col_frame(r);
+        if (f0 >= 0) {
+          for (int f = f0 - 1; f <= f0; f++) {
+            if (f < 0 || f >= LFVIO_WINDOW_SIZE) continue;
+            const int p = imu_local(r, f), q = imu_local(c, f);
+            if (p >= 0 && q >= 0) val += S->imu_out[(size_t)f * IMU_OUT + p * 30 + q];
+          }
+        }
+        // ---- prior: A' = J0^T J0
+        if (S->prior_valid) {
+          const int pr = S->prior_inv[r], pc = S->prior_inv[c];
+          if (pr >= 0 && pc >= 0) val += S->prior_A[pr * S->prior_n + pc];
+        }
+      }
+      S->Hpp[e] = val;
+    } else {
+      const int r = e - PACKED;
+      if (col_active(S, r, mode)) {
+        if (r < KC) {
+          int fr, lr;
+          cam_block(r, fr, lr);
+          if (fr < 11) {
+            for (int j = fr + 1; j < 11; j++) val += gram_pair_sum(S, fr, j, gidx20(lr, 19), chunk_limit);
+            for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lr, 19), chunk_limit);
+          } else {
+            const int lo = fr == 11 ? 12 + lr : 18;
+            for (int i = 0; i < 10; i++)
+              for (int j = i + 1; j < 11; j++) val += gram_pair_sum(S, i, j, gidx20(lo, 19), chunk_limit);
+          }
+        }
+        const int f0 = col_frame(r);
+        if (f0 >= 0) {
+          for (int f = f0 - 1; f <= f0; f++) {
+            if (f < 0 || f >= LFVIO_WINDOW_SIZE) continue;
+            const int p = imu_local(r, f);
+            if (p >= 0) val += S->imu_out[(size_t)f * IMU_OUT + 900 + p];
+          }
+        }
+        val += S->prior_g[r];
+      }
+      S->gp[r] = val;
     }
     return;
   }
-  b -= NPAIR;
+  b -= HPP_BLOCKS;
   if (b < SCHUR_LEN / 256) {
     if (!tr->do_schur) return;
     const int e = b * 256 + tid;
     int parts = S->nSchurParts;
-    if (is_marg(mode)) parts = (marg_plan(S, mode)->N0 + SCHUR_LM - 1) / SCHUR_LM;
+    if (is_marg(mode)) parts = (marg_plan(S, mode)->N0 + S->schur_lm - 1) / S->schur_lm;
     double s = 0;
     for (int p = 0; p < parts; p++) s += S->schur_part[(size_t)p * SCHUR_LEN + e];
     S->schur_sum[e] = s;
     return;
   }
   if (!tr->do_lin) return;
-  // landmark scalar partials: wave 0 sums, wave 1 takes the max
   int blocks = S->nLmBlocks;
   if (tid < 4) {
     double s = 0;

@@ -15,7 +15,7 @@
 #pragma once
 #include "kernels_solve.h"
 
-constexpr int MARG_THREADS = 256;
+constexpr int MARG_THREADS = 1024;  // 4 waves / SIMD: the Jacobi steps are LDS-latency bound
 constexpr int MARG_MAXD = 96;  // 15 dropped + 76 kept, padded
 constexpr size_t MARG_LDS = (size_t)17408 * sizeof(double);  // >= LPACK + KP + 64 and >= the eigen-phase carve below
 
@@ -85,37 +85,52 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
 
 // Parallel cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (LDS, ld = n).
 // On exit diag(A) holds the eigenvalues and the columns of V (LDS, ld = n) the eigenvectors.
-DEV void jacobi_eig(double *A, double *V, int n, int tid, int nthreads, double *rotc, double *rots, int *rp, int *rq,
-                    double *scratch) {
-  for (int e = tid; e < n * n; e += nthreads) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+// Round-robin ordering: np/2 disjoint rotations per step, np-1 steps per sweep; every 2x2 block
+// A[{p_a,q_a}][{p_b,q_b}] is touched by exactly one thread (J_a^T B J_b), so a step needs two
+// barriers and no atomics.  Threads are mapped 16 x 16 over (pair a, pair b): no integer division.
+// Stops when the off-diagonal mass is below 1e-24 of the diagonal mass (off/||A|| < 1e-12, below the
+// conditioning error of A' itself, which is ~1e-10: A_mm carries IMU information ~1e10) or stagnates.
+DEV int jacobi_eig(double *A, double *V, int n, int tid, int nthreads, double *rotc, double *rots, int *rp, int *rq,
+                   double *scratch) {
+  for (int e = tid; e < n * n; e += nthreads) V[e] = 0.0;
+  __syncthreads();
+  for (int e = tid; e < n; e += nthreads) V[e * n + e] = 1.0;
   __syncthreads();
   const int np = n + (n & 1);
   const int half = np / 2;
-  if (n < 2) return;
-  for (int sweep = 0; sweep < 30; sweep++) {
-    // convergence: off-diagonal mass relative to the diagonal
+  if (n < 2) return 0;
+  int sweeps = 0;
+  const int tx = tid & 15, ty = tid >> 4, nty = nthreads >> 4;
+  double prev_off = 1e300;
+  for (int sweep = 0; sweep < 24; sweep++) {
     double off = 0, dia = 0;
-    for (int e = tid; e < n * n; e += nthreads) {
-      const double v = A[e];
-      if (e / n == e % n) dia += v * v;
-      else off += v * v;
-    }
+    for (int r = ty; r < n; r += nty)
+      for (int c = tx; c < n; c += 16) {
+        const double v = A[r * n + c];
+        if (r == c) dia += v * v;
+        else off += v * v;
+      }
     off = wave_sum(off), dia = wave_sum(dia);
     __syncthreads();
-    if ((tid & 63) == 0) scratch[tid >> 6] = off, scratch[8 + (tid >> 6)] = dia;
+    if ((tid & 63) == 0) scratch[tid >> 6] = off, scratch[16 + (tid >> 6)] = dia;
     __syncthreads();
     double so = 0, sd = 0;
-    for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[8 + w];
+    for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[16 + w];
     __syncthreads();
-    if (so <= 1e-30 * sd || so == 0.0) break;
+    if (so <= 1e-24 * sd || so == 0.0) break;
+    if (sweep >= 4 && so > 0.25 * prev_off) break;  // rounding floor reached
+    prev_off = so;
+    sweeps++;
     for (int step = 0; step < np - 1; step++) {
       if (tid < half) {
         int p, q;
         if (tid == 0) {
-          p = np - 1, q = step % (np - 1);
+          p = np - 1, q = step;
         } else {
-          p = (step + tid) % (np - 1);
-          q = (step - tid + (np - 1)) % (np - 1);
+          p = step + tid;
+          if (p >= np - 1) p -= np - 1;
+          q = step - tid;
+          if (q < 0) q += np - 1;
         }
         if (p > q) {
           int t = p;
@@ -131,39 +146,48 @@ DEV void jacobi_eig(double *A, double *V, int n, int tid, int nthreads, double *
             s = t * c;
           }
         }
-        rp[tid] = p, rq[tid] = q, rotc[tid] = c, rots[tid] = s;
+        rp[tid] = p, rq[tid] = (q < n) ? q : -1;
+        rotc[tid] = c, rots[tid] = s;
       }
       __syncthreads();
-      // A <- J^T A J on disjoint 2x2 blocks
-      for (int e = tid; e < half * half; e += nthreads) {
-        const int ka = e / half, kb = e % half;
-        const int pa = rp[ka], qa = rq[ka], pb = rp[kb], qb = rq[kb];
-        const double ca = rotc[ka], sa = rots[ka], cb = rotc[kb], sb = rots[kb];
-        const bool va = qa < n, vb = qb < n;  // dummy index present?
-        double b00 = A[pa * n + pb];
-        double b01 = vb ? A[pa * n + qb] : 0.0;
-        double b10 = va ? A[qa * n + pb] : 0.0;
-        double b11 = (va && vb) ? A[qa * n + qb] : 0.0;
-        const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
-        const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
-        A[pa * n + pb] = ca * t00 - sa * t10;
-        if (vb) A[pa * n + qb] = ca * t01 - sa * t11;
-        if (va) A[qa * n + pb] = sa * t00 + ca * t10;
-        if (va && vb) A[qa * n + qb] = sa * t01 + ca * t11;
+      // A <- J^T A J on disjoint 2x2 blocks (q = -1: the dummy index of an odd n)
+      for (int ka = ty; ka < half; ka += nty) {
+        const int pa = rp[ka], qa = rq[ka];
+        const double ca = rotc[ka], sa = rots[ka];
+        double *rowp = A + pa * n;
+        double *rowq = A + (qa >= 0 ? qa : pa) * n;
+        for (int kb = tx; kb < half; kb += 16) {
+          const int pb = rp[kb], qb = rq[kb];
+          const double cb = rotc[kb], sb = rots[kb];
+          const bool va = qa >= 0, vb = qb >= 0;
+          const double b00 = rowp[pb];
+          const double b01 = vb ? rowp[qb] : 0.0;
+          const double b10 = va ? rowq[pb] : 0.0;
+          const double b11 = (va && vb) ? rowq[qb] : 0.0;
+          const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
+          const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
+          rowp[pb] = ca * t00 - sa * t10;
+          if (vb) rowp[qb] = ca * t01 - sa * t11;
+          if (va) rowq[pb] = sa * t00 + ca * t10;
+          if (va && vb) rowq[qb] = sa * t01 + ca * t11;
+        }
       }
       // V <- V J
-      for (int e = tid; e < n * half; e += nthreads) {
-        const int r = e / half, kb = e % half;
-        const int pb = rp[kb], qb = rq[kb];
-        if (qb >= n) continue;
-        const double cb = rotc[kb], sb = rots[kb];
-        const double v0 = V[r * n + pb], v1 = V[r * n + qb];
-        V[r * n + pb] = cb * v0 - sb * v1;
-        V[r * n + qb] = sb * v0 + cb * v1;
+      for (int r = ty; r < n; r += nty) {
+        double *vr = V + r * n;
+        for (int kb = tx; kb < half; kb += 16) {
+          const int pb = rp[kb], qb = rq[kb];
+          if (qb < 0) continue;
+          const double cb = rotc[kb], sb = rots[kb];
+          const double v0 = vr[pb], v1 = vr[qb];
+          vr[pb] = cb * v0 - sb * v1;
+          vr[qb] = sb * v0 + cb * v1;
+        }
       }
       __syncthreads();
     }
   }
+  return sweeps;
 }
 
 // grid (1, batch) x 256, dynamic LDS = MARG_LDS
@@ -182,7 +206,9 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   double *Hs = smem;            // PACKED, then reused: A (D x D), V (n x n), ...
   double *g = Hs + LPACK;       // KP
   double *scratch = g + KP;     // 64
-  assemble_Hpp(S, Hs, g, tid, MODE_MARG);
+  for (int e = tid; e < PACKED; e += MARG_THREADS) Hs[e] = S->Hpp[e];
+  for (int c = tid; c < KP; c += MARG_THREADS) g[c] = S->gp[c];
+  __syncthreads();
   // eliminate the frame-0 landmarks: H -= sum c_l w_l w_l^T, g -= sum c_l b_l w_l
   const double *Sc = S->schur_sum;
   if (mp->N0 > 0) {
@@ -198,7 +224,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   __syncthreads();
   // ---- gather the dense system over the present blocks: D = m15 + n
   const int m15 = mp->m15, n = mp->n, D = m15 + n;
-  double *Ag = S->Hpp;  // global scratch, D x D + D
+  double *Ag = S->mscr;  // global scratch, D x D + D
   for (int e = tid; e < KP * KP; e += MARG_THREADS) {
     const int r = e / KP, c = e % KP;
     const int ar = mp->col[r], ac = mp->col[c];
@@ -229,7 +255,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     Am[e] = 0.5 * (A[r * D + c] + A[c * D + r]);
   }
   __syncthreads();
-  jacobi_eig(Am, Vm, m15, tid, MARG_THREADS, rotc, rots, rp, rq, scr);
+  const int sw1 = jacobi_eig(Am, Vm, m15, tid, MARG_THREADS, rotc, rots, rp, rq, scr);
   __syncthreads();
   const double eps = 1e-8;
   for (int e = tid; e < m15 * m15; e += MARG_THREADS) {
@@ -268,7 +294,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   for (int r = tid; r < n; r += MARG_THREADS) Aout[n * n + r] = br[r];
   __syncthreads();
   // ---- second eigen-decomposition -> J0 = sqrt(S) V^T, r0 = sqrt(1/S) V^T b'  (:283-291)
-  jacobi_eig(Ar, V2, n, tid, MARG_THREADS, rotc, rots, rp, rq, scr);
+  const int sw2 = jacobi_eig(Ar, V2, n, tid, MARG_THREADS, rotc, rots, rp, rq, scr);
+  if (tid == 0) S->dbg[24] = sw1, S->dbg[25] = sw2;
   __syncthreads();
   for (int e = tid; e < n * n; e += MARG_THREADS) {
     const int k = e / n, i = e % n;

@@ -13,34 +13,7 @@ constexpr int NROW = KP + 1;                       // + rhs row (forward substit
 constexpr int LPACK = NROW * (NROW + 1) / 2;       // 15051
 constexpr size_t SOLVE_LDS = (size_t)(LPACK + 2 * 176 + 8 * KP + 64) * sizeof(double);
 
-DEV bool col_active(const Slot *S, int c, int mode) {
-  if (mode >= MODE_MARG) return true;
-  if (!S->est_ex && c >= off_ex() && c < off_ex() + 6) return false;
-  if (!S->est_td && c == off_td()) return false;
-  return true;
-}
-
-// frame block of a camera-side column: 0..10 pose, 11 ex, 12 td; lc = index inside the block
-DEV void cam_block(int c, int &f, int &lc) {
-  if (c < 66) {
-    f = c / 6;
-    lc = c - 6 * f;
-  } else if (c < 72) {
-    f = 11;
-    lc = c - 66;
-  } else {
-    f = 12;
-    lc = 0;
-  }
-}
-// local column (0..19) of camera-side block (f, lc) inside pair (i, j), or -1
-DEV int pair_local(int f, int lc, int i, int j) {
-  if (f == i) return lc;
-  if (f == j) return 6 + lc;
-  if (f == 11) return 12 + lc;
-  if (f == 12) return 18;
-  return -1;
-}
+#define STAMP(S, k) do { if (threadIdx.x == 0) (S)->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 
 DEV double block_sum(double v, double *scratch, int tid) {
   v = wave_sum(v);
@@ -61,95 +34,30 @@ DEV double block_max(double v, double *scratch, int tid) {
   return s;
 }
 
-// Assemble the unscaled pose-side Gauss-Newton Hessian (packed lower, LDS) and gradient.
-DEV void assemble_Hpp(Slot *S, double *Hs, double *g, int tid, int mode) {
-  for (int e = tid; e < PACKED; e += SOLVE_THREADS) Hs[e] = 0.0;
-  for (int c = tid; c < KP; c += SOLVE_THREADS) g[c] = 0.0;
-  __syncthreads();
-  // ---- visual: owner-computes over the pair Grams (fixed order => deterministic)
-  const double *PG = S->pairG;
-  for (int e = tid; e < KC * (KC + 1) / 2; e += SOLVE_THREADS) {
-    int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-    while ((r + 1) * (r + 2) / 2 <= e) r++;
-    while (r * (r + 1) / 2 > e) r--;
-    const int c = e - r * (r + 1) / 2;
-    int fr, lr, fc, lc;
-    cam_block(r, fr, lr);
-    cam_block(c, fc, lc);
-    double s = 0;
-    for (int i = 0; i < 10; i++)
-      for (int j = i + 1; j < 11; j++) {
-        const int pr = pair_local(fr, lr, i, j);
-        if (pr < 0) continue;
-        const int pc = pair_local(fc, lc, i, j);
-        if (pc < 0) continue;
-        const int lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
-        s += PG[(size_t)(i * 11 + j) * NGP + gidx20(lo, hi)];
-      }
-    Hs[e] = s;
-  }
-  for (int r = tid; r < KC; r += SOLVE_THREADS) {
-    int fr, lr;
-    cam_block(r, fr, lr);
-    double s = 0;
-    for (int i = 0; i < 10; i++)
-      for (int j = i + 1; j < 11; j++) {
-        const int pr = pair_local(fr, lr, i, j);
-        if (pr >= 0) s += PG[(size_t)(i * 11 + j) * NGP + gidx20(pr, 19)];
-      }
-    g[r] = s;
-  }
-  __syncthreads();
-  // ---- IMU factors, one after the other (neighbouring factors share blocks)
-  for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) {
-    const double *out = S->imu_out + (size_t)f * IMU_OUT;
-    for (int e = tid; e < 930; e += SOLVE_THREADS) {
-      if (e < 900) {
-        const int p = e / 30, q = e % 30;
-        const int tp = p < 6 ? off_pose(f) + p : p < 15 ? off_sb(f) + p - 6 : p < 21 ? off_pose(f + 1) + p - 15 : off_sb(f + 1) + p - 21;
-        const int tq = q < 6 ? off_pose(f) + q : q < 15 ? off_sb(f) + q - 6 : q < 21 ? off_pose(f + 1) + q - 15 : off_sb(f + 1) + q - 21;
-        if (tp >= tq) Hs[pidx(tp, tq)] += out[e];
-      } else {
-        const int p = e - 900;
-        const int tp = p < 6 ? off_pose(f) + p : p < 15 ? off_sb(f) + p - 6 : p < 21 ? off_pose(f + 1) + p - 15 : off_sb(f + 1) + p - 21;
-        g[tp] += out[e];
-      }
-    }
-    __syncthreads();
-  }
-  // ---- prior: A' = J0^T J0 in prior column order -> tangent columns (one-to-one)
-  if (S->prior_valid) {
-    const int n = S->prior_n;
-    for (int e = tid; e < n * n; e += SOLVE_THREADS) {
-      const int tp = S->prior_cmap[e / n], tq = S->prior_cmap[e % n];
-      if (tp >= tq) Hs[pidx(tp, tq)] += S->prior_A[e];
-    }
-    for (int c = tid; c < KP; c += SOLVE_THREADS) g[c] += S->prior_g[c];
-  }
-  __syncthreads();
-  // ---- constant blocks leave the program (SetParameterBlockConstant / block never added)
-  if (mode == MODE_SOLVE && (!S->est_ex || !S->est_td)) {
-    for (int e = tid; e < KP * KP; e += SOLVE_THREADS) {
-      const int r = e / KP, c = e % KP;
-      if (r >= c && (!col_active(S, r, mode) || !col_active(S, c, mode))) Hs[pidx(r, c)] = 0.0;
-    }
-    for (int c = tid; c < KP; c += SOLVE_THREADS)
-      if (!col_active(S, c, mode)) g[c] = 0.0;
-    __syncthreads();
-  }
-}
-
-// y = H x with H packed-lower symmetric (LDS or global)
-DEV double sym_row_dot(const double *H, const double *x, int i) {
+// sum over the packed lower triangle of  w_ij H_ij (x_i y_j + x_j y_i) / 2  = x^T H y
+// (each thread walks entries e = tid, tid + T, ...; (i, j) advance incrementally)
+DEV double packed_bilinear(const double *H, const double *x, const double *y, int tid, int nthreads) {
   double s = 0;
-  const int base = i * (i + 1) / 2;
-  for (int j = 0; j <= i; j++) s = fma(H[base + j], x[j], s);
-  for (int j = i + 1; j < KP; j++) s = fma(H[j * (j + 1) / 2 + i], x[j], s);
+  int i = 0, j = tid;
+  while (j > i) {
+    j -= (i + 1);
+    i++;
+  }
+  for (int e = tid; e < PACKED; e += nthreads) {
+    const double h = H[e];
+    s = fma(h, (i == j) ? x[i] * y[i] : (x[i] * y[j] + x[j] * y[i]), s);
+    j += nthreads;
+    while (j > i) {
+      j -= (i + 1);
+      i++;
+    }
+  }
   return s;
 }
 
 // ---------------------------------------------------------------------------
-// k_solve: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS
+// k_solve: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS.
+// Input: H_pp (packed) and g_p assembled by k_sum, Schur sums, landmark scalars.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stride) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -165,28 +73,40 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   double *gr = dg + KP;              // gradient_
   double *Gd = gr + KP;              // unscaled Cauchy direction  S gr / dg
   double *yv = Gd + KP;              // y, then N direction
-  double *hv = yv + KP;              // H N
+  double *hv = yv + KP;              // gauss_newton_step_
   double *invd = hv + KP;            // 1 / L_ii
   double *scratch = invd + KP;       // 64
-
-  if (tr->do_lin) {
-    assemble_Hpp(S, Hs, g, tid, MODE_SOLVE);
-    for (int e = tid; e < PACKED; e += SOLVE_THREADS) S->Hpp[e] = Hs[e];
-    for (int c = tid; c < KP; c += SOLVE_THREADS) S->gp[c] = g[c];
-    if (tid == 0) {
-      double cost = S->lm_sum[0] + S->prior_g[KP];
-      for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += S->imu_out[(size_t)f * IMU_OUT + 930];
-      tr->x_cost = cost;
+  const bool est_ex = S->est_ex != 0, est_td = S->est_td != 0;
+  auto active = [&](int c) { return (est_ex || c < off_ex() || c >= off_ex() + 6) && (est_td || c != off_td()); };
+  STAMP(S, 0);
+  {  // H_pp global -> LDS, 16-byte loads, 4 in flight per thread
+    const double2 *src = (const double2 *)S->Hpp;
+    double2 *dst = (double2 *)Hs;
+    constexpr int NV2 = PACKED / 2;
+    for (int e = tid; e < NV2; e += 4 * SOLVE_THREADS) {
+      double2 v0 = src[e], v1, v2, v3;
+      const bool b1 = e + SOLVE_THREADS < NV2, b2 = e + 2 * SOLVE_THREADS < NV2, b3 = e + 3 * SOLVE_THREADS < NV2;
+      if (b1) v1 = src[e + SOLVE_THREADS];
+      if (b2) v2 = src[e + 2 * SOLVE_THREADS];
+      if (b3) v3 = src[e + 3 * SOLVE_THREADS];
+      dst[e] = v0;
+      if (b1) dst[e + SOLVE_THREADS] = v1;
+      if (b2) dst[e + 2 * SOLVE_THREADS] = v2;
+      if (b3) dst[e + 3 * SOLVE_THREADS] = v3;
     }
-  } else {
-    for (int e = tid; e < PACKED; e += SOLVE_THREADS) Hs[e] = S->Hpp[e];
-    for (int c = tid; c < KP; c += SOLVE_THREADS) g[c] = S->gp[c];
+    if (tid < KP) g[tid] = S->gp[tid];
+  }
+  if (tr->do_lin && tid == 0) {
+    double cost = S->lm_sum[0] + S->prior_g[KP];
+    for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += S->imu_out[(size_t)f * IMU_OUT + 930];
+    tr->x_cost = cost;
   }
   __syncthreads();
-
+  STAMP(S, 1);
   // ---- Jacobi scaling (iteration 0 only), diagonal_, gradient_  (dogleg_strategy.cc ComputeStep)
   const double mu = tr->mu;
-  for (int i = tid; i < KP; i += SOLVE_THREADS) {
+  if (tid < KP) {
+    const int i = tid;
     const double hii = Hs[pidx(i, i)];
     double s;
     if (!tr->scaled) {
@@ -196,45 +116,80 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       s = S->scale_p[i];
     }
     const double d = sqrt(fmin(fmax(s * s * hii, 1e-6), 1e32));
-    const bool act = col_active(S, i, MODE_SOLVE);
-    const double gi = act ? s * g[i] / d : 0.0;
+    const double gi = active(i) ? s * g[i] / d : 0.0;
     sc[i] = s, dg[i] = d, gr[i] = gi;
     Gd[i] = s * gi / d;
     S->diag_p[i] = d;
     S->grad_p[i] = gi;
   }
   __syncthreads();
-  // gradient_max_norm: x - Plus(x, -g) over the pose-side blocks (EvaluateGradientAndJacobian)
-  if (tr->do_lin) {
-    const FrameState *x = &S->x[tr->cur];
-    double mx = 0;
-    if (tid < 12) {
-      const double *xb = tid < 11 ? x->pose[tid] : x->ex;
-      const int o = tid < 11 ? off_pose(tid) : off_ex();
-      if (tid < 11 || S->est_ex) {
-        double d[6], xo[7];
-        for (int k = 0; k < 6; k++) d[k] = -g[o + k];
-        pose_plus(xb, d, xo);
-        for (int k = 0; k < 7; k++) mx = fmax(mx, fabs(xb[k] - xo[k]));
-      }
-    } else if (tid >= 64 && tid < 64 + 99) {
-      mx = fabs(g[off_sb(0) + tid - 64]);
-    } else if (tid == 200 && S->est_td) {
-      mx = fabs(g[off_td()]);
+  STAMP(S, 2);
+  // ---- reduced system in registers: thread (trow, tcol) owns (i, j) = (trow + 16 a, tcol + 16 b);
+  //      the Cauchy-point quadratic form G^T H G is accumulated from the same owned entries.
+  const double *Sc = S->schur_sum;
+  const int trow = tid & 15, tcol = tid >> 4;
+  double qgg_part = 0;
+  {  // pass 1: G^T H G over the owned entries (kept apart from pass 2 to bound register pressure)
+    double gi[11], gj[11];
+#pragma unroll
+    for (int a = 0; a < 11; a++) {
+      const int i = trow + 16 * a, j = tcol + 16 * a;
+      gi[a] = i < KP ? Gd[i] : 0.0;
+      gj[a] = j < KP ? Gd[j] : 0.0;
     }
-    mx = block_max(mx, scratch, tid);
-    if (tid == 0) tr->gmax_pose = fmax(mx, S->lm_sum[4]);
+#pragma unroll
+    for (int a = 0; a < 11; a++)
+#pragma unroll
+      for (int b = 0; b <= a; b++) {
+        const int i = trow + 16 * a, j = tcol + 16 * b;
+        if (i < KP && j <= i) {
+          const double h = Hs[i * (i + 1) / 2 + j];
+          qgg_part = fma(h * gi[a], (i == j) ? gj[b] : 2.0 * gj[b], qgg_part);
+        }
+      }
+  }
+  double m[11][11];
+  {  // pass 2: S = S_p (H_pp - Schur) S_p + mu D^2, rhs row
+    double si[11], sj[11];
+#pragma unroll
+    for (int a = 0; a < 11; a++) {
+      const int i = trow + 16 * a, j = tcol + 16 * a;
+      si[a] = i < KP ? sc[i] : 0.0;
+      sj[a] = j < KP ? sc[j] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 11; a++)
+#pragma unroll
+      for (int b = 0; b <= a; b++) {
+        const int i = trow + 16 * a, j = tcol + 16 * b;
+        double v = 0.0;
+        if (i < KP && j <= i) {
+          if (active(i) && active(j)) {
+            double h = Hs[i * (i + 1) / 2 + j];
+            if (i < KC) h -= Sc[schur_index(j, i)];  // j <= i < 73
+            v = si[a] * sj[b] * h;
+            if (i == j) v += mu * dg[i] * dg[i];
+          } else {
+            v = (i == j) ? 1.0 : 0.0;
+          }
+        } else if (i == KP && j < KP) {
+          if (active(j)) {
+            double r = g[j];
+            if (j < KC) r -= Sc[schur_index(j, COL_B)];  // z1
+            v = sj[b] * r;
+          }
+        }
+        m[a][b] = v;
+      }
   }
   // ---- Cauchy point: alpha = ||gradient_||^2 / ||J (gradient_/diagonal_)||^2
-  const double *Sc = S->schur_sum;
   {
-    double part = 0, gs = 0, cross = 0;
+    double gs = 0, cross = 0;
     if (tid < KP) {
-      part = Gd[tid] * sym_row_dot(Hs, Gd, tid);
       gs = gr[tid] * gr[tid];
       if (tid < KC) cross = Sc[schur_index(tid, COL_K)] * Gd[tid];  // z2 . G_c
     }
-    const double q_gg = block_sum(part, scratch, tid);
+    const double q_gg = block_sum(qgg_part, scratch, tid);
     const double gsq = block_sum(gs, scratch, tid);
     const double cr = block_sum(cross, scratch, tid);
     if (tid == 0) {
@@ -246,69 +201,50 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       tr->q[Q_GRAD_SQ] = gsq;
     }
   }
-  __syncthreads();
-
-  // ---- reduced system in registers: thread (trow, tcol) owns (i, j) = (trow + 16 a, tcol + 16 b)
-  const int trow = tid & 15, tcol = tid >> 4;
-  double m[11][11];
-#pragma unroll
-  for (int a = 0; a < 11; a++)
-#pragma unroll
-    for (int b = 0; b <= a; b++) {
-      const int i = trow + 16 * a, j = tcol + 16 * b;
-      double v = 0.0;
-      if (i < KP && j <= i) {
-        const bool ai = col_active(S, i, MODE_SOLVE), aj = col_active(S, j, MODE_SOLVE);
-        if (ai && aj) {
-          double h = Hs[pidx(i, j)];
-          if (i < KC) h -= schur_get(Sc, j, i);  // j <= i < 73
-          v = sc[i] * sc[j] * h;
-          if (i == j) v += mu * dg[i] * dg[i];
-        } else {
-          v = (i == j) ? 1.0 : 0.0;
-        }
-      } else if (i == KP && j < KP) {
-        if (col_active(S, j, MODE_SOLVE)) {
-          double r = g[j];
-          if (j < KC) r -= Sc[schur_index(j, COL_B)];  // z1
-          v = sc[j] * r;
-        }
-      }
-      m[a][b] = v;
-    }
   __syncthreads();  // Hs may now be overwritten
+  STAMP(S, 3);
 
   // ---- right-looking Cholesky, one barrier per pivot (column owners live in one 16-lane group)
   bool bad = !(mu < 1.0);  // ComputeGaussNewtonStep: `while (mu_ < max_mu_)` — no attempt at mu >= 1
 #pragma unroll
   for (int kb = 0; kb < 11; kb++) {
+#pragma nounroll
     for (int kk = 0; kk < 16; kk++) {
       const int k = kb * 16 + kk;
       if (k >= KP) break;
       double *cb = colbuf + (k & 1) * 176;
+      // the diagonal entry lives in lane ((kk&3)<<4)|kk of wave kk>>2: scalar broadcast
+      const int src = ((kk & 3) << 4) | kk;
+      const double dd = m[kb][kb];
+      const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dd), src),
+                                        __builtin_amdgcn_readlane(__double2loint(dd), src));
       if (tcol == kk) {
-        const double d = __shfl(m[kb][kb], ((kk & 3) << 4) | kk, 64);
         if (!(d > 0.0)) bad = true;
+        // library rsqrt: the raw v_rsq_f64 estimate + hand Newton steps went wrong on hardware
+        // (bring-up finding), so keep the correctly scaled OCML sequence here
         const double dinv = rsqrt(d);
 #pragma unroll
         for (int a = kb; a < 11; a++) {
           const int i = trow + 16 * a;
+          // the column buffer is written for EVERY row of the owner (zero outside (k, KP]) so that
+          // readers load it unconditionally with immediate offsets: the pivot loop is issue-bound
+          double v = 0.0;
           if (i > k && i <= KP) {
             m[a][kb] *= dinv;
-            cb[i] = m[a][kb];
+            v = m[a][kb];
           } else if (i == k) {
             m[a][kb] = d * dinv;
             invd[k] = dinv;
           }
+          cb[i] = v;
         }
       }
       __syncthreads();
       double li[11], lj[11];
 #pragma unroll
       for (int a = kb; a < 11; a++) {
-        const int i = trow + 16 * a, j = tcol + 16 * a;
-        li[a] = (i > k && i <= KP) ? cb[i] : 0.0;
-        lj[a] = (j > k && j < KP) ? cb[j] : 0.0;
+        li[a] = cb[trow + 16 * a];
+        lj[a] = cb[tcol + 16 * a];
       }
 #pragma unroll
       for (int a = kb; a < 11; a++)
@@ -316,7 +252,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
         for (int b = kb; b <= a; b++) m[a][b] = fma(-li[a], lj[b], m[a][b]);
     }
   }
-  // failure detection: any non-positive pivot or non-finite entry in the solution row
+  STAMP(S, 4);
   {
     double f = bad ? 1.0 : 0.0;
     f = block_max(f, scratch, tid);
@@ -328,36 +264,74 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
 #pragma unroll
     for (int b = 0; b <= a; b++) {
       const int i = trow + 16 * a, j = tcol + 16 * b;
-      if (i <= KP && j <= i && j < KP) Hs[pidx(i, j)] = m[a][b];
+      if (i <= KP && j <= i && j < KP) Hs[i * (i + 1) / 2 + j] = m[a][b];
     }
   __syncthreads();
-  // ---- back-substitution L^T y = z by wave 0 (readlane broadcast, no barriers)
+  STAMP(S, 5);
+  // ---- back-substitution L^T y = z by wave 0: scalar (readlane) broadcast of the owner's partial
+  //      sum, rows fetched four steps ahead so the LDS latency stays off the dependent chain.
   if (tid < 64) {
     const int lane = tid;
     double s0 = 0, s1 = 0, s2 = 0, y0 = 0, y1 = 0, y2 = 0;
     const int zbase = KP * (KP + 1) / 2;
-    for (int i = KP - 1; i >= 0; i--) {
-      const int owner = i & 63, slot = i >> 6;
-      const double ssel = slot == 0 ? s0 : (slot == 1 ? s1 : s2);
-      const int lo = __builtin_amdgcn_readlane(__double2loint(ssel), owner);
-      const int hi = __builtin_amdgcn_readlane(__double2hiint(ssel), owner);
-      const double sown = __hiloint2double(hi, lo);
-      const double yi = (Hs[zbase + i] - sown) * invd[i];
-      if (lane == owner) {
-        if (slot == 0) y0 = yi;
-        else if (slot == 1) y1 = yi;
-        else y2 = yi;
-      }
-      const int rb = i * (i + 1) / 2;
-      if (lane < i) s0 = fma(Hs[rb + lane], yi, s0);
-      if (lane + 64 < i) s1 = fma(Hs[rb + lane + 64], yi, s1);
-      if (lane + 128 < i) s2 = fma(Hs[rb + lane + 128], yi, s2);
+#define BS_FETCH(I, A0, A1, A2, Z, DV)                                   \
+  do {                                                                   \
+    const int ii_ = (I) >= 0 ? (I) : 0;                                  \
+    const int rb_ = ii_ * (ii_ + 1) / 2;                                 \
+    A0 = ((I) >= 0 && lane < ii_) ? Hs[rb_ + lane] : 0.0;                \
+    A1 = ((I) >= 0 && lane + 64 < ii_) ? Hs[rb_ + lane + 64] : 0.0;     \
+    A2 = ((I) >= 0 && lane + 128 < ii_) ? Hs[rb_ + lane + 128] : 0.0;    \
+    Z = Hs[zbase + ii_];                                                 \
+    DV = invd[ii_];                                                      \
+  } while (0)
+#define BS_STEP(I, A0, A1, A2, Z, DV)                                                   \
+  do {                                                                                  \
+    const int i_ = (I);                                                                 \
+    if (i_ >= 0) {                                                                      \
+      const int owner_ = i_ & 63, slot_ = i_ >> 6;                                      \
+      const double ssel_ = slot_ == 0 ? s0 : (slot_ == 1 ? s1 : s2);                    \
+      const int lo_ = __builtin_amdgcn_readlane(__double2loint(ssel_), owner_);         \
+      const int hi_ = __builtin_amdgcn_readlane(__double2hiint(ssel_), owner_);         \
+      const double yi_ = (Z - __hiloint2double(hi_, lo_)) * DV;                         \
+      if (lane == owner_) {                                                             \
+        if (slot_ == 0) y0 = yi_;                                                       \
+        else if (slot_ == 1) y1 = yi_;                                                  \
+        else y2 = yi_;                                                                  \
+      }                                                                                 \
+      s0 = fma(A0, yi_, s0);                                                            \
+      s1 = fma(A1, yi_, s1);                                                            \
+      s2 = fma(A2, yi_, s2);                                                            \
+    }                                                                                   \
+  } while (0)
+    double a00, a01, a02, az0, ad0, a10, a11, a12, az1, ad1, a20, a21, a22, az2, ad2, a30, a31, a32, az3, ad3;
+    BS_FETCH(KP - 1, a00, a01, a02, az0, ad0);
+    BS_FETCH(KP - 2, a10, a11, a12, az1, ad1);
+    BS_FETCH(KP - 3, a20, a21, a22, az2, ad2);
+    BS_FETCH(KP - 4, a30, a31, a32, az3, ad3);
+#pragma nounroll
+    for (int ib = KP - 1; ib >= 0; ib -= 4) {
+      double b00, b01, b02, bz0, bd0, b10, b11, b12, bz1, bd1, b20, b21, b22, bz2, bd2, b30, b31, b32, bz3, bd3;
+      BS_FETCH(ib - 4, b00, b01, b02, bz0, bd0);
+      BS_FETCH(ib - 5, b10, b11, b12, bz1, bd1);
+      BS_FETCH(ib - 6, b20, b21, b22, bz2, bd2);
+      BS_FETCH(ib - 7, b30, b31, b32, bz3, bd3);
+      BS_STEP(ib, a00, a01, a02, az0, ad0);
+      BS_STEP(ib - 1, a10, a11, a12, az1, ad1);
+      BS_STEP(ib - 2, a20, a21, a22, az2, ad2);
+      BS_STEP(ib - 3, a30, a31, a32, az3, ad3);
+      a00 = b00, a01 = b01, a02 = b02, az0 = bz0, ad0 = bd0;
+      a10 = b10, a11 = b11, a12 = b12, az1 = bz1, ad1 = bd1;
+      a20 = b20, a21 = b21, a22 = b22, az2 = bz2, ad2 = bd2;
+      a30 = b30, a31 = b31, a32 = b32, az3 = bz3, ad3 = bd3;
     }
+#undef BS_FETCH
+#undef BS_STEP
     yv[lane] = y0;
     yv[lane + 64] = y1;
     if (lane + 128 < KP) yv[lane + 128] = y2;
   }
   __syncthreads();
+  STAMP(S, 6);
   {
     double f = 0.0;
     if (tid < KP && !isfinite(yv[tid])) f = 1.0;
@@ -379,6 +353,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     S->gn_p[tid] = gn;
     const double Nd = -sc[tid] * y;  // unscaled GN direction
     yv[tid] = Nd;
+    hv[tid] = gn;
     if (tid < KC) {
       S->uc_grad[tid] = Gd[tid];
       S->uc_gn[tid] = Nd;
@@ -387,16 +362,42 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   if (tid >= KC && tid < WLD) S->uc_grad[tid] = S->uc_gn[tid] = 0.0;
   __syncthreads();
   {
-    double hn = 0, gn2 = 0, ggn = 0, gG = 0, gN = 0, qgn = 0, qnn = 0;
+    // G^T H N and N^T H N from the global copy of H_pp (LDS now holds L): every thread re-reads the
+    // entries it owned (static pattern, all loads independent)
+    double qgn = 0, qnn = 0;
+    {
+      const double *Hg = S->Hpp;
+      double Gi[11], Ni[11], Gj[11], Nj[11];
+#pragma unroll
+      for (int a = 0; a < 11; a++) {
+        const int i = trow + 16 * a, j = tcol + 16 * a;
+        Gi[a] = i < KP ? Gd[i] : 0.0, Ni[a] = i < KP ? yv[i] : 0.0;
+        Gj[a] = j < KP ? Gd[j] : 0.0, Nj[a] = j < KP ? yv[j] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 11; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) {
+          const int i = trow + 16 * a, j = tcol + 16 * b;
+          if (i < KP && j <= i) {
+            const double h = Hg[i * (i + 1) / 2 + j];
+            if (i == j) {
+              qgn = fma(h, Gi[a] * Nj[b], qgn);
+              qnn = fma(h, Ni[a] * Nj[b], qnn);
+            } else {
+              qgn = fma(h, Gi[a] * Nj[b] + Ni[a] * Gj[b], qgn);
+              qnn = fma(h, 2.0 * Ni[a] * Nj[b], qnn);
+            }
+          }
+        }
+    }
+    double gn2 = 0, ggn = 0, gG = 0, gN = 0;
     if (tid < KP) {
-      hn = sym_row_dot(S->Hpp, yv, tid);  // H_pp N from the global copy (LDS now holds L)
-      const double gn = S->gn_p[tid];
+      const double gn = hv[tid];
       gn2 = gn * gn;
       ggn = gr[tid] * gn;
       gG = g[tid] * Gd[tid];
       gN = g[tid] * yv[tid];
-      qgn = Gd[tid] * hn;
-      qnn = yv[tid] * hn;
     }
     gn2 = block_sum(gn2, scratch, tid);
     ggn = block_sum(ggn, scratch, tid);
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     gN = block_sum(gN, scratch, tid);
     qgn = block_sum(qgn, scratch, tid);
     qnn = block_sum(qnn, scratch, tid);
+    STAMP(S, 7);
     if (tid == 0) {
       tr->q[Q_GN_SQ] = gn2;
       tr->q[Q_GRAD_GN] = ggn;
@@ -412,17 +414,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       tr->q[Q_GN] = qgn;
       tr->q[Q_NN] = qnn;
       tr->chol_fail = 0;
-      if (tr->iteration > 0 && tr->do_lin && tr->trace_len > 0) {
-        // HandleSuccessfulStep -> EvaluateGradientAndJacobian at the accepted point
-        LfvioIterationSummary *last = &tr->trace[tr->trace_len - 1];
-        last->cost = tr->x_cost;
-        last->gradient_max_norm = tr->gmax_pose;
-        if (last->step_is_successful && tr->gmax_pose <= 1e-10) {  // GradientToleranceReached
-          tr->termination = LFVIO_CONVERGENCE;
-          tr->done = 1;
-        }
-      }
+      // gradient_max_norm of the pose side is filled in by k_dogleg (off the critical path)
       if (tr->iteration == 0) {
+        // IterationZero + first FinalizeIterationAndCheckIfMinimizerCanContinue
         {
           const FrameState *x0 = &S->x[tr->cur];
           double xn = S->lm_sum[3];
@@ -435,11 +429,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
           if (S->est_td) xn += x0->td * x0->td;
           tr->x_norm = sqrt(xn);
         }
-        // IterationZero + first FinalizeIterationAndCheckIfMinimizerCanContinue
         LfvioIterationSummary it;
         it.cost = tr->x_cost;
         it.cost_change = 0;
-        it.gradient_max_norm = tr->gmax_pose;
+        it.gradient_max_norm = 0;
         it.step_norm = 0;
         it.relative_decrease = 0;
         it.trust_region_radius = tr->radius;
@@ -451,11 +444,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
         tr->initial_cost = tr->x_cost;
         tr->iteration = 1;
         tr->scaled = 1;
+        tr->new_point = 1;
         if (S->max_iter <= 0) tr->done = 1;
         if (!isfinite(tr->x_cost)) {
           tr->done = 1;
           tr->error = LFVIO_ERR_NONFINITE;
         }
+      } else if (tr->do_lin && tr->trace_len > 0) {
+        tr->trace[tr->trace_len - 1].cost = tr->x_cost;  // HandleSuccessfulStep: cost re-evaluated at x
+        tr->new_point = 1;
       }
     }
   }
@@ -562,6 +559,42 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
   const int cur = tr->cur;
   const FrameState *x = &S->x[cur];
   FrameState *xc = &S->x[cur ^ 1];
+  if (tr->new_point) {
+    // gradient_max_norm = max |x - Plus(x, -g)| (EvaluateGradientAndJacobian), pose side + landmarks
+    double mx = 0;
+    if (tid < 12) {
+      const double *xb = tid < 11 ? x->pose[tid] : x->ex;
+      const int o = tid < 11 ? off_pose(tid) : off_ex();
+      if (tid < 11 || S->est_ex) {
+        double d[6], xo[7];
+        for (int k = 0; k < 6; k++) d[k] = -S->gp[o + k];
+        pose_plus(xb, d, xo);
+        for (int k = 0; k < 7; k++) mx = fmax(mx, fabs(xb[k] - xo[k]));
+      }
+    } else if (tid >= 16 && tid < 16 + 99) {
+      mx = fabs(S->gp[off_sb(0) + tid - 16]);
+    } else if (tid == 120 && S->est_td) {
+      mx = fabs(S->gp[off_td()]);
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      const double gm = fmax(fmax(sh[0], sh[1]), S->lm_sum[4]);
+      tr->gmax_pose = gm;
+      if (tr->trace_len > 0) {
+        LfvioIterationSummary *last = &tr->trace[tr->trace_len - 1];
+        last->gradient_max_norm = gm;
+        if (last->step_is_successful && gm <= 1e-10) {  // GradientToleranceReached
+          tr->termination = LFVIO_CONVERGENCE;
+          tr->done = 1;
+        }
+      }
+      tr->new_point = 0;
+    }
+    __syncthreads();
+  }
   // delta = (step / diagonal_) * scale, step = cg gradient_ + cn gauss_newton_
   for (int i = tid; i < KP; i += 128) {
     const double st = (cg * S->grad_p[i] + cn * S->gn_p[i]) / S->diag_p[i];

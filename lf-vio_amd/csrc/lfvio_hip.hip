@@ -37,7 +37,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, prior_J,
       prior_r;
   size_t lam[2], prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
-      schur_sum, lm_part, cost_part, imu_out, Hpp;
+      schur_sum, lm_part, cost_part, imu_out, Hpp, mscr;
 };
 
 Layout make_layout(int maxN, int maxM) {
@@ -46,7 +46,7 @@ Layout make_layout(int maxN, int maxM) {
   L.maxM = maxM;
   L.capLmBlocks = std::max(1, (maxN + LM_BLOCK - 1) / LM_BLOCK);
   L.capChunks = 64 + maxM / CHUNK_MAX;
-  L.capSchurParts = std::max(1, (maxN + SCHUR_LM - 1) / SCHUR_LM);
+  L.capSchurParts = std::min(SCHUR_PARTS_MAX, std::max(1, (maxN + SCHUR_LM_MIN - 1) / SCHUR_LM_MIN)) + 1;
   size_t o = align_up(sizeof(Slot), 256);
   auto take = [&](size_t bytes) {
     size_t r = o;
@@ -77,6 +77,7 @@ Layout make_layout(int maxN, int maxM) {
   L.cost_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.imu_out = take((size_t)LFVIO_WINDOW_SIZE * IMU_OUT * 8);
   L.Hpp = take((size_t)HPP_CAP * 8);
+  L.mscr = take((size_t)HPP_CAP * 8);
   L.total = align_up(o, 4096);
   return L;
 }
@@ -335,10 +336,16 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w) {
   S->pair_chunk0[NPAIR] = nChunks;
   S->nChunks = nChunks;
   S->nLmBlocks = (N + LM_BLOCK - 1) / LM_BLOCK;
-  S->nSchurParts = (N + SCHUR_LM - 1) / SCHUR_LM;
+  {
+    int lm = SCHUR_LM_MIN;
+    if ((N + lm - 1) / lm > SCHUR_PARTS_MAX) lm = ((N + SCHUR_PARTS_MAX - 1) / SCHUR_PARTS_MAX + 3) / 4 * 4;
+    S->schur_lm = lm;
+    S->nSchurParts = (N + lm - 1) / lm;
+  }
   info.gLm = S->nLmBlocks, info.gCh = nChunks, info.gSc = S->nSchurParts;
   // ---- prior
   info.has_in_prior = pr != nullptr;
+  for (int c2 = 0; c2 < KP; c2++) S->prior_inv[c2] = -1;
   if (pr) {
     info.in_prior = *pr;
     S->prior_valid = 1, S->prior_n = pr->n, S->prior_nb = pr->num_blocks;
@@ -346,7 +353,10 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w) {
       S->prior_kind[i] = pr->blocks[i].kind, S->prior_frame[i] = pr->blocks[i].frame, S->prior_idx[i] = pr->block_idx[i];
       std::memcpy(S->prior_x0[i], pr->block_x0[i], sizeof(double) * 9);
       const int to = tangent_off(pr->blocks[i].kind, pr->blocks[i].frame);
-      for (int e = 0; e < local_size(pr->blocks[i].kind); e++) S->prior_cmap[pr->block_idx[i] + e] = to + e;
+      for (int e = 0; e < local_size(pr->blocks[i].kind); e++) {
+        S->prior_cmap[pr->block_idx[i] + e] = to + e;
+        S->prior_inv[to + e] = pr->block_idx[i] + e;
+      }
     }
     std::memcpy(h + L.prior_J, pr->linearized_jacobians, sizeof(double) * pr->n * pr->n);
     std::memcpy(h + L.prior_r, pr->linearized_residuals, sizeof(double) * pr->n);
@@ -376,6 +386,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w) {
     W.schur_part = (double *)(d + L.schur_part), W.schur_sum = (double *)(d + L.schur_sum);
     W.lm_part = (double *)(d + L.lm_part), W.cost_part = (double *)(d + L.cost_part), W.imu_out = (double *)(d + L.imu_out);
     W.Hpp = (double *)(d + L.Hpp);
+    W.mscr = (double *)(d + L.mscr);
     // field-by-field so that only pointer members are touched
 #define PUTP(field) HIPCHK(c, hipMemcpyAsync(d + offsetof(Slot, field), &W.field, sizeof W.field, hipMemcpyHostToDevice, c->stream))
     PUTP(lam);
@@ -383,6 +394,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w) {
     PUTP(a); PUTP(b); PUTP(W); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
     PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out);
     PUTP(Hpp);
+    PUTP(mscr);
 #undef PUTP
     HIPCHK(c, hipStreamSynchronize(c->stream));  // W is on the stack
     info.uploaded = true;
@@ -410,7 +422,7 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const size_t st = c->L.total;
   hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, mode, g.lm, g.ch);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, mode);
-  hipLaunchKernelGGL(k_sum, dim3(NPAIR + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode);
+  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode);
   if (mode == MODE_SOLVE) {
     hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
     hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
@@ -659,7 +671,7 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, 1), dim3(64), 0, c->stream, c->d_base, c->L.total,
                      MODE_SOLVE, g.lm, g.ch);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, 1), dim3(64), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
-  hipLaunchKernelGGL(k_sum, dim3(NPAIR + SCHUR_LEN / 256 + 1, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
   hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -691,9 +703,50 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
 int lfvio_debug_marg_system(lfvio_ctx *c, int n, double *A, double *b) {
   if (!c || !c->d_base) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
-  char *d = c->d_base + c->L.Hpp;
+  char *d = c->d_base + c->L.mscr;
   HIPCHK(c, hipMemcpy(A, d + sizeof(double) * (92 * 92 + 96), sizeof(double) * n * n, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(b, d + sizeof(double) * (92 * 92 + 96 + n * n), sizeof(double) * n, hipMemcpyDeviceToHost));
+  return LFVIO_OK;
+}
+
+int lfvio_debug_read_clocks(lfvio_ctx *c, long long *out32) {
+  if (!c || !c->d_base) return LFVIO_ERR_ARG;
+  HIPCHK(c, hipMemcpy(out32, c->d_base + offsetof(Slot, dbg), sizeof(long long) * 32, hipMemcpyDeviceToHost));
+  return LFVIO_OK;
+}
+
+// Average duration (ms) of `reps` launches of one pipeline kernel on slots [0, count), measured with
+// HIP events on the context's own stream.  which: 0 k_lin, 1 k_schur, 2 k_sum, 3 k_solve.
+// The slots must hold an uploaded window; the trust-region flags are re-armed by k_setup first.
+int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double *avg_ms) {
+  if (!c || !c->d_base || count <= 0 || count > c->batch || reps <= 0) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  const Grid g = grid_for(c, count);
+  const size_t st = c->L.total;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_setup, dim3(3, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
+  // one full linearization so that every kernel has valid inputs
+  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE, g.lm, g.ch);
+  hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE);
+  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; r++) {
+    switch (which) {
+      case 0: hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE, g.lm, g.ch); break;
+      case 1: hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE); break;
+      case 2: hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE); break;
+      default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st); break;
+    }
+  }
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  *avg_ms = (double)ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return LFVIO_OK;
 }
 

@@ -18,6 +18,7 @@ class Engine:
         self.lib.lfvio_debug_linearize.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), _dp, _dp, _dp, _dp, _dp, _dp]
         self.lib.lfvio_debug_marg_system.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         self.lib.lfvio_debug_set_graph.argtypes = [C.c_void_p, C.c_int]
+        self.lib.lfvio_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
         self.ctx = self.lib.lfvio_create(device)
         if not self.ctx:
             raise RuntimeError("lfvio_create failed: no usable HIP device (there is no CPU fallback)")
@@ -94,6 +95,11 @@ class Engine:
         self.batch_upload(0, win)
         self.batch_optimize(1, flag)
         return self.batch_download(0, win.N)
+
+    def time_kernel(self, which, count, reps):
+        ms = np.zeros(1)
+        self._check(self.lib.lfvio_debug_time_kernel(self.ctx, which, count, reps, _p(ms)), "time_kernel")
+        return float(ms[0])
 
     def stream(self):
         return self.lib.lfvio_stream(self.ctx)

@@ -14,3 +14,16 @@ t = time.time()
 for _ in range(K): eng.batch_optimize(B, 0)
 dt = (time.time() - t) / K
 print(f"N={N} batch={B}: {dt*1e3:.3f} ms per batch-optimize, {B/dt:.1f} solves/s")
+import ctypes as C
+clk = (C.c_longlong * 32)()
+eng.lib.lfvio_debug_read_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+# single solve pass, no graph, read the stamps of the LAST k_solve
+eng.lib.lfvio_debug_read_clocks(eng.ctx, clk)
+c = list(clk)
+names = {1: "load H", 2: "scale/grad", 3: "regs+cauchy", 4: "cholesky", 5: "L to LDS", 6: "backsub", 7: "forms"}
+print("k_solve phases (cycles @ shader clock):")
+prev = c[0]
+for k in range(1, 8):
+    print(f"  {names[k]:20s} {c[k]-prev:10d}")
+    prev = c[k]
+print("  total", c[7] - c[0], " jacobi sweeps (m15, n):", c[24], c[25])
