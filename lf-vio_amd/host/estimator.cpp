@@ -1,0 +1,415 @@
+// estimator.cpp — host mirror (see estimator.h).  Reference lines are relative to
+// /root/reference/vins_estimator/src.
+#include "estimator.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace lfvio {
+
+double ACC_N = 0.02, ACC_W = 0.04, GYR_N = 0.01, GYR_W = 0.001;  // config/mindvision/mindvision.yaml:138-141
+Vector3d G{0.0, 0.0, 9.81007};                                     // :142
+double SOLVER_TIME = 0.04;                                         // :133
+int NUM_ITERATIONS = 8;                                            // :134
+int ESTIMATE_EXTRINSIC = 1, ESTIMATE_TD = 1;                       // :83, :151
+double TD = -0.008, TR = 0.0, ROW = 960, COL = 1280;
+
+// ---------------------------------------------------------------- Utility (utility.h:66-113)
+Vector3d Utility::R2ypr(const Matrix3d &R) {
+  Vector3d n = R.col(0), o = R.col(1), a = R.col(2);
+  double y = atan2(n(1), n(0));
+  double p = atan2(-n(2), n(0) * cos(y) + n(1) * sin(y));
+  double r = atan2(a(0) * sin(y) - a(1) * cos(y), -o(0) * sin(y) + o(1) * cos(y));
+  return Vector3d(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);
+}
+Matrix3d Utility::ypr2R(const Vector3d &ypr) {
+  double y = ypr(0) / 180.0 * M_PI, p = ypr(1) / 180.0 * M_PI, r = ypr(2) / 180.0 * M_PI;
+  Matrix3d Rz, Ry, Rx;
+  Rz(0, 0) = cos(y), Rz(0, 1) = -sin(y), Rz(1, 0) = sin(y), Rz(1, 1) = cos(y), Rz(2, 2) = 1;
+  Ry(0, 0) = cos(p), Ry(0, 2) = sin(p), Ry(1, 1) = 1, Ry(2, 0) = -sin(p), Ry(2, 2) = cos(p);
+  Rx(0, 0) = 1, Rx(1, 1) = cos(r), Rx(1, 2) = -sin(r), Rx(2, 1) = sin(r), Rx(2, 2) = cos(r);
+  return Rz * Ry * Rx;
+}
+
+// ---------------------------------------------------------------- IntegrationBase
+IntegrationBase::IntegrationBase(const Vector3d &_acc_0, const Vector3d &_gyr_0, const Vector3d &_linearized_ba,
+                                 const Vector3d &_linearized_bg)
+    : acc_0{_acc_0}, gyr_0{_gyr_0}, linearized_acc{_acc_0}, linearized_gyr{_gyr_0}, linearized_ba{_linearized_ba},
+      linearized_bg{_linearized_bg}, sum_dt{0.0}, delta_q{Quaterniond::Identity()} {
+  // integration_base.h:13-28
+  jacobian.setIdentity();
+  covariance.setZero();
+  noise.setZero();
+  const double nn[6] = {ACC_N * ACC_N, GYR_N * GYR_N, ACC_N * ACC_N, GYR_N * GYR_N, ACC_W * ACC_W, GYR_W * GYR_W};
+  for (int b = 0; b < 6; b++)
+    for (int i = 0; i < 3; i++) noise(3 * b + i, 3 * b + i) = nn[b];
+}
+
+void IntegrationBase::push_back(double _dt, const Vector3d &acc, const Vector3d &gyr) {  // :30-36
+  dt_buf.push_back(_dt);
+  acc_buf.push_back(acc);
+  gyr_buf.push_back(gyr);
+  propagate(_dt, acc, gyr);
+}
+
+void IntegrationBase::repropagate(const Vector3d &_linearized_ba, const Vector3d &_linearized_bg) {  // :38-52
+  sum_dt = 0.0;
+  acc_0 = linearized_acc;
+  gyr_0 = linearized_gyr;
+  delta_p.setZero();
+  delta_q.setIdentity();
+  delta_v.setZero();
+  linearized_ba = _linearized_ba;
+  linearized_bg = _linearized_bg;
+  jacobian.setIdentity();
+  covariance.setZero();
+  for (int i = 0; i < static_cast<int>(dt_buf.size()); i++) propagate(dt_buf[i], acc_buf[i], gyr_buf[i]);
+}
+
+void IntegrationBase::midPointIntegration(double _dt, const Vector3d &_acc_0, const Vector3d &_gyr_0, const Vector3d &_acc_1,
+                                          const Vector3d &_gyr_1, const Vector3d &delta_p, const Quaterniond &delta_q,
+                                          const Vector3d &delta_v, const Vector3d &linearized_ba, const Vector3d &linearized_bg,
+                                          Vector3d &result_delta_p, Quaterniond &result_delta_q, Vector3d &result_delta_v,
+                                          Vector3d &result_linearized_ba, Vector3d &result_linearized_bg, bool update_jacobian) {
+  // :63-71 — note: result_delta_q is NOT normalised here and is used as is below
+  Vector3d un_acc_0 = delta_q * (_acc_0 - linearized_ba);
+  Vector3d un_gyr = 0.5 * (_gyr_0 + _gyr_1) - linearized_bg;
+  result_delta_q = delta_q * Quaterniond(1, un_gyr(0) * _dt / 2, un_gyr(1) * _dt / 2, un_gyr(2) * _dt / 2);
+  Vector3d un_acc_1 = result_delta_q * (_acc_1 - linearized_ba);
+  Vector3d un_acc = 0.5 * (un_acc_0 + un_acc_1);
+  result_delta_p = delta_p + delta_v * _dt + 0.5 * un_acc * _dt * _dt;
+  result_delta_v = delta_v + un_acc * _dt;
+  result_linearized_ba = linearized_ba;
+  result_linearized_bg = linearized_bg;
+  if (!update_jacobian) return;
+  // :75-125
+  Vector3d w_x = 0.5 * (_gyr_0 + _gyr_1) - linearized_bg;
+  Vector3d a_0_x = _acc_0 - linearized_ba, a_1_x = _acc_1 - linearized_ba;
+  Matrix3d R_w_x = Utility::skewSymmetric(w_x), R_a_0_x = Utility::skewSymmetric(a_0_x), R_a_1_x = Utility::skewSymmetric(a_1_x);
+  Matrix3d Rdq = delta_q.toRotationMatrix(), Rrdq = result_delta_q.toRotationMatrix();
+  Matrix3d I = Matrix3d::Identity();
+  Mat<15, 15> F;
+  F.setBlock3(0, 0, I);
+  F.setBlock3(0, 3, (-0.25 * Rdq * R_a_0_x * _dt * _dt) + (-0.25 * Rrdq * R_a_1_x * (I - R_w_x * _dt) * _dt * _dt));
+  F.setBlock3(0, 6, I * _dt);
+  F.setBlock3(0, 9, -0.25 * (Rdq + Rrdq) * _dt * _dt);
+  F.setBlock3(0, 12, -0.25 * Rrdq * R_a_1_x * _dt * _dt * -_dt);
+  F.setBlock3(3, 3, I - R_w_x * _dt);
+  F.setBlock3(3, 12, -1.0 * I * _dt);
+  F.setBlock3(6, 3, (-0.5 * Rdq * R_a_0_x * _dt) + (-0.5 * Rrdq * R_a_1_x * (I - R_w_x * _dt) * _dt));
+  F.setBlock3(6, 6, I);
+  F.setBlock3(6, 9, -0.5 * (Rdq + Rrdq) * _dt);
+  F.setBlock3(6, 12, -0.5 * Rrdq * R_a_1_x * _dt * -_dt);
+  F.setBlock3(9, 9, I);
+  F.setBlock3(12, 12, I);
+  Mat<15, 18> V;
+  Matrix3d V03 = 0.25 * (-Rrdq) * R_a_1_x * _dt * _dt * 0.5 * _dt;
+  Matrix3d V63 = 0.5 * (-Rrdq) * R_a_1_x * _dt * 0.5 * _dt;
+  V.setBlock3(0, 0, 0.25 * Rdq * _dt * _dt);
+  V.setBlock3(0, 3, V03);
+  V.setBlock3(0, 6, 0.25 * Rrdq * _dt * _dt);
+  V.setBlock3(0, 9, V03);
+  V.setBlock3(3, 3, 0.5 * I * _dt);
+  V.setBlock3(3, 9, 0.5 * I * _dt);
+  V.setBlock3(6, 0, 0.5 * Rdq * _dt);
+  V.setBlock3(6, 3, V63);
+  V.setBlock3(6, 6, 0.5 * Rrdq * _dt);
+  V.setBlock3(6, 9, V63);
+  V.setBlock3(9, 12, I * _dt);
+  V.setBlock3(12, 15, I * _dt);
+  // jacobian = F * jacobian; covariance = F * covariance * F^T + V * noise * V^T
+  Mat<15, 15> FJ, FC, NC;
+  Mat<15, 18> VN;
+  for (int i = 0; i < 15; i++)
+    for (int j = 0; j < 15; j++) {
+      double s = 0, c = 0;
+      for (int k = 0; k < 15; k++) s += F(i, k) * jacobian(k, j), c += F(i, k) * covariance(k, j);
+      FJ(i, j) = s, FC(i, j) = c;
+    }
+  for (int i = 0; i < 15; i++)
+    for (int j = 0; j < 18; j++) {
+      double s = 0;
+      for (int k = 0; k < 18; k++) s += V(i, k) * noise(k, j);
+      VN(i, j) = s;
+    }
+  for (int i = 0; i < 15; i++)
+    for (int j = 0; j < 15; j++) {
+      double s = 0, t = 0;
+      for (int k = 0; k < 15; k++) s += FC(i, k) * F(j, k);
+      for (int k = 0; k < 18; k++) t += VN(i, k) * V(j, k);
+      NC(i, j) = s + t;
+    }
+  jacobian = FJ;
+  covariance = NC;
+}
+
+void IntegrationBase::propagate(double _dt, const Vector3d &_acc_1, const Vector3d &_gyr_1) {  // :130-158
+  dt = _dt;
+  acc_1 = _acc_1;
+  gyr_1 = _gyr_1;
+  Vector3d result_delta_p, result_delta_v, result_linearized_ba, result_linearized_bg;
+  Quaterniond result_delta_q;
+  midPointIntegration(_dt, acc_0, gyr_0, _acc_1, _gyr_1, delta_p, delta_q, delta_v, linearized_ba, linearized_bg, result_delta_p,
+                      result_delta_q, result_delta_v, result_linearized_ba, result_linearized_bg, 1);
+  delta_p = result_delta_p;
+  delta_q = result_delta_q;
+  delta_v = result_delta_v;
+  linearized_ba = result_linearized_ba;
+  linearized_bg = result_linearized_bg;
+  delta_q.normalize();
+  sum_dt += dt;
+  acc_0 = acc_1;
+  gyr_0 = gyr_1;
+}
+
+// ---------------------------------------------------------------- FeatureManager (feature_manager.cpp:28-42,139-197)
+int FeatureManager::getFeatureCount() {
+  int cnt = 0;
+  for (auto &it : feature) {
+    it.used_num = it.feature_per_frame.size();
+    if (it.used_num >= 2 && it.start_frame < WINDOW_SIZE - 2) cnt++;
+  }
+  return cnt;
+}
+void FeatureManager::setDepth(const VectorXd &x) {
+  int feature_index = -1;
+  for (auto &it_per_id : feature) {
+    it_per_id.used_num = it_per_id.feature_per_frame.size();
+    if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
+    it_per_id.estimated_depth = 1.0 / x(++feature_index);
+    it_per_id.solve_flag = 1;  // both branches of the reference set 1 (feature_manager.cpp:149-154)
+  }
+}
+void FeatureManager::clearDepth(const VectorXd &x) {
+  int feature_index = -1;
+  for (auto &it_per_id : feature) {
+    it_per_id.used_num = it_per_id.feature_per_frame.size();
+    if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
+    it_per_id.estimated_depth = 1.0 / x(++feature_index);
+  }
+}
+void FeatureManager::removeFailures() {
+  for (auto it = feature.begin(), it_next = feature.begin(); it != feature.end(); it = it_next) {
+    it_next++;
+    if (it->solve_flag == 2) feature.erase(it);
+  }
+}
+VectorXd FeatureManager::getDepthVector() {
+  VectorXd dep_vec(getFeatureCount());
+  int feature_index = -1;
+  for (auto &it_per_id : feature) {
+    it_per_id.used_num = it_per_id.feature_per_frame.size();
+    if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
+    dep_vec(++feature_index) = 1. / it_per_id.estimated_depth;
+  }
+  return dep_vec;
+}
+FeaturePerId &FeatureManager::addFeature(int feature_id, int start_frame) {
+  feature.emplace_back(feature_id, start_frame);
+  return feature.back();
+}
+
+// ---------------------------------------------------------------- Estimator
+Estimator::Estimator() {
+  for (int i = 0; i <= WINDOW_SIZE; i++) pre_integrations[i] = nullptr;
+  clearState();
+}
+Estimator::~Estimator() {
+  for (int i = 0; i <= WINDOW_SIZE; i++) delete pre_integrations[i];
+  delete last_marginalization_info;
+  if (gpu) lfvio_destroy(gpu);
+}
+void Estimator::setParameter() {  // estimator.cpp:10-21 (the sqrt_info statics travel in LfvioWindow::sqrt_info)
+  td = TD;
+}
+void Estimator::clearState() {  // estimator.cpp:23-84 (subset owned by the mirror)
+  for (int i = 0; i < WINDOW_SIZE + 1; i++) {
+    Rs[i].setIdentity();
+    Ps[i].setZero();
+    Vs[i].setZero();
+    Bas[i].setZero();
+    Bgs[i].setZero();
+    delete pre_integrations[i];
+    pre_integrations[i] = nullptr;
+  }
+  for (int i = 0; i < NUM_OF_CAM; i++) {
+    tic[i] = Vector3d::Zero();
+    ric[i] = Matrix3d::Identity();
+  }
+  td = TD;
+  delete last_marginalization_info;
+  last_marginalization_info = nullptr;
+  f_manager.clearState();
+  failure_occur = 0;
+}
+
+void Estimator::vector2double() {  // estimator.cpp:488-530
+  for (int i = 0; i <= WINDOW_SIZE; i++) {
+    para_Pose[i][0] = Ps[i].x();
+    para_Pose[i][1] = Ps[i].y();
+    para_Pose[i][2] = Ps[i].z();
+    Quaterniond q{Rs[i]};
+    para_Pose[i][3] = q.x();
+    para_Pose[i][4] = q.y();
+    para_Pose[i][5] = q.z();
+    para_Pose[i][6] = q.w();
+    para_SpeedBias[i][0] = Vs[i].x();
+    para_SpeedBias[i][1] = Vs[i].y();
+    para_SpeedBias[i][2] = Vs[i].z();
+    para_SpeedBias[i][3] = Bas[i].x();
+    para_SpeedBias[i][4] = Bas[i].y();
+    para_SpeedBias[i][5] = Bas[i].z();
+    para_SpeedBias[i][6] = Bgs[i].x();
+    para_SpeedBias[i][7] = Bgs[i].y();
+    para_SpeedBias[i][8] = Bgs[i].z();
+  }
+  for (int i = 0; i < NUM_OF_CAM; i++) {
+    para_Ex_Pose[i][0] = tic[i].x();
+    para_Ex_Pose[i][1] = tic[i].y();
+    para_Ex_Pose[i][2] = tic[i].z();
+    Quaterniond q{ric[i]};
+    para_Ex_Pose[i][3] = q.x();
+    para_Ex_Pose[i][4] = q.y();
+    para_Ex_Pose[i][5] = q.z();
+    para_Ex_Pose[i][6] = q.w();
+  }
+  VectorXd dep = f_manager.getDepthVector();
+  para_Feature.resize(f_manager.getFeatureCount());
+  for (int i = 0; i < f_manager.getFeatureCount(); i++) para_Feature[i] = dep(i);
+  if (ESTIMATE_TD) para_Td[0][0] = td;
+}
+
+void Estimator::double2vector() {  // estimator.cpp:532-600 (relocalization tail :603-625 is a dead branch as shipped)
+  Vector3d origin_R0 = Utility::R2ypr(Rs[0]);
+  Vector3d origin_P0 = Ps[0];
+  if (failure_occur) {
+    origin_R0 = Utility::R2ypr(last_R0);
+    origin_P0 = last_P0;
+    failure_occur = 0;
+  }
+  Vector3d origin_R00 =
+      Utility::R2ypr(Quaterniond(para_Pose[0][6], para_Pose[0][3], para_Pose[0][4], para_Pose[0][5]).toRotationMatrix());
+  double y_diff = origin_R0.x() - origin_R00.x();
+  Matrix3d rot_diff = Utility::ypr2R(Vector3d(y_diff, 0, 0));
+  if (std::abs(std::abs(origin_R0.y()) - 90) < 1.0 || std::abs(std::abs(origin_R00.y()) - 90) < 1.0) {
+    rot_diff = Rs[0] * Quaterniond(para_Pose[0][6], para_Pose[0][3], para_Pose[0][4], para_Pose[0][5]).toRotationMatrix().transpose();
+  }
+  for (int i = 0; i <= WINDOW_SIZE; i++) {
+    Rs[i] = rot_diff * Quaterniond(para_Pose[i][6], para_Pose[i][3], para_Pose[i][4], para_Pose[i][5]).normalized().toRotationMatrix();
+    Ps[i] = rot_diff * Vector3d(para_Pose[i][0] - para_Pose[0][0], para_Pose[i][1] - para_Pose[0][1], para_Pose[i][2] - para_Pose[0][2]) +
+            origin_P0;
+    Vs[i] = rot_diff * Vector3d(para_SpeedBias[i][0], para_SpeedBias[i][1], para_SpeedBias[i][2]);
+    Bas[i] = Vector3d(para_SpeedBias[i][3], para_SpeedBias[i][4], para_SpeedBias[i][5]);
+    Bgs[i] = Vector3d(para_SpeedBias[i][6], para_SpeedBias[i][7], para_SpeedBias[i][8]);
+  }
+  for (int i = 0; i < NUM_OF_CAM; i++) {
+    tic[i] = Vector3d(para_Ex_Pose[i][0], para_Ex_Pose[i][1], para_Ex_Pose[i][2]);
+    ric[i] = Quaterniond(para_Ex_Pose[i][6], para_Ex_Pose[i][3], para_Ex_Pose[i][4], para_Ex_Pose[i][5]).toRotationMatrix();
+  }
+  VectorXd dep = f_manager.getDepthVector();
+  for (int i = 0; i < f_manager.getFeatureCount(); i++) dep(i) = para_Feature[i];
+  f_manager.setDepth(dep);
+  if (ESTIMATE_TD) td = para_Td[0][0];
+}
+
+void Estimator::packWindow(LfvioWindow *w) {
+  std::memset(w, 0, sizeof *w);
+  std::memcpy(w->para_pose, para_Pose, sizeof para_Pose);
+  std::memcpy(w->para_speed_bias, para_SpeedBias, sizeof para_SpeedBias);
+  std::memcpy(w->para_ex_pose, para_Ex_Pose[0], sizeof para_Ex_Pose[0]);
+  w->para_td = ESTIMATE_TD ? para_Td[0][0] : td;
+  w->estimate_extrinsic = ESTIMATE_EXTRINSIC != 0;
+  w->estimate_td = ESTIMATE_TD != 0;
+  w->max_num_iterations = NUM_ITERATIONS;
+  // estimator.cpp:819-822; <= 0 disables the cap (parity / bench)
+  w->max_solver_time_in_seconds = SOLVER_TIME <= 0 ? -1.0 : (marginalization_flag == MARGIN_OLD ? SOLVER_TIME * 4.0 / 5.0 : SOLVER_TIME);
+  w->g[0] = G.x(), w->g[1] = G.y(), w->g[2] = G.z();
+  w->tr = TR, w->row = ROW;
+  w->sqrt_info = FOCAL_LENGTH / 1.5;  // estimator.cpp:18-19
+  // features: same filter and order as the loops at estimator.cpp:727-772
+  Scratch &s = scratch_;
+  s.start_frame.clear(), s.obs_offset.assign(1, 0), s.inv_depth.clear();
+  s.point.clear(), s.velocity.clear(), s.cur_td.clear(), s.uv_y.clear();
+  int feature_index = -1;
+  for (auto &it_per_id : f_manager.feature) {
+    it_per_id.used_num = it_per_id.feature_per_frame.size();
+    if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
+    ++feature_index;
+    s.start_frame.push_back(it_per_id.start_frame);
+    s.inv_depth.push_back(para_Feature[feature_index]);
+    for (auto &it_per_frame : it_per_id.feature_per_frame) {
+      for (int k = 0; k < 3; k++) s.point.push_back(it_per_frame.point(k)), s.velocity.push_back(it_per_frame.velocity(k));
+      s.cur_td.push_back(it_per_frame.cur_td);
+      s.uv_y.push_back(it_per_frame.uv.y());
+    }
+    s.obs_offset.push_back((int)s.cur_td.size());
+  }
+  w->num_landmarks = (int)s.start_frame.size();
+  w->num_observations = (int)s.cur_td.size();
+  w->start_frame = s.start_frame.data(), w->obs_offset = s.obs_offset.data(), w->inv_depth = s.inv_depth.data();
+  w->obs_point = s.point.data(), w->obs_velocity = s.velocity.data(), w->obs_cur_td = s.cur_td.data(), w->obs_uv_y = s.uv_y.data();
+  // pre_integrations[1..10] (estimator.cpp:717-724)
+  for (int i = 0; i < WINDOW_SIZE; i++) {
+    const IntegrationBase *p = pre_integrations[i + 1];
+    LfvioPreintegration &o = w->imu[i];
+    if (!p) {
+      o.sum_dt = 1e9;  // no factor
+      continue;
+    }
+    o.sum_dt = p->sum_dt;
+    for (int k = 0; k < 3; k++) {
+      o.delta_p[k] = p->delta_p(k), o.delta_v[k] = p->delta_v(k);
+      o.linearized_ba[k] = p->linearized_ba(k), o.linearized_bg[k] = p->linearized_bg(k);
+    }
+    o.delta_q[0] = p->delta_q.x(), o.delta_q[1] = p->delta_q.y(), o.delta_q[2] = p->delta_q.z(), o.delta_q[3] = p->delta_q.w();
+    std::memcpy(o.jacobian, p->jacobian.a, sizeof o.jacobian);
+    std::memcpy(o.covariance, p->covariance.a, sizeof o.covariance);
+  }
+  w->prior = last_marginalization_info;
+}
+
+// Estimator::optimization(), estimator.cpp:676-1009, over the C-ABI:
+//   vector2double -> [ceres::Solve := lfvio_solve] -> double2vector
+//   -> vector2double -> [MarginalizationInfo := lfvio_marginalize] -> new prior
+// On any error the state is left as the caller had it (the reference has no error channel at all).
+void Estimator::optimization() {
+  if (!gpu) gpu = lfvio_create(0);
+  if (!gpu) {
+    last_status = LFVIO_ERR_DEVICE;  // no fallback: the caller sees the failure
+    return;
+  }
+  vector2double();  // :707
+  LfvioWindow w;
+  packWindow(&w);
+  std::vector<double> lam(w.num_landmarks > 0 ? w.num_landmarks : 1);
+  last_summary.inv_depth = lam.data();
+  last_status = lfvio_solve(gpu, &w, &last_summary);  // :810-825
+  last_summary.inv_depth = nullptr;
+  if (last_status != LFVIO_OK) return;
+  std::memcpy(para_Pose, last_summary.para_pose, sizeof para_Pose);
+  std::memcpy(para_SpeedBias, last_summary.para_speed_bias, sizeof para_SpeedBias);
+  std::memcpy(para_Ex_Pose[0], last_summary.para_ex_pose, sizeof para_Ex_Pose[0]);
+  if (ESTIMATE_TD) para_Td[0][0] = last_summary.para_td;
+  for (int i = 0; i < w.num_landmarks; i++) para_Feature[i] = lam[i];
+  double2vector();  // :830
+
+  // :833-1005 — both branches start with vector2double() and differ only in the factor set, which the
+  // library derives from the flag
+  const bool second_new_needed =
+      marginalization_flag == MARGIN_SECOND_NEW && last_marginalization_info && last_marginalization_info->valid;
+  if (marginalization_flag == MARGIN_OLD || second_new_needed) {
+    vector2double();
+    packWindow(&w);
+    LfvioPrior *next = new LfvioPrior();
+    last_status = lfvio_marginalize(gpu, &w, marginalization_flag == MARGIN_OLD ? LFVIO_MARGIN_OLD : LFVIO_MARGIN_SECOND_NEW, next);
+    if (last_status != LFVIO_OK) {
+      delete next;
+      return;
+    }
+    delete last_marginalization_info;  // :935-938
+    last_marginalization_info = next;
+  }
+}
+
+}  // namespace lfvio

@@ -1,0 +1,144 @@
+// host_capi.cpp — extern "C" driver of the host mirror, so that the Python tests (and bench) can
+// exercise Estimator::optimization() the way estimator_node.cpp would.
+#include <cstring>
+
+#include "estimator.h"
+
+using namespace lfvio;
+
+extern "C" {
+
+void *lfvio_host_create(void) { return new Estimator(); }
+void lfvio_host_destroy(void *h) { delete (Estimator *)h; }
+
+// globals of parameters.cpp (readParameters); p = {ACC_N, GYR_N, ACC_W, GYR_W, g_norm, TR, ROW, SOLVER_TIME, TD}
+void lfvio_host_set_params(const double *p, int estimate_extrinsic, int estimate_td, int num_iterations) {
+  ACC_N = p[0], GYR_N = p[1], ACC_W = p[2], GYR_W = p[3];
+  G = Vector3d(0, 0, p[4]);
+  TR = p[5], ROW = p[6], SOLVER_TIME = p[7], TD = p[8];
+  ESTIMATE_EXTRINSIC = estimate_extrinsic, ESTIMATE_TD = estimate_td, NUM_ITERATIONS = num_iterations;
+}
+
+static void setM(Matrix3d &m, const double *a) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) m(i, j) = a[i * 3 + j];
+}
+static void getM(const Matrix3d &m, double *a) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) a[i * 3 + j] = m(i, j);
+}
+
+void lfvio_host_set_state(void *h, const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs,
+                          const double *tic, const double *ric, double td) {
+  Estimator *e = (Estimator *)h;
+  for (int i = 0; i <= WINDOW_SIZE; i++) {
+    e->Ps[i] = Vector3d(Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2]);
+    e->Vs[i] = Vector3d(Vs[3 * i], Vs[3 * i + 1], Vs[3 * i + 2]);
+    e->Bas[i] = Vector3d(Bas[3 * i], Bas[3 * i + 1], Bas[3 * i + 2]);
+    e->Bgs[i] = Vector3d(Bgs[3 * i], Bgs[3 * i + 1], Bgs[3 * i + 2]);
+    setM(e->Rs[i], Rs + 9 * i);
+  }
+  e->tic[0] = Vector3d(tic[0], tic[1], tic[2]);
+  setM(e->ric[0], ric);
+  e->td = td;
+}
+
+void lfvio_host_get_state(void *h, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, double *tic, double *ric, double *td) {
+  Estimator *e = (Estimator *)h;
+  for (int i = 0; i <= WINDOW_SIZE; i++) {
+    for (int k = 0; k < 3; k++) {
+      Ps[3 * i + k] = e->Ps[i](k), Vs[3 * i + k] = e->Vs[i](k), Bas[3 * i + k] = e->Bas[i](k), Bgs[3 * i + k] = e->Bgs[i](k);
+    }
+    getM(e->Rs[i], Rs + 9 * i);
+  }
+  for (int k = 0; k < 3; k++) tic[k] = e->tic[0](k);
+  getM(e->ric[0], ric);
+  *td = e->td;
+}
+
+void lfvio_host_clear_features(void *h) { ((Estimator *)h)->f_manager.clearState(); }
+
+// obs: n x 8 = [bearing xyz, pixel uv, bearing-velocity xyz] like the 8-vector of estimator_node.cpp:308
+void lfvio_host_add_feature(void *h, int id, int start_frame, int n, const double *obs, const double *cur_td, double estimated_depth) {
+  Estimator *e = (Estimator *)h;
+  FeaturePerId &f = e->f_manager.addFeature(id, start_frame);
+  for (int k = 0; k < n; k++) f.feature_per_frame.push_back(FeaturePerFrame(obs + 8 * k, cur_td[k]));
+  f.estimated_depth = estimated_depth;
+}
+
+int lfvio_host_feature_count(void *h) { return ((Estimator *)h)->f_manager.getFeatureCount(); }
+void lfvio_host_get_depths(void *h, double *out) {
+  Estimator *e = (Estimator *)h;
+  int k = 0;
+  for (auto &f : e->f_manager.feature) out[k++] = f.estimated_depth;
+}
+
+// pre_integrations[frame] := IntegrationBase{acc0, gyr0, ba, bg}; push_back() of the n samples (processIMU, estimator.cpp:86-120)
+void lfvio_host_set_imu(void *h, int frame, const double *acc0, const double *gyr0, const double *ba, const double *bg, int n,
+                        const double *dt, const double *acc, const double *gyr) {
+  Estimator *e = (Estimator *)h;
+  delete e->pre_integrations[frame];
+  e->pre_integrations[frame] = new IntegrationBase(Vector3d(acc0[0], acc0[1], acc0[2]), Vector3d(gyr0[0], gyr0[1], gyr0[2]),
+                                                   Vector3d(ba[0], ba[1], ba[2]), Vector3d(bg[0], bg[1], bg[2]));
+  for (int k = 0; k < n; k++)
+    e->pre_integrations[frame]->push_back(dt[k], Vector3d(acc[3 * k], acc[3 * k + 1], acc[3 * k + 2]),
+                                          Vector3d(gyr[3 * k], gyr[3 * k + 1], gyr[3 * k + 2]));
+}
+
+void lfvio_host_repropagate(void *h, int frame, const double *ba, const double *bg) {
+  Estimator *e = (Estimator *)h;
+  if (e->pre_integrations[frame]) e->pre_integrations[frame]->repropagate(Vector3d(ba[0], ba[1], ba[2]), Vector3d(bg[0], bg[1], bg[2]));
+}
+
+void lfvio_host_vector2double(void *h) { ((Estimator *)h)->vector2double(); }
+void lfvio_host_double2vector(void *h) { ((Estimator *)h)->double2vector(); }
+
+void lfvio_host_get_para(void *h, double *pose, double *sb, double *ex, double *td, double *feature) {
+  Estimator *e = (Estimator *)h;
+  std::memcpy(pose, e->para_Pose, sizeof e->para_Pose);
+  std::memcpy(sb, e->para_SpeedBias, sizeof e->para_SpeedBias);
+  std::memcpy(ex, e->para_Ex_Pose[0], sizeof e->para_Ex_Pose[0]);
+  *td = e->para_Td[0][0];
+  for (size_t i = 0; i < e->para_Feature.size(); i++) feature[i] = e->para_Feature[i];
+}
+void lfvio_host_set_para(void *h, const double *pose, const double *sb, const double *ex, double td, const double *feature, int n) {
+  Estimator *e = (Estimator *)h;
+  std::memcpy(e->para_Pose, pose, sizeof e->para_Pose);
+  std::memcpy(e->para_SpeedBias, sb, sizeof e->para_SpeedBias);
+  std::memcpy(e->para_Ex_Pose[0], ex, sizeof e->para_Ex_Pose[0]);
+  e->para_Td[0][0] = td;
+  e->para_Feature.assign(feature, feature + n);
+}
+
+// LfvioWindow exactly as optimization() hands it to the C-ABI (pointers stay valid until the next pack)
+void lfvio_host_pack(void *h, LfvioWindow *out) {
+  Estimator *e = (Estimator *)h;
+  e->vector2double();
+  e->packWindow(out);
+}
+
+void lfvio_host_set_flag(void *h, int flag) { ((Estimator *)h)->marginalization_flag = (Estimator::MarginalizationFlag)flag; }
+void lfvio_host_set_prior(void *h, const LfvioPrior *p) {
+  Estimator *e = (Estimator *)h;
+  delete e->last_marginalization_info;
+  e->last_marginalization_info = (p && p->valid) ? new LfvioPrior(*p) : nullptr;
+}
+int lfvio_host_get_prior(void *h, LfvioPrior *out) {
+  Estimator *e = (Estimator *)h;
+  if (!e->last_marginalization_info) {
+    out->valid = 0;
+    return 0;
+  }
+  *out = *e->last_marginalization_info;
+  return 1;
+}
+
+int lfvio_host_optimization(void *h) {
+  Estimator *e = (Estimator *)h;
+  e->optimization();
+  return e->last_status;
+}
+int lfvio_host_last_iterations(void *h) { return ((Estimator *)h)->last_summary.num_iterations; }
+double lfvio_host_last_cost(void *h) { return ((Estimator *)h)->last_summary.final_cost; }
+
+}  // extern "C"

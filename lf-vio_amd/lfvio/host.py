@@ -1,0 +1,114 @@
+"""ctypes driver of the host-side C++ mirror (liblfvio_host.so): Estimator / FeatureManager /
+IntegrationBase with the reference's member names, optimization() re-implemented over the C-ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi, synth
+
+_dp = C.POINTER(C.c_double)
+HOST_LIB_PATH = os.path.join(abi.PKG_DIR, "liblfvio_host.so")
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class HostEstimator:
+    def __init__(self):
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} not found: run __graft_entry__.build()")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.lfvio_host_create.restype = C.c_void_p
+        L.lfvio_host_destroy.argtypes = [C.c_void_p]
+        L.lfvio_host_set_params.argtypes = [_dp, C.c_int, C.c_int, C.c_int]
+        L.lfvio_host_set_state.argtypes = [C.c_void_p] + [_dp] * 7 + [C.c_double]
+        L.lfvio_host_get_state.argtypes = [C.c_void_p] + [_dp] * 8
+        L.lfvio_host_clear_features.argtypes = [C.c_void_p]
+        L.lfvio_host_add_feature.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double]
+        L.lfvio_host_feature_count.argtypes = [C.c_void_p]
+        L.lfvio_host_get_depths.argtypes = [C.c_void_p, _dp]
+        L.lfvio_host_set_imu.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp]
+        L.lfvio_host_repropagate.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.lfvio_host_vector2double.argtypes = [C.c_void_p]
+        L.lfvio_host_double2vector.argtypes = [C.c_void_p]
+        L.lfvio_host_get_para.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        L.lfvio_host_set_para.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, _dp, C.c_int]
+        L.lfvio_host_pack.argtypes = [C.c_void_p, C.POINTER(abi.WindowC)]
+        L.lfvio_host_set_flag.argtypes = [C.c_void_p, C.c_int]
+        L.lfvio_host_set_prior.argtypes = [C.c_void_p, C.POINTER(abi.Prior)]
+        L.lfvio_host_get_prior.argtypes = [C.c_void_p, C.POINTER(abi.Prior)]
+        L.lfvio_host_optimization.argtypes = [C.c_void_p]
+        L.lfvio_host_last_iterations.argtypes = [C.c_void_p]
+        L.lfvio_host_last_cost.argtypes = [C.c_void_p]
+        L.lfvio_host_last_cost.restype = C.c_double
+        self.L = L
+        self.h = L.lfvio_host_create()
+
+    def close(self):
+        if self.h:
+            self.L.lfvio_host_destroy(self.h)
+            self.h = None
+
+    def load_window(self, win):
+        """Feed the Estimator members the way processIMU()/processImage() would have (estimator.cpp:86-220)."""
+        p = _f([synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W, win.g[2], win.tr, win.row, -1.0, synth.TD0])
+        self.L.lfvio_host_set_params(_p(p), win.estimate_extrinsic, win.estimate_td, win.max_num_iterations)
+        Ps = _f(win.pose[:, :3])
+        Rs = _f([synth.pose_R(win.pose[f]) for f in range(11)])
+        Vs, Bas, Bgs = _f(win.speed_bias[:, 0:3]), _f(win.speed_bias[:, 3:6]), _f(win.speed_bias[:, 6:9])
+        tic, ric = _f(win.ex_pose[:3]), _f(synth.pose_R(win.ex_pose))
+        self.L.lfvio_host_set_state(self.h, _p(Ps), _p(Rs), _p(Vs), _p(Bas), _p(Bgs), _p(tic), _p(ric), win.td)
+        self.L.lfvio_host_clear_features(self.h)
+        for l in range(win.N):
+            o0, o1 = int(win.obs_offset[l]), int(win.obs_offset[l + 1])
+            obs = np.zeros((o1 - o0, 8))
+            obs[:, 0:3] = win.obs_point[o0:o1]
+            obs[:, 4] = win.obs_uv_y[o0:o1]
+            obs[:, 5:8] = win.obs_velocity[o0:o1]
+            ctd = _f(win.obs_cur_td[o0:o1])
+            self.L.lfvio_host_add_feature(self.h, l, int(win.start_frame[l]), o1 - o0, _p(_f(obs)), _p(ctd),
+                                          1.0 / float(win.inv_depth[l]))
+        for i, (ba, bg, a0, g0, dts, accs, gyrs) in enumerate(win.raw_imu):
+            self.L.lfvio_host_set_imu(self.h, i + 1, _p(_f(a0)), _p(_f(g0)), _p(_f(ba)), _p(_f(bg)), len(dts), _p(_f(dts)),
+                                      _p(_f(accs)), _p(_f(gyrs)))
+        self.L.lfvio_host_set_prior(self.h, C.byref(win.prior) if win.prior is not None else None)
+
+    def pack(self):
+        w = abi.WindowC()
+        self.L.lfvio_host_pack(self.h, C.byref(w))
+        return w
+
+    def state(self):
+        Ps, Rs, Vs, Bas, Bgs = np.zeros((11, 3)), np.zeros((11, 3, 3)), np.zeros((11, 3)), np.zeros((11, 3)), np.zeros((11, 3))
+        tic, ric, td = np.zeros(3), np.zeros((3, 3)), np.zeros(1)
+        self.L.lfvio_host_get_state(self.h, _p(Ps), _p(Rs), _p(Vs), _p(Bas), _p(Bgs), _p(tic), _p(ric), _p(td))
+        return dict(Ps=Ps, Rs=Rs, Vs=Vs, Bas=Bas, Bgs=Bgs, tic=tic, ric=ric, td=float(td[0]))
+
+    def para(self, n):
+        pose, sb, ex, td, feat = np.zeros((11, 7)), np.zeros((11, 9)), np.zeros(7), np.zeros(1), np.zeros(max(n, 1))
+        self.L.lfvio_host_get_para(self.h, _p(pose), _p(sb), _p(ex), _p(td), _p(feat))
+        return pose, sb, ex, float(td[0]), feat[:n]
+
+    def set_para(self, pose, sb, ex, td, feat):
+        feat = _f(feat)
+        self.L.lfvio_host_set_para(self.h, _p(_f(pose)), _p(_f(sb)), _p(_f(ex)), td, _p(feat), len(feat))
+
+    def depths(self, n):
+        d = np.zeros(max(n, 1))
+        self.L.lfvio_host_get_depths(self.h, _p(d))
+        return d[:n]
+
+    def optimization(self, flag):
+        self.L.lfvio_host_set_flag(self.h, flag)
+        return self.L.lfvio_host_optimization(self.h)
+
+    def prior(self):
+        p = abi.Prior()
+        self.L.lfvio_host_get_prior(self.h, C.byref(p))
+        return p

@@ -374,16 +374,23 @@ def make_window(seed, n_landmarks=300, kf0=0, scene=None, prior=None, init_state
         ex = np.array(init_state["ex_pose"], dtype=np.float64)
         td = float(init_state["td"])
     inv_depth = 1.0 / (lm["true_depth"] * rng.uniform(0.8, 1.25, size=N))
-    imu = []
+    imu, raw_imu = [], []
     for i in range(abi.WINDOW_SIZE):
         # linearisation biases: the bias estimate at the time the interval was integrated
         ba_lin = sb[i, 3:6] + rng.normal(0, 1e-3, 3)
         bg_lin = sb[i, 6:9] + rng.normal(0, 1e-4, 3)
         imu.append(scene.preintegration(kf0 + i, ba_lin, bg_lin))
-    return abi.Window(pose, sb, ex, td, lm["start"], lm["obs_offset"], inv_depth, lm["point"], lm["velocity"],
+        raw_imu.append((ba_lin, bg_lin) + scene.imu_samples(kf0 + i))
+    win = _window(pose, sb, ex, td, lm["start"], lm["obs_offset"], inv_depth, lm["point"], lm["velocity"],
                       lm["cur_td"], lm["uv_y"], imu, prior=prior, estimate_extrinsic=estimate_extrinsic,
                       estimate_td=estimate_td, max_num_iterations=max_num_iterations, max_solver_time=-1.0,
                       g=(0.0, 0.0, G_NORM), tr=tr, row=960.0, sqrt_info=160.0 / 1.5)
+    win.raw_imu = raw_imu  # (ba_lin, bg_lin, acc0, gyr0, dts, accs, gyrs) per interval: input of the host mirror
+    return win
+
+
+def _window(*a, **kw):
+    return abi.Window(*a, **kw)
 
 
 def continue_state(scene, kf0_next, sol_pose, sol_sb, sol_ex, sol_td, rng):

@@ -1,0 +1,112 @@
+"""Host-side mirror of the reference API (Estimator / FeatureManager / IntegrationBase).
+CPU tests check the host logic against the oracle; the GPU test drives Estimator::optimization()
+end to end through the C-ABI like estimator_node.cpp would."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from lfvio import abi, synth
+
+
+@pytest.fixture(scope="module")
+def host():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from lfvio.host import HostEstimator
+
+    h = HostEstimator()
+    yield h
+    h.close()
+
+
+def arr(ptr, n):
+    return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+
+def test_pack_matches_python_window(host, oracle):
+    """vector2double() + packWindow(): the POD handed to the C-ABI equals the test-side window, and the
+    host IntegrationBase::push_back reproduces the oracle's pre-integration bit for bit."""
+    w = synth.make_window(3, 120)
+    host.load_window(w)
+    c = host.pack()
+    assert (c.num_landmarks, c.num_observations) == (w.N, w.M)
+    assert np.array_equal(arr(c.start_frame, w.N), w.start_frame)
+    assert np.array_equal(arr(c.obs_offset, w.N + 1), w.obs_offset)
+    assert np.array_equal(arr(c.obs_point, 3 * w.M), w.obs_point.ravel())
+    assert np.array_equal(arr(c.obs_velocity, 3 * w.M), w.obs_velocity.ravel())
+    assert np.array_equal(arr(c.obs_cur_td, w.M), w.obs_cur_td)
+    assert np.array_equal(arr(c.obs_uv_y, w.M), w.obs_uv_y)
+    assert np.abs(arr(c.inv_depth, w.N) - w.inv_depth).max() < 1e-15  # 1/(1/x)
+    pose = np.array([[c.para_pose[f][k] for k in range(7)] for f in range(11)])
+    sb = np.array([[c.para_speed_bias[f][k] for k in range(9)] for f in range(11)])
+    # R -> quaternion -> R round trip of vector2double(); sign fixed by Eigen's branch (w >= 0 here)
+    assert np.abs(pose - w.pose).max() < 1e-14 and np.array_equal(sb, w.speed_bias)
+    assert (c.estimate_extrinsic, c.estimate_td, c.max_num_iterations) == (1, 1, 8)
+    assert c.sqrt_info == 160.0 / 1.5 and c.max_solver_time_in_seconds < 0
+    for i in range(10):
+        ba, bg, a0, g0, dts, accs, gyrs = w.raw_imu[i]
+        ref = oracle.preintegrate(a0, g0, ba, bg, dts, accs, gyrs, [synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W])
+        got = abi.preint_to_array(c.imu[i])
+        assert np.array_equal(got, abi.preint_to_array(ref)), i        # same formulas, same order: bit-identical
+        assert np.abs(got - abi.preint_to_array(w.imu[i])).max() <= 1e-12 * np.abs(got).max()  # numpy statement
+
+
+def test_feature_manager_depth_vector(host):
+    w = synth.make_window(4, 50)
+    host.load_window(w)
+    assert host.L.lfvio_host_feature_count(host.h) == w.N
+    host.L.lfvio_host_vector2double(host.h)
+    pose, sb, ex, td, feat = host.para(w.N)
+    assert np.abs(feat - w.inv_depth).max() < 1e-15          # getDepthVector: 1 / estimated_depth
+    host.set_para(pose, sb, ex, td, feat * 2.0)
+    host.L.lfvio_host_double2vector(host.h)                  # setDepth: estimated_depth = 1 / x
+    assert np.abs(host.depths(w.N) - 1.0 / (2.0 * feat)).max() < 1e-15
+
+
+def test_double2vector_matches_oracle_gauge_fix(host, oracle):
+    """double2vector() (yaw re-anchoring) + vector2double() on the host == oracle gauge_fix."""
+    w = synth.make_window(6, 40)
+    sol = oracle.solve(w)
+    host.load_window(w)
+    host.L.lfvio_host_vector2double(host.h)
+    host.set_para(sol.pose, sol.speed_bias, sol.ex_pose, sol.td, sol.lam)
+    host.L.lfvio_host_double2vector(host.h)
+    host.L.lfvio_host_vector2double(host.h)
+    pose, sb, ex, td, feat = host.para(w.N)
+    oracle.gauge_fix(w, sol)
+    assert np.abs(pose - sol.pose).max() < 1e-12
+    assert np.abs(sb - sol.speed_bias).max() < 1e-13
+    assert np.abs(ex - sol.ex_pose).max() < 1e-14
+    assert np.abs(feat - sol.lam).max() <= 1e-15 * np.abs(sol.lam).max()
+    st = host.state()
+    assert np.abs(st["Ps"][0] - w.pose[0, :3]).max() < 1e-12   # frame 0 keeps its position
+
+
+def test_repropagate_is_idempotent(host):
+    w = synth.make_window(8, 10)
+    host.load_window(w)
+    c0 = abi.preint_to_array(host.pack().imu[2])
+    ba, bg = w.raw_imu[2][0], w.raw_imu[2][1]
+    host.L.lfvio_host_repropagate(host.h, 3, ba.ctypes.data_as(C.POINTER(C.c_double)), bg.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.array_equal(abi.preint_to_array(host.pack().imu[2]), c0)
+
+
+@pytest.mark.gpu
+def test_host_optimization_end_to_end(host, oracle):
+    """Estimator::optimization() of the mirror (host C++ -> C-ABI -> HIP) against the oracle, two frames in a row."""
+    win, warm = synth.make_window_with_prior(2, 200, lambda w, f: oracle.optimize(w, f))
+    for w in (warm, win):
+        host.load_window(w)
+        assert host.optimization(abi.MARGIN_OLD) == 0
+        ref_sol, ref_prior = oracle.optimize(w, abi.MARGIN_OLD)
+        host.L.lfvio_host_vector2double(host.h)
+        pose, sb, ex, td, feat = host.para(w.N)
+        assert np.abs(pose - ref_sol.pose).max() < 1e-6 * max(1.0, np.abs(ref_sol.pose).max())
+        assert np.abs(sb - ref_sol.speed_bias).max() < 1e-6
+        assert np.abs(feat - ref_sol.lam).max() < 1e-6 * np.abs(ref_sol.lam).max()
+        p = host.prior()
+        assert p.block_list() == ref_prior.block_list()
+        J, Jr = p.J(), ref_prior.J()
+        assert np.abs(J.T @ J - Jr.T @ Jr).max() < 1e-5 * np.abs(Jr.T @ Jr).max()
