@@ -207,23 +207,27 @@ int lfvio_batch_download(lfvio_ctx *ctx, int slot, LfvioSolution *sol, LfvioPrio
 void *lfvio_stream(lfvio_ctx *ctx);
 
 /* ---- landmark-sharded API (multi-GPU) ------------------------
- * Every rank uploads the same window but linearizes only landmarks
- * [lm_begin, lm_end).  Between the phases the caller sum-all-reduces the
- * exchange buffer (device pointer, `lfvio_shard_exchange_len()` doubles) over
- * RCCL.  Pose-side factors (IMU, prior) are added on the rank with
- * add_pose_side != 0 only. */
+ * Every rank passes the same window but linearizes only landmarks [lm_begin, lm_end) (caller order);
+ * IMU factors and the prior are added on the rank(s) with add_pose_side != 0 — exactly one rank.
+ * The library exposes a device exchange buffer of lfvio_shard_exchange_len() doubles,
+ *   [ H_pp packed | g_p | Schur sums | 16 scalars ],  scalars at lfvio_shard_scalar_offset();
+ * the CALLER sum-all-reduces it in place (RCCL) where a phase function returns 1:
+ *   while (state != 2) {
+ *     if (lfvio_shard_linearize(ctx) == 1) all_reduce(buf[0 : len]);            // 151 KB
+ *     if (lfvio_shard_solve(ctx)     == 1) all_reduce(buf[scalar_offset : len]); // 128 B
+ *     if (lfvio_shard_candidate(ctx) == 1) all_reduce(buf[scalar_offset : len]); // 128 B
+ *     lfvio_shard_decide(ctx, &state);   // identical decision on every rank, no broadcast
+ *   }
+ *   lfvio_shard_finish(ctx, &sol);       // pose-side state replicated; inv_depth: own range only
+ */
 int lfvio_shard_begin(lfvio_ctx *ctx, const LfvioWindow *in, int lm_begin, int lm_end, int add_pose_side);
 int lfvio_shard_exchange_len(void);
+int lfvio_shard_scalar_offset(void);
 double *lfvio_shard_exchange_ptr(lfvio_ctx *ctx);
-/* phase A: linearize local landmarks at the current point -> partial [S|g|cost|sums] */
 int lfvio_shard_linearize(lfvio_ctx *ctx);
-/* phase B (after all-reduce): solve reduced system, back-substitute local
- * landmarks, write partial step norms into the exchange buffer */
 int lfvio_shard_solve(lfvio_ctx *ctx);
-/* phase C (after all-reduce): dogleg step, candidate, partial candidate cost */
 int lfvio_shard_candidate(lfvio_ctx *ctx);
-/* phase D (after all-reduce): accept/reject, radius update.  *state: 0 = need
- * linearize, 1 = retry candidate (step rejected, reuse), 2 = terminated */
+/* *state: 0 = linearize next, 1 = step rejected (only a new candidate), 2 = terminated */
 int lfvio_shard_decide(lfvio_ctx *ctx, int *state);
 int lfvio_shard_finish(lfvio_ctx *ctx, LfvioSolution *out);
 

@@ -27,7 +27,15 @@ constexpr int NPAIR = 121; // pair slot = i * 11 + j
 constexpr int NT = 15;     // upper tiles of the 5x5 tiling of the 80x80 Schur accumulator
 constexpr int SCHUR_LEN = NT * 256;
 constexpr int PACKED = KP * (KP + 1) / 2;
-constexpr int HPP_CAP = 16384;   // packed H_pp (14878), reused as dense scratch by the marginalization
+constexpr int HPP_CAP = 16384;
+// exchange buffer of the landmark-sharded mode (one contiguous sum-all-reduce):
+//   [ H_pp packed | g_p | Schur sums (80x80 upper tiles) | 16 scalars ]
+constexpr int XOFF_H = 0;
+constexpr int XOFF_G = 14880;                 // PACKED rounded up to even
+constexpr int XOFF_S = XOFF_G + 176;          // KP rounded up
+constexpr int XOFF_C = XOFF_S + 15 * 256;
+constexpr int XCH_LEN = XOFF_C + 16;
+enum { XS_COST = 0, XS_G2, XS_ASV2, XS_LAM2, XS_BMAX, XS_GN2, XS_GGN, XS_CCOST, XS_MLIN, XS_MQUAD, XS_DN, XS_XN };   // packed H_pp (14878), reused as dense scratch by the marginalization
 constexpr int LM_BLOCK = 64;     // landmarks per workgroup (one wave) in the landmark sweep
 constexpr int CHUNK_LANES = 64;
 constexpr int CHUNK_MAX = 512;   // observations per Gram chunk (8 per lane)
@@ -79,7 +87,7 @@ struct TRState {
   double gn_sq_total, grad_sq_total, grad_gn_total;
   double step_sq_pose;  // ||x - candidate||^2, pose side (ambient)
   double xn2_pose_cand; // ||candidate||^2, pose side (ambient)
-  double gmax_pose;
+  double gmax_pose, lm_bmax;
   double initial_cost;
   double q[Q_COUNT];
   int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled;
@@ -105,7 +113,8 @@ struct Slot {
   // ---------------- header: sizes, flags, constants
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
   int max_iter, prior_valid, prior_n, prior_nb;
-  int schur_lm, pad1;
+  int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
+  int pose_side, pad2;           // sharded: this rank adds the IMU + prior factors
   double g[3], tr_over_row, half_row, sqrt_info;
   FrameState x0;
   LfvioPreintegration imu[LFVIO_WINDOW_SIZE];
@@ -132,16 +141,17 @@ struct Slot {
   double *prior_A;               // n*n  (J0^T J0)
   double prior_b0[KP];           // J0^T r0
   double *a, *b, *W, *scale_l, *grad_l, *gn_l, *diag_l, *einv_l, *d1, *d2;
-  double *gram_part, *pairG, *schur_part, *schur_sum;
+  double *gram_part, *pairG, *schur_part, *schur_sum;   // schur_sum = xch + XOFF_S
+  double *xch, *gp;              // exchange buffer; gp = xch + XOFF_G, Hpp = xch + XOFF_H
   double *lm_part;               // nLmBlocks * LMS
   double lm_sum[LMS];
   double *cost_part;             // nLmBlocks * LMS (candidate sweep)
   double *imu_out;               // 10 * IMU_OUT
   double prior_g[KP + 4];        // prior gradient (tangent cols) + cost
   double pose_cost[16];          // candidate costs of imu[0..9], prior [10]
-  double *Hpp;                   // packed lower KP (assembled by k_sum)
+  double *Hpp;                   // packed lower KP (assembled by k_sum) = xch + XOFF_H
   double *mscr;                  // dense scratch of the marginalization (HPP_CAP)
-  double gp[KP], scale_p[KP], diag_p[KP], grad_p[KP], gn_p[KP], step_p[KP];
+  double scale_p[KP], diag_p[KP], grad_p[KP], gn_p[KP], step_p[KP];
   double uc_grad[WLD], uc_gn[WLD], uc_y[WLD];
   double z1[WLD], z2[WLD];
   long long dbg[32];             // shader-clock stamps (bring-up instrumentation)

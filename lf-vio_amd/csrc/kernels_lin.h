@@ -355,7 +355,8 @@ DEV void lin_imu_role(Slot *S, int f, int mode, double *lds) {
   double *rr = lds + 450 + 465, *rw = rr + 16;
   const int lane = threadIdx.x;
   double *out = S->imu_out + (size_t)f * IMU_OUT;
-  const bool active = S->imu_active[f] && (mode == MODE_SOLVE || (f == 0 && marg_plan(S, mode)->use_imu0));
+  const bool active = S->imu_active[f] && (mode == MODE_SOLVE || (f == 0 && marg_plan(S, mode)->use_imu0)) &&
+                      (!S->sharded || S->pose_side);
   if (!active) {
     for (int e = lane; e < IMU_OUT; e += 64) out[e] = 0.0;
     return;
@@ -406,7 +407,7 @@ DEV void lin_prior_role(Slot *S, int mode, double *lds) {
   const int lane = threadIdx.x;
   double *g = S->prior_g;
   for (int c = lane; c < KP + 4; c += 64) g[c] = 0.0;
-  if (!S->prior_valid) return;
+  if (!S->prior_valid || (S->sharded && !S->pose_side)) return;
   const int n = S->prior_n;
   const FrameState *x = &S->x[S->tr.cur];
   if (lane < S->prior_nb) prior_block_dx(S, x, lane, dx);
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
           }
         }
         // ---- prior: A' = J0^T J0
-        if (S->prior_valid) {
+        if (S->prior_valid && (!S->sharded || S->pose_side)) {
           const int pr = S->prior_inv[r], pc = S->prior_inv[c];
           if (pr >= 0 && pc >= 0) val += S->prior_A[pr * S->prior_n + pc];
         }
@@ -698,5 +699,23 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
     double m = 0;
     for (int k = 0; k < blocks; k++) m = fmax(m, S->lm_part[(size_t)k * LMS + 4]);
     S->lm_sum[4] = m;
+  }
+  if (S->sharded) {
+    // exchange scalars of phase A: local cost (pose-side factors on the owning rank only), gradient
+    // norms, Cauchy landmark term, ||lambda||^2; the max is sent as a sum (upper bound, only feeds the
+    // 1e-10 gradient tolerance)
+    __syncthreads();
+    double *sc = S->xch + XOFF_C;
+    if (tid < 16) sc[tid] = 0.0;
+    __syncthreads();
+    if (tid == 0) {
+      double cost = S->lm_sum[0];
+      if (S->pose_side) {
+        cost += S->prior_g[KP];
+        for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += S->imu_out[(size_t)f * IMU_OUT + 930];
+      }
+      sc[XS_COST] = cost;
+      sc[XS_G2] = S->lm_sum[1], sc[XS_ASV2] = S->lm_sum[2], sc[XS_LAM2] = S->lm_sum[3], sc[XS_BMAX] = S->lm_sum[4];
+    }
   }
 }

@@ -96,9 +96,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     }
     if (tid < KP) g[tid] = S->gp[tid];
   }
+  // landmark-side scalars: local sums, or the all-reduced totals of the sharded mode
+  const double *ls = S->sharded ? S->xch + XOFF_C : S->lm_sum;
   if (tr->do_lin && tid == 0) {
-    double cost = S->lm_sum[0] + S->prior_g[KP];
-    for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += S->imu_out[(size_t)f * IMU_OUT + 930];
+    double cost = ls[0];
+    if (!S->sharded) {
+      cost += S->prior_g[KP];
+      for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += S->imu_out[(size_t)f * IMU_OUT + 930];
+    }
     tr->x_cost = cost;
   }
   __syncthreads();
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     const double gsq = block_sum(gs, scratch, tid);
     const double cr = block_sum(cross, scratch, tid);
     if (tid == 0) {
-      const double Jg2 = q_gg + 2.0 * cr + S->lm_sum[2];
-      const double gtot = gsq + S->lm_sum[1];
+      const double Jg2 = q_gg + 2.0 * cr + ls[2];
+      const double gtot = gsq + ls[1];
       tr->alpha = gtot / Jg2;
       tr->grad_sq_total = gtot;
       tr->q[Q_GG] = q_gg;
@@ -415,11 +420,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       tr->q[Q_NN] = qnn;
       tr->chol_fail = 0;
       // gradient_max_norm of the pose side is filled in by k_dogleg (off the critical path)
+      if (S->sharded) tr->lm_bmax = ls[XS_BMAX];
       if (tr->iteration == 0) {
         // IterationZero + first FinalizeIterationAndCheckIfMinimizerCanContinue
         {
           const FrameState *x0 = &S->x[tr->cur];
-          double xn = S->lm_sum[3];
+          double xn = ls[3];
           for (int f = 0; f < LFVIO_NUM_FRAMES; f++) {
             for (int k = 0; k < 7; k++) xn += x0->pose[f][k] * x0->pose[f][k];
             for (int k = 0; k < 9; k++) xn += x0->sb[f][k] * x0->sb[f][k];
@@ -528,8 +534,10 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
     if ((tid & 63) == 0) sh[(tid >> 6) * 2] = a, sh[(tid >> 6) * 2 + 1] = b;
     __syncthreads();
     if (tid == 0) {
-      tr->gn_sq_total = tr->q[Q_GN_SQ] + sh[0] + sh[2];
-      tr->grad_gn_total = tr->q[Q_GRAD_GN] + sh[1] + sh[3];
+      double lgn = sh[0] + sh[2], lgg = sh[1] + sh[3];
+      if (S->sharded) lgn = S->xch[XOFF_C + XS_GN2], lgg = S->xch[XOFF_C + XS_GGN];  // all-reduced (k_xpack 2)
+      tr->gn_sq_total = tr->q[Q_GN_SQ] + lgn;
+      tr->grad_gn_total = tr->q[Q_GRAD_GN] + lgg;
     }
     __syncthreads();
   }
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
     if ((tid & 63) == 0) sh[tid >> 6] = mx;
     __syncthreads();
     if (tid == 0) {
-      const double gm = fmax(fmax(sh[0], sh[1]), S->lm_sum[4]);
+      const double gm = fmax(fmax(sh[0], sh[1]), S->sharded ? tr->lm_bmax : S->lm_sum[4]);
       tr->gmax_pose = gm;
       if (tr->trace_len > 0) {
         LfvioIterationSummary *last = &tr->trace[tr->trace_len - 1];
@@ -730,6 +738,41 @@ __global__ __launch_bounds__(64) void k_cost(char *base, size_t stride, int gLm)
 }
 
 // ---------------------------------------------------------------------------
+// k_xpack: grid (1, batch) x 64 — sharded mode only: local scalar partials of phase B (which = 2: after
+// k_backsub) or phase C (which = 3: after k_cost) into the exchange scalars, everything else zeroed so that
+// the caller can sum-all-reduce the 16-scalar tail blindly.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_xpack(char *base, size_t stride, int which) {
+  Slot *S = SLOT(base, stride);
+  const TRState *tr = &S->tr;
+  if (!S->sharded) return;
+  const int lane = threadIdx.x;
+  double *sc = S->xch + XOFF_C;
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+  if (!tr->done && !tr->chol_fail) {
+    for (int k = lane; k < S->nLmBlocks; k += 64) {
+      if (which == 2) {
+        v0 += S->lm_part[(size_t)k * LMS + 8], v1 += S->lm_part[(size_t)k * LMS + 9];
+      } else {
+        const double *p = S->cost_part + (size_t)k * LMS;
+        v0 += p[0], v1 += p[1], v2 += p[2], v3 += p[3], v4 += p[4];
+      }
+    }
+    if (which == 3 && S->pose_side && lane < 11) v0 += S->pose_cost[lane];
+  }
+  v0 = wave_sum(v0), v1 = wave_sum(v1), v2 = wave_sum(v2), v3 = wave_sum(v3), v4 = wave_sum(v4);
+  if (lane < 16) sc[lane] = 0.0;
+  __syncthreads();
+  if (lane == 0) {
+    if (which == 2) {
+      sc[XS_GN2] = v0, sc[XS_GGN] = v1;
+    } else {
+      sc[XS_CCOST] = v0, sc[XS_MLIN] = v1, sc[XS_MQUAD] = v2, sc[XS_DN] = v3, sc[XS_XN] = v4;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_decide: grid (1, batch) x 64 — TrustRegionMinimizer bookkeeping for one iteration.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
@@ -741,7 +784,7 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
     // retry the Gauss-Newton solve with the larger mu; LINEAR_SOLVER_FAILURE once mu >= max_mu
     if (lane == 0) {
       if (tr->mu < 1.0) {
-        tr->do_lin = 0;
+        tr->do_lin = S->sharded ? 1 : 0;
         tr->do_schur = 1;
         tr->chol_fail = 0;
         tr->skip_step = 1;
@@ -757,6 +800,10 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
     }
     if (lane < 11) cost += S->pose_cost[lane];
     cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn);
+    if (S->sharded) {  // all-reduced by the caller after k_xpack 3
+      const double *sc = S->xch + XOFF_C;
+      cost = sc[XS_CCOST], mlin = sc[XS_MLIN], mquad = sc[XS_MQUAD], dn = sc[XS_DN], xn = sc[XS_XN];
+    }
   }
   if (lane != 0) return;
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
@@ -787,7 +834,7 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
     } else {
       tr->mu *= 10.0;  // StepIsInvalid
       tr->chol_fail = 0;
-      tr->do_lin = 0;
+      tr->do_lin = S->sharded ? 1 : 0;  // sharded: the exchange buffers were reduced in place, rebuild them
       tr->do_schur = 1;
     }
   } else {

@@ -37,7 +37,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, prior_J,
       prior_r;
   size_t lam[2], prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
-      schur_sum, lm_part, cost_part, imu_out, Hpp, mscr;
+      xch, lm_part, cost_part, imu_out, mscr;
 };
 
 Layout make_layout(int maxN, int maxM) {
@@ -72,11 +72,10 @@ Layout make_layout(int maxN, int maxM) {
   L.gram_part = take((size_t)L.capChunks * NGP * 8);
   L.pairG = take((size_t)NPAIR * NGP * 8);
   L.schur_part = take((size_t)L.capSchurParts * SCHUR_LEN * 8);
-  L.schur_sum = take((size_t)SCHUR_LEN * 8);
+  L.xch = take((size_t)XCH_LEN * 8);
   L.lm_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.cost_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.imu_out = take((size_t)LFVIO_WINDOW_SIZE * IMU_OUT * 8);
-  L.Hpp = take((size_t)HPP_CAP * 8);
   L.mscr = take((size_t)HPP_CAP * 8);
   L.total = align_up(o, 4096);
   return L;
@@ -107,6 +106,10 @@ struct lfvio_ctx {
   hipGraphExec_t graph = nullptr;
   int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0;
   bool use_graph = true;
+  // landmark-sharded mode (multi-GPU)
+  bool shard_active = false;
+  int shard_begin = 0, shard_end = 0, shard_state = 0;
+  std::vector<int> sh_start, sh_off;
 };
 
 namespace {
@@ -225,7 +228,7 @@ void plan_marg(const LfvioWindow *w, int flag, int N0, int kmax0, int nChunks0, 
 }
 
 // Pack one window into the pinned staging blob and upload it to slot `slot`.
-int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w) {
+int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0, int pose_side = 1) {
   if (!w || w->num_landmarks < 0 || w->num_observations < 0) {
     c->err = "null window / negative sizes";
     return LFVIO_ERR_ARG;
@@ -260,6 +263,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w) {
   S->N = N, S->M = M, S->NV = M - N;
   S->est_ex = w->estimate_extrinsic != 0, S->est_td = w->estimate_td != 0;
   S->max_iter = w->max_num_iterations;
+  S->sharded = sharded, S->pose_side = pose_side;
   for (int k = 0; k < 3; k++) S->g[k] = w->g[k];
   S->tr_over_row = w->tr / w->row;
   S->half_row = w->row / 2;
@@ -383,16 +387,17 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w) {
     W.scale_l = (double *)(d + L.scale_l), W.grad_l = (double *)(d + L.grad_l), W.gn_l = (double *)(d + L.gn_l);
     W.diag_l = (double *)(d + L.diag_l), W.einv_l = (double *)(d + L.einv_l), W.d1 = (double *)(d + L.d1), W.d2 = (double *)(d + L.d2);
     W.gram_part = (double *)(d + L.gram_part), W.pairG = (double *)(d + L.pairG);
-    W.schur_part = (double *)(d + L.schur_part), W.schur_sum = (double *)(d + L.schur_sum);
+    W.schur_part = (double *)(d + L.schur_part);
+    W.xch = (double *)(d + L.xch);
+    W.schur_sum = W.xch + XOFF_S, W.gp = W.xch + XOFF_G, W.Hpp = W.xch + XOFF_H;
     W.lm_part = (double *)(d + L.lm_part), W.cost_part = (double *)(d + L.cost_part), W.imu_out = (double *)(d + L.imu_out);
-    W.Hpp = (double *)(d + L.Hpp);
     W.mscr = (double *)(d + L.mscr);
     // field-by-field so that only pointer members are touched
 #define PUTP(field) HIPCHK(c, hipMemcpyAsync(d + offsetof(Slot, field), &W.field, sizeof W.field, hipMemcpyHostToDevice, c->stream))
     PUTP(lam);
     PUTP(prior_A);
     PUTP(a); PUTP(b); PUTP(W); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
-    PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out);
+    PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(xch); PUTP(gp); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out);
     PUTP(Hpp);
     PUTP(mscr);
 #undef PUTP
@@ -679,8 +684,8 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   char *d = c->d_base;
   const int N = in->num_landmarks;
   std::vector<double> packed(PACKED), av(N), bv(N), Wv((size_t)N * WLD);
-  HIPCHK(c, hipMemcpy(packed.data(), d + L.Hpp, sizeof(double) * PACKED, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(gp, d + offsetof(Slot, gp), sizeof(double) * KP, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(packed.data(), d + L.xch + sizeof(double) * XOFF_H, sizeof(double) * PACKED, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(gp, d + L.xch + sizeof(double) * XOFF_G, sizeof(double) * KP, hipMemcpyDeviceToHost));
   if (N) {
     HIPCHK(c, hipMemcpy(av.data(), d + L.a, sizeof(double) * N, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(bv.data(), d + L.b, sizeof(double) * N, hipMemcpyDeviceToHost));

@@ -278,7 +278,7 @@ HIP_SYMBOLS = [
     "lfvio_create", "lfvio_destroy", "lfvio_last_error", "lfvio_version", "lfvio_solve", "lfvio_marginalize",
     "lfvio_batch_reserve", "lfvio_batch_upload", "lfvio_batch_optimize", "lfvio_batch_optimize_async",
     "lfvio_batch_sync", "lfvio_batch_download", "lfvio_stream",
-    "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
+    "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_scalar_offset", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
     "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_finish",
 ]
 
@@ -309,6 +309,7 @@ def load_hip_library(path=None):
     lib.lfvio_stream.argtypes = [C.c_void_p]
     lib.lfvio_shard_begin.argtypes = [C.c_void_p, C.POINTER(WindowC), C.c_int, C.c_int, C.c_int]
     lib.lfvio_shard_exchange_len.restype = C.c_int
+    lib.lfvio_shard_scalar_offset.restype = C.c_int
     lib.lfvio_shard_exchange_ptr.restype = C.c_void_p
     lib.lfvio_shard_exchange_ptr.argtypes = [C.c_void_p]
     for name in ("lfvio_shard_linearize", "lfvio_shard_solve", "lfvio_shard_candidate"):

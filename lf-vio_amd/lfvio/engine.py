@@ -101,5 +101,31 @@ class Engine:
         self._check(self.lib.lfvio_debug_time_kernel(self.ctx, which, count, reps, _p(ms)), "time_kernel")
         return float(ms[0])
 
+    # ---- landmark-sharded API (multi-GPU)
+    def shard_begin(self, win, lm_begin, lm_end, add_pose_side):
+        self._shard_win = win  # keep the arrays alive
+        self._check(self.lib.lfvio_shard_begin(self.ctx, C.byref(win.c()), lm_begin, lm_end, int(add_pose_side)), "shard_begin")
+
+    def shard_exchange(self):
+        """(device pointer, total length, scalar offset) of the exchange buffer, in doubles."""
+        return (self.lib.lfvio_shard_exchange_ptr(self.ctx), self.lib.lfvio_shard_exchange_len(),
+                self.lib.lfvio_shard_scalar_offset())
+
+    def shard_phase(self, name):
+        rc = getattr(self.lib, "lfvio_shard_" + name)(self.ctx)
+        if rc < 0:
+            self._check(rc, "shard_" + name)
+        return rc
+
+    def shard_decide(self):
+        st = C.c_int(0)
+        self._check(self.lib.lfvio_shard_decide(self.ctx, C.byref(st)), "shard_decide")
+        return st.value
+
+    def shard_finish(self, n_landmarks_total):
+        sol = abi.Solution(n_landmarks_total)
+        self._check(self.lib.lfvio_shard_finish(self.ctx, C.byref(sol.c)), "shard_finish")
+        return sol
+
     def stream(self):
         return self.lib.lfvio_stream(self.ctx)
