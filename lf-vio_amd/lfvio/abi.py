@@ -289,6 +289,15 @@ def load_hip_library(path=None):
     if not os.path.exists(path):
         raise RuntimeError(f"{path} not found: build it with __graft_entry__.build() (hipcc, gfx950); "
                            "there is no CPU fallback for the product path")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; the dynamic linker de-duplicates by soname, so
+    # whichever HIP runtime is loaded FIRST serves both.  torch cannot run on a foreign runtime ("No HIP GPUs
+    # are available"), while this library is happy on torch's — so when torch is part of the process (bench,
+    # sharded tests: device pointers are shared with torch.distributed/RCCL) it must be loaded first.
+    try:
+        import torch  # noqa: F401
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.lfvio_create.restype = C.c_void_p
     lib.lfvio_create.argtypes = [C.c_int]
