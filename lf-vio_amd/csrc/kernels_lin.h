@@ -591,6 +591,22 @@ DEV double gram_pair_sum(const Slot *S, int i, int j, int idx, int chunk_limit) 
   return s;
 }
 
+// the ex/td entries receive a term from EVERY chunk: chunks are contiguous in pair order, so this is a plain
+// strided sweep with independent loads (4 accumulators, fixed association => still deterministic)
+DEV double gram_all_pairs(const Slot *S, int idx, int chunk_limit) {
+  const double *gp = S->gram_part + idx;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int c = 0;
+  for (; c + 4 <= chunk_limit; c += 4) {
+    s0 += gp[(size_t)c * NGP];
+    s1 += gp[(size_t)(c + 1) * NGP];
+    s2 += gp[(size_t)(c + 2) * NGP];
+    s3 += gp[(size_t)(c + 3) * NGP];
+  }
+  for (; c < chunk_limit; c++) s0 += gp[(size_t)c * NGP];
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
@@ -628,8 +644,7 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
               for (int i = 0; i < fc; i++) val += gram_pair_sum(S, i, fc, gidx20(6 + lc, hi), chunk_limit);
             } else {
               const int lo = fc == 11 ? 12 + lc : 18;
-              for (int i = 0; i < 10; i++)
-                for (int j = i + 1; j < 11; j++) val += gram_pair_sum(S, i, j, gidx20(lo, hi), chunk_limit);
+              val += gram_all_pairs(S, gidx20(lo, hi), chunk_limit);
             }
           }
         }
@@ -660,8 +675,7 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
             for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lr, 19), chunk_limit);
           } else {
             const int lo = fr == 11 ? 12 + lr : 18;
-            for (int i = 0; i < 10; i++)
-              for (int j = i + 1; j < 11; j++) val += gram_pair_sum(S, i, j, gidx20(lo, 19), chunk_limit);
+            val += gram_all_pairs(S, gidx20(lo, 19), chunk_limit);
           }
         }
         const int f0 = col_frame(r);

@@ -11,7 +11,7 @@
 constexpr int SOLVE_THREADS = 256;
 constexpr int NROW = KP + 1;                       // + rhs row (forward substitution fused)
 constexpr int LPACK = NROW * (NROW + 1) / 2;       // 15051
-constexpr size_t SOLVE_LDS = (size_t)(LPACK + 2 * 176 + 8 * KP + 64) * sizeof(double);
+constexpr size_t SOLVE_LDS = (size_t)(LPACK + 2 * 176 + 8 * KP + 256 + 64 + 11 * 256) * sizeof(double);
 
 #define STAMP(S, k) do { if (threadIdx.x == 0) (S)->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   double *yv = Gd + KP;              // y, then N direction
   double *hv = yv + KP;              // gauss_newton_step_
   double *invd = hv + KP;            // 1 / L_ii
-  double *scratch = invd + KP;       // 64
+  double *scratch = invd + KP;       // 256 (+64 pad), then 11 x 256 inverted diagonal blocks
   const bool est_ex = S->est_ex != 0, est_td = S->est_td != 0;
   auto active = [&](int c) { return (est_ex || c < off_ex() || c >= off_ex() + 6) && (est_td || c != off_td()); };
   STAMP(S, 0);
@@ -273,67 +273,65 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     }
   __syncthreads();
   STAMP(S, 5);
-  // ---- back-substitution L^T y = z by wave 0: scalar (readlane) broadcast of the owner's partial
-  //      sum, rows fetched four steps ahead so the LDS latency stays off the dependent chain.
-  if (tid < 64) {
-    const int lane = tid;
-    double s0 = 0, s1 = 0, s2 = 0, y0 = 0, y1 = 0, y2 = 0;
-    const int zbase = KP * (KP + 1) / 2;
-#define BS_FETCH(I, A0, A1, A2, Z, DV)                                   \
-  do {                                                                   \
-    const int ii_ = (I) >= 0 ? (I) : 0;                                  \
-    const int rb_ = ii_ * (ii_ + 1) / 2;                                 \
-    A0 = ((I) >= 0 && lane < ii_) ? Hs[rb_ + lane] : 0.0;                \
-    A1 = ((I) >= 0 && lane + 64 < ii_) ? Hs[rb_ + lane + 64] : 0.0;     \
-    A2 = ((I) >= 0 && lane + 128 < ii_) ? Hs[rb_ + lane + 128] : 0.0;    \
-    Z = Hs[zbase + ii_];                                                 \
-    DV = invd[ii_];                                                      \
-  } while (0)
-#define BS_STEP(I, A0, A1, A2, Z, DV)                                                   \
-  do {                                                                                  \
-    const int i_ = (I);                                                                 \
-    if (i_ >= 0) {                                                                      \
-      const int owner_ = i_ & 63, slot_ = i_ >> 6;                                      \
-      const double ssel_ = slot_ == 0 ? s0 : (slot_ == 1 ? s1 : s2);                    \
-      const int lo_ = __builtin_amdgcn_readlane(__double2loint(ssel_), owner_);         \
-      const int hi_ = __builtin_amdgcn_readlane(__double2hiint(ssel_), owner_);         \
-      const double yi_ = (Z - __hiloint2double(hi_, lo_)) * DV;                         \
-      if (lane == owner_) {                                                             \
-        if (slot_ == 0) y0 = yi_;                                                       \
-        else if (slot_ == 1) y1 = yi_;                                                  \
-        else y2 = yi_;                                                                  \
-      }                                                                                 \
-      s0 = fma(A0, yi_, s0);                                                            \
-      s1 = fma(A1, yi_, s1);                                                            \
-      s2 = fma(A2, yi_, s2);                                                            \
-    }                                                                                   \
-  } while (0)
-    double a00, a01, a02, az0, ad0, a10, a11, a12, az1, ad1, a20, a21, a22, az2, ad2, a30, a31, a32, az3, ad3;
-    BS_FETCH(KP - 1, a00, a01, a02, az0, ad0);
-    BS_FETCH(KP - 2, a10, a11, a12, az1, ad1);
-    BS_FETCH(KP - 3, a20, a21, a22, az2, ad2);
-    BS_FETCH(KP - 4, a30, a31, a32, az3, ad3);
-#pragma nounroll
-    for (int ib = KP - 1; ib >= 0; ib -= 4) {
-      double b00, b01, b02, bz0, bd0, b10, b11, b12, bz1, bd1, b20, b21, b22, bz2, bd2, b30, b31, b32, bz3, bd3;
-      BS_FETCH(ib - 4, b00, b01, b02, bz0, bd0);
-      BS_FETCH(ib - 5, b10, b11, b12, bz1, bd1);
-      BS_FETCH(ib - 6, b20, b21, b22, bz2, bd2);
-      BS_FETCH(ib - 7, b30, b31, b32, bz3, bd3);
-      BS_STEP(ib, a00, a01, a02, az0, ad0);
-      BS_STEP(ib - 1, a10, a11, a12, az1, ad1);
-      BS_STEP(ib - 2, a20, a21, a22, az2, ad2);
-      BS_STEP(ib - 3, a30, a31, a32, az3, ad3);
-      a00 = b00, a01 = b01, a02 = b02, az0 = bz0, ad0 = bd0;
-      a10 = b10, a11 = b11, a12 = b12, az1 = bz1, ad1 = bd1;
-      a20 = b20, a21 = b21, a22 = b22, az2 = bz2, ad2 = bd2;
-      a30 = b30, a31 = b31, a32 = b32, az3 = bz3, ad3 = bd3;
+  // ---- blocked back-substitution  L^T y = z  (11 diagonal blocks of 16):
+  //   1. every diagonal block L_kk is inverted up front, all blocks in parallel (one thread per column);
+  //   2. going from the last block to the first, y_k = L_kk^-T (z_k - sum_{m>k} L_mk^T y_m): the sum is a
+  //      dense 16 x (rows below) product done by all threads, the solve is a 16x16 mat-vec — 11 short
+  //      steps instead of 172 dependent ones.
+  double *Binv = scratch + 320;  // 11 x 256, after the (256 + 64) scratch area
+  {
+    const int blk = tid >> 4, c = tid & 15;  // thread -> (diagonal block, column)
+    if (blk < 11) {
+      const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) x[r] = 0.0;
+      // column c of X = L_kk^-1 by forward substitution: X[r][c] = (delta_rc - sum_{t<r} L[r][t] X[t][c]) / L[r][r]
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        if (r < nb && c < nb && r >= c) {
+          double s = (r == c) ? 1.0 : 0.0;
+          const int rb = (o + r) * (o + r + 1) / 2 + o;
+#pragma unroll
+          for (int t = 0; t < 16; t++)
+            if (t < r && t >= c) s = fma(-Hs[rb + t], x[t], s);
+          x[r] = s * invd[o + r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) Binv[blk * 256 + r * 16 + c] = x[r];
     }
-#undef BS_FETCH
-#undef BS_STEP
-    yv[lane] = y0;
-    yv[lane + 64] = y1;
-    if (lane + 128 < KP) yv[lane + 128] = y2;
+  }
+  __syncthreads();
+  {
+    const int zbase = KP * (KP + 1) / 2;
+    double *rhs = colbuf;  // 16 entries, reused
+    for (int blk = 10; blk >= 0; blk--) {
+      const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
+      // partial sums: thread (c = tid & 15, part = tid >> 4) covers rows o+16+part, +16, ...
+      const int c = tid & 15, part = tid >> 4;
+      double acc = 0.0;
+      if (c < nb)
+        for (int i = o + 16 + part; i < KP; i += 16) acc = fma(Hs[i * (i + 1) / 2 + o + c], yv[i], acc);
+      // reduce the 16 parts of each column (parts live in different 16-lane groups -> LDS)
+      scratch[part * 16 + c] = acc;
+      __syncthreads();
+      if (tid < 16) {
+        double s = 0;
+#pragma unroll
+        for (int p2 = 0; p2 < 16; p2++) s += scratch[p2 * 16 + tid];
+        rhs[tid] = (tid < nb) ? Hs[zbase + o + tid] - s : 0.0;
+      }
+      __syncthreads();
+      // y_k = L_kk^-T rhs : y[c] = sum_r Binv[r][c] rhs[r]
+      if (tid < 16 && tid < nb) {
+        double s = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s = fma(Binv[blk * 256 + r * 16 + tid], rhs[r], s);
+        yv[o + tid] = s;
+      }
+      __syncthreads();
+    }
   }
   __syncthreads();
   STAMP(S, 6);
