@@ -586,9 +586,15 @@ DEV double gram_pair_sum(const Slot *S, int i, int j, int idx, int chunk_limit) 
   const int c0 = S->pair_chunk0[p];
   int c1 = S->pair_chunk0[p + 1];
   if (c1 > chunk_limit) c1 = chunk_limit;
-  double s = 0;
-  for (int c = c0; c < c1; c++) s += S->gram_part[(size_t)c * NGP + idx];
-  return s;
+  const double *gp = S->gram_part + idx;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int c = c0;
+  for (; c + 4 <= c1; c += 4) {
+    s0 += gp[(size_t)c * NGP], s1 += gp[(size_t)(c + 1) * NGP];
+    s2 += gp[(size_t)(c + 2) * NGP], s3 += gp[(size_t)(c + 3) * NGP];
+  }
+  for (; c < c1; c++) s0 += gp[(size_t)c * NGP];
+  return (s0 + s1) + (s2 + s3);
 }
 
 // the ex/td entries receive a term from EVERY chunk: chunks are contiguous in pair order, so this is a plain
@@ -698,9 +704,18 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
     const int e = b * 256 + tid;
     int parts = S->nSchurParts;
     if (is_marg(mode)) parts = (marg_plan(S, mode)->N0 + S->schur_lm - 1) / S->schur_lm;
-    double s = 0;
-    for (int p = 0; p < parts; p++) s += S->schur_part[(size_t)p * SCHUR_LEN + e];
-    S->schur_sum[e] = s;
+    // fixed association (8 interleaved accumulators, then a fixed tree): deterministic, 8 loads in flight
+    const double *sp = S->schur_part + e;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    int p = 0;
+    for (; p + 8 <= parts; p += 8) {
+      a0 += sp[(size_t)p * SCHUR_LEN], a1 += sp[(size_t)(p + 1) * SCHUR_LEN];
+      a2 += sp[(size_t)(p + 2) * SCHUR_LEN], a3 += sp[(size_t)(p + 3) * SCHUR_LEN];
+      a4 += sp[(size_t)(p + 4) * SCHUR_LEN], a5 += sp[(size_t)(p + 5) * SCHUR_LEN];
+      a6 += sp[(size_t)(p + 6) * SCHUR_LEN], a7 += sp[(size_t)(p + 7) * SCHUR_LEN];
+    }
+    for (; p < parts; p++) a0 += sp[(size_t)p * SCHUR_LEN];
+    S->schur_sum[e] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     return;
   }
   if (!tr->do_lin) return;
