@@ -27,6 +27,9 @@ constexpr int NPAIR = 121; // pair slot = i * 11 + j
 constexpr int NT = 15;     // upper tiles of the 5x5 tiling of the 80x80 Schur accumulator
 constexpr int SCHUR_LEN = NT * 256;
 constexpr int PACKED = KP * (KP + 1) / 2;
+constexpr int JLOG_LD = 48;      // rotation slots per logged Jacobi step (>= ceil(n/2), n <= 96)
+constexpr int JLOG_STEPS = 1600;  // >= JMAX_SWEEPS * (n - 1)
+constexpr int JMAX_SWEEPS = 20;
 constexpr int HPP_CAP = 16384;
 // exchange buffer of the landmark-sharded mode (one contiguous sum-all-reduce):
 //   [ H_pp packed | g_p | Schur sums (80x80 upper tiles) | 16 scalars ]
@@ -109,6 +112,19 @@ struct MargPlan {  // structure of the marginalization, computed on the host at 
   int idx[LFVIO_MAX_PRIOR_BLOCKS];
 };
 
+// Device arrays of the slot blob, addressed from inside the blob.  A pointer loaded from memory is "generic" to the
+// compiler, which then emits flat_load / flat_store: those count on both the vector-memory and the LDS counters, so
+// every LDS wait also waits for the HBM traffic in flight.  GP<T> therefore stores the distance from itself to the
+// array: the address is formed from the Slot pointer, which descends from a kernel argument, so the address-space
+// inference selects global_* instructions.  (Self-relative: never copy a GP out of its Slot.)
+template <class T>
+struct GP {
+  long long off;
+  __device__ __forceinline__ operator T *() const { return (T *)((char *)this + off); }
+  // host: slot = start of the (staging copy of the) Slot this member lives in, target = byte offset inside the blob
+  void set(const void *slot, size_t target) { off = (long long)target - (long long)((const char *)this - (const char *)slot); }
+};
+
 struct Slot {
   // ---------------- header: sizes, flags, constants
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
@@ -126,35 +142,39 @@ struct Slot {
   int pair_chunk0[NPAIR + 1];    // chunk range per pair slot
   MargPlan marg[2];              // [MARGIN_OLD, MARGIN_SECOND_NEW]
   // ---------------- input arrays (device pointers into the blob)
-  int *lm_start, *lm_cnt, *lm_obs0, *lm_perm;
-  double *lam0;
-  double *obs[8];                // px py pz vx vy vz cur_td uv_y, each [M]
-  int *pm_obs, *pm_lm;           // [NV] pair-major: observation index, landmark index
-  int *chunk_pair, *chunk_begin, *chunk_end;
-  double *prior_J, *prior_r;     // n*n, n
+  GP<int> lm_start, lm_cnt, lm_obs0, lm_perm;
+  GP<double> lam0;
+  GP<double> obs[8];                // px py pz vx vy vz cur_td uv_y, each [M]
+  GP<int> pm_obs, pm_lm;           // [NV] pair-major: observation index, landmark index
+  GP<int> chunk_pair, chunk_begin, chunk_end;
+  GP<double> prior_J, prior_r;     // n*n, n
   // ---------------- work arrays
   FrameState x[2];
   TRState tr;                    // directly after x[]: one small D2H copy fetches state + trace
   Tab tab[2];
-  double *lam[2];
+  GP<double> lam[2];
   double imu_sqrt[LFVIO_WINDOW_SIZE][225];
-  double *prior_A;               // n*n  (J0^T J0)
+  GP<double> prior_A;               // n*n  (J0^T J0)
   double prior_b0[KP];           // J0^T r0
-  double *a, *b, *W, *scale_l, *grad_l, *gn_l, *diag_l, *einv_l, *d1, *d2;
-  double *gram_part, *pairG, *schur_part, *schur_sum;   // schur_sum = xch + XOFF_S
-  double *xch, *gp;              // exchange buffer; gp = xch + XOFF_G, Hpp = xch + XOFF_H
-  double *lm_part;               // nLmBlocks * LMS
+  GP<double> a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2;
+  GP<double> gram_part, pairG, schur_part, schur_sum;   // schur_sum = xch + XOFF_S
+  GP<double> xch, gp;              // exchange buffer; gp = xch + XOFF_G, Hpp = xch + XOFF_H
+  GP<double> lm_part;               // nLmBlocks * LMS
   double lm_sum[LMS];
-  double *cost_part;             // nLmBlocks * LMS (candidate sweep)
-  double *imu_out;               // 10 * IMU_OUT
+  GP<double> cost_part;             // nLmBlocks * LMS (candidate sweep)
+  GP<double> imu_out;               // 10 * IMU_OUT
   double prior_g[KP + 4];        // prior gradient (tangent cols) + cost
   double pose_cost[16];          // candidate costs of imu[0..9], prior [10]
-  double *Hpp;                   // packed lower KP (assembled by k_sum) = xch + XOFF_H
-  double *mscr;                  // dense scratch of the marginalization (HPP_CAP)
+  GP<double> Hpp;                   // packed lower KP (assembled by k_sum) = xch + XOFF_H
+  GP<double> mscr;                  // dense scratch of the marginalization (HPP_CAP)
+  GP<double2> rotlog;               // [JLOG_STEPS][JLOG_LD] (cos, sin) of every Jacobi step of the n x n eigen-problem
+  GP<double> eig_aux;               // eigenvalues[96] | sorted b'[96] | (int) diagonal-sort permutation[96]
   double scale_p[KP], diag_p[KP], grad_p[KP], gn_p[KP], step_p[KP];
   double uc_grad[WLD], uc_gn[WLD], uc_y[WLD];
   double z1[WLD], z2[WLD];
-  long long dbg[32];             // shader-clock stamps (bring-up instrumentation)
+  long long dbg[32];
+  double jtrace[32];             // off/diag mass per Jacobi sweep (instrumentation)             // shader-clock stamps (bring-up instrumentation)
+  int eig_steps, eig_pad;        // Jacobi steps logged in rotlog
   // marginalization outputs
   LfvioPrior prior_out;
 };

@@ -15,8 +15,9 @@
 #pragma once
 #include "kernels_solve.h"
 
-constexpr int MARG_THREADS = 1024;  // 4 waves / SIMD: the Jacobi steps are LDS-latency bound
+constexpr int MARG_THREADS = 768;   // 12 waves: one 2x2 block of the 38 x 39 / 2 = 741 lower blocks per thread
 constexpr int MARG_MAXD = 96;  // 15 dropped + 76 kept, padded
+constexpr int LDN = 80;              // LDS row stride of the n x n (n <= 76) eigen-problem, see jacobi_eig
 constexpr size_t MARG_LDS = (size_t)17408 * sizeof(double);  // >= LPACK + KP + 64 and >= the eigen-phase carve below
 
 __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
@@ -90,23 +91,82 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
 // barriers and no atomics.  Threads are mapped 16 x 16 over (pair a, pair b): no integer division.
 // Stops when the off-diagonal mass is below 1e-24 of the diagonal mass (off/||A|| < 1e-12, below the
 // conditioning error of A' itself, which is ~1e-10: A_mm carries IMU information ~1e10) or stagnates.
-DEV int jacobi_eig(double *A, double *V, int n, int tid, int nthreads, double *rotc, double *rots, int *rp, int *rq,
-                   double *scratch) {
-  for (int e = tid; e < n * n; e += nthreads) V[e] = 0.0;
+// round-robin pairing of step `step`: slot k rotates (step+k, step-k) mod (np-1), slot 0 pairs the fixed index np-1.
+// q = -1 marks the dummy index of an odd n.  Consecutive slots give consecutive rows / columns (no p<q reordering),
+// which keeps a half-wave's LDS accesses in distinct banks for the row stride LDN.
+DEV void rr_pair(int k, int step, int np, int n, int &p, int &q) {
+  if (k == 0) {
+    p = step, q = np - 1;  // for an odd n the dummy index np-1 = n never leaves this place
+  } else {
+    p = step + k;
+    if (p >= np - 1) p -= np - 1;
+    q = step - k;
+    if (q < 0) q += np - 1;
+  }
+  if (q >= n) q = -1;
+}
+
+// Parallel cyclic Jacobi, A = V diag V^T (A, V: n x n, row stride ld; A is overwritten with the eigenvalues on its
+// diagonal).  One step = np/2 disjoint rotations.  The step is software-pipelined so that the serial
+// divide / sqrt / rsqrt chain of the rotation angles (wave 0) overlaps the eigenvector update of the previous step:
+//   phase 1: wave 0 computes the rotations of step g from A | all waves apply V <- V J(g-1)
+//   phase 2: A <- J(g)^T A J(g)
+// Work is split statically: thread t owns 2x2 blocks {t, t+T} of the half x half block grid and the (row, slot) items
+// {t, t+T, t+2T} of V, so every element is loaded once, rotated in registers and stored once per step.
+DEV int jacobi_eig(double *A, double *V, int n, int ld, int tid, int nthreads, double2 *cs, double *scratch,
+                   double *trace = nullptr) {
+  for (int e = tid; e < n * ld; e += nthreads) V[e] = 0.0;
   __syncthreads();
-  for (int e = tid; e < n; e += nthreads) V[e * n + e] = 1.0;
+  for (int e = tid; e < n; e += nthreads) V[e * ld + e] = 1.0;
   __syncthreads();
   const int np = n + (n & 1);
   const int half = np / 2;
   if (n < 2) return 0;
   int sweeps = 0;
   const int tx = tid & 15, ty = tid >> 4, nty = nthreads >> 4;
+  // static ownership (requires half^2 <= 2T and n*half <= 3T: 1444 <= 2048, 2888 <= 3072 for n = 76, T = 1024)
+  int aka[2], akb[2], vrow[3], vk[3];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int e = tid + u * nthreads;
+    aka[u] = e < half * half ? e / half : -1;
+    akb[u] = e % half;
+  }
+#pragma unroll
+  for (int u = 0; u < 3; u++) {
+    const int e = tid + u * nthreads;
+    vrow[u] = e < n * half ? e / half : -1;
+    vk[u] = e % half;
+  }
+  auto apply_v = [&](int step, int buf) {
+    int p[3], q[3];
+    double v0[3], v1[3];
+    double2 r[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      p[u] = q[u] = -1;
+      if (vrow[u] < 0) continue;
+      rr_pair(vk[u], step, np, n, p[u], q[u]);
+      if (q[u] < 0) continue;
+      r[u] = cs[buf * 48 + vk[u]];
+      v0[u] = V[vrow[u] * ld + p[u]], v1[u] = V[vrow[u] * ld + q[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      if (vrow[u] < 0 || q[u] < 0) continue;
+      V[vrow[u] * ld + p[u]] = r[u].x * v0[u] - r[u].y * v1[u];
+      V[vrow[u] * ld + q[u]] = r[u].y * v0[u] + r[u].x * v1[u];
+    }
+  };
+  int g = 0;           // global step counter: rotation / flag double buffer = g & 1
+  bool pend = false;   // V has not seen the rotations of step pend_step yet (uniform)
+  int pend_step = 0;
   double prev_off = 1e300;
   for (int sweep = 0; sweep < 24; sweep++) {
     double off = 0, dia = 0;
     for (int r = ty; r < n; r += nty)
       for (int c = tx; c < n; c += 16) {
-        const double v = A[r * n + c];
+        const double v = A[r * ld + c];
         if (r == c) dia += v * v;
         else off += v * v;
       }
@@ -117,77 +177,328 @@ DEV int jacobi_eig(double *A, double *V, int n, int tid, int nthreads, double *r
     double so = 0, sd = 0;
     for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[16 + w];
     __syncthreads();
+    if (trace && tid == 0 && sweep < 12) trace[sweep] = so / sd;
     if (so <= 1e-24 * sd || so == 0.0) break;
     if (sweep >= 4 && so > 0.25 * prev_off) break;  // rounding floor reached
     prev_off = so;
     sweeps++;
-    for (int step = 0; step < np - 1; step++) {
-      if (tid < half) {
-        int p, q;
-        if (tid == 0) {
-          p = np - 1, q = step;
-        } else {
-          p = step + tid;
-          if (p >= np - 1) p -= np - 1;
-          q = step - tid;
-          if (q < 0) q += np - 1;
-        }
-        if (p > q) {
-          int t = p;
-          p = q, q = t;
-        }
-        double c = 1.0, s = 0.0;
-        if (q < n) {
-          const double apq = A[p * n + q];
-          if (apq != 0.0) {
-            const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = rsqrt(t * t + 1.0);
-            s = t * c;
+    for (int step = 0; step < np - 1; step++, g++) {
+      const int buf = g & 1;
+      // ---- phase 1
+      if (tid < 64) {
+        if (tid == 0) scratch[40 + buf] = 0.0;  // same wave as the setters below: LDS operations of a wave stay in order
+        if (tid < half) {
+          int p, q;
+          rr_pair(tid, step, np, n, p, q);
+          double c = 1.0, s = 0.0;
+          if (q >= 0) {
+            const double apq = A[p * ld + q], app = A[p * ld + p], aqq = A[q * ld + q];
+            // rotations that cannot change either diagonal entry in FP64 are skipped
+            if (apq != 0.0 && fabs(apq) > 1e-18 * (fabs(app) + fabs(aqq))) {
+              const double theta = (aqq - app) / (2.0 * apq);
+              const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+              c = rsqrt(t * t + 1.0);
+              s = t * c;
+            }
           }
+          cs[buf * 48 + tid] = make_double2(c, s);
+          if (s != 0.0) scratch[40 + buf] = 1.0;  // some rotation of this step is non-trivial (same value from every writer)
         }
-        rp[tid] = p, rq[tid] = (q < n) ? q : -1;
-        rotc[tid] = c, rots[tid] = s;
       }
+      if (pend) apply_v(pend_step, buf ^ 1);
       __syncthreads();
-      // A <- J^T A J on disjoint 2x2 blocks (q = -1: the dummy index of an odd n)
-      for (int ka = ty; ka < half; ka += nty) {
-        const int pa = rp[ka], qa = rq[ka];
-        const double ca = rotc[ka], sa = rots[ka];
-        double *rowp = A + pa * n;
-        double *rowq = A + (qa >= 0 ? qa : pa) * n;
-        for (int kb = tx; kb < half; kb += 16) {
-          const int pb = rp[kb], qb = rq[kb];
-          const double cb = rotc[kb], sb = rots[kb];
-          const bool va = qa >= 0, vb = qb >= 0;
-          const double b00 = rowp[pb];
-          const double b01 = vb ? rowp[qb] : 0.0;
-          const double b10 = va ? rowq[pb] : 0.0;
-          const double b11 = (va && vb) ? rowq[qb] : 0.0;
-          const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
-          const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
-          rowp[pb] = ca * t00 - sa * t10;
-          if (vb) rowp[qb] = ca * t01 - sa * t11;
-          if (va) rowq[pb] = sa * t00 + ca * t10;
-          if (va && vb) rowq[qb] = sa * t01 + ca * t11;
+      const bool any_rot = scratch[40 + buf] != 0.0;  // uniform
+      pend = any_rot, pend_step = step;
+      if (!any_rot) continue;  // nothing is written in phase 2; the next phase 1 only touches the other buffer
+      // ---- phase 2: A <- J^T A J on this thread's 2x2 blocks
+      {
+        int pa[2], qa[2], pb[2], qb[2];
+        double b00[2], b01[2], b10[2], b11[2];
+        double2 ra[2], rb[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          if (aka[u] < 0) continue;
+          rr_pair(aka[u], step, np, n, pa[u], qa[u]);
+          rr_pair(akb[u], step, np, n, pb[u], qb[u]);
+          ra[u] = cs[buf * 48 + aka[u]], rb[u] = cs[buf * 48 + akb[u]];
+          const bool va = qa[u] >= 0, vb = qb[u] >= 0;
+          const double *rowp = A + pa[u] * ld, *rowq = A + (va ? qa[u] : pa[u]) * ld;
+          b00[u] = rowp[pb[u]];
+          b01[u] = vb ? rowp[qb[u]] : 0.0;
+          b10[u] = va ? rowq[pb[u]] : 0.0;
+          b11[u] = (va && vb) ? rowq[qb[u]] : 0.0;
         }
-      }
-      // V <- V J
-      for (int r = ty; r < n; r += nty) {
-        double *vr = V + r * n;
-        for (int kb = tx; kb < half; kb += 16) {
-          const int pb = rp[kb], qb = rq[kb];
-          if (qb < 0) continue;
-          const double cb = rotc[kb], sb = rots[kb];
-          const double v0 = vr[pb], v1 = vr[qb];
-          vr[pb] = cb * v0 - sb * v1;
-          vr[qb] = sb * v0 + cb * v1;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          if (aka[u] < 0) continue;
+          const bool va = qa[u] >= 0, vb = qb[u] >= 0;
+          double *rowp = A + pa[u] * ld, *rowq = A + (va ? qa[u] : pa[u]) * ld;
+          const double ca = ra[u].x, sa = ra[u].y, cb = rb[u].x, sb = rb[u].y;
+          const double t00 = cb * b00[u] - sb * b01[u], t01 = sb * b00[u] + cb * b01[u];
+          const double t10 = cb * b10[u] - sb * b11[u], t11 = sb * b10[u] + cb * b11[u];
+          rowp[pb[u]] = ca * t00 - sa * t10;
+          if (vb) rowp[qb[u]] = ca * t01 - sa * t11;
+          if (va) rowq[pb[u]] = sa * t00 + ca * t10;
+          if (va && vb) rowq[qb[u]] = sa * t01 + ca * t11;
         }
       }
       __syncthreads();
     }
   }
+  if (pend) apply_v(pend_step, (g - 1) & 1);
+  __syncthreads();
   return sweeps;
+}
+
+// 1/sqrt(x) and 1/x from the hardware estimates (v_rsq_f64 / v_rcp_f64, about 2^-26) with two Newton steps each: a
+// quarter of the dependent instructions of the correctly-rounded library forms, and the Jacobi step waits on this chain.
+// x is a normal, positive (rsqrt) or non-zero (rcp) double far from the range ends.
+DEV double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  return y;
+}
+DEV double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+}
+
+// Jacobi rotation that annihilates a_pq: t = tan(phi) is the smaller root of t^2 + 2 theta t - 1 = 0,
+// theta = (a_qq - a_pp) / (2 a_pq), written without the division by a_pq:  t = sgn(d) e / (|d| + sqrt(d^2 + e^2)),
+// d = a_qq - a_pp, e = 2 a_pq.  (cos, sin) = (1, t) / sqrt(1 + t^2); cos^2 + sin^2 = 1 to rounding whatever the error of t.
+DEV void jacobi_angle(double app, double aqq, double apq, double &c, double &s) {
+  c = 1.0, s = 0.0;
+  // rotations that cannot change either diagonal entry in FP64 are skipped
+  if (apq != 0.0 && fabs(apq) > 1e-18 * (fabs(app) + fabs(aqq))) {
+#if defined(JAC_TRIVIAL)
+    c = 0.8, s = 0.6;
+#elif defined(JAC_IEEE)
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    c = rsqrt(t * t + 1.0);
+    s = t * c;
+#else
+    const double d = aqq - app, e = 2.0 * apq;
+    const double h2 = fma(d, d, e * e);
+    const double h = h2 * fast_rsqrt(h2);
+    const double t = (d >= 0 ? e : -e) * fast_rcp(fabs(d) + h);
+    c = fast_rsqrt(fma(t, t, 1.0));
+    s = t * c;
+#endif
+  }
+}
+
+// The n x n eigen-problem of the prior (n = 76), eigenvalues only; the rotations are logged and the eigenvectors are
+// accumulated from the log by k_marg_vecs, whose rows are independent and therefore spread over many CUs.
+//
+// Brent-Luk arrangement: the matrix is kept in "position space".  Slot k always rotates positions (top k, bot k); after
+// every step the indices move one place round the tournament ring (top row towards slot 0, bottom row away from it,
+// bot 0 fixed), so the pairing of step g is (p_k, q_k) = rr_pair(k, g mod (np-1)).  Thread (ka >= kb) keeps the 2x2 block
+// [top ka, bot ka] x [top kb, bot kb] of the symmetric matrix in registers: the angle comes from the registers of the
+// diagonal threads, the rotation is applied in registers, and the ring move is one LDS round trip through addresses
+// that never change (4 stores to the blocks the elements move to, 4 loads of the own block).  Blocks above the diagonal
+// are not stored: an element that moves there is written to its mirror place.
+// B: np x np doubles, row stride ldb, memory index of position (bot, k) = bot * half + k.
+#if defined(JAC_TIMING)  // bring-up: cycles of thread 0 per segment of the Jacobi step, summed into trace[12 + segment]
+#define JT(k)                                                            \
+  do {                                                                   \
+    const long long t_ = __builtin_readcyclecounter();                   \
+    if (tid == 0 && (k) > 0) trace[12 + (k)] += (double)(t_ - jt_last);  \
+    jt_last = t_;                                                        \
+  } while (0)
+#else
+#define JT(k)
+#endif
+DEV int jacobi_systolic(const double *As, int lda, const int *perm, double *B, int ldb, int n, int tid, int nthreads,
+                        double2 *cs, double *scratch, double2 *rotlog, double *ev_out, double *trace) {
+  const int np = n + (n & 1), half = np / 2;
+  // position space at step 0: top k <- index k, bot k <- index np-1-k  (= rr_pair(k, 0))
+  for (int e = tid; e < np * np; e += nthreads) {
+    const int mi = e / np, mj = e % np;
+    const int i = mi < half ? mi : np - 1 - (mi - half), j = mj < half ? mj : np - 1 - (mj - half);
+    B[mi * ldb + mj] = (i < n && j < n) ? As[perm[i] * lda + perm[j]] : 0.0;
+  }
+  __syncthreads();
+  const int nblk = half * (half + 1) / 2;
+  const bool own = tid < nblk;
+  int ka = 0, kb = 0;
+  if (own) {
+    ka = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
+    while ((ka + 1) * (ka + 2) / 2 <= tid) ka++;
+    while (ka * (ka + 1) / 2 > tid) ka--;
+    kb = tid - ka * (ka + 1) / 2;
+  }
+  const bool diag = own && ka == kb;
+  const int r00 = ka * ldb + kb, r01 = ka * ldb + half + kb, r10 = (half + ka) * ldb + kb, r11 = (half + ka) * ldb + half + kb;
+  // where the four elements go in the ring move
+  auto sigma = [&](int bot, int k, int &nb, int &nk) {
+    if (!bot) {
+      if (k >= 1) nb = 0, nk = k - 1;
+      else nb = 1, nk = 1;
+    } else {
+      if (k == 0) nb = 1, nk = 0;
+      else if (k <= half - 2) nb = 1, nk = k + 1;
+      else nb = 0, nk = half - 1;
+    }
+  };
+  auto dest = [&](int bx, int by) {
+    int dbx, dkx, dby, dky;
+    sigma(bx, ka, dbx, dkx);
+    sigma(by, kb, dby, dky);
+    bool flip = dkx < dky || (dkx == dky && dbx < dby);  // keep block row >= block column, (bot, top) inside a diagonal block
+    const int mr = flip ? dby * half + dky : dbx * half + dkx, mc = flip ? dbx * half + dkx : dby * half + dky;
+    return mr * ldb + mc;
+  };
+  const int w00 = dest(0, 0), w01 = diag ? -1 : dest(0, 1), w10 = dest(1, 0), w11 = dest(1, 1);
+  double b00 = 0, b01 = 0, b10 = 0, b11 = 0;
+  if (own) {
+    b00 = B[r00], b10 = B[r10], b11 = B[r11];
+    b01 = diag ? b10 : B[r01];
+  }
+  __syncthreads();
+  int sweeps = 0, g = 0;
+  double prev_off = 1e300, maxrel = 0.0;
+#if defined(JAC_TIMING)
+  long long jt_last = 0;
+  if (tid == 0)
+    for (int k = 12; k < 20; k++) trace[k] = 0.0;
+#endif
+  for (int sweep = 0; sweep < JMAX_SWEEPS; sweep++) {
+    const double mrw = wave_max(maxrel);
+    maxrel = 0.0;
+    double off = 0, dia = 0;
+    if (diag) dia = b00 * b00 + b11 * b11, off = 2.0 * b10 * b10;
+    else if (own) off = 2.0 * (b00 * b00 + b01 * b01 + b10 * b10 + b11 * b11);
+    off = wave_sum(off), dia = wave_sum(dia);
+    if ((tid & 63) == 0) scratch[tid >> 6] = off, scratch[16 + (tid >> 6)] = dia, scratch[32 + (tid >> 6)] = mrw;
+    __syncthreads();
+    double so = 0, sd = 0, mr = 0;
+    for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[16 + w], mr = fmax(mr, scratch[32 + w]);
+    if (trace && tid == 0 && sweep >= 1 && sweep <= 12) trace[19 + sweep] = mr;
+    __syncthreads();
+    if (trace && tid == 0 && sweep < 12) trace[sweep] = so / sd;
+    if (so <= 1e-24 * sd || so == 0.0) break;
+    if (sweep >= 4 && so > 0.25 * prev_off) break;  // rounding floor reached
+    prev_off = so;
+    sweeps++;
+    for (int step = 0; step < np - 1; step++, g++) {
+      JT(0);
+      if (diag) {
+        double c = 1.0, s = 0.0;
+        if (ka > 0 || np == n) {  // slot 0 of an odd n holds the dummy index
+          jacobi_angle(b00, b11, b10, c, s);
+          const double den = fabs(b00 * b11);
+          if (b10 != 0.0) maxrel = fmax(maxrel, den > 0.0 ? b10 * b10 / den : 1e300);
+        }
+        const double2 r = make_double2(c, s);
+        cs[ka] = r;
+        rotlog[(size_t)g * JLOG_LD + ka] = r;
+      }
+      JT(1);
+      __syncthreads();
+      JT(2);
+      if (own) {
+        const double2 ra = cs[ka], rb = cs[kb];
+        const double t00 = rb.x * b00 - rb.y * b01, t01 = rb.y * b00 + rb.x * b01;
+        const double t10 = rb.x * b10 - rb.y * b11, t11 = rb.y * b10 + rb.x * b11;
+        B[w00] = ra.x * t00 - ra.y * t10;
+        if (w01 >= 0) B[w01] = ra.x * t01 - ra.y * t11;
+        B[w10] = ra.y * t00 + ra.x * t10;
+        B[w11] = ra.y * t01 + ra.x * t11;
+      }
+      JT(3);
+      __syncthreads();
+      JT(4);
+      if (own) {
+        b00 = B[r00], b10 = B[r10], b11 = B[r11];
+        b01 = diag ? b10 : B[r01];
+      }
+      JT(5);
+    }
+  }
+  if (diag) {
+    int p, q;
+    rr_pair(ka, g % (np - 1), np, n, p, q);
+    ev_out[p] = b00;
+    if (q >= 0) ev_out[q] = b11;
+  }
+  __syncthreads();
+  return sweeps;
+}
+
+// Eigenvectors of the prior's eigen-problem from the rotation log, and with them the outputs of
+// marginalization_factor.cpp:283-291:  J0 = sqrt(S) V^T,  r0 = sqrt(1/S) V^T b'.
+// V = J_1 J_2 ... J_G applied to the rows of the identity: one wave per row, lane k = tournament slot k holding the row's
+// entries in columns (p_k, q_k); a step is one in-register rotation and the ring move by two lane shifts.  Row n carries
+// b' instead of a unit vector, which gives V^T b' without a reduction.
+// grid (MARG_VEC_WGS, batch) x 256
+constexpr int MARG_VEC_WGS = 20;  // 4 rows per workgroup, rows 0 .. n (n <= 79)
+__global__ __launch_bounds__(256) void k_marg_vecs(char *base, size_t stride, int flag) {
+  Slot *S = SLOT(base, stride);
+  const MargPlan *mp = &S->marg[flag];
+  if (!mp->valid) return;
+  const int n = mp->n, np = n + (n & 1), half = np / 2;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row > n) return;
+  const int k = threadIdx.x & 63;
+  const int kc = k < half ? k : half - 1;
+  const double *ev = S->eig_aux, *brp = S->eig_aux + 96;
+  const int *perm = (const int *)(S->eig_aux + 192);
+  const int G = S->eig_steps;
+  const double2 *log = S->rotlog + kc;
+  int p0, q0;
+  rr_pair(kc, 0, np, n, p0, q0);
+  double vp, vq;
+  if (row < n) vp = p0 == row ? 1.0 : 0.0, vq = q0 == row ? 1.0 : 0.0;
+  else vp = brp[p0], vq = q0 >= 0 ? brp[q0] : 0.0;
+  constexpr int UB = 16;
+  double2 cur[UB], nxt[UB];
+#pragma unroll
+  for (int u = 0; u < UB; u++) cur[u] = log[(size_t)min(u, JLOG_STEPS - 1) * JLOG_LD];
+  for (int g0 = 0; g0 < G; g0 += UB) {
+#pragma unroll
+    for (int u = 0; u < UB; u++) nxt[u] = log[(size_t)min(g0 + UB + u, JLOG_STEPS - 1) * JLOG_LD];
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      if (g0 + u < G) {
+        const double c = cur[u].x, s = cur[u].y;
+        const double np_ = c * vp - s * vq, nq = s * vp + c * vq;
+        // ring move: top row one slot towards slot 0, bottom row one slot away from it; top 0 -> bot 1,
+        // bot (half-1) -> top (half-1), bot 0 stays
+        const double up = __shfl_down(np_, 1);
+        const double dn = __shfl_up(k == 0 ? np_ : nq, 1);
+        vp = k == half - 1 ? nq : up;
+        vq = k == 0 ? nq : dn;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) cur[u] = nxt[u];
+  }
+  if (k >= half) return;
+  int p, q;
+  rr_pair(k, G % (np - 1), np, n, p, q);
+  LfvioPrior *out = &S->prior_out;
+  const double eps = 1e-8;
+  if (row < n) {
+    const int col = perm[row];
+    const double e0 = ev[p];
+    out->linearized_jacobians[p * n + col] = e0 > eps ? sqrt(e0) * vp : 0.0;
+    if (q >= 0) {
+      const double e1 = ev[q];
+      out->linearized_jacobians[q * n + col] = e1 > eps ? sqrt(e1) * vq : 0.0;
+    }
+  } else {
+    const double e0 = ev[p];
+    out->linearized_residuals[p] = e0 > eps ? sqrt(1.0 / e0) * vp : 0.0;
+    if (q >= 0) {
+      const double e1 = ev[q];
+      out->linearized_residuals[q] = e1 > eps ? sqrt(1.0 / e1) * vq : 0.0;
+    }
+  }
 }
 
 // grid (1, batch) x 256, dynamic LDS = MARG_LDS
@@ -203,6 +514,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     if (tid == 0) out->valid = -1;  // host copies the input prior through
     return;
   }
+  STAMP(S, 10);
   double *Hs = smem;            // PACKED, then reused: A (D x D), V (n x n), ...
   double *g = Hs + LPACK;       // KP
   double *scratch = g + KP;     // 64
@@ -235,27 +547,28 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   __syncthreads();
   // LDS re-use (16.7k doubles): A dies once A' is formed, so the second eigenvector matrix aliases it
   double *A = smem;                        // D x D           (<= 92*92 = 8464)
-  double *V2 = smem;                       // n x n, aliases A after the Schur step
+  double *V2 = smem;                       // n x n (row stride LDN), aliases A after the Schur step
   double *bv = A + 92 * 92;                // D
   double *Am = bv + 96;                    // m15 x m15 (then its eigenvalues on the diagonal)
   double *Vm = Am + 256;                   // m15 x m15
   double *Ainv = Vm + 256;                 // m15 x m15
   double *Tm = Ainv + 256;                 // n x m15
-  double *Ar = Tm + 80 * 16;               // n x n
-  double *br = Ar + 76 * 76;               // n
-  double *rotc = br + 80, *rots = rotc + 48;
-  int *rp = (int *)(rots + 48), *rq = rp + 48;
-  double *scr = (double *)(rq + 48);
+  double *Ar = Tm + 80 * 16;               // n x n, row stride LDN
+  double *br = Ar + 76 * LDN;              // n
+  double2 *cs = (double2 *)(br + 80);      // [2][48] (cos, sin) of the Jacobi rotations, double-buffered
+  int *perm = (int *)(cs + 96);            // n ints
+  double *scr = (double *)(perm + 96);     // 64
   for (int e = tid; e < D * D; e += MARG_THREADS) A[e] = Ag[e];
   for (int c = tid; c < D; c += MARG_THREADS) bv[c] = Ag[D * D + c];
   __syncthreads();
+  STAMP(S, 11);
   // ---- A_mm pseudo-inverse by eigen-decomposition (marginalization_factor.cpp:267-272)
   for (int e = tid; e < m15 * m15; e += MARG_THREADS) {
     const int r = e / m15, c = e % m15;
     Am[e] = 0.5 * (A[r * D + c] + A[c * D + r]);
   }
   __syncthreads();
-  const int sw1 = jacobi_eig(Am, Vm, m15, tid, MARG_THREADS, rotc, rots, rp, rq, scr);
+  const int sw1 = jacobi_eig(Am, Vm, m15, m15, tid, MARG_THREADS, cs, scr);
   __syncthreads();
   const double eps = 1e-8;
   for (int e = tid; e < m15 * m15; e += MARG_THREADS) {
@@ -268,6 +581,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     Ainv[e] = s;
   }
   __syncthreads();
+  STAMP(S, 12);
   // ---- A' = Arr - Arm Amm^+ Amr, b' = brr - Arm Amm^+ bmm  (:275-281)
   for (int e = tid; e < n * m15; e += MARG_THREADS) {
     const int r = e / m15, c = e % m15;
@@ -280,7 +594,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     const int r = e / n, c = e % n;
     double s = 0;
     for (int k = 0; k < m15; k++) s = fma(Tm[r * m15 + k], A[k * D + m15 + c], s);
-    Ar[e] = A[(m15 + r) * D + m15 + c] - s;
+    Ar[r * LDN + c] = A[(m15 + r) * D + m15 + c] - s;
   }
   for (int r = tid; r < n; r += MARG_THREADS) {
     double s = 0;
@@ -290,24 +604,30 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   __syncthreads();
   // keep A', b' for parity checks (global scratch after the gathered system)
   double *Aout = Ag + 92 * 92 + 96;
-  for (int e = tid; e < n * n; e += MARG_THREADS) Aout[e] = Ar[e];
+  for (int e = tid; e < n * n; e += MARG_THREADS) Aout[e] = Ar[(e / n) * LDN + e % n];
   for (int r = tid; r < n; r += MARG_THREADS) Aout[n * n + r] = br[r];
   __syncthreads();
   // ---- second eigen-decomposition -> J0 = sqrt(S) V^T, r0 = sqrt(1/S) V^T b'  (:283-291)
-  const int sw2 = jacobi_eig(Ar, V2, n, tid, MARG_THREADS, rotc, rots, rp, rq, scr);
-  if (tid == 0) S->dbg[24] = sw1, S->dbg[25] = sw2;
+  // The matrix is strongly graded (eigenvalues 1e-6 .. 1e6): cyclic Jacobi converges markedly faster when the
+  // diagonal is sorted in decreasing order first (de Rijk), which is a permutation similarity.
+  STAMP(S, 13);
+  if (tid < n) {
+    const double di = Ar[tid * LDN + tid];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const double dj = Ar[j * LDN + j];
+      rank += (dj > di) || (dj == di && j < tid);
+    }
+    perm[rank] = tid;
+  }
   __syncthreads();
-  for (int e = tid; e < n * n; e += MARG_THREADS) {
-    const int k = e / n, i = e % n;
-    const double ev = Ar[k * n + k];
-    out->linearized_jacobians[e] = (ev > eps) ? sqrt(ev) * V2[i * n + k] : 0.0;
-  }
-  for (int k = tid; k < n; k += MARG_THREADS) {
-    const double ev = Ar[k * n + k];
-    double vb = 0;
-    for (int i = 0; i < n; i++) vb = fma(V2[i * n + k], br[i], vb);
-    out->linearized_residuals[k] = (ev > eps) ? sqrt(1.0 / ev) * vb : 0.0;
-  }
+  double *ev = S->eig_aux, *brp = S->eig_aux + 96;
+  int *gperm = (int *)(S->eig_aux + 192);
+  if (tid < n) gperm[tid] = perm[tid], brp[tid] = br[perm[tid]];
+  const int sw2 = jacobi_systolic(Ar, LDN, perm, V2, LDN, n, tid, MARG_THREADS, cs, scr, S->rotlog, ev, S->jtrace);  // V2 aliases the dead A
+  if (tid == 0) S->dbg[24] = sw1, S->dbg[25] = sw2, S->eig_steps = sw2 * (n + (n & 1) - 1);
+  STAMP(S, 14);
+  // J0 and r0 follow in k_marg_vecs
   // ---- getParameterBlocks + addr_shift
   const FrameState *x = &S->x[tr->cur];
   if (tid < mp->nb) {
@@ -322,6 +642,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     const int gs = (kind == LFVIO_BLOCK_POSE || kind == LFVIO_BLOCK_EX_POSE) ? 7 : (kind == LFVIO_BLOCK_SPEEDBIAS ? 9 : 1);
     for (int k = 0; k < 9; k++) out->block_x0[tid][k] = k < gs ? xb[k] : 0.0;
   }
+  STAMP(S, 15);
   if (tid == 0) {
     out->valid = 1;
     out->m = m15 + mp->N0;

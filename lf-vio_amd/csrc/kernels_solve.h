@@ -80,7 +80,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   auto active = [&](int c) { return (est_ex || c < off_ex() || c >= off_ex() + 6) && (est_td || c != off_td()); };
   STAMP(S, 0);
   {  // H_pp global -> LDS, 16-byte loads, 4 in flight per thread
-    const double2 *src = (const double2 *)S->Hpp;
+    const double2 *src = (const double2 *)(const double *)S->Hpp;
     double2 *dst = (double2 *)Hs;
     constexpr int NV2 = PACKED / 2;
     for (int e = tid; e < NV2; e += 4 * SOLVE_THREADS) {

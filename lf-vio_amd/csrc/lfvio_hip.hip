@@ -37,7 +37,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, prior_J,
       prior_r;
   size_t lam[2], prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
-      xch, lm_part, cost_part, imu_out, mscr;
+      xch, lm_part, cost_part, imu_out, mscr, rotlog, eig_aux;
 };
 
 Layout make_layout(int maxN, int maxM) {
@@ -77,6 +77,8 @@ Layout make_layout(int maxN, int maxM) {
   L.cost_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.imu_out = take((size_t)LFVIO_WINDOW_SIZE * IMU_OUT * 8);
   L.mscr = take((size_t)HPP_CAP * 8);
+  L.rotlog = take((size_t)JLOG_STEPS * JLOG_LD * 16);
+  L.eig_aux = take(4096);
   L.total = align_up(o, 4096);
   return L;
 }
@@ -368,12 +370,12 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   plan_marg(w, LFVIO_MARGIN_OLD, N0, kmax0, S->pair_chunk0[11], true, &S->marg[0]);
   plan_marg(w, LFVIO_MARGIN_SECOND_NEW, 0, 0, 0, true, &S->marg[1]);
   // ---- device pointers
-  S->lm_start = (int *)(d + L.lm_start), S->lm_cnt = (int *)(d + L.lm_cnt), S->lm_obs0 = (int *)(d + L.lm_obs0);
-  S->lm_perm = (int *)(d + L.lm_perm), S->lam0 = (double *)(d + L.lam0);
-  for (int k = 0; k < 8; k++) S->obs[k] = (double *)(d + L.obs[k]);
-  S->pm_obs = (int *)(d + L.pm_obs), S->pm_lm = (int *)(d + L.pm_lm);
-  S->chunk_pair = (int *)(d + L.chunk_pair), S->chunk_begin = (int *)(d + L.chunk_begin), S->chunk_end = (int *)(d + L.chunk_end);
-  S->prior_J = (double *)(d + L.prior_J), S->prior_r = (double *)(d + L.prior_r);
+  S->lm_start.set(S, L.lm_start), S->lm_cnt.set(S, L.lm_cnt), S->lm_obs0.set(S, L.lm_obs0), S->lm_perm.set(S, L.lm_perm);
+  S->lam0.set(S, L.lam0);
+  for (int k = 0; k < 8; k++) S->obs[k].set(S, L.obs[k]);
+  S->pm_obs.set(S, L.pm_obs), S->pm_lm.set(S, L.pm_lm);
+  S->chunk_pair.set(S, L.chunk_pair), S->chunk_begin.set(S, L.chunk_begin), S->chunk_end.set(S, L.chunk_end);
+  S->prior_J.set(S, L.prior_J), S->prior_r.set(S, L.prior_r);
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, L.in_end - L.in_begin, hipMemcpyHostToDevice, c->stream));
@@ -381,17 +383,18 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     // work-array pointers: fixed per slot until the next reserve()
     Slot W;
     std::memset(&W, 0, sizeof W);
-    W.lam[0] = (double *)(d + L.lam[0]), W.lam[1] = (double *)(d + L.lam[1]);
-    W.prior_A = (double *)(d + L.prior_A);
-    W.a = (double *)(d + L.a), W.b = (double *)(d + L.b), W.W = (double *)(d + L.W);
-    W.scale_l = (double *)(d + L.scale_l), W.grad_l = (double *)(d + L.grad_l), W.gn_l = (double *)(d + L.gn_l);
-    W.diag_l = (double *)(d + L.diag_l), W.einv_l = (double *)(d + L.einv_l), W.d1 = (double *)(d + L.d1), W.d2 = (double *)(d + L.d2);
-    W.gram_part = (double *)(d + L.gram_part), W.pairG = (double *)(d + L.pairG);
-    W.schur_part = (double *)(d + L.schur_part);
-    W.xch = (double *)(d + L.xch);
-    W.schur_sum = W.xch + XOFF_S, W.gp = W.xch + XOFF_G, W.Hpp = W.xch + XOFF_H;
-    W.lm_part = (double *)(d + L.lm_part), W.cost_part = (double *)(d + L.cost_part), W.imu_out = (double *)(d + L.imu_out);
-    W.mscr = (double *)(d + L.mscr);
+    W.lam[0].set(&W, L.lam[0]), W.lam[1].set(&W, L.lam[1]);
+    W.prior_A.set(&W, L.prior_A);
+    W.a.set(&W, L.a), W.b.set(&W, L.b), W.W.set(&W, L.W);
+    W.scale_l.set(&W, L.scale_l), W.grad_l.set(&W, L.grad_l), W.gn_l.set(&W, L.gn_l);
+    W.diag_l.set(&W, L.diag_l), W.einv_l.set(&W, L.einv_l), W.d1.set(&W, L.d1), W.d2.set(&W, L.d2);
+    W.gram_part.set(&W, L.gram_part), W.pairG.set(&W, L.pairG);
+    W.schur_part.set(&W, L.schur_part);
+    W.xch.set(&W, L.xch);
+    W.schur_sum.set(&W, L.xch + (size_t)XOFF_S * 8), W.gp.set(&W, L.xch + (size_t)XOFF_G * 8), W.Hpp.set(&W, L.xch + (size_t)XOFF_H * 8);
+    W.lm_part.set(&W, L.lm_part), W.cost_part.set(&W, L.cost_part), W.imu_out.set(&W, L.imu_out);
+    W.mscr.set(&W, L.mscr);
+    W.rotlog.set(&W, L.rotlog), W.eig_aux.set(&W, L.eig_aux);
     // field-by-field so that only pointer members are touched
 #define PUTP(field) HIPCHK(c, hipMemcpyAsync(d + offsetof(Slot, field), &W.field, sizeof W.field, hipMemcpyHostToDevice, c->stream))
     PUTP(lam);
@@ -399,7 +402,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     PUTP(a); PUTP(b); PUTP(W); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
     PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(xch); PUTP(gp); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out);
     PUTP(Hpp);
-    PUTP(mscr);
+    PUTP(mscr); PUTP(rotlog); PUTP(eig_aux);
 #undef PUTP
     HIPCHK(c, hipStreamSynchronize(c->stream));  // W is on the stack
     info.uploaded = true;
@@ -469,6 +472,7 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone) {
     hipLaunchKernelGGL(k_setup, dim3(3, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
   launch_iteration(c, count, g, mode);
   hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag);
+  hipLaunchKernelGGL(k_marg_vecs, dim3(MARG_VEC_WGS, count), dim3(256), 0, c->stream, c->d_base, c->L.total, flag);
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
 }
@@ -717,6 +721,7 @@ int lfvio_debug_marg_system(lfvio_ctx *c, int n, double *A, double *b) {
 int lfvio_debug_read_clocks(lfvio_ctx *c, long long *out32) {
   if (!c || !c->d_base) return LFVIO_ERR_ARG;
   HIPCHK(c, hipMemcpy(out32, c->d_base + offsetof(Slot, dbg), sizeof(long long) * 32, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(out32 + 32, c->d_base + offsetof(Slot, jtrace), sizeof(double) * 32, hipMemcpyDeviceToHost));
   return LFVIO_OK;
 }
 
