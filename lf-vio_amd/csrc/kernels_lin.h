@@ -18,8 +18,11 @@ DEV const MargPlan *marg_plan(const Slot *S, int mode) { return &S->marg[mode - 
 DEV int gidx20(int p, int q) { return p * 20 - (p * (p - 1)) / 2 + (q - p); }  // upper index, p <= q
 
 // ---------------------------------------------------------------------------
-// k_setup: grid (3, batch) x 256
+// k_setup: grid (SETUP_WGS + ceil(N / 256), batch) x 256:
+//   [0] state, [1..10] IMU information roots, [11..26] prior normal matrix, [27..] inverse depths
 // ---------------------------------------------------------------------------
+constexpr int SETUP_PRIOR_WGS = 16;
+constexpr int SETUP_WGS = 1 + LFVIO_WINDOW_SIZE + SETUP_PRIOR_WGS;
 __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mode) {
   Slot *S = SLOT(base, stride);
   const int tid = threadIdx.x;
@@ -28,7 +31,6 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     const double *src = (const double *)&S->x0;
     double *dst = (double *)&S->x[0];
     for (int k = tid; k < (int)(sizeof(FrameState) / 8); k += 256) dst[k] = src[k];
-    for (int l = tid; l < S->N; l += 256) S->lam[0][l] = S->lam0[l];
     if (tid == 0) {
       TRState *t = &S->tr;
       t->radius = 1e4;
@@ -51,97 +53,97 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     }
     __syncthreads();
     build_tab(&S->x0, &S->tab[0], tid);
-  } else if (blockIdx.x == 1) {
+  } else if (blockIdx.x <= LFVIO_WINDOW_SIZE) {
     // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64), hoisted out of the iteration loop:
-    // the reference recomputes it in every Evaluate().  One factor per wave: Gauss-Jordan with
-    // partial pivoting on [cov | I] in LDS, then a 15x15 Cholesky of the inverse.
-    __shared__ double A[4][15][31];
-    const int wv = tid >> 6, lane = tid & 63;
-    for (int it = 0; it < 3; it++) {
-      const int f = wv + 4 * it;
-      const bool act = f < LFVIO_WINDOW_SIZE && S->imu_active[f];
-      double(*M)[31] = A[wv];
-      if (act)
-        for (int e = lane; e < 225; e += 64) {
-          int r = e / 15, c = e % 15;
-          M[r][c] = S->imu[f].covariance[e];
-          M[r][15 + c] = (r == c) ? 1.0 : 0.0;
-        }
+    // the reference recomputes it in every Evaluate().  One factor per workgroup: Gauss-Jordan with
+    // partial pivoting on [cov | I] in LDS, then a 15x15 column Cholesky of the inverse.
+    const int f = blockIdx.x - 1;
+    if (!S->imu_active[f]) return;
+    __shared__ double M[15][31];
+    __shared__ double L[15][16];
+    __shared__ double col[16];
+    for (int e = tid; e < 225; e += 256) {
+      int r = e / 15, c = e % 15;
+      M[r][c] = S->imu[f].covariance[e];
+      M[r][15 + c] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < 15; k++) {
+      int p = k;
+      double best = fabs(M[k][k]);
+      for (int r = k + 1; r < 15; r++) {
+        double v = fabs(M[r][k]);
+        if (v > best) best = v, p = r;
+      }
       __syncthreads();
-      for (int k = 0; k < 15; k++) {
-        int p = k;
-        if (act) {
-          double best = fabs(M[k][k]);
-          for (int r = k + 1; r < 15; r++) {
-            double v = fabs(M[r][k]);
-            if (v > best) best = v, p = r;
-          }
-        }
-        __syncthreads();
-        if (act && p != k && lane < 30) {
-          double t = M[k][lane];
-          M[k][lane] = M[p][lane];
-          M[p][lane] = t;
-        }
-        __syncthreads();
-        double piv = act ? M[k][k] : 1.0;
-        __syncthreads();
-        if (act && lane < 30) M[k][lane] /= piv;
-        __syncthreads();
-        double fac[15];
-#pragma unroll
-        for (int r = 0; r < 15; r++) fac[r] = act ? M[r][k] : 0.0;
-        __syncthreads();
-        if (act && lane < 30) {
-          double mk = M[k][lane];
-#pragma unroll
-          for (int r = 0; r < 15; r++)
-            if (r != k) M[r][lane] -= fac[r] * mk;
-        }
-        __syncthreads();
+      if (p != k && tid < 30) {
+        double t = M[k][tid];
+        M[k][tid] = M[p][tid];
+        M[p][tid] = t;
       }
-      if (act && lane == 0) {
-        double L[15][15];
-        bool ok = true;
-        for (int j = 0; j < 15; j++) {
-          double s = M[j][15 + j];
-          for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
-          if (!(s > 0.0)) ok = false;
-          double d = sqrt(s);
-          L[j][j] = d;
-          for (int i = j + 1; i < 15; i++) {
-            double t = M[i][15 + j];
-            for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-            L[i][j] = t / d;
-          }
-        }
-        for (int i = 0; i < 15; i++)
-          for (int j = 0; j < 15; j++) S->imu_sqrt[f][i * 15 + j] = (j >= i && ok) ? L[j][i] : 0.0;
-        if (!ok) S->imu_active[f] = 0;
-      }
+      __syncthreads();
+      const double piv = M[k][k];
+      __syncthreads();
+      if (tid < 30) M[k][tid] /= piv;
+      __syncthreads();
+      // rows r != k: thread (r, c) <- M[r][c] - M[r][k] M[k][c]; the column of factors is read before it is overwritten
+      const int r = tid / 30, c = tid % 30;
+      double fac = 0, mk = 0, cur = 0;
+      if (tid < 450) fac = M[r][k], mk = M[k][c], cur = M[r][c];
+      double fac2 = 0, mk2 = 0, cur2 = 0;
+      const int t2 = tid + 256, r2 = t2 / 30, c2 = t2 % 30;
+      if (t2 < 450) fac2 = M[r2][k], mk2 = M[k][c2], cur2 = M[r2][c2];
+      __syncthreads();
+      if (r != k) M[r][c] = cur - fac * mk;
+      if (t2 < 450 && r2 != k) M[r2][c2] = cur2 - fac2 * mk2;
       __syncthreads();
     }
+    bool ok = true;
+    for (int j = 0; j < 15; j++) {
+      if (tid >= j && tid < 15) {
+        double t = M[tid][15 + j];
+        for (int k = 0; k < j; k++) t -= L[tid][k] * L[j][k];
+        col[tid] = t;
+      }
+      __syncthreads();
+      const double sj = col[j];
+      if (!(sj > 0.0)) ok = false;
+      const double d = sqrt(sj);
+      if (tid >= j && tid < 15) L[tid][j] = tid == j ? d : col[tid] / d;
+      __syncthreads();
+    }
+    if (tid < 225) {
+      const int i = tid / 15, j = tid % 15;
+      S->imu_sqrt[f][tid] = (j >= i && ok) ? L[j][i] : 0.0;
+    }
+    if (!ok && tid == 0) S->imu_active[f] = 0;
+  } else if (blockIdx.x >= SETUP_WGS) {
+    // inverse depths of the window: 256 landmarks per workgroup
+    const int l = (blockIdx.x - SETUP_WGS) * 256 + tid;
+    if (l < S->N) S->lam[0][l] = S->lam0[l];
   } else {
-    // prior: A' = J0^T J0, b0 = J0^T r0 (constant over the solve)
+    // prior: A' = J0^T J0, b0 = J0^T r0 (constant over the solve), entries spread over SETUP_PRIOR_WGS workgroups
     if (!S->prior_valid) return;
     const int n = S->prior_n;
+    const int part = blockIdx.x - (LFVIO_WINDOW_SIZE + 1);
     const double *J = S->prior_J;
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = part * 256 + tid; e < n * n; e += 256 * SETUP_PRIOR_WGS) {
       int r = e / n, c = e % n;
       double s = 0;
       for (int k = 0; k < n; k++) s = fma(J[k * n + r], J[k * n + c], s);
       S->prior_A[e] = s;
     }
-    for (int c = tid; c < n; c += 256) {
-      double s = 0;
-      for (int k = 0; k < n; k++) s = fma(J[k * n + c], S->prior_r[k], s);
-      S->prior_b0[c] = s;
-    }
+    if (part == 0)
+      for (int c = tid; c < n; c += 256) {
+        double s = 0;
+        for (int k = 0; k < n; k++) s = fma(J[k * n + c], S->prior_r[k], s);
+        S->prior_b0[c] = s;
+      }
   }
 }
 
 // ---------------------------------------------------------------------------
-// k_lin: grid (nLmBlocks + nChunks + 10 + 1, batch) x 64
+// k_lin: grid (nLmBlocks + nChunks + 10 + 1, batch) x 256
 // ---------------------------------------------------------------------------
 DEV void load_pair_uniform(const Tab *T, int pair, PairU &u) {
   u.M2 = ldm(T->M2[pair]);
@@ -152,30 +154,47 @@ DEV void load_pair_uniform(const Tab *T, int pair, PairU &u) {
   u.tic = ld3(T->tic);
 }
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int LIN_THREADS = 256;
+constexpr int LIN_LDS = LM_BLOCK * (WLD + 1) + 64;  // doubles: the W tile of the landmark role + reduction scratch
+
+DEV double quad_sum(double v) {  // sum over the 4 lanes of a quad, same value and same order in every lane
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+DEV d3 quad_sum3(d3 v) { return mk3(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z)); }
+
+// Landmark role: 64 landmarks per workgroup, 4 lanes per landmark (lane q takes the observations 1+q, 5+q, 9+q of the
+// track), so the dependent chain per lane is a quarter of the track.  The 80-wide row w_l is built in an LDS tile and
+// leaves as whole 512-byte lines.
 DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
-  const int lane = threadIdx.x;
+  double *red = lds + LM_BLOCK * (WLD + 1);
+  const int tid = threadIdx.x, lml = tid >> 2, q = tid & 3;
   const TRState *tr = &S->tr;
   const int cur = tr->cur;
   const Tab *T = &S->tab[cur];
   const int Nlim = is_marg(mode) ? marg_plan(S, mode)->N0 : S->N;
-  const int l = blk * LM_BLOCK + lane;
+  const int l = blk * LM_BLOCK + lml;
   const bool valid = l < Nlim;
   const int est_td = S->est_td;
   const int est_ex = is_marg(mode) ? 1 : S->est_ex;  // ResidualBlockInfo::Evaluate asks for every Jacobian
   const double td = S->x[cur].td;
-#pragma unroll 8
-  for (int c = 0; c < WLD; c++) tile[lane][c] = 0.0;
-  double a = 0, b = 0, cost = 0, lam = 1.0;
+  for (int e = tid; e < LM_BLOCK * (WLD + 1); e += LIN_THREADS) lds[e] = 0.0;
+  __syncthreads();
+  double a = 0, b = 0, cost = 0, lam = 1.0, wtd = 0;
+  d3 wPi = mk3(0, 0, 0), wTi = wPi, wTic = wPi, wTx = wPi;
+  int i = 0;
   if (valid) {
-    const int i = S->lm_start[l], k = S->lm_cnt[l], o0 = S->lm_obs0[l];
+    i = S->lm_start[l];
+    const int k = S->lm_cnt[l], o0 = S->lm_obs0[l];
     lam = S->lam[cur][l];
     ObsPair ob;
     load_obs(S, o0, ob.pi, ob.vi, ob.tdi, ob.rowi);
-    d3 wPi = mk3(0, 0, 0), wTi = wPi, wTic = wPi, wTx = wPi;
-    double wtd = 0;
     const m33 ricT = ldm(T->ricT);
-    for (int o = 1; o < k; o++) {
+    for (int o = 1 + q; o < k; o += 4) {
       const int j = i + o, pair = i * 11 + j;
       load_obs(S, o0 + o, ob.pj, ob.vj, ob.tdj, ob.rowj);
       PairU u;
@@ -189,8 +208,8 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
       wPi = wPi + wp;
       wTi = wTi + (jl0 * B.jti[0] + jl1 * B.jti[1]);
       d3 wtj = jl0 * B.jtj[0] + jl1 * B.jtj[1];
-      tile[lane][6 * j + 0] = -wp.x, tile[lane][6 * j + 1] = -wp.y, tile[lane][6 * j + 2] = -wp.z;
-      tile[lane][6 * j + 3] = wtj.x, tile[lane][6 * j + 4] = wtj.y, tile[lane][6 * j + 5] = wtj.z;
+      tile[lml][6 * j + 0] = -wp.x, tile[lml][6 * j + 1] = -wp.y, tile[lml][6 * j + 2] = -wp.z;
+      tile[lml][6 * j + 3] = wtj.x, tile[lml][6 * j + 4] = wtj.y, tile[lml][6 * j + 5] = wtj.z;
       m33 M3 = u.M2;
 #pragma unroll
       for (int e = 0; e < 9; e++) M3.a[e] -= ricT.a[e];
@@ -201,17 +220,23 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
       b += jl0 * B.r[0] + jl1 * B.r[1];
       cost += 0.5 * B.rho0;
     }
-    tile[lane][6 * i + 0] = wPi.x, tile[lane][6 * i + 1] = wPi.y, tile[lane][6 * i + 2] = wPi.z;
-    tile[lane][6 * i + 3] = wTi.x, tile[lane][6 * i + 4] = wTi.y, tile[lane][6 * i + 5] = wTi.z;
+  }
+  // the track's sums over its 4 lanes (fixed order)
+  wPi = quad_sum3(wPi), wTi = quad_sum3(wTi), wTic = quad_sum3(wTic), wTx = quad_sum3(wTx);
+  wtd = quad_sum(wtd), a = quad_sum(a), b = quad_sum(b), cost = quad_sum(cost);
+  const bool lead = valid && q == 0;
+  if (lead) {
+    tile[lml][6 * i + 0] = wPi.x, tile[lml][6 * i + 1] = wPi.y, tile[lml][6 * i + 2] = wPi.z;
+    tile[lml][6 * i + 3] = wTi.x, tile[lml][6 * i + 4] = wTi.y, tile[lml][6 * i + 5] = wTi.z;
     if (est_ex) {
-      tile[lane][66] = wTic.x, tile[lane][67] = wTic.y, tile[lane][68] = wTic.z;
-      tile[lane][69] = wTx.x, tile[lane][70] = wTx.y, tile[lane][71] = wTx.z;
+      tile[lml][66] = wTic.x, tile[lml][67] = wTic.y, tile[lml][68] = wTic.z;
+      tile[lml][69] = wTx.x, tile[lml][70] = wTx.y, tile[lml][71] = wTx.z;
     }
-    if (est_td) tile[lane][72] = wtd;
+    if (est_td) tile[lml][72] = wtd;
   }
   // per-landmark scalars
   double g2 = 0, asv2 = 0, lam2 = 0, bmax = 0;
-  if (valid) {
+  if (lead) {
     double s = 1.0, D2 = a;
     if (mode == MODE_SOLVE) {
       if (!tr->scaled) {
@@ -228,33 +253,47 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
       g2 = gr * gr;
       const double v = gr / dg;
       asv2 = s * s * a * v * v;
-      tile[lane][COL_K] = b / D2;
+      tile[lml][COL_K] = b / D2;
     }
     S->a[l] = a;
     S->b[l] = b;
-    tile[lane][COL_B] = b;
+    tile[lml][COL_B] = b;
     lam2 = lam * lam;
     bmax = fabs(b);
+  } else {
+    cost = 0.0;  // counted once per track
   }
   cost = wave_sum(cost);
   g2 = wave_sum(g2);
   asv2 = wave_sum(asv2);
   lam2 = wave_sum(lam2);
   bmax = wave_max(bmax);
-  if (lane == 0) {
-    double *p = S->lm_part + (size_t)blk * LMS;
-    p[0] = cost, p[1] = g2, p[2] = asv2, p[3] = lam2, p[4] = bmax;
+  if ((tid & 63) == 0) {
+    double *r = red + 8 * (tid >> 6);
+    r[0] = cost, r[1] = g2, r[2] = asv2, r[3] = lam2, r[4] = bmax;
   }
   __syncthreads();
+  if (tid < 5) {
+    double *p = S->lm_part + (size_t)blk * LMS;
+    p[tid] = tid < 4 ? ((red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]))
+                     : fmax(fmax(red[4], red[12]), fmax(red[20], red[28]));
+  }
   double *Wb = S->W + (size_t)blk * LM_BLOCK * WLD;
-  for (int e = lane; e < LM_BLOCK * WLD; e += 64) Wb[e] = tile[e / WLD][e % WLD];
+  for (int e = tid; e < LM_BLOCK * WLD; e += LIN_THREADS) Wb[e] = tile[e / WLD][e % WLD];
 }
 
+// Gram role: one chunk (<= CHUNK_MAX observations of one frame pair) per workgroup, 64 observations per wave pass.
+// Every lane turns its observation into the two 14-wide basis rows c0, c1; the 14x14 Gram sum of c c^T over the chunk is
+// a SYRK and runs on the FP64 matrix pipe: 16 lanes at a time put their rows in LDS ([32 rows][16 + 1]), then eight
+// v_mfma_f64_16x16x4_f64 take four rows each (lane (k, col) feeds row k, column col to both operands: D += C^T C).
+// The accumulator is 4 doubles per lane instead of 105, and no cross-lane reduction of the Gram entries is left.
 DEV void lin_gram_role(Slot *S, int chunk, int mode, double *lds) {
-  double(*Qf)[15] = (double(*)[15]) lds;
-  double(*E)[20] = (double(*)[20])(lds + 14 * 15);
-  double(*T1)[20] = (double(*)[20])(lds + 14 * 15 + 14 * 20);
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  double(*stage)[17] = (double(*)[17])(lds + wv * 32 * 17);          // per wave: 32 rows x (16 + 1 pad)
+  double *accw = lds + 4 * 32 * 17;                                   // [4 waves][256]
+  double(*Qf)[16] = (double(*)[16])(accw + 4 * 256);                  // 16 x 16
+  double(*E)[20] = (double(*)[20])(accw + 4 * 256 + 256);             // 14 x 20
+  double(*T1)[20] = (double(*)[20])(accw + 4 * 256 + 256 + 14 * 20);  // 14 x 20
   const TRState *tr = &S->tr;
   const int cur = tr->cur;
   const Tab *T = &S->tab[cur];
@@ -265,72 +304,74 @@ DEV void lin_gram_role(Slot *S, int chunk, int mode, double *lds) {
   const double td = S->x[cur].td;
   PairU u;
   load_pair_uniform(T, pair, u);
-  double q[NQ];
-#pragma unroll
-  for (int e = 0; e < NQ; e++) q[e] = 0.0;
-  for (int idx = begin + lane; idx < end; idx += 64) {
-    const int oj = S->pm_obs[idx], l = S->pm_lm[idx];
-    const int oi = S->lm_obs0[l];
-    const double lam = S->lam[cur][l];
-    ObsPair ob;
-    load_obs(S, oi, ob.pi, ob.vi, ob.tdi, ob.rowi);
-    load_obs(S, oj, ob.pj, ob.vj, ob.tdj, ob.rowj);
-    Basis B;
-    visual_basis(ob, lam, td, est_td, S->tr_over_row, S->half_row, S->sqrt_info, u, B);
-    double c0[14], c1[14];
-    c0[0] = B.red[0].x, c0[1] = B.red[0].y, c0[2] = B.red[0].z;
-    c1[0] = B.red[1].x, c1[1] = B.red[1].y, c1[2] = B.red[1].z;
-    c0[3] = B.jti[0].x, c0[4] = B.jti[0].y, c0[5] = B.jti[0].z;
-    c1[3] = B.jti[1].x, c1[4] = B.jti[1].y, c1[5] = B.jti[1].z;
-    c0[6] = B.jtj[0].x, c0[7] = B.jtj[0].y, c0[8] = B.jtj[0].z;
-    c1[6] = B.jtj[1].x, c1[7] = B.jtj[1].y, c1[8] = B.jtj[1].z;
-    c0[9] = B.jtx[0].x, c0[10] = B.jtx[0].y, c0[11] = B.jtx[0].z;
-    c1[9] = B.jtx[1].x, c1[10] = B.jtx[1].y, c1[11] = B.jtx[1].z;
-    c0[12] = B.jtd[0], c1[12] = B.jtd[1];
-    c0[13] = B.r[0], c1[13] = B.r[1];
-    int e = 0;
-#pragma unroll
-    for (int p = 0; p < 14; p++)
-#pragma unroll
-      for (int r = p; r < 14; r++) {
-        q[e] = fma(c0[p], c0[r], fma(c1[p], c1[r], q[e]));
-        e++;
-      }
-  }
-  // wave reduction (fixed butterfly order => deterministic)
-#pragma unroll
-  for (int e = 0; e < NQ; e++) q[e] = wave_sum(q[e]);
-  if (lane == 0) {
-    int e = 0;
-#pragma unroll
-    for (int p = 0; p < 14; p++)
-#pragma unroll
-      for (int r = p; r < 14; r++) {
-        Qf[p][r] = q[e];
-        Qf[r][p] = q[e];
-        e++;
-      }
-  }
   // E: basis(14) -> factor columns(20) = [Pi th_i Pj th_j tic th_ic td r]
-  for (int e = lane; e < 14 * 20; e += 64) E[e / 20][e % 20] = 0.0;
+  for (int e = tid; e < 14 * 20; e += LIN_THREADS) E[e / 20][e % 20] = 0.0;
+  for (int e = lane; e < 32 * 17; e += 64) stage[0][e] = 0.0;  // columns 14, 15 stay zero
   __syncthreads();
-  if (lane < 9) {
-    const int r = lane / 3, c = lane % 3;
-    const double m1 = T->M1[j][lane];
-    E[r][c] = m1;                                  // dr/dPi  = red M1
-    E[r][6 + c] = -m1;                             // dr/dPj  = -red M1
-    E[r][12 + c] = T->M2[pair][lane] - T->ricT[lane];  // dr/dtic = red (M2 - ric^T)
-  } else if (lane < 12) {
-    const int k = lane - 9;
+  double4_t acc = double4_t{0, 0, 0, 0};
+  for (int base = begin + 64 * wv; base < end; base += LIN_THREADS) {  // wave-uniform trip count
+    const int idx = base + lane;
+    double c0[14], c1[14];
+#pragma unroll
+    for (int e = 0; e < 14; e++) c0[e] = c1[e] = 0.0;
+    if (idx < end) {
+      const int oj = S->pm_obs[idx], l = S->pm_lm[idx];
+      const int oi = S->lm_obs0[l];
+      const double lam = S->lam[cur][l];
+      ObsPair ob;
+      load_obs(S, oi, ob.pi, ob.vi, ob.tdi, ob.rowi);
+      load_obs(S, oj, ob.pj, ob.vj, ob.tdj, ob.rowj);
+      Basis B;
+      visual_basis(ob, lam, td, est_td, S->tr_over_row, S->half_row, S->sqrt_info, u, B);
+      c0[0] = B.red[0].x, c0[1] = B.red[0].y, c0[2] = B.red[0].z;
+      c1[0] = B.red[1].x, c1[1] = B.red[1].y, c1[2] = B.red[1].z;
+      c0[3] = B.jti[0].x, c0[4] = B.jti[0].y, c0[5] = B.jti[0].z;
+      c1[3] = B.jti[1].x, c1[4] = B.jti[1].y, c1[5] = B.jti[1].z;
+      c0[6] = B.jtj[0].x, c0[7] = B.jtj[0].y, c0[8] = B.jtj[0].z;
+      c1[6] = B.jtj[1].x, c1[7] = B.jtj[1].y, c1[8] = B.jtj[1].z;
+      c0[9] = B.jtx[0].x, c0[10] = B.jtx[0].y, c0[11] = B.jtx[0].z;
+      c1[9] = B.jtx[1].x, c1[10] = B.jtx[1].y, c1[11] = B.jtx[1].z;
+      c0[12] = B.jtd[0], c1[12] = B.jtd[1];
+      c0[13] = B.r[0], c1[13] = B.r[1];
+    }
+    for (int r = 0; r < 4; r++) {
+      // LDS operations of one wave execute in program order: only the compiler has to be kept from moving them
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if ((lane >> 4) == r) {
+        const int row = 2 * (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 14; e++) stage[row][e] = c0[e], stage[row + 1][e] = c1[e];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        const double v = stage[4 * g + (lane >> 4)][lane & 15];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+      }
+    }
+  }
+  // accumulator element (row = (lane >> 4) + 4 reg, col = lane & 15); the four waves are added in fixed order
+#pragma unroll
+  for (int r = 0; r < 4; r++) accw[wv * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+  __syncthreads();
+  Qf[tid >> 4][tid & 15] = (accw[tid] + accw[256 + tid]) + (accw[512 + tid] + accw[768 + tid]);
+  if (tid < 9) {
+    const int r = tid / 3, c = tid % 3;
+    const double m1 = T->M1[j][tid];
+    E[r][c] = m1;                                      // dr/dPi  = red M1
+    E[r][6 + c] = -m1;                                 // dr/dPj  = -red M1
+    E[r][12 + c] = T->M2[pair][tid] - T->ricT[tid];    // dr/dtic = red (M2 - ric^T)
+  } else if (tid < 12) {
+    const int k = tid - 9;
     E[3 + k][3 + k] = 1.0;
     E[6 + k][9 + k] = 1.0;
     E[9 + k][15 + k] = 1.0;
-  } else if (lane == 12) {
+  } else if (tid == 12) {
     E[12][18] = 1.0;
     E[13][19] = 1.0;
   }
   __syncthreads();
-  for (int e = lane; e < 14 * 20; e += 64) {
+  for (int e = tid; e < 14 * 20; e += LIN_THREADS) {
     const int r = e / 20, c = e % 20;
     double s = 0;
 #pragma unroll
@@ -339,7 +380,7 @@ DEV void lin_gram_role(Slot *S, int chunk, int mode, double *lds) {
   }
   __syncthreads();
   double *out = S->gram_part + (size_t)chunk * NGP;
-  for (int e = lane; e < 400; e += 64) {
+  for (int e = tid; e < 400; e += LIN_THREADS) {
     const int p = e / 20, c = e % 20;
     if (p > c) continue;
     double s = 0;
@@ -353,49 +394,48 @@ DEV void lin_imu_role(Slot *S, int f, int mode, double *lds) {
   double(*Jr)[30] = (double(*)[30]) lds;
   double(*Jw)[31] = (double(*)[31])(lds + 450);
   double *rr = lds + 450 + 465, *rw = rr + 16;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   double *out = S->imu_out + (size_t)f * IMU_OUT;
   const bool active = S->imu_active[f] && (mode == MODE_SOLVE || (f == 0 && marg_plan(S, mode)->use_imu0)) &&
                       (!S->sharded || S->pose_side);
   if (!active) {
-    for (int e = lane; e < IMU_OUT; e += 64) out[e] = 0.0;
+    for (int e = tid; e < IMU_OUT; e += LIN_THREADS) out[e] = 0.0;
     return;
   }
   const FrameState *x = &S->x[S->tr.cur];
-  for (int e = lane; e < 450; e += 64) Jr[e / 30][e % 30] = 0.0;
+  for (int e = tid; e < 450; e += LIN_THREADS) Jr[e / 30][e % 30] = 0.0;
   __syncthreads();
-  if (lane == 0) {
-    imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
-    imu_raw_jacobian(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], &Jr[0][0]);
-  }
+  // two single-lane jobs on two waves: residual | Jacobian
+  if (tid == 0) imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
+  if (tid == 64) imu_raw_jacobian(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], &Jr[0][0]);
   __syncthreads();
   const double *Sq = S->imu_sqrt[f];
-  if (lane < 15) {
+  if (tid < 15) {
     double s = 0;
-    for (int k = 0; k < 15; k++) s = fma(Sq[lane * 15 + k], rr[k], s);
-    rw[lane] = s;
+    for (int k = 0; k < 15; k++) s = fma(Sq[tid * 15 + k], rr[k], s);
+    rw[tid] = s;
   }
-  for (int e = lane; e < 450; e += 64) {
+  for (int e = tid; e < 450; e += LIN_THREADS) {
     const int r = e / 30, c = e % 30;
     double s = 0;
     for (int k = r; k < 15; k++) s = fma(Sq[r * 15 + k], Jr[k][c], s);  // sqrt_info is upper triangular
     Jw[r][c] = s;
   }
   __syncthreads();
-  for (int e = lane; e < 900; e += 64) {
+  for (int e = tid; e < 900; e += LIN_THREADS) {
     const int p = e / 30, c = e % 30;
     double s = 0;
 #pragma unroll
     for (int k = 0; k < 15; k++) s = fma(Jw[k][p], Jw[k][c], s);
     out[e] = s;
   }
-  if (lane < 30) {
+  if (tid < 30) {
     double s = 0;
 #pragma unroll
-    for (int k = 0; k < 15; k++) s = fma(Jw[k][lane], rw[k], s);
-    out[900 + lane] = s;
+    for (int k = 0; k < 15; k++) s = fma(Jw[k][tid], rw[k], s);
+    out[900 + tid] = s;
   }
-  if (lane == 32) {
+  if (tid == 32) {
     double s = 0;
     for (int k = 0; k < 15; k++) s = fma(rw[k], rw[k], s);
     out[930] = 0.5 * s;
@@ -403,38 +443,48 @@ DEV void lin_imu_role(Slot *S, int f, int mode, double *lds) {
 }
 
 DEV void lin_prior_role(Slot *S, int mode, double *lds) {
-  double *dx = lds, *r = lds + KP;
-  const int lane = threadIdx.x;
+  double *dx = lds, *r = lds + KP, *part = r + KP;  // part: [2][KP]
+  const int tid = threadIdx.x;
   double *g = S->prior_g;
-  for (int c = lane; c < KP + 4; c += 64) g[c] = 0.0;
+  for (int c = tid; c < KP + 4; c += LIN_THREADS) g[c] = 0.0;
   if (!S->prior_valid || (S->sharded && !S->pose_side)) return;
   const int n = S->prior_n;
   const FrameState *x = &S->x[S->tr.cur];
-  if (lane < S->prior_nb) prior_block_dx(S, x, lane, dx);
+  if (tid < S->prior_nb) prior_block_dx(S, x, tid, dx);
   __syncthreads();
   const double *J = S->prior_J;
-  for (int row = lane; row < n; row += 64) {
-    double s = S->prior_r[row];
-    for (int c = 0; c < n; c++) s = fma(J[row * n + c], dx[c], s);
-    r[row] = s;
+  // r = r0 + J0 dx: 4 lanes per row
+  for (int row = tid >> 2; row < n; row += LIN_THREADS / 4) {
+    double s = 0;
+    for (int c = tid & 3; c < n; c += 4) s = fma(J[row * n + c], dx[c], s);
+    s = quad_sum(s);
+    if ((tid & 3) == 0) r[row] = S->prior_r[row] + s;
   }
   __syncthreads();
-  for (int c = lane; c < n; c += 64) {
-    double s = 0;
-    for (int k = 0; k < n; k++) s = fma(J[k * n + c], r[k], s);
-    g[S->prior_cmap[c]] = s;
+  // g = J0^T r: column c, two halves of the rows
+  {
+    const int c = tid & 127, h = tid >> 7, k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
+    for (int cc = c; cc < n; cc += 128) {
+      double s = 0;
+      for (int k = k0; k < k1; k++) s = fma(J[k * n + cc], r[k], s);
+      part[h * KP + cc] = s;
+    }
   }
-  double cs = 0;
-  for (int row = lane; row < n; row += 64) cs += r[row] * r[row];
-  cs = wave_sum(cs);
-  if (lane == 0) g[KP] = 0.5 * cs;
+  __syncthreads();
+  for (int c = tid; c < n; c += LIN_THREADS) g[S->prior_cmap[c]] = part[c] + part[KP + c];
+  if (tid < 64) {
+    double cs = 0;
+    for (int row = tid; row < n; row += 64) cs += r[row] * r[row];
+    cs = wave_sum(cs);
+    if (tid == 0) g[KP] = 0.5 * cs;
+  }
 }
 
-__global__ __launch_bounds__(64) void k_lin(char *base, size_t stride, int mode, int gLm, int gCh) {
+__global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode, int gLm, int gCh) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   if (tr->done || !tr->do_lin) return;
-  __shared__ __attribute__((aligned(16))) double lds[LM_BLOCK * (WLD + 1)];  // one workspace, aliased per role
+  __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLm, gCh); each slot uses its own counts
   int b = blockIdx.x;
   if (b < gLm) {
@@ -464,8 +514,6 @@ __global__ __launch_bounds__(64) void k_lin(char *base, size_t stride, int mode,
 // FP64 matrix pipe.  Lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the
 // accumulator holds D[row = (l>>4) + 4*reg][col = l&15].
 // ---------------------------------------------------------------------------
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
 __global__ __launch_bounds__(64) void k_schur(char *base, size_t stride, int mode) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
@@ -534,7 +582,7 @@ DEV int schur_index(int R, int Cc) {
 DEV double schur_get(const double *Sc, int r, int c) { return r <= c ? Sc[schur_index(r, c)] : Sc[schur_index(c, r)]; }
 
 // ---------------------------------------------------------------------------
-// k_sum: grid (HPP_BLOCKS + SCHUR_LEN/256 + 1, batch) x 256
+// k_sum: grid (HPP_BLOCKS + SCHUR_LEN/256 + 1, batch) x 256   (pre = 1: second level, after k_presum)
 //   role 1: every packed entry of the pose-side Gauss-Newton Hessian H_pp (and of g_p) is
 //           produced by exactly ONE thread that adds its contributions in a fixed order —
 //           Gram chunks of the frame pairs touching it, the (at most two) IMU factors, the
@@ -581,8 +629,9 @@ DEV bool col_active(const Slot *S, int c, int mode) {
   return true;
 }
 
-DEV double gram_pair_sum(const Slot *S, int i, int j, int idx, int chunk_limit) {
+DEV double gram_pair_sum(const Slot *S, int i, int j, int idx, int chunk_limit, int pre) {
   const int p = i * 11 + j;
+  if (pre) return S->pairG[(size_t)p * NGP + idx];
   const int c0 = S->pair_chunk0[p];
   int c1 = S->pair_chunk0[p + 1];
   if (c1 > chunk_limit) c1 = chunk_limit;
@@ -599,21 +648,100 @@ DEV double gram_pair_sum(const Slot *S, int i, int j, int idx, int chunk_limit) 
 
 // the ex/td entries receive a term from EVERY chunk: chunks are contiguous in pair order, so this is a plain
 // strided sweep with independent loads (4 accumulators, fixed association => still deterministic)
-DEV double gram_all_pairs(const Slot *S, int idx, int chunk_limit) {
-  const double *gp = S->gram_part + idx;
+DEV double gram_all_pairs(const Slot *S, int idx, int chunk_limit, int pre) {
+  const double *gp = pre ? S->pairG + idx : S->gram_part + idx;
+  const int lim = pre ? NPAIR : chunk_limit;
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   int c = 0;
-  for (; c + 4 <= chunk_limit; c += 4) {
+  for (; c + 4 <= lim; c += 4) {
     s0 += gp[(size_t)c * NGP];
     s1 += gp[(size_t)(c + 1) * NGP];
     s2 += gp[(size_t)(c + 2) * NGP];
     s3 += gp[(size_t)(c + 3) * NGP];
   }
-  for (; c < chunk_limit; c++) s0 += gp[(size_t)c * NGP];
+  for (; c < lim; c++) s0 += gp[(size_t)c * NGP];
   return (s0 + s1) + (s2 + s3);
 }
 
-__global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode) {
+// ---------------------------------------------------------------------------
+// k_presum: grid (NPAIR + PRE_SCHUR_BLOCKS + 1, batch) x 256 — only launched for large windows, where one thread of
+// k_sum would otherwise walk thousands of partials.  First level of the fixed-order reductions:
+//   [0, NPAIR)            Gram chunks of one frame pair -> pairG[pair]
+//   [NPAIR, +25*G)        Schur SYRK partials in groups of PRE_GROUP, in place (the sum lands in the group's first part)
+//   last                  landmark scalar partials -> lm_sum
+// ---------------------------------------------------------------------------
+constexpr int PRE_GROUP = 32;
+constexpr int PRE_GROUPS = (SCHUR_PARTS_MAX + PRE_GROUP - 1) / PRE_GROUP + 1;
+constexpr int PRE_SCHUR_BLOCKS = (SCHUR_LEN / 256) * PRE_GROUPS;
+__global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int mode) {
+  Slot *S = SLOT(base, stride);
+  const TRState *tr = &S->tr;
+  if (tr->done) return;
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  if (b < NPAIR) {
+    if (!tr->do_lin) return;
+    const int chunk_limit = is_marg(mode) ? marg_plan(S, mode)->nChunks0 : S->nChunks;
+    const int c0 = S->pair_chunk0[b];
+    int c1 = S->pair_chunk0[b + 1];
+    if (c1 > chunk_limit) c1 = chunk_limit;
+    if (tid < NGP) {
+      const double *gp = S->gram_part + tid;
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      int c = c0;
+      for (; c + 4 <= c1; c += 4) {
+        s0 += gp[(size_t)c * NGP], s1 += gp[(size_t)(c + 1) * NGP];
+        s2 += gp[(size_t)(c + 2) * NGP], s3 += gp[(size_t)(c + 3) * NGP];
+      }
+      for (; c < c1; c++) s0 += gp[(size_t)c * NGP];
+      S->pairG[(size_t)b * NGP + tid] = (s0 + s1) + (s2 + s3);
+    }
+    return;
+  }
+  b -= NPAIR;
+  if (b < PRE_SCHUR_BLOCKS) {
+    if (!tr->do_schur) return;
+    const int grp = b / (SCHUR_LEN / 256), e = (b % (SCHUR_LEN / 256)) * 256 + tid;
+    int parts = S->nSchurParts;
+    if (is_marg(mode)) parts = (marg_plan(S, mode)->N0 + S->schur_lm - 1) / S->schur_lm;
+    const int p0 = grp * PRE_GROUP;
+    if (p0 >= parts) return;
+    const int p1 = min(parts, p0 + PRE_GROUP);
+    double *sp = S->schur_part + e;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int p = p0;
+    for (; p + 4 <= p1; p += 4) {
+      a0 += sp[(size_t)p * SCHUR_LEN], a1 += sp[(size_t)(p + 1) * SCHUR_LEN];
+      a2 += sp[(size_t)(p + 2) * SCHUR_LEN], a3 += sp[(size_t)(p + 3) * SCHUR_LEN];
+    }
+    for (; p < p1; p++) a0 += sp[(size_t)p * SCHUR_LEN];
+    sp[(size_t)p0 * SCHUR_LEN] = (a0 + a1) + (a2 + a3);
+    return;
+  }
+  if (!tr->do_lin) return;
+  // landmark scalars: 4 sums + 1 max over the blocks; lane-strided partials, then a fixed tree
+  __shared__ double red[5][256];
+  const int blocks = S->nLmBlocks;
+  double v[5] = {0, 0, 0, 0, 0};
+  for (int k = tid; k < blocks; k += 256) {
+    const double *q = S->lm_part + (size_t)k * LMS;
+    v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3], v[4] = fmax(v[4], q[4]);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++) red[k][tid] = v[k];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) red[k][tid] += red[k][tid + w];
+      red[4][tid] = fmax(red[4][tid], red[4][tid + w]);
+    }
+    __syncthreads();
+  }
+  if (tid < 5) S->lm_sum[tid] = red[tid][0];
+}
+
+__global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode, int pre) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   if (tr->done) return;
@@ -638,19 +766,19 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
           cam_block(c, fc, lc);
           if (fr < 11) {  // both pose blocks (c <= r => fc <= fr)
             if (fr == fc) {
-              for (int j = fr + 1; j < 11; j++) val += gram_pair_sum(S, fr, j, gidx20(lc, lr), chunk_limit);
-              for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lc, 6 + lr), chunk_limit);
+              for (int j = fr + 1; j < 11; j++) val += gram_pair_sum(S, fr, j, gidx20(lc, lr), chunk_limit, pre);
+              for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lc, 6 + lr), chunk_limit, pre);
             } else {
-              val += gram_pair_sum(S, fc, fr, gidx20(lc, 6 + lr), chunk_limit);
+              val += gram_pair_sum(S, fc, fr, gidx20(lc, 6 + lr), chunk_limit, pre);
             }
           } else {
             const int hi = fr == 11 ? 12 + lr : 18;
             if (fc < 11) {
-              for (int j = fc + 1; j < 11; j++) val += gram_pair_sum(S, fc, j, gidx20(lc, hi), chunk_limit);
-              for (int i = 0; i < fc; i++) val += gram_pair_sum(S, i, fc, gidx20(6 + lc, hi), chunk_limit);
+              for (int j = fc + 1; j < 11; j++) val += gram_pair_sum(S, fc, j, gidx20(lc, hi), chunk_limit, pre);
+              for (int i = 0; i < fc; i++) val += gram_pair_sum(S, i, fc, gidx20(6 + lc, hi), chunk_limit, pre);
             } else {
               const int lo = fc == 11 ? 12 + lc : 18;
-              val += gram_all_pairs(S, gidx20(lo, hi), chunk_limit);
+              val += gram_all_pairs(S, gidx20(lo, hi), chunk_limit, pre);
             }
           }
         }
@@ -677,11 +805,11 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
           int fr, lr;
           cam_block(r, fr, lr);
           if (fr < 11) {
-            for (int j = fr + 1; j < 11; j++) val += gram_pair_sum(S, fr, j, gidx20(lr, 19), chunk_limit);
-            for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lr, 19), chunk_limit);
+            for (int j = fr + 1; j < 11; j++) val += gram_pair_sum(S, fr, j, gidx20(lr, 19), chunk_limit, pre);
+            for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lr, 19), chunk_limit, pre);
           } else {
             const int lo = fr == 11 ? 12 + lr : 18;
-            val += gram_all_pairs(S, gidx20(lo, 19), chunk_limit);
+            val += gram_all_pairs(S, gidx20(lo, 19), chunk_limit, pre);
           }
         }
         const int f0 = col_frame(r);
@@ -705,22 +833,23 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
     int parts = S->nSchurParts;
     if (is_marg(mode)) parts = (marg_plan(S, mode)->N0 + S->schur_lm - 1) / S->schur_lm;
     // fixed association (8 interleaved accumulators, then a fixed tree): deterministic, 8 loads in flight
+    const size_t ps = pre ? (size_t)PRE_GROUP * SCHUR_LEN : (size_t)SCHUR_LEN;  // pre: one partial per group
+    if (pre) parts = (parts + PRE_GROUP - 1) / PRE_GROUP;
     const double *sp = S->schur_part + e;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
     int p = 0;
     for (; p + 8 <= parts; p += 8) {
-      a0 += sp[(size_t)p * SCHUR_LEN], a1 += sp[(size_t)(p + 1) * SCHUR_LEN];
-      a2 += sp[(size_t)(p + 2) * SCHUR_LEN], a3 += sp[(size_t)(p + 3) * SCHUR_LEN];
-      a4 += sp[(size_t)(p + 4) * SCHUR_LEN], a5 += sp[(size_t)(p + 5) * SCHUR_LEN];
-      a6 += sp[(size_t)(p + 6) * SCHUR_LEN], a7 += sp[(size_t)(p + 7) * SCHUR_LEN];
+      a0 += sp[p * ps], a1 += sp[(p + 1) * ps], a2 += sp[(p + 2) * ps], a3 += sp[(p + 3) * ps];
+      a4 += sp[(p + 4) * ps], a5 += sp[(p + 5) * ps], a6 += sp[(p + 6) * ps], a7 += sp[(p + 7) * ps];
     }
-    for (; p < parts; p++) a0 += sp[(size_t)p * SCHUR_LEN];
+    for (; p < parts; p++) a0 += sp[p * ps];
     S->schur_sum[e] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     return;
   }
   if (!tr->do_lin) return;
-  int blocks = S->nLmBlocks;
-  if (tid < 4) {
+  int blocks = pre ? 0 : S->nLmBlocks;  // pre: lm_sum comes from k_presum
+  if (pre) {
+  } else if (tid < 4) {
     double s = 0;
     for (int k = 0; k < blocks; k++) s += S->lm_part[(size_t)k * LMS + tid];
     S->lm_sum[tid] = s;

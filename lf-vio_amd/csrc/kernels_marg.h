@@ -24,6 +24,13 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
   TRState *ts = &S->tr;
   const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {
+    // setDepth / getDepthVector round trip (feature_manager.cpp:148,191), 128 landmarks per workgroup
+    const int l = (blockIdx.x - 1) * 128 + tid;
+    double *lam = S->lam[ts->cur];
+    if (l < S->N) lam[l] = 1.0 / (1.0 / lam[l]);
+    return;
+  }
   __shared__ double rot[9], P0[3], oP0[3];
   FrameState *x = &S->x[ts->cur];
   if (tid == 0) {
@@ -71,9 +78,6 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
   } else if (tid == 11) {
     x->ex[3] = qn.x, x->ex[4] = qn.y, x->ex[5] = qn.z, x->ex[6] = qn.w;
   }
-  // setDepth / getDepthVector round trip (feature_manager.cpp:148,191)
-  double *lam = S->lam[ts->cur];
-  for (int l = tid; l < S->N; l += 128) lam[l] = 1.0 / (1.0 / lam[l]);
   __syncthreads();
   if (tid == 0) {
     ts->done = 0;
@@ -430,6 +434,21 @@ DEV int jacobi_systolic(const double *As, int lda, const int *perm, double *B, i
   return sweeps;
 }
 
+// whole-wave shifts by one lane as DPP moves (wave_shl:1 / wave_shr:1): a few cycles instead of the LDS-crossbar round
+// trip of ds_bpermute, and the eigenvector recurrence below is one dependent chain per wave
+DEV double wave_from_next(double v) {  // lane i <- lane i+1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+DEV double wave_from_prev(double v) {  // lane i <- lane i-1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // Eigenvectors of the prior's eigen-problem from the rotation log, and with them the outputs of
 // marginalization_factor.cpp:283-291:  J0 = sqrt(S) V^T,  r0 = sqrt(1/S) V^T b'.
 // V = J_1 J_2 ... J_G applied to the rows of the identity: one wave per row, lane k = tournament slot k holding the row's
@@ -469,8 +488,8 @@ __global__ __launch_bounds__(256) void k_marg_vecs(char *base, size_t stride, in
         const double np_ = c * vp - s * vq, nq = s * vp + c * vq;
         // ring move: top row one slot towards slot 0, bottom row one slot away from it; top 0 -> bot 1,
         // bot (half-1) -> top (half-1), bot 0 stays
-        const double up = __shfl_down(np_, 1);
-        const double dn = __shfl_up(k == 0 ? np_ : nq, 1);
+        const double up = wave_from_next(np_);
+        const double dn = wave_from_prev(k == 0 ? np_ : nq);
         vp = k == half - 1 ? nq : up;
         vq = k == 0 ? nq : dn;
       }

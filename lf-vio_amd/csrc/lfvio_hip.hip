@@ -426,11 +426,19 @@ Grid grid_for(lfvio_ctx *c, int count) {
   return g;
 }
 
+// fixed-order reduction of the partials; two levels once a single k_sum thread would have to walk hundreds of them
+void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
+  const size_t st = c->L.total;
+  const int pre = (g.ch > 2 * NPAIR || g.sc > 4 * PRE_GROUP) ? 1 : 0;
+  if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + PRE_SCHUR_BLOCKS + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode);
+  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre);
+}
+
 void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const size_t st = c->L.total;
-  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, mode, g.lm, g.ch);
+  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lm, g.ch);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, mode);
-  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode);
+  launch_sum(c, count, g, mode);
   if (mode == MODE_SOLVE) {
     hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
     hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
@@ -445,7 +453,7 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
 int enqueue_solve(lfvio_ctx *c, int count, int max_iter) {
   const Grid g = grid_for(c, count);
   const int passes = std::max(max_iter, 0) + 4;
-  hipLaunchKernelGGL(k_setup, dim3(3, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
   if (c->use_graph) {
     if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes) {
       destroy_graph(c);
@@ -469,7 +477,7 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone) {
   const Grid g = grid_for(c, count);
   const int mode = MODE_MARG + flag;
   if (standalone)
-    hipLaunchKernelGGL(k_setup, dim3(3, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
+    hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
   launch_iteration(c, count, g, mode);
   hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag);
   hipLaunchKernelGGL(k_marg_vecs, dim3(MARG_VEC_WGS, count), dim3(256), 0, c->stream, c->d_base, c->L.total, flag);
@@ -642,7 +650,7 @@ int lfvio_batch_optimize_async(lfvio_ctx *c, int count, int marg_flag) {
     }
   int rc = enqueue_solve(c, count, max_iter);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_gauge, dim3(1, count), dim3(128), 0, c->stream, c->d_base, c->L.total);
+  hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total);
   return enqueue_marg(c, count, marg_flag, false);
 }
 
@@ -676,11 +684,11 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   if (rc) return rc;
   if ((rc = upload_window(c, 0, in))) return rc;
   const Grid g = grid_for(c, 1);
-  hipLaunchKernelGGL(k_setup, dim3(3, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
-  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, 1), dim3(64), 0, c->stream, c->d_base, c->L.total,
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, 1).lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, c->stream, c->d_base, c->L.total,
                      MODE_SOLVE, g.lm, g.ch);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, 1), dim3(64), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
-  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  launch_sum(c, 1, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -736,17 +744,17 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
-  hipLaunchKernelGGL(k_setup, dim3(3, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
   // one full linearization so that every kernel has valid inputs
-  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE, g.lm, g.ch);
+  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, g.lm, g.ch);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE);
-  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
+  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
-      case 0: hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE, g.lm, g.ch); break;
+      case 0: hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, g.lm, g.ch); break;
       case 1: hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE); break;
-      case 2: hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE); break;
+      case 2: hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0); break;
       default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st); break;
     }
   }

@@ -53,7 +53,7 @@ def test_linearization_vs_golden(eng, golden_dir, name):
     check_linearization(lin, ref)
 
 
-@pytest.mark.parametrize("seed,n", [(0, 300), (1, 300), (2, 1000), (3, 7)])
+@pytest.mark.parametrize("seed,n", [(0, 300), (1, 300), (2, 1000), (3, 7), (4, 3000)])
 def test_linearization_vs_oracle(eng, oracle, seed, n):
     w = synth.make_window(seed, n)
     check_linearization(eng.linearize(w), oracle.linearize(w))
@@ -89,7 +89,8 @@ def test_solve_vs_golden_windows(eng, oracle, golden_dir, name):
 
 
 @pytest.mark.parametrize("seed,n,kw", [(0, 300, {}), (1, 300, dict(estimate_td=0)), (2, 300, dict(estimate_extrinsic=0)),
-                                        (3, 1000, {}), (4, 300, dict(tr=0.02)), (5, 64, {}), (6, 65, {})])
+                                        (3, 1000, {}), (4, 300, dict(tr=0.02)), (5, 64, {}), (6, 65, {}),
+                                        (7, 3000, {})])  # 3000: the two-level partial reduction (k_presum)
 def test_solve_vs_oracle(eng, oracle, seed, n, kw):
     w = synth.make_window(seed, n, **kw)
     check_solution(eng.solve(w), oracle.solve(w), w)
