@@ -41,7 +41,7 @@ constexpr int XCH_LEN = XOFF_C + 16;
 enum { XS_COST = 0, XS_G2, XS_ASV2, XS_LAM2, XS_BMAX, XS_GN2, XS_GGN, XS_CCOST, XS_MLIN, XS_MQUAD, XS_DN, XS_XN };   // packed H_pp (14878), reused as dense scratch by the marginalization
 constexpr int LM_BLOCK = 64;     // landmarks per workgroup (one wave) in the landmark sweep
 constexpr int CHUNK_LANES = 64;
-constexpr int CHUNK_MAX = 512;   // observations per Gram chunk (8 per lane)
+constexpr int CHUNK_MAX = 64;    // observations per Gram chunk: one wave pass; a workgroup of k_lin takes 4 chunks
 constexpr int SCHUR_LM_MIN = 16;  // landmarks per wave in the Schur SYRK: >= 16, grown so that parts <= SCHUR_PARTS_MAX
 constexpr int SCHUR_PARTS_MAX = 1024;
 constexpr int LMS = 16;          // per-block landmark scalar partials

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
 }
 
 // ---------------------------------------------------------------------------
-// k_lin: grid (nLmBlocks + nChunks + 10 + 1, batch) x 256
+// k_lin: grid (nLmBlocks + ceil(nChunks / 4) + 10 + 1, batch) x 256
 // ---------------------------------------------------------------------------
 DEV void load_pair_uniform(const Tab *T, int pair, PairU &u) {
   u.M2 = ldm(T->M2[pair]);
@@ -282,18 +282,23 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
   for (int e = tid; e < LM_BLOCK * WLD; e += LIN_THREADS) Wb[e] = tile[e / WLD][e % WLD];
 }
 
-// Gram role: one chunk (<= CHUNK_MAX observations of one frame pair) per workgroup, 64 observations per wave pass.
-// Every lane turns its observation into the two 14-wide basis rows c0, c1; the 14x14 Gram sum of c c^T over the chunk is
-// a SYRK and runs on the FP64 matrix pipe: 16 lanes at a time put their rows in LDS ([32 rows][16 + 1]), then eight
-// v_mfma_f64_16x16x4_f64 take four rows each (lane (k, col) feeds row k, column col to both operands: D += C^T C).
-// The accumulator is 4 doubles per lane instead of 105, and no cross-lane reduction of the Gram entries is left.
-DEV void lin_gram_role(Slot *S, int chunk, int mode, double *lds) {
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  double(*stage)[17] = (double(*)[17])(lds + wv * 32 * 17);          // per wave: 32 rows x (16 + 1 pad)
-  double *accw = lds + 4 * 32 * 17;                                   // [4 waves][256]
-  double(*Qf)[16] = (double(*)[16])(accw + 4 * 256);                  // 16 x 16
-  double(*E)[20] = (double(*)[20])(accw + 4 * 256 + 256);             // 14 x 20
-  double(*T1)[20] = (double(*)[20])(accw + 4 * 256 + 256 + 14 * 20);  // 14 x 20
+// Gram role: one chunk (<= 64 observations of one frame pair) per WAVE, four chunks per workgroup; the waves never
+// meet (no workgroup barrier in this role).  Every lane turns its observation into the two 14-wide basis rows c0, c1;
+// the 14x14 Gram sum of c c^T over the chunk is a SYRK and runs on the FP64 matrix pipe: 16 lanes at a time put their
+// rows in LDS ([32 rows][16 + 1]), then eight v_mfma_f64_16x16x4_f64 take four rows each (lane (k, col) feeds row k,
+// column col to both operands: D += C^T C).  The accumulator is 4 doubles per lane instead of 105 and no cross-lane
+// reduction of the Gram entries is left.  LDS operations of one wave execute in program order, so between the phases
+// only the compiler has to be kept from moving them (wavefront-scope fences).
+DEV void lin_gram_role(Slot *S, int wg, int mode, double *lds) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = 4 * wg + wv;
+  if (chunk >= S->nChunks) return;
+  if (is_marg(mode) && chunk >= marg_plan(S, mode)->nChunks0) return;
+  double *my = lds + wv * (32 * 17 + 256 + 14 * 20);
+  double(*stage)[17] = (double(*)[17]) my;              // 32 rows x (16 + 1 pad); later T1 (14 x 20)
+  double(*Qf)[16] = (double(*)[16])(my + 32 * 17);      // 16 x 16
+  double(*E)[20] = (double(*)[20])(my + 32 * 17 + 256);  // 14 x 20
+  double(*T1)[20] = (double(*)[20]) my;
   const TRState *tr = &S->tr;
   const int cur = tr->cur;
   const Tab *T = &S->tab[cur];
@@ -305,82 +310,78 @@ DEV void lin_gram_role(Slot *S, int chunk, int mode, double *lds) {
   PairU u;
   load_pair_uniform(T, pair, u);
   // E: basis(14) -> factor columns(20) = [Pi th_i Pj th_j tic th_ic td r]
-  for (int e = tid; e < 14 * 20; e += LIN_THREADS) E[e / 20][e % 20] = 0.0;
+  for (int e = lane; e < 14 * 20; e += 64) E[0][e] = 0.0;
   for (int e = lane; e < 32 * 17; e += 64) stage[0][e] = 0.0;  // columns 14, 15 stay zero
-  __syncthreads();
+  const int idx = begin + lane;
+  double c0[14], c1[14];
+#pragma unroll
+  for (int e = 0; e < 14; e++) c0[e] = c1[e] = 0.0;
+  if (idx < end) {
+    const int oj = S->pm_obs[idx], l = S->pm_lm[idx];
+    const int oi = S->lm_obs0[l];
+    const double lam = S->lam[cur][l];
+    ObsPair ob;
+    load_obs(S, oi, ob.pi, ob.vi, ob.tdi, ob.rowi);
+    load_obs(S, oj, ob.pj, ob.vj, ob.tdj, ob.rowj);
+    Basis B;
+    visual_basis(ob, lam, td, est_td, S->tr_over_row, S->half_row, S->sqrt_info, u, B);
+    c0[0] = B.red[0].x, c0[1] = B.red[0].y, c0[2] = B.red[0].z;
+    c1[0] = B.red[1].x, c1[1] = B.red[1].y, c1[2] = B.red[1].z;
+    c0[3] = B.jti[0].x, c0[4] = B.jti[0].y, c0[5] = B.jti[0].z;
+    c1[3] = B.jti[1].x, c1[4] = B.jti[1].y, c1[5] = B.jti[1].z;
+    c0[6] = B.jtj[0].x, c0[7] = B.jtj[0].y, c0[8] = B.jtj[0].z;
+    c1[6] = B.jtj[1].x, c1[7] = B.jtj[1].y, c1[8] = B.jtj[1].z;
+    c0[9] = B.jtx[0].x, c0[10] = B.jtx[0].y, c0[11] = B.jtx[0].z;
+    c1[9] = B.jtx[1].x, c1[10] = B.jtx[1].y, c1[11] = B.jtx[1].z;
+    c0[12] = B.jtd[0], c1[12] = B.jtd[1];
+    c0[13] = B.r[0], c1[13] = B.r[1];
+  }
   double4_t acc = double4_t{0, 0, 0, 0};
-  for (int base = begin + 64 * wv; base < end; base += LIN_THREADS) {  // wave-uniform trip count
-    const int idx = base + lane;
-    double c0[14], c1[14];
+  const int nrounds = (end - begin + 15) >> 4;  // rounds of 16 observations that hold any
+  for (int r = 0; r < nrounds; r++) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if ((lane >> 4) == r) {
+      const int row = 2 * (lane & 15);
 #pragma unroll
-    for (int e = 0; e < 14; e++) c0[e] = c1[e] = 0.0;
-    if (idx < end) {
-      const int oj = S->pm_obs[idx], l = S->pm_lm[idx];
-      const int oi = S->lm_obs0[l];
-      const double lam = S->lam[cur][l];
-      ObsPair ob;
-      load_obs(S, oi, ob.pi, ob.vi, ob.tdi, ob.rowi);
-      load_obs(S, oj, ob.pj, ob.vj, ob.tdj, ob.rowj);
-      Basis B;
-      visual_basis(ob, lam, td, est_td, S->tr_over_row, S->half_row, S->sqrt_info, u, B);
-      c0[0] = B.red[0].x, c0[1] = B.red[0].y, c0[2] = B.red[0].z;
-      c1[0] = B.red[1].x, c1[1] = B.red[1].y, c1[2] = B.red[1].z;
-      c0[3] = B.jti[0].x, c0[4] = B.jti[0].y, c0[5] = B.jti[0].z;
-      c1[3] = B.jti[1].x, c1[4] = B.jti[1].y, c1[5] = B.jti[1].z;
-      c0[6] = B.jtj[0].x, c0[7] = B.jtj[0].y, c0[8] = B.jtj[0].z;
-      c1[6] = B.jtj[1].x, c1[7] = B.jtj[1].y, c1[8] = B.jtj[1].z;
-      c0[9] = B.jtx[0].x, c0[10] = B.jtx[0].y, c0[11] = B.jtx[0].z;
-      c1[9] = B.jtx[1].x, c1[10] = B.jtx[1].y, c1[11] = B.jtx[1].z;
-      c0[12] = B.jtd[0], c1[12] = B.jtd[1];
-      c0[13] = B.r[0], c1[13] = B.r[1];
+      for (int e = 0; e < 14; e++) stage[row][e] = c0[e], stage[row + 1][e] = c1[e];
     }
-    for (int r = 0; r < 4; r++) {
-      // LDS operations of one wave execute in program order: only the compiler has to be kept from moving them
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      if ((lane >> 4) == r) {
-        const int row = 2 * (lane & 15);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int e = 0; e < 14; e++) stage[row][e] = c0[e], stage[row + 1][e] = c1[e];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-      for (int g = 0; g < 8; g++) {
-        const double v = stage[4 * g + (lane >> 4)][lane & 15];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
-      }
+    for (int g = 0; g < 8; g++) {
+      const double v = stage[4 * g + (lane >> 4)][lane & 15];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
     }
   }
-  // accumulator element (row = (lane >> 4) + 4 reg, col = lane & 15); the four waves are added in fixed order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // accumulator element (row = (lane >> 4) + 4 reg, col = lane & 15)
 #pragma unroll
-  for (int r = 0; r < 4; r++) accw[wv * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
-  __syncthreads();
-  Qf[tid >> 4][tid & 15] = (accw[tid] + accw[256 + tid]) + (accw[512 + tid] + accw[768 + tid]);
-  if (tid < 9) {
-    const int r = tid / 3, c = tid % 3;
-    const double m1 = T->M1[j][tid];
-    E[r][c] = m1;                                      // dr/dPi  = red M1
-    E[r][6 + c] = -m1;                                 // dr/dPj  = -red M1
-    E[r][12 + c] = T->M2[pair][tid] - T->ricT[tid];    // dr/dtic = red (M2 - ric^T)
-  } else if (tid < 12) {
-    const int k = tid - 9;
+  for (int r = 0; r < 4; r++) Qf[(lane >> 4) + 4 * r][lane & 15] = acc[r];
+  if (lane < 9) {
+    const int r = lane / 3, c = lane % 3;
+    const double m1 = T->M1[j][lane];
+    E[r][c] = m1;                                       // dr/dPi  = red M1
+    E[r][6 + c] = -m1;                                  // dr/dPj  = -red M1
+    E[r][12 + c] = T->M2[pair][lane] - T->ricT[lane];   // dr/dtic = red (M2 - ric^T)
+  } else if (lane < 12) {
+    const int k = lane - 9;
     E[3 + k][3 + k] = 1.0;
     E[6 + k][9 + k] = 1.0;
     E[9 + k][15 + k] = 1.0;
-  } else if (tid == 12) {
+  } else if (lane == 12) {
     E[12][18] = 1.0;
     E[13][19] = 1.0;
   }
-  __syncthreads();
-  for (int e = tid; e < 14 * 20; e += LIN_THREADS) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int e = lane; e < 14 * 20; e += 64) {
     const int r = e / 20, c = e % 20;
     double s = 0;
 #pragma unroll
     for (int k = 0; k < 14; k++) s = fma(Qf[r][k], E[k][c], s);
     T1[r][c] = s;
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   double *out = S->gram_part + (size_t)chunk * NGP;
-  for (int e = tid; e < 400; e += LIN_THREADS) {
+  for (int e = lane; e < 400; e += 64) {
     const int p = e / 20, c = e % 20;
     if (p > c) continue;
     double s = 0;
@@ -494,9 +495,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t strid
     return;
   }
   b -= gLm;
-  if (b < gCh) {
-    if (b >= S->nChunks) return;
-    if (is_marg(mode) && b >= marg_plan(S, mode)->nChunks0) return;
+  if (b < gCh) {  // gCh workgroups of 4 chunks
     lin_gram_role(S, b, mode, lds);
     return;
   }

@@ -426,6 +426,12 @@ Grid grid_for(lfvio_ctx *c, int count) {
   return g;
 }
 
+void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
+  const int gram_wgs = (g.ch + 3) / 4;  // one chunk per wave
+  hipLaunchKernelGGL(k_lin, dim3(g.lm + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, c->L.total,
+                     mode, g.lm, gram_wgs);
+}
+
 // fixed-order reduction of the partials; two levels once a single k_sum thread would have to walk hundreds of them
 void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const size_t st = c->L.total;
@@ -436,7 +442,7 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
 
 void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const size_t st = c->L.total;
-  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lm, g.ch);
+  launch_lin(c, count, g, mode);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, mode);
   launch_sum(c, count, g, mode);
   if (mode == MODE_SOLVE) {
@@ -685,8 +691,7 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   if ((rc = upload_window(c, 0, in))) return rc;
   const Grid g = grid_for(c, 1);
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, 1).lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
-  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, c->stream, c->d_base, c->L.total,
-                     MODE_SOLVE, g.lm, g.ch);
+  launch_lin(c, 1, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, 1), dim3(64), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
   launch_sum(c, 1, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total);
@@ -746,13 +751,13 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   HIPCHK(c, hipEventCreate(&e1));
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
   // one full linearization so that every kernel has valid inputs
-  hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, g.lm, g.ch);
+  launch_lin(c, count, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE);
   hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
-      case 0: hipLaunchKernelGGL(k_lin, dim3(g.lm + g.ch + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, g.lm, g.ch); break;
+      case 0: launch_lin(c, count, g, MODE_SOLVE); break;
       case 1: hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE); break;
       case 2: hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0); break;
       default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st); break;
