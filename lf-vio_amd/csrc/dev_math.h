@@ -141,6 +141,24 @@ DEV void pose_plus(const double *x, const double *d, double *o) {
 }
 
 // wave64 butterfly sum
+// 1/sqrt(x) and 1/x from the hardware estimates (v_rsq_f64 / v_rcp_f64, about 2^-26) with two Newton steps each: a
+// quarter of the dependent instructions of the correctly-rounded library forms; the Jacobi step and the Cholesky pivot
+// wait on these chains.
+// x is a normal, positive (rsqrt) or non-zero (rcp) double far from the range ends.
+DEV double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  return y;
+}
+DEV double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+}
+
 DEV double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

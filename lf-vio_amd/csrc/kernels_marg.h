@@ -254,23 +254,6 @@ DEV int jacobi_eig(double *A, double *V, int n, int ld, int tid, int nthreads, d
   return sweeps;
 }
 
-// 1/sqrt(x) and 1/x from the hardware estimates (v_rsq_f64 / v_rcp_f64, about 2^-26) with two Newton steps each: a
-// quarter of the dependent instructions of the correctly-rounded library forms, and the Jacobi step waits on this chain.
-// x is a normal, positive (rsqrt) or non-zero (rcp) double far from the range ends.
-DEV double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double hx = 0.5 * x;
-  y = fma(y, fma(-hx * y, y, 0.5), y);
-  y = fma(y, fma(-hx * y, y, 0.5), y);
-  return y;
-}
-DEV double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = fma(y, fma(-x, y, 1.0), y);
-  y = fma(y, fma(-x, y, 1.0), y);
-  return y;
-}
-
 // Jacobi rotation that annihilates a_pq: t = tan(phi) is the smaller root of t^2 + 2 theta t - 1 = 0,
 // theta = (a_qq - a_pp) / (2 a_pq), written without the division by a_pq:  t = sgn(d) e / (|d| + sqrt(d^2 + e^2)),
 // d = a_qq - a_pp, e = 2 a_pq.  (cos, sin) = (1, t) / sqrt(1 + t^2); cos^2 + sin^2 = 1 to rounding whatever the error of t.

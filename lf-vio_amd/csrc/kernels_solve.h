@@ -209,54 +209,85 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   __syncthreads();  // Hs may now be overwritten
   STAMP(S, 3);
 
-  // ---- right-looking Cholesky, one barrier per pivot (column owners live in one 16-lane group)
+  // ---- right-looking Cholesky with one column of look-ahead, one barrier per pivot.
+  // Column k+1 is brought up to date first, its owners (16 lanes of one wave) scale it and publish it, and only then
+  // is the rest of the rank-1 update of pivot k applied: the rsqrt / scale / LDS-write chain of the next pivot runs
+  // while the other three waves are still in their trailing update.
   bool bad = !(mu < 1.0);  // ComputeGaussNewtonStep: `while (mu_ < max_mu_)` — no attempt at mu >= 1
+  // scale column k (tile column KB of the register tile, lane group kk) by 1/sqrt(pivot) and publish it; the column
+  // buffer is written for EVERY row of the owner (zero outside (k, KP]) so that readers load it unconditionally
+#define FACTOR_COLUMN(KB, kk_, k_)                                                                       \
+  do {                                                                                                   \
+    const int fk = (kk_), k2 = (k_);                                                                     \
+    const int src = ((fk & 3) << 4) | fk; /* the diagonal lives in this lane of wave fk >> 2 */          \
+    const double dd = m[KB][KB];                                                                         \
+    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dd), src),                \
+                                      __builtin_amdgcn_readlane(__double2loint(dd), src));               \
+    if (tcol == fk) {                                                                                    \
+      double *cbw = colbuf + (k2 & 1) * 176;                                                             \
+      if (!(d > 0.0)) bad = true;                                                                        \
+      const double dinv = fast_rsqrt(d);                                                                 \
+      _Pragma("unroll") for (int a = KB; a < 11; a++) {                                                  \
+        const int i = trow + 16 * a;                                                                     \
+        double v = 0.0;                                                                                  \
+        if (i > k2 && i <= KP) {                                                                         \
+          m[a][KB] *= dinv;                                                                              \
+          v = m[a][KB];                                                                                  \
+        } else if (i == k2) {                                                                            \
+          m[a][KB] = d * dinv;                                                                           \
+          invd[k2] = dinv;                                                                               \
+        }                                                                                                \
+        cbw[i] = v;                                                                                      \
+      }                                                                                                  \
+    }                                                                                                    \
+  } while (0)
+#define LOAD_COLUMN(KB, k_)                                              \
+  do {                                                                   \
+    const double *cbr = colbuf + ((k_) & 1) * 176;                       \
+    _Pragma("unroll") for (int a = KB; a < 11; a++) {                    \
+      li[a] = cbr[trow + 16 * a];                                        \
+      lj[a] = cbr[tcol + 16 * a];                                        \
+    }                                                                    \
+  } while (0)
+  FACTOR_COLUMN(0, 0, 0);
+  __syncthreads();
 #pragma unroll
   for (int kb = 0; kb < 11; kb++) {
+    // pivots whose successor column sits in the same tile column kb
 #pragma nounroll
-    for (int kk = 0; kk < 16; kk++) {
+    for (int kk = 0; kk < 15; kk++) {
       const int k = kb * 16 + kk;
       if (k >= KP) break;
-      double *cb = colbuf + (k & 1) * 176;
-      // the diagonal entry lives in lane ((kk&3)<<4)|kk of wave kk>>2: scalar broadcast
-      const int src = ((kk & 3) << 4) | kk;
-      const double dd = m[kb][kb];
-      const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dd), src),
-                                        __builtin_amdgcn_readlane(__double2loint(dd), src));
-      if (tcol == kk) {
-        if (!(d > 0.0)) bad = true;
-        // library rsqrt: the raw v_rsq_f64 estimate + hand Newton steps went wrong on hardware
-        // (bring-up finding), so keep the correctly scaled OCML sequence here
-        const double dinv = rsqrt(d);
-#pragma unroll
-        for (int a = kb; a < 11; a++) {
-          const int i = trow + 16 * a;
-          // the column buffer is written for EVERY row of the owner (zero outside (k, KP]) so that
-          // readers load it unconditionally with immediate offsets: the pivot loop is issue-bound
-          double v = 0.0;
-          if (i > k && i <= KP) {
-            m[a][kb] *= dinv;
-            v = m[a][kb];
-          } else if (i == k) {
-            m[a][kb] = d * dinv;
-            invd[k] = dinv;
-          }
-          cb[i] = v;
-        }
-      }
-      __syncthreads();
       double li[11], lj[11];
+      LOAD_COLUMN(kb, k);
 #pragma unroll
-      for (int a = kb; a < 11; a++) {
-        li[a] = cb[trow + 16 * a];
-        lj[a] = cb[tcol + 16 * a];
-      }
+      for (int a = kb; a < 11; a++) m[a][kb] = fma(-li[a], lj[kb], m[a][kb]);
+      if (k + 1 < KP) FACTOR_COLUMN(kb, kk + 1, k + 1);
 #pragma unroll
-      for (int a = kb; a < 11; a++)
+      for (int a = kb + 1; a < 11; a++)
 #pragma unroll
-        for (int b = kb; b <= a; b++) m[a][b] = fma(-li[a], lj[b], m[a][b]);
+        for (int b = kb + 1; b <= a; b++) m[a][b] = fma(-li[a], lj[b], m[a][b]);
+      __syncthreads();
+    }
+    // last pivot of the tile column: its successor opens tile column kb + 1
+    if (kb < 10) {
+      const int k = kb * 16 + 15;
+      double li[11], lj[11];
+      LOAD_COLUMN(kb, k);
+#pragma unroll
+      for (int a = kb + 1; a < 11; a++) m[a][kb + 1] = fma(-li[a], lj[kb + 1], m[a][kb + 1]);
+      FACTOR_COLUMN(kb + 1 < 11 ? kb + 1 : 10, 0, k + 1);
+#pragma unroll
+      for (int a = kb; a < 11; a++) m[a][kb] = fma(-li[a], lj[kb], m[a][kb]);
+#pragma unroll
+      for (int a = kb + 2; a < 11; a++)
+#pragma unroll
+        for (int b = kb + 2; b <= a; b++) m[a][b] = fma(-li[a], lj[b], m[a][b]);
+      __syncthreads();
     }
   }
+#undef FACTOR_COLUMN
+#undef LOAD_COLUMN
   STAMP(S, 4);
   {
     double f = bad ? 1.0 : 0.0;

@@ -37,3 +37,4 @@ mn = {11: "gather", 12: "eig15", 13: "schur+store", 14: "sort+eig76", 15: "J0/r0
 print("k_marg_solve phases:", {mn[k]: c[k] - c[k - 1] for k in range(11, 16)})
 
 print("jacobi step segments, cycles/step (angle, barrier1, rotate+store, barrier2, load):", [int(v / max(1, c[25] * 75)) for v in tr[13:18]])
+
