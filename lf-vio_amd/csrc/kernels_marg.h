@@ -312,12 +312,18 @@ DEV int jacobi_systolic(const double *As, int lda, const int *perm, double *B, i
   __syncthreads();
   const int nblk = half * (half + 1) / 2;
   const bool own = tid < nblk;
+  // the diagonal blocks go to the first lanes (one wave computes all rotation angles, the others skip that code),
+  // the strictly lower blocks follow in triangular order
   int ka = 0, kb = 0;
-  if (own) {
-    ka = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
-    while ((ka + 1) * (ka + 2) / 2 <= tid) ka++;
-    while (ka * (ka + 1) / 2 > tid) ka--;
-    kb = tid - ka * (ka + 1) / 2;
+  if (tid < half) {
+    ka = kb = tid;
+  } else if (own) {
+    const int t = tid - half;
+    ka = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ka + 1) * (ka + 2) / 2 <= t) ka++;
+    while (ka * (ka + 1) / 2 > t) ka--;
+    kb = t - ka * (ka + 1) / 2;
+    ka += 1;
   }
   const bool diag = own && ka == kb;
   const int r00 = ka * ldb + kb, r01 = ka * ldb + half + kb, r10 = (half + ka) * ldb + kb, r11 = (half + ka) * ldb + half + kb;
@@ -348,24 +354,21 @@ DEV int jacobi_systolic(const double *As, int lda, const int *perm, double *B, i
   }
   __syncthreads();
   int sweeps = 0, g = 0;
-  double prev_off = 1e300, maxrel = 0.0;
+  double prev_off = 1e300;
 #if defined(JAC_TIMING)
   long long jt_last = 0;
   if (tid == 0)
     for (int k = 12; k < 20; k++) trace[k] = 0.0;
 #endif
   for (int sweep = 0; sweep < JMAX_SWEEPS; sweep++) {
-    const double mrw = wave_max(maxrel);
-    maxrel = 0.0;
     double off = 0, dia = 0;
     if (diag) dia = b00 * b00 + b11 * b11, off = 2.0 * b10 * b10;
     else if (own) off = 2.0 * (b00 * b00 + b01 * b01 + b10 * b10 + b11 * b11);
     off = wave_sum(off), dia = wave_sum(dia);
-    if ((tid & 63) == 0) scratch[tid >> 6] = off, scratch[16 + (tid >> 6)] = dia, scratch[32 + (tid >> 6)] = mrw;
+    if ((tid & 63) == 0) scratch[tid >> 6] = off, scratch[16 + (tid >> 6)] = dia;
     __syncthreads();
-    double so = 0, sd = 0, mr = 0;
-    for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[16 + w], mr = fmax(mr, scratch[32 + w]);
-    if (trace && tid == 0 && sweep >= 1 && sweep <= 12) trace[19 + sweep] = mr;
+    double so = 0, sd = 0;
+    for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[16 + w];
     __syncthreads();
     if (trace && tid == 0 && sweep < 12) trace[sweep] = so / sd;
     if (so <= 1e-24 * sd || so == 0.0) break;
@@ -376,11 +379,7 @@ DEV int jacobi_systolic(const double *As, int lda, const int *perm, double *B, i
       JT(0);
       if (diag) {
         double c = 1.0, s = 0.0;
-        if (ka > 0 || np == n) {  // slot 0 of an odd n holds the dummy index
-          jacobi_angle(b00, b11, b10, c, s);
-          const double den = fabs(b00 * b11);
-          if (b10 != 0.0) maxrel = fmax(maxrel, den > 0.0 ? b10 * b10 / den : 1e300);
-        }
+        if (ka > 0 || np == n) jacobi_angle(b00, b11, b10, c, s);  // slot 0 of an odd n holds the dummy index
         const double2 r = make_double2(c, s);
         cs[ka] = r;
         rotlog[(size_t)g * JLOG_LD + ka] = r;
@@ -390,12 +389,13 @@ DEV int jacobi_systolic(const double *As, int lda, const int *perm, double *B, i
       JT(2);
       if (own) {
         const double2 ra = cs[ka], rb = cs[kb];
-        const double t00 = rb.x * b00 - rb.y * b01, t01 = rb.y * b00 + rb.x * b01;
-        const double t10 = rb.x * b10 - rb.y * b11, t11 = rb.y * b10 + rb.x * b11;
-        B[w00] = ra.x * t00 - ra.y * t10;
-        if (w01 >= 0) B[w01] = ra.x * t01 - ra.y * t11;
-        B[w10] = ra.y * t00 + ra.x * t10;
-        B[w11] = ra.y * t01 + ra.x * t11;
+        // (explicit fma: the step is bound by the instructions a wave can issue)
+        const double t00 = fma(rb.x, b00, -(rb.y * b01)), t01 = fma(rb.y, b00, rb.x * b01);
+        const double t10 = fma(rb.x, b10, -(rb.y * b11)), t11 = fma(rb.y, b10, rb.x * b11);
+        B[w00] = fma(ra.x, t00, -(ra.y * t10));
+        if (w01 >= 0) B[w01] = fma(ra.x, t01, -(ra.y * t11));
+        B[w10] = fma(ra.y, t00, ra.x * t10);
+        B[w11] = fma(ra.y, t01, ra.x * t11);
       }
       JT(3);
       __syncthreads();

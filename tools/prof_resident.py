@@ -31,7 +31,6 @@ print("  total", c[7] - c[0], " jacobi sweeps (m15, n):", c[24], c[25])
 import struct
 tr = [struct.unpack("d", struct.pack("q", clk[32 + k]))[0] for k in range(32)]
 print("  jacobi off/diag mass per sweep:", ["%.1e" % v for v in tr[:12]])
-print("  jacobi max a_pq^2/(a_pp a_qq) seen in sweep:", ["%.1e" % v for v in tr[20:32]])
 
 mn = {11: "gather", 12: "eig15", 13: "schur+store", 14: "sort+eig76", 15: "J0/r0 out"}
 print("k_marg_solve phases:", {mn[k]: c[k] - c[k - 1] for k in range(11, 16)})
