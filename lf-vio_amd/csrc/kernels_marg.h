@@ -17,7 +17,7 @@
 
 constexpr int MARG_THREADS = 768;   // 12 waves: one 2x2 block of the 38 x 39 / 2 = 741 lower blocks per thread
 constexpr int MARG_MAXD = 96;  // 15 dropped + 76 kept, padded
-constexpr int LDN = 80;              // LDS row stride of the n x n (n <= 76) eigen-problem, see jacobi_eig
+constexpr int LDN = 80;              // LDS row stride of the n x n (n <= 76) eigen-problem, see jacobi_systolic
 constexpr size_t MARG_LDS = (size_t)17408 * sizeof(double);  // >= LPACK + KP + 64 and >= the eigen-phase carve below
 
 __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
@@ -108,150 +108,6 @@ DEV void rr_pair(int k, int step, int np, int n, int &p, int &q) {
     if (q < 0) q += np - 1;
   }
   if (q >= n) q = -1;
-}
-
-// Parallel cyclic Jacobi, A = V diag V^T (A, V: n x n, row stride ld; A is overwritten with the eigenvalues on its
-// diagonal).  One step = np/2 disjoint rotations.  The step is software-pipelined so that the serial
-// divide / sqrt / rsqrt chain of the rotation angles (wave 0) overlaps the eigenvector update of the previous step:
-//   phase 1: wave 0 computes the rotations of step g from A | all waves apply V <- V J(g-1)
-//   phase 2: A <- J(g)^T A J(g)
-// Work is split statically: thread t owns 2x2 blocks {t, t+T} of the half x half block grid and the (row, slot) items
-// {t, t+T, t+2T} of V, so every element is loaded once, rotated in registers and stored once per step.
-DEV int jacobi_eig(double *A, double *V, int n, int ld, int tid, int nthreads, double2 *cs, double *scratch,
-                   double *trace = nullptr) {
-  for (int e = tid; e < n * ld; e += nthreads) V[e] = 0.0;
-  __syncthreads();
-  for (int e = tid; e < n; e += nthreads) V[e * ld + e] = 1.0;
-  __syncthreads();
-  const int np = n + (n & 1);
-  const int half = np / 2;
-  if (n < 2) return 0;
-  int sweeps = 0;
-  const int tx = tid & 15, ty = tid >> 4, nty = nthreads >> 4;
-  // static ownership (requires half^2 <= 2T and n*half <= 3T: 1444 <= 2048, 2888 <= 3072 for n = 76, T = 1024)
-  int aka[2], akb[2], vrow[3], vk[3];
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int e = tid + u * nthreads;
-    aka[u] = e < half * half ? e / half : -1;
-    akb[u] = e % half;
-  }
-#pragma unroll
-  for (int u = 0; u < 3; u++) {
-    const int e = tid + u * nthreads;
-    vrow[u] = e < n * half ? e / half : -1;
-    vk[u] = e % half;
-  }
-  auto apply_v = [&](int step, int buf) {
-    int p[3], q[3];
-    double v0[3], v1[3];
-    double2 r[3];
-#pragma unroll
-    for (int u = 0; u < 3; u++) {
-      p[u] = q[u] = -1;
-      if (vrow[u] < 0) continue;
-      rr_pair(vk[u], step, np, n, p[u], q[u]);
-      if (q[u] < 0) continue;
-      r[u] = cs[buf * 48 + vk[u]];
-      v0[u] = V[vrow[u] * ld + p[u]], v1[u] = V[vrow[u] * ld + q[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < 3; u++) {
-      if (vrow[u] < 0 || q[u] < 0) continue;
-      V[vrow[u] * ld + p[u]] = r[u].x * v0[u] - r[u].y * v1[u];
-      V[vrow[u] * ld + q[u]] = r[u].y * v0[u] + r[u].x * v1[u];
-    }
-  };
-  int g = 0;           // global step counter: rotation / flag double buffer = g & 1
-  bool pend = false;   // V has not seen the rotations of step pend_step yet (uniform)
-  int pend_step = 0;
-  double prev_off = 1e300;
-  for (int sweep = 0; sweep < 24; sweep++) {
-    double off = 0, dia = 0;
-    for (int r = ty; r < n; r += nty)
-      for (int c = tx; c < n; c += 16) {
-        const double v = A[r * ld + c];
-        if (r == c) dia += v * v;
-        else off += v * v;
-      }
-    off = wave_sum(off), dia = wave_sum(dia);
-    __syncthreads();
-    if ((tid & 63) == 0) scratch[tid >> 6] = off, scratch[16 + (tid >> 6)] = dia;
-    __syncthreads();
-    double so = 0, sd = 0;
-    for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[16 + w];
-    __syncthreads();
-    if (trace && tid == 0 && sweep < 12) trace[sweep] = so / sd;
-    if (so <= 1e-24 * sd || so == 0.0) break;
-    if (sweep >= 4 && so > 0.25 * prev_off) break;  // rounding floor reached
-    prev_off = so;
-    sweeps++;
-    for (int step = 0; step < np - 1; step++, g++) {
-      const int buf = g & 1;
-      // ---- phase 1
-      if (tid < 64) {
-        if (tid == 0) scratch[40 + buf] = 0.0;  // same wave as the setters below: LDS operations of a wave stay in order
-        if (tid < half) {
-          int p, q;
-          rr_pair(tid, step, np, n, p, q);
-          double c = 1.0, s = 0.0;
-          if (q >= 0) {
-            const double apq = A[p * ld + q], app = A[p * ld + p], aqq = A[q * ld + q];
-            // rotations that cannot change either diagonal entry in FP64 are skipped
-            if (apq != 0.0 && fabs(apq) > 1e-18 * (fabs(app) + fabs(aqq))) {
-              const double theta = (aqq - app) / (2.0 * apq);
-              const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-              c = rsqrt(t * t + 1.0);
-              s = t * c;
-            }
-          }
-          cs[buf * 48 + tid] = make_double2(c, s);
-          if (s != 0.0) scratch[40 + buf] = 1.0;  // some rotation of this step is non-trivial (same value from every writer)
-        }
-      }
-      if (pend) apply_v(pend_step, buf ^ 1);
-      __syncthreads();
-      const bool any_rot = scratch[40 + buf] != 0.0;  // uniform
-      pend = any_rot, pend_step = step;
-      if (!any_rot) continue;  // nothing is written in phase 2; the next phase 1 only touches the other buffer
-      // ---- phase 2: A <- J^T A J on this thread's 2x2 blocks
-      {
-        int pa[2], qa[2], pb[2], qb[2];
-        double b00[2], b01[2], b10[2], b11[2];
-        double2 ra[2], rb[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          if (aka[u] < 0) continue;
-          rr_pair(aka[u], step, np, n, pa[u], qa[u]);
-          rr_pair(akb[u], step, np, n, pb[u], qb[u]);
-          ra[u] = cs[buf * 48 + aka[u]], rb[u] = cs[buf * 48 + akb[u]];
-          const bool va = qa[u] >= 0, vb = qb[u] >= 0;
-          const double *rowp = A + pa[u] * ld, *rowq = A + (va ? qa[u] : pa[u]) * ld;
-          b00[u] = rowp[pb[u]];
-          b01[u] = vb ? rowp[qb[u]] : 0.0;
-          b10[u] = va ? rowq[pb[u]] : 0.0;
-          b11[u] = (va && vb) ? rowq[qb[u]] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          if (aka[u] < 0) continue;
-          const bool va = qa[u] >= 0, vb = qb[u] >= 0;
-          double *rowp = A + pa[u] * ld, *rowq = A + (va ? qa[u] : pa[u]) * ld;
-          const double ca = ra[u].x, sa = ra[u].y, cb = rb[u].x, sb = rb[u].y;
-          const double t00 = cb * b00[u] - sb * b01[u], t01 = sb * b00[u] + cb * b01[u];
-          const double t10 = cb * b10[u] - sb * b11[u], t11 = sb * b10[u] + cb * b11[u];
-          rowp[pb[u]] = ca * t00 - sa * t10;
-          if (vb) rowp[qb[u]] = ca * t01 - sa * t11;
-          if (va) rowq[pb[u]] = sa * t00 + ca * t10;
-          if (va && vb) rowq[qb[u]] = sa * t01 + ca * t11;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (pend) apply_v(pend_step, (g - 1) & 1);
-  __syncthreads();
-  return sweeps;
 }
 
 // Jacobi rotation that annihilates a_pq: t = tan(phi) is the smaller root of t^2 + 2 theta t - 1 = 0,
@@ -503,6 +359,84 @@ __global__ __launch_bounds__(256) void k_marg_vecs(char *base, size_t stride, in
   }
 }
 
+// Eigen-decomposition of a small symmetric matrix (n <= 16: the dropped pose-side block of the marginalization).
+// Same tournament as jacobi_systolic, one thread per matrix ELEMENT: thread (u, v) of the first np^2 threads forms
+// element (u, v) of J^T A J and of V J from the 2x2 blocks it sits in and stores it at its place after the ring move
+// (double-buffered position space: one LDS round trip and two barriers per step, a few dozen instructions per thread).
+// On return Am holds the eigenvalues on its diagonal and Vm the eigenvectors in its columns (row stride n).
+// buf: 4 * 256 doubles.
+DEV int jacobi_small(double *Am, double *Vm, int n, int tid, int nthreads, double *buf, double2 *cs, double *scratch) {
+  const int np = n + (n & 1), half = np / 2;
+  double *Ac = buf, *An = buf + 256, *Vc = buf + 512, *Vn = buf + 768;
+  const bool act = tid < np * np;
+  const int u = act ? tid / np : 0, v = act ? tid % np : 0;
+  const int ku = u >> 1, bu = u & 1, kv = v >> 1, bv = v & 1;
+  auto idx0 = [&](int p) { return (p & 1) ? np - 1 - (p >> 1) : (p >> 1); };  // position -> index at step 0
+  auto sigma = [&](int p) {                                                   // position after the ring move
+    const int k = p >> 1;
+    if (!(p & 1)) return k >= 1 ? 2 * (k - 1) : 3;
+    if (k == 0) return 1;
+    return k <= half - 2 ? 2 * (k + 1) + 1 : 2 * (half - 1);
+  };
+  if (act) {
+    const int iu = idx0(u), iv = idx0(v);
+    Ac[tid] = (iu < n && iv < n) ? Am[iu * n + iv] : 0.0;
+    Vc[tid] = (u == iv) ? 1.0 : 0.0;  // V rows keep their index, columns live in position space
+  }
+  const int dst_a = sigma(u) * np + sigma(v), dst_v = u * np + sigma(v);
+  const int blk = (2 * ku) * np + 2 * kv;
+  __syncthreads();
+  int sweeps = 0, g = 0;
+  double prev_off = 1e300;
+  for (int sweep = 0; sweep < JMAX_SWEEPS; sweep++) {
+    double off = 0, dia = 0;
+    if (act) {
+      const double a = Ac[tid];
+      if (u == v) dia = a * a;
+      else off = a * a;
+    }
+    off = wave_sum(off), dia = wave_sum(dia);
+    if ((tid & 63) == 0) scratch[tid >> 6] = off, scratch[16 + (tid >> 6)] = dia;
+    __syncthreads();
+    double so = 0, sd = 0;
+    for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[16 + w];
+    __syncthreads();
+    if (so <= 1e-24 * sd || so == 0.0) break;
+    if (sweep >= 4 && so > 0.25 * prev_off) break;  // rounding floor reached
+    prev_off = so;
+    sweeps++;
+    for (int step = 0; step < np - 1; step++, g++) {
+      if (tid < half) {
+        const int p = 2 * tid, q = p + 1;
+        double c = 1.0, s = 0.0;
+        if (tid > 0 || np == n) jacobi_angle(Ac[p * np + p], Ac[q * np + q], Ac[q * np + p], c, s);  // bot 0 of an odd n is the dummy
+        cs[tid] = make_double2(c, s);
+      }
+      __syncthreads();
+      if (act) {
+        const double2 ra = cs[ku], rb = cs[kv];
+        const double ru0 = bu ? ra.y : ra.x, ru1 = bu ? ra.x : -ra.y;  // (new_p, new_q) = (c x_p - s x_q, s x_p + c x_q)
+        const double cv0 = bv ? rb.y : rb.x, cv1 = bv ? rb.x : -rb.y;
+        const double a00 = Ac[blk], a01 = Ac[blk + 1], a10 = Ac[blk + np], a11 = Ac[blk + np + 1];
+        An[dst_a] = ru0 * fma(a00, cv0, a01 * cv1) + ru1 * fma(a10, cv0, a11 * cv1);
+        Vn[dst_v] = fma(Vc[u * np + 2 * kv], cv0, Vc[u * np + 2 * kv + 1] * cv1);
+      }
+      __syncthreads();
+      double *t = Ac;
+      Ac = An, An = t, t = Vc, Vc = Vn, Vn = t;
+    }
+  }
+  if (act) {
+    int p, q;
+    rr_pair(kv, g % (np - 1), np, n, p, q);
+    const int iv = bv ? q : p;  // index held by position v now (-1: dummy)
+    if (u == v && iv >= 0) Am[iv * n + iv] = Ac[tid];
+    if (u < n && iv >= 0) Vm[u * n + iv] = Vc[tid];
+  }
+  __syncthreads();
+  return sweeps;
+}
+
 // grid (1, batch) x 256, dynamic LDS = MARG_LDS
 __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t stride, int flag) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -570,7 +504,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     Am[e] = 0.5 * (A[r * D + c] + A[c * D + r]);
   }
   __syncthreads();
-  const int sw1 = jacobi_eig(Am, Vm, m15, m15, tid, MARG_THREADS, cs, scr);
+  const int sw1 = jacobi_small(Am, Vm, m15, tid, MARG_THREADS, Tm, cs, scr);  // Tm (n x m15) is free until the Schur step
   __syncthreads();
   const double eps = 1e-8;
   for (int e = tid; e < m15 * m15; e += MARG_THREADS) {

@@ -753,13 +753,13 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   // one full linearization so that every kernel has valid inputs
   launch_lin(c, count, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE);
-  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
+  launch_sum(c, count, g, MODE_SOLVE);
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
       case 0: launch_lin(c, count, g, MODE_SOLVE); break;
       case 1: hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE); break;
-      case 2: hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0); break;
+      case 2: launch_sum(c, count, g, MODE_SOLVE); break;  // k_presum + k_sum for large windows
       default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st); break;
     }
   }

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Runs on the GPU box (through gpurun): bench lines, rocprofv3 kernel statistics and PMC passes for the three bench
+workloads; everything lands under gpurun_out/profiles/ and is copied into profiles/rNN/ by hand afterwards.
+
+  python tools/collect_profiles.py [round_tag]
+
+PMC passes are separate runs with --pmc only (no tracing domains), as MI355X_MICROARCH.md prescribes; FETCH_SIZE and
+WRITE_SIZE cannot share a pass (TCC has 4 slots, they cost 3 + 2)."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "profiles")
+os.makedirs(OUT, exist_ok=True)
+os.environ["TMPDIR"] = "/tmp"
+WORK = {"window300": ["--steps", "100", "--warmup", "10"], "batch512": ["--workload", "batch512", "--steps", "20", "--warmup", "3"],
+        "window100k": ["--workload", "window100k", "--steps", "40", "--warmup", "5"]}
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"],
+              ["SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]]
+
+
+def sh(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    return subprocess.run(cmd, cwd="/tmp", text=True, capture_output=True, **kw)
+
+
+def short(name):
+    return name.split("(")[0]
+
+
+def main():
+    py = sys.executable
+    bench = os.path.join(ROOT, "bench.py")
+    for w, args in WORK.items():
+        # 1. the bench line itself (full default length for the headline workload)
+        r = sh([py, bench] + (args if w != "window300" else []))
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if line:
+            open(os.path.join(OUT, f"bench_{w}.json"), "w").write(line[-1] + "\n")
+        else:
+            print(r.stdout[-2000:], r.stderr[-2000:])
+        # 2. kernel statistics of the same command (shorter run, no CPU baseline leg)
+        d = f"/tmp/prof_{w}"
+        sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", py, bench, "--no-cpu-baseline"] + args)
+        for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+            rows = list(csv.reader(open(f)))
+            with open(os.path.join(OUT, f"bench_{w}_kernel_stats.csv"), "w", newline="") as fo:
+                wr = csv.writer(fo)
+                for row in rows:
+                    row[0] = short(row[0])
+                    wr.writerow(row)
+    # 3. PMC passes (window300 and window100k)
+    md = ["# PMC summary — rocprofv3 --pmc, separate passes, values per launch (mean over launches)", "",
+          "FETCH_SIZE / WRITE_SIZE are KB as rocprofv3 reports them.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide",
+          "(16 B/lane) streaming reads by 2x and is uncalibrated for other widths; the kernels here read 8 B per lane, so the",
+          "figures are kept as measured and compared with the algorithmic bytes only as an order of magnitude.", ""]
+    for w in ("window300", "window100k"):
+        agg = defaultdict(lambda: defaultdict(list))
+        for i, ctrs in enumerate(PMC_PASSES):
+            d = f"/tmp/pmc_{w}_{i}"
+            sh(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--", py, bench, "--no-cpu-baseline",
+                                                 "--steps", "10", "--warmup", "2"] + (WORK[w][:2] if w != "window300" else []))
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        names = [c for p in PMC_PASSES for c in p]
+        md += [f"## {w}", "", "| kernel | launches | " + " | ".join(names) + " |", "|---|---|" + "---|" * len(names)]
+        for k, cs in sorted(agg.items()):
+            if k.startswith("__amd"):
+                continue
+            n = max(len(v) for v in cs.values())
+            md.append(f"| {k} | {n} | " + " | ".join(f"{sum(cs[c]) / len(cs[c]):.1f}" if cs.get(c) else "-" for c in names) + " |")
+        md.append("")
+    open(os.path.join(OUT, "pmc_summary.md"), "w").write("\n".join(md) + "\n")
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    main()
