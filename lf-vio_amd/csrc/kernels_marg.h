@@ -281,10 +281,9 @@ DEV double wave_from_next(double v) {  // lane i <- lane i+1
   hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-DEV double wave_from_prev(double v) {  // lane i <- lane i-1
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+DEV double wave_from_prev(double v, double lane0) {  // lane i <- lane i-1; lane 0 (no source) keeps `lane0`
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), __double2loint(v), 0x138, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), __double2hiint(v), 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -324,13 +323,12 @@ __global__ __launch_bounds__(256) void k_marg_vecs(char *base, size_t stride, in
     for (int u = 0; u < UB; u++) {
       if (g0 + u < G) {
         const double c = cur[u].x, s = cur[u].y;
-        const double np_ = c * vp - s * vq, nq = s * vp + c * vq;
+        const double np_ = fma(c, vp, -(s * vq)), nq = fma(s, vp, c * vq);
         // ring move: top row one slot towards slot 0, bottom row one slot away from it; top 0 -> bot 1,
-        // bot (half-1) -> top (half-1), bot 0 stays
+        // bot (half-1) -> top (half-1), bot 0 stays (lane 0 has no source lane in the shift and keeps its own)
         const double up = wave_from_next(np_);
-        const double dn = wave_from_prev(k == 0 ? np_ : nq);
+        vq = wave_from_prev(k == 0 ? np_ : nq, nq);
         vp = k == half - 1 ? nq : up;
-        vq = k == 0 ? nq : dn;
       }
     }
 #pragma unroll
