@@ -30,6 +30,8 @@ constexpr int PACKED = KP * (KP + 1) / 2;
 constexpr int JLOG_LD = 48;      // rotation slots per logged Jacobi step (>= ceil(n/2), n <= 96)
 constexpr int JLOG_STEPS = 1600;  // >= JMAX_SWEEPS * (n - 1)
 constexpr int JMAX_SWEEPS = 20;
+constexpr int PRE_CHUNK_LIMIT = 2 * 121;  // windows with more Gram chunks reduce them per frame pair first (k_presum)
+constexpr int SUM_ITEMS_CAP = PRE_CHUNK_LIMIT * 209 + 64;
 constexpr int HPP_CAP = 16384;
 // exchange buffer of the landmark-sharded mode (one contiguous sum-all-reduce):
 //   [ H_pp packed | g_p | Schur sums (80x80 upper tiles) | 16 scalars ]
@@ -130,7 +132,7 @@ struct Slot {
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
   int max_iter, prior_valid, prior_n, prior_nb;
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
-  int pose_side, pad2;           // sharded: this rank adds the IMU + prior factors
+  int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
   double g[3], tr_over_row, half_row, sqrt_info;
   FrameState x0;
   LfvioPreintegration imu[LFVIO_WINDOW_SIZE];
@@ -148,6 +150,7 @@ struct Slot {
   GP<int> pm_obs, pm_lm;           // [NV] pair-major: observation index, landmark index
   GP<int> chunk_pair, chunk_begin, chunk_end;
   GP<double> prior_J, prior_r;     // n*n, n
+  GP<int> sum_off, sum_end_marg, sum_items;  // gather lists of k_sum: per H_pp / g_p entry, offsets into gram_part (or pairG)
   // ---------------- work arrays
   FrameState x[2];
   TRState tr;                    // directly after x[]: one small D2H copy fetches state + trace

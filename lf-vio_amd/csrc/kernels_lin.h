@@ -628,37 +628,22 @@ DEV bool col_active(const Slot *S, int c, int mode) {
   return true;
 }
 
-DEV double gram_pair_sum(const Slot *S, int i, int j, int idx, int chunk_limit, int pre) {
-  const int p = i * 11 + j;
-  if (pre) return S->pairG[(size_t)p * NGP + idx];
-  const int c0 = S->pair_chunk0[p];
-  int c1 = S->pair_chunk0[p + 1];
-  if (c1 > chunk_limit) c1 = chunk_limit;
-  const double *gp = S->gram_part + idx;
+// Gram part of one H_pp / g_p entry: the upload built, per entry, the list of Gram-partial offsets that add up to it
+// (lfvio_hip.hip).  Two dependent loads (list bounds -> offsets -> values) instead of a walk over pair and chunk tables;
+// four accumulators, fixed association => deterministic.
+DEV double gram_gather(const Slot *S, int e, int mode) {
+  const int beg = S->sum_off[e];
+  int end = S->sum_off[e + 1];
+  if (is_marg(mode)) end = marg_plan(S, mode)->nChunks0 > 0 ? S->sum_end_marg[e] : beg;
+  const int *it = S->sum_items;
+  const double *gp = S->pre_gram ? (const double *)S->pairG : (const double *)S->gram_part;
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int c = c0;
-  for (; c + 4 <= c1; c += 4) {
-    s0 += gp[(size_t)c * NGP], s1 += gp[(size_t)(c + 1) * NGP];
-    s2 += gp[(size_t)(c + 2) * NGP], s3 += gp[(size_t)(c + 3) * NGP];
+  int k = beg;
+  for (; k + 4 <= end; k += 4) {
+    const int o0 = it[k], o1 = it[k + 1], o2 = it[k + 2], o3 = it[k + 3];
+    s0 += gp[o0], s1 += gp[o1], s2 += gp[o2], s3 += gp[o3];
   }
-  for (; c < c1; c++) s0 += gp[(size_t)c * NGP];
-  return (s0 + s1) + (s2 + s3);
-}
-
-// the ex/td entries receive a term from EVERY chunk: chunks are contiguous in pair order, so this is a plain
-// strided sweep with independent loads (4 accumulators, fixed association => still deterministic)
-DEV double gram_all_pairs(const Slot *S, int idx, int chunk_limit, int pre) {
-  const double *gp = pre ? S->pairG + idx : S->gram_part + idx;
-  const int lim = pre ? NPAIR : chunk_limit;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int c = 0;
-  for (; c + 4 <= lim; c += 4) {
-    s0 += gp[(size_t)c * NGP];
-    s1 += gp[(size_t)(c + 1) * NGP];
-    s2 += gp[(size_t)(c + 2) * NGP];
-    s3 += gp[(size_t)(c + 3) * NGP];
-  }
-  for (; c < lim; c++) s0 += gp[(size_t)c * NGP];
+  for (; k < end; k++) s0 += gp[it[k]];
   return (s0 + s1) + (s2 + s3);
 }
 
@@ -750,7 +735,6 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
     if (!tr->do_lin) return;
     const int e = b * 256 + tid;
     if (e >= HPP_ITEMS) return;
-    const int chunk_limit = is_marg(mode) ? marg_plan(S, mode)->nChunks0 : S->nChunks;
     double val = 0.0;
     if (e < PACKED) {
       int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
@@ -758,29 +742,8 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
       while (r * (r + 1) / 2 > e) r--;
       const int c = e - r * (r + 1) / 2;
       if (col_active(S, r, mode) && col_active(S, c, mode)) {
-        // ---- visual: Gram blocks of the frame pairs that contain both columns
-        if (r < KC) {
-          int fr, lr, fc, lc;
-          cam_block(r, fr, lr);
-          cam_block(c, fc, lc);
-          if (fr < 11) {  // both pose blocks (c <= r => fc <= fr)
-            if (fr == fc) {
-              for (int j = fr + 1; j < 11; j++) val += gram_pair_sum(S, fr, j, gidx20(lc, lr), chunk_limit, pre);
-              for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lc, 6 + lr), chunk_limit, pre);
-            } else {
-              val += gram_pair_sum(S, fc, fr, gidx20(lc, 6 + lr), chunk_limit, pre);
-            }
-          } else {
-            const int hi = fr == 11 ? 12 + lr : 18;
-            if (fc < 11) {
-              for (int j = fc + 1; j < 11; j++) val += gram_pair_sum(S, fc, j, gidx20(lc, hi), chunk_limit, pre);
-              for (int i = 0; i < fc; i++) val += gram_pair_sum(S, i, fc, gidx20(6 + lc, hi), chunk_limit, pre);
-            } else {
-              const int lo = fc == 11 ? 12 + lc : 18;
-              val += gram_all_pairs(S, gidx20(lo, hi), chunk_limit, pre);
-            }
-          }
-        }
+        // ---- visual: Gram entries of the frame pairs that contain both columns
+        if (r < KC) val += gram_gather(S, e, mode);
         // ---- IMU factors covering both columns (at most two)
         const int f0 = col_frame(r);
         if (f0 >= 0) {
@@ -800,17 +763,7 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
     } else {
       const int r = e - PACKED;
       if (col_active(S, r, mode)) {
-        if (r < KC) {
-          int fr, lr;
-          cam_block(r, fr, lr);
-          if (fr < 11) {
-            for (int j = fr + 1; j < 11; j++) val += gram_pair_sum(S, fr, j, gidx20(lr, 19), chunk_limit, pre);
-            for (int i = 0; i < fr; i++) val += gram_pair_sum(S, i, fr, gidx20(6 + lr, 19), chunk_limit, pre);
-          } else {
-            const int lo = fr == 11 ? 12 + lr : 18;
-            val += gram_all_pairs(S, gidx20(lo, 19), chunk_limit, pre);
-          }
-        }
+        if (r < KC) val += gram_gather(S, e, mode);
         const int f0 = col_frame(r);
         if (f0 >= 0) {
           for (int f = f0 - 1; f <= f0; f++) {

@@ -34,7 +34,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   int maxN = 0, maxM = 0;
   int capLmBlocks = 0, capChunks = 0, capSchurParts = 0;
   size_t in_begin = 0, in_end = 0, total = 0;
-  size_t lm_start, lm_cnt, lm_obs0, lm_perm, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, prior_J,
+  size_t lm_start, lm_cnt, lm_obs0, lm_perm, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
   size_t lam[2], prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
       xch, lm_part, cost_part, imu_out, mscr, rotlog, eig_aux;
@@ -63,6 +63,8 @@ Layout make_layout(int maxN, int maxM) {
   L.chunk_end = take((size_t)L.capChunks * 4);
   L.prior_J = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
   L.prior_r = take(LFVIO_MAX_PRIOR_DIM * 8);
+  L.sum_off = take((size_t)(PACKED + KP + 1) * 4), L.sum_end_marg = take((size_t)(PACKED + KP) * 4);
+  L.sum_items = take((size_t)SUM_ITEMS_CAP * 4);
   L.in_end = o;
   L.lam[0] = take(LB * 8), L.lam[1] = take(LB * 8);
   L.prior_A = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
@@ -349,6 +351,50 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     S->nSchurParts = (N + lm - 1) / lm;
   }
   info.gLm = S->nLmBlocks, info.gCh = nChunks, info.gSc = S->nSchurParts;
+  // ---- gather lists of k_sum: which Gram entries (chunk or, for large windows, frame pair; local index of the
+  //      20 x 20 block [Pi th_i Pj th_j tic th_ic td | r]) add up to each packed H_pp / g_p entry.  Units ascend, so the
+  //      marginalization's subset (pairs (0, j)) is a prefix of every list.
+  {
+    S->pre_gram = nChunks > PRE_CHUNK_LIMIT ? 1 : 0;
+    static thread_local std::vector<std::vector<int>> lists;
+    lists.assign(PACKED + KP, {});
+    auto col = [](int l, int i, int j) { return l < 6 ? 6 * i + l : l < 12 ? 6 * j + (l - 6) : l < 18 ? 66 + (l - 12) : 72; };
+    const int units = S->pre_gram ? NPAIR : nChunks;
+    for (int u = 0; u < units; u++) {
+      const int p = S->pre_gram ? u : chunk_pair[u];
+      if (S->pre_gram && S->pair_chunk0[p + 1] == S->pair_chunk0[p]) continue;
+      const int i = p / 11, j = p % 11;
+      for (int lp = 0; lp < 19; lp++)
+        for (int lq = lp; lq < 20; lq++) {
+          const int cp = col(lp, i, j), g20 = lp * 20 - (lp * (lp - 1)) / 2 + (lq - lp);
+          int e;
+          if (lq == 19) {
+            e = PACKED + cp;
+          } else {
+            const int cq = col(lq, i, j);
+            e = cq * (cq + 1) / 2 + cp;  // cp <= cq: the local order follows the tangent order (i < j < ex < td)
+          }
+          lists[e].push_back(u * NGP + g20);
+        }
+    }
+    int *sum_off = (int *)(h + L.sum_off), *sum_end_marg = (int *)(h + L.sum_end_marg), *sum_items = (int *)(h + L.sum_items);
+    const int marg_units = S->pre_gram ? 11 : S->pair_chunk0[11];  // pairs (0, j) / their chunks
+    int pos = 0;
+    for (int e = 0; e < PACKED + KP; e++) {
+      sum_off[e] = pos;
+      int nm = 0;
+      for (int it : lists[e]) {
+        if (pos >= SUM_ITEMS_CAP) {
+          c->err = "gather list overflow";
+          return LFVIO_ERR_ARG;
+        }
+        sum_items[pos++] = it;
+        if (it / NGP < marg_units) nm++;
+      }
+      sum_end_marg[e] = sum_off[e] + nm;
+    }
+    sum_off[PACKED + KP] = pos;
+  }
   // ---- prior
   info.has_in_prior = pr != nullptr;
   for (int c2 = 0; c2 < KP; c2++) S->prior_inv[c2] = -1;
@@ -376,6 +422,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->pm_obs.set(S, L.pm_obs), S->pm_lm.set(S, L.pm_lm);
   S->chunk_pair.set(S, L.chunk_pair), S->chunk_begin.set(S, L.chunk_begin), S->chunk_end.set(S, L.chunk_end);
   S->prior_J.set(S, L.prior_J), S->prior_r.set(S, L.prior_r);
+  S->sum_off.set(S, L.sum_off), S->sum_end_marg.set(S, L.sum_end_marg), S->sum_items.set(S, L.sum_items);
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, L.in_end - L.in_begin, hipMemcpyHostToDevice, c->stream));
@@ -435,7 +482,7 @@ void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
 // fixed-order reduction of the partials; two levels once a single k_sum thread would have to walk hundreds of them
 void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const size_t st = c->L.total;
-  const int pre = (g.ch > 2 * NPAIR || g.sc > 4 * PRE_GROUP) ? 1 : 0;
+  const int pre = (g.ch > PRE_CHUNK_LIMIT || g.sc > 4 * PRE_GROUP) ? 1 : 0;
   if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + PRE_SCHUR_BLOCKS + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode);
   hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre);
 }
