@@ -86,7 +86,7 @@ enum {
   Q_COUNT = 16
 };
 
-struct TRState {
+struct TRHead {  // the scalar part: the single-lane bookkeeping kernels copy it to registers in one batch of loads
   double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha;
   double cg, cn;        // dogleg step = cg * gradient_ + cn * gauss_newton_step_ (D-scaled space)
   double gn_sq_total, grad_sq_total, grad_gn_total;
@@ -97,6 +97,8 @@ struct TRState {
   double q[Q_COUNT];
   int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled;
   int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, new_point;
+};
+struct TRState : TRHead {
   LfvioIterationSummary it;
   LfvioIterationSummary trace[LFVIO_MAX_TRACE];
 };

@@ -550,36 +550,39 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
   TRState *tr = &S->tr;
   if (tr->done || tr->chol_fail) return;
   const int tid = threadIdx.x;
-  __shared__ double sh[4];
+  __shared__ double sh[4], sh2[2];
   __shared__ double delta[KP];
-  if (tr->do_schur) {
-    // total norms: pose side (k_solve) + landmark partials (k_backsub)
-    double a = 0, b = 0;
+  // total norms: pose side (k_solve) + landmark partials (k_backsub)
+  const int do_schur = tr->do_schur;
+  double a = 0, b = 0;
+  if (do_schur)
     for (int k = tid; k < S->nLmBlocks; k += 128) {
       a += S->lm_part[(size_t)k * LMS + 8];
       b += S->lm_part[(size_t)k * LMS + 9];
     }
-    a = wave_sum(a), b = wave_sum(b);
-    if ((tid & 63) == 0) sh[(tid >> 6) * 2] = a, sh[(tid >> 6) * 2 + 1] = b;
-    __syncthreads();
-    if (tid == 0) {
+  a = wave_sum(a), b = wave_sum(b);
+  if ((tid & 63) == 0) sh[(tid >> 6) * 2] = a, sh[(tid >> 6) * 2 + 1] = b;
+  __syncthreads();
+  if (tid == 0) {
+    // scalars in one batch of loads; results go back in one batch and reach the other lanes through LDS
+    double gn_sq_total = tr->gn_sq_total, grad_gn_total = tr->grad_gn_total;
+    const double grad_sq_total = tr->grad_sq_total, radius = tr->radius, alpha = tr->alpha;
+    if (do_schur) {
       double lgn = sh[0] + sh[2], lgg = sh[1] + sh[3];
       if (S->sharded) lgn = S->xch[XOFF_C + XS_GN2], lgg = S->xch[XOFF_C + XS_GGN];  // all-reduced (k_xpack 2)
-      tr->gn_sq_total = tr->q[Q_GN_SQ] + lgn;
-      tr->grad_gn_total = tr->q[Q_GRAD_GN] + lgg;
+      gn_sq_total = tr->q[Q_GN_SQ] + lgn;
+      grad_gn_total = tr->q[Q_GRAD_GN] + lgg;
+      tr->gn_sq_total = gn_sq_total;
+      tr->grad_gn_total = grad_gn_total;
     }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    const double radius = tr->radius, alpha = tr->alpha;
-    const double gradient_norm = sqrt(tr->grad_sq_total), gauss_newton_norm = sqrt(tr->gn_sq_total);
+    const double gradient_norm = sqrt(grad_sq_total), gauss_newton_norm = sqrt(gn_sq_total);
     double cg, cn, sn;
     if (gauss_newton_norm <= radius) {  // Case 1
       cg = 0.0, cn = 1.0, sn = gauss_newton_norm;
     } else if (gradient_norm * alpha >= radius) {  // Case 2
       cg = -(radius / gradient_norm), cn = 0.0, sn = radius;
     } else {  // Case 3
-      const double b_dot_a = -alpha * tr->grad_gn_total;
+      const double b_dot_a = -alpha * grad_gn_total;
       const double a_squared_norm = (alpha * gradient_norm) * (alpha * gradient_norm);
       const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gauss_newton_norm * gauss_newton_norm;
       const double c = b_dot_a - a_squared_norm;
@@ -587,12 +590,13 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
       const double beta = (c <= 0) ? (d - c) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d + c);
       cg = -alpha * (1.0 - beta), cn = beta;
       // ||cg g + cn n||
-      sn = sqrt(cg * cg * tr->grad_sq_total + 2.0 * cg * cn * tr->grad_gn_total + cn * cn * tr->gn_sq_total);
+      sn = sqrt(cg * cg * grad_sq_total + 2.0 * cg * cn * grad_gn_total + cn * cn * gn_sq_total);
     }
     tr->cg = cg, tr->cn = cn, tr->dogleg_step_norm = sn;
+    sh2[0] = cg, sh2[1] = cn;
   }
   __syncthreads();
-  const double cg = tr->cg, cn = tr->cn;
+  const double cg = sh2[0], cn = sh2[1];
   const int cur = tr->cur;
   const FrameState *x = &S->x[cur];
   FrameState *xc = &S->x[cur ^ 1];
@@ -807,119 +811,130 @@ __global__ __launch_bounds__(64) void k_xpack(char *base, size_t stride, int whi
 __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
-  if (tr->done) return;
   const int lane = threadIdx.x;
-  if (tr->chol_fail) {
+  // Everything the kernel needs from the slot header in ONE batch of loads, before the first branch: a load issued
+  // behind a branch waits a full memory round trip (~0.6 us) of its own, and this kernel is nothing but such a chain.
+  TRHead t = *static_cast<const TRHead *>(tr);
+  const int sharded = S->sharded, max_iter = S->max_iter, nLmBlocks = S->nLmBlocks;
+  const double *cost_part = S->cost_part;
+  const double pc = lane < 11 ? S->pose_cost[lane] : 0.0;
+  if (t.done) return;
+  if (t.chol_fail) {
     // retry the Gauss-Newton solve with the larger mu; LINEAR_SOLVER_FAILURE once mu >= max_mu
-    if (lane == 0) {
-      if (tr->mu < 1.0) {
-        tr->do_lin = S->sharded ? 1 : 0;
+    if (t.mu < 1.0) {
+      if (lane == 0) {
+        tr->do_lin = sharded ? 1 : 0;
         tr->do_schur = 1;
         tr->chol_fail = 0;
         tr->skip_step = 1;
       }
+      return;
     }
-    if (tr->mu < 1.0) return;
   }
   double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
-  if (!tr->chol_fail) {
-    for (int k = lane; k < S->nLmBlocks; k += 64) {
-      const double *p = S->cost_part + (size_t)k * LMS;
+  if (!t.chol_fail) {
+    for (int k = lane; k < nLmBlocks; k += 64) {
+      const double *p = cost_part + (size_t)k * LMS;
       cost += p[0], mlin += p[1], mquad += p[2], dn += p[3], xn += p[4];
     }
-    if (lane < 11) cost += S->pose_cost[lane];
+    cost += pc;
     cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn);
-    if (S->sharded) {  // all-reduced by the caller after k_xpack 3
+    if (sharded) {  // all-reduced by the caller after k_xpack 3
       const double *sc = S->xch + XOFF_C;
       cost = sc[XS_CCOST], mlin = sc[XS_MLIN], mquad = sc[XS_MQUAD], dn = sc[XS_DN], xn = sc[XS_XN];
     }
   }
   if (lane != 0) return;
+  TRState *trg = tr;
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
   LfvioIterationSummary it;
-  it.cost = tr->x_cost, it.cost_change = 0, it.gradient_max_norm = 0, it.step_norm = 0, it.relative_decrease = 0;
+  it.cost = t.x_cost, it.cost_change = 0, it.gradient_max_norm = 0, it.step_norm = 0, it.relative_decrease = 0;
   it.step_is_valid = 0, it.step_is_successful = 0;
   bool finished = false;
   bool step_valid = false;
   double model_cost_change = 0;
-  if (!tr->chol_fail) {
+  if (!t.chol_fail) {
     // model_cost_change = -(J step)^T (r + J step / 2) = -delta.g - 1/2 delta^T H delta
-    const double cg = tr->cg, cn = tr->cn;
+    const double cg = t.cg, cn = t.cn;
     // unscaled pose direction delta_p = cg' G + cn' N where gradient_/diagonal_*scale = G, gn/diag*scale = N
-    const double lin = cg * tr->q[Q_gG] + cn * tr->q[Q_gN] + mlin;
-    const double quad = cg * cg * tr->q[Q_GG] + 2.0 * cg * cn * tr->q[Q_GN] + cn * cn * tr->q[Q_NN] + mquad;
+    const double lin = cg * t.q[Q_gG] + cn * t.q[Q_gN] + mlin;
+    const double quad = cg * cg * t.q[Q_GG] + 2.0 * cg * cn * t.q[Q_GN] + cn * cn * t.q[Q_NN] + mquad;
     model_cost_change = -lin - 0.5 * quad;
     step_valid = model_cost_change > 0.0;
   }
-  tr->model_cost_change = model_cost_change;
+  t.model_cost_change = model_cost_change;
   it.step_is_valid = step_valid ? 1 : 0;
   if (!step_valid) {
     // HandleInvalidStep
-    if (++tr->consec_invalid >= 5) {
-      tr->termination = LFVIO_FAILURE;
-      tr->done = 1;
+    if (++t.consec_invalid >= 5) {
+      t.termination = LFVIO_FAILURE;
+      t.done = 1;
       finished = true;
     } else {
-      tr->mu *= 10.0;  // StepIsInvalid
-      tr->chol_fail = 0;
-      tr->do_lin = S->sharded ? 1 : 0;  // sharded: the exchange buffers were reduced in place, rebuild them
-      tr->do_schur = 1;
+      t.mu *= 10.0;  // StepIsInvalid
+      t.chol_fail = 0;
+      t.do_lin = sharded ? 1 : 0;  // sharded: the exchange buffers were reduced in place, rebuild them
+      t.do_schur = 1;
     }
   } else {
-    tr->consec_invalid = 0;
+    t.consec_invalid = 0;
     const double candidate_cost = isfinite(cost) ? cost : 1.79769313486231570815e+308;
-    tr->cand_cost = candidate_cost;
-    it.step_norm = sqrt(tr->step_sq_pose + dn);
-    if (it.step_norm <= parameter_tolerance * (tr->x_norm + parameter_tolerance)) {
-      tr->termination = LFVIO_CONVERGENCE;
-      tr->done = 1;
+    t.cand_cost = candidate_cost;
+    it.step_norm = sqrt(t.step_sq_pose + dn);
+    if (it.step_norm <= parameter_tolerance * (t.x_norm + parameter_tolerance)) {
+      t.termination = LFVIO_CONVERGENCE;
+      t.done = 1;
       finished = true;
     } else {
-      it.cost_change = tr->x_cost - candidate_cost;
-      if (fabs(it.cost_change) <= function_tolerance * tr->x_cost) {
-        tr->termination = LFVIO_CONVERGENCE;
-        tr->done = 1;
+      it.cost_change = t.x_cost - candidate_cost;
+      if (fabs(it.cost_change) <= function_tolerance * t.x_cost) {
+        t.termination = LFVIO_CONVERGENCE;
+        t.done = 1;
         finished = true;
       } else {
         it.relative_decrease = it.cost_change / model_cost_change;
         if (it.relative_decrease > min_relative_decrease) {
           // HandleSuccessfulStep: x <- candidate; the next k_lin re-evaluates cost/gradient there
-          tr->cur ^= 1;
-          tr->x_norm = sqrt(tr->xn2_pose_cand + xn);
+          t.cur ^= 1;
+          t.x_norm = sqrt(t.xn2_pose_cand + xn);
           it.step_is_successful = 1;
           it.cost = candidate_cost;  // replaced by the re-evaluated x_cost when the trace is read
-          if (it.relative_decrease < 0.25) tr->radius *= 0.5;
-          if (it.relative_decrease > 0.75) tr->radius = fmax(tr->radius, 3.0 * tr->dogleg_step_norm);
-          tr->mu = fmax(1e-8, 2.0 * tr->mu / 10.0);
-          tr->do_lin = 1;
-          tr->do_schur = 1;
-          tr->x_cost = candidate_cost;
+          if (it.relative_decrease < 0.25) t.radius *= 0.5;
+          if (it.relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * t.dogleg_step_norm);
+          t.mu = fmax(1e-8, 2.0 * t.mu / 10.0);
+          t.do_lin = 1;
+          t.do_schur = 1;
+          t.x_cost = candidate_cost;
         } else {
           // HandleUnsuccessfulStep / StepRejected
-          tr->radius *= 0.5;
-          tr->do_lin = 0;
-          tr->do_schur = 0;
+          t.radius *= 0.5;
+          t.do_lin = 0;
+          t.do_schur = 0;
           it.cost = candidate_cost;
         }
       }
     }
   }
-  if (finished) return;  // the converged iteration is not pushed (Minimize() returns before Finalize)
+  if (finished) {  // the converged iteration is not pushed (Minimize() returns before Finalize)
+    *static_cast<TRHead *>(trg) = t;
+    return;
+  }
   // FinalizeIterationAndCheckIfMinimizerCanContinue
   if (it.step_is_successful)
-    tr->num_succ++;
+    t.num_succ++;
   else
-    tr->num_unsucc++;
-  it.trust_region_radius = tr->radius;
-  if (tr->trace_len < LFVIO_MAX_TRACE) tr->trace[tr->trace_len++] = it;
-  if (tr->iteration >= S->max_iter) {
-    tr->termination = LFVIO_NO_CONVERGENCE;
-    tr->done = 1;
-  } else if (tr->radius <= min_trust_region_radius) {
-    tr->termination = LFVIO_CONVERGENCE;
-    tr->done = 1;
+    t.num_unsucc++;
+  it.trust_region_radius = t.radius;
+  if (t.trace_len < LFVIO_MAX_TRACE) trg->trace[t.trace_len++] = it;
+  if (t.iteration >= max_iter) {
+    t.termination = LFVIO_NO_CONVERGENCE;
+    t.done = 1;
+  } else if (t.radius <= min_trust_region_radius) {
+    t.termination = LFVIO_CONVERGENCE;
+    t.done = 1;
   }
   (void)gradient_tolerance;
-  tr->iteration++;
+  t.iteration++;
+  *static_cast<TRHead *>(trg) = t;
 }
