@@ -164,12 +164,11 @@ def main():
     lin_ms = eng.time_kernel(0, batch, reps)
     bytes_per_launch = sum(algorithmic_bytes(w) for w in wins)
     achieved = bytes_per_launch / (lin_ms * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel="k_lin (visual residual/Jacobian sweep + Gram + IMU + prior roles)",
+    roofline = dict(bound="hbm", kernel="k_lin (visual residual/Jacobian sweep: landmark rows + Schur SYRK, Gram chunks, IMU, prior)",
                     achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
                     algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_us=lin_ms * 1e3,
                     note="latency-bound at N=300 (0.12 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep")
-    extra = dict(k_schur_us=eng.time_kernel(1, batch, reps) * 1e3, k_sum_us=eng.time_kernel(2, batch, reps) * 1e3,
-                 k_solve_us=eng.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
+    extra = dict(k_sum_us=eng.time_kernel(2, batch, reps) * 1e3, k_solve_us=eng.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
 
     out = dict(metric="sliding-window solves/sec (10 KF x N landmarks)", value=value, unit="solves/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,

@@ -12,12 +12,15 @@ extern "C" {
  * Hpp 172x172 row-major, gp 172, a/b N, W N x 73, cost. */
 int lfvio_debug_linearize(lfvio_ctx *ctx, const LfvioWindow *in, double *Hpp, double *gp, double *a, double *b,
                           double *W, double *cost);
+/* The Schur sums of a solve repeated with a new mu on the stored linearization (do_schur without do_lin) against a
+ * full re-linearization at the same mu: largest absolute difference (expected 0). */
+int lfvio_debug_schur_repeat(lfvio_ctx *ctx, const LfvioWindow *in, double mu, double *max_abs_diff);
 /* Post-Schur system (A' n x n, b' n) of the last marginalization run on slot 0. */
 int lfvio_debug_marg_system(lfvio_ctx *ctx, int n, double *A, double *b);
 /* shader-clock stamps written by the last k_solve of slot 0 (bring-up instrumentation) */
 int lfvio_debug_read_clocks(lfvio_ctx *ctx, long long *out32);
 /* Average ms of `reps` launches of one pipeline kernel over slots [0,count) (HIP events on the context stream).
- * which: 0 k_lin (residual/Jacobian sweep), 1 k_schur (MFMA SYRK), 2 k_sum, 3 k_solve. */
+ * which: 0 k_lin (residual/Jacobian sweep + Schur SYRK of the landmark blocks), 2 k_sum (+ k_presum), 3 k_solve. */
 int lfvio_debug_time_kernel(lfvio_ctx *ctx, int which, int count, int reps, double *avg_ms);
 /* 0: launch kernels directly, 1: replay the captured hipGraph (default). */
 int lfvio_debug_set_graph(lfvio_ctx *ctx, int on);

@@ -44,8 +44,7 @@ enum { XS_COST = 0, XS_G2, XS_ASV2, XS_LAM2, XS_BMAX, XS_GN2, XS_GGN, XS_CCOST, 
 constexpr int LM_BLOCK = 64;     // landmarks per workgroup (one wave) in the landmark sweep
 constexpr int CHUNK_LANES = 64;
 constexpr int CHUNK_MAX = 64;    // observations per Gram chunk: one wave pass; a workgroup of k_lin takes 4 chunks
-constexpr int SCHUR_LM_MIN = 16;  // landmarks per wave in the Schur SYRK: >= 16, grown so that parts <= SCHUR_PARTS_MAX
-constexpr int SCHUR_PARTS_MAX = 1024;
+constexpr int SCHUR_LM = 64;      // landmarks per Schur SYRK part = one landmark block of k_lin
 constexpr int LMS = 16;          // per-block landmark scalar partials
 constexpr int IMU_OUT = 900 + 30 + 2;
 
@@ -86,19 +85,25 @@ enum {
   Q_COUNT = 16
 };
 
-struct TRHead {  // the scalar part: the single-lane bookkeeping kernels copy it to registers in one batch of loads
-  double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha;
-  double cg, cn;        // dogleg step = cg * gradient_ + cn * gauss_newton_step_ (D-scaled space)
-  double gn_sq_total, grad_sq_total, grad_gn_total;
-  double step_sq_pose;  // ||x - candidate||^2, pose side (ambient)
-  double xn2_pose_cand; // ||candidate||^2, pose side (ambient)
-  double gmax_pose, lm_bmax;
-  double initial_cost;
-  double q[Q_COUNT];
-  int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled;
+// The scalar part of the trust-region state.  TRHead and TRState share it as a common initial sequence, so the single-lane
+// bookkeeping kernels can copy it to registers in one batch of loads (reinterpret_cast<TRHead *>) while Slot stays a
+// standard-layout type for offsetof on the host.
+#define TR_HEAD_FIELDS \
+  double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha; \
+  double cg, cn; \
+  double gn_sq_total, grad_sq_total, grad_gn_total; \
+  double step_sq_pose; \
+  double xn2_pose_cand; \
+  double gmax_pose, lm_bmax; \
+  double initial_cost; \
+  double q[Q_COUNT]; \
+  int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled; \
   int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, new_point;
+struct TRHead {
+  TR_HEAD_FIELDS
 };
-struct TRState : TRHead {
+struct TRState {
+  TR_HEAD_FIELDS
   LfvioIterationSummary it;
   LfvioIterationSummary trace[LFVIO_MAX_TRACE];
 };

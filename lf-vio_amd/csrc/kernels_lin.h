@@ -2,8 +2,7 @@
 //
 //   k_setup   : state reset, per-pair tables, IMU sqrt-information, prior A' = J0^T J0
 //   k_lin     : ONE launch, four workgroup roles selected by blockIdx.x
-//                 [landmark blocks | Gram chunks | IMU factors | prior]
-//   k_schur   : sum_l c_l w_l w_l^T (80x80) on v_mfma_f64_16x16x4_f64
+//                 [landmark blocks (+ Schur SYRK of the block on v_mfma_f64_16x16x4_f64) | Gram chunks | IMU factors | prior]
 //   k_sum     : deterministic fixed-order reduction of the per-workgroup partials
 #pragma once
 #include "dev_factors.h"
@@ -157,7 +156,7 @@ DEV void load_pair_uniform(const Tab *T, int pair, PairU &u) {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int LIN_THREADS = 256;
-constexpr int LIN_LDS = LM_BLOCK * (WLD + 1) + 64;  // doubles: the W tile of the landmark role + reduction scratch
+constexpr int LIN_LDS = LM_BLOCK * (WLD + 1) + 64 + 2 * LM_BLOCK;  // doubles: W tile of the landmark role, reduction scratch, Schur weights
 
 DEV double quad_sum(double v) {  // sum over the 4 lanes of a quad, same value and same order in every lane
   v += __shfl_xor(v, 1, 64);
@@ -166,12 +165,80 @@ DEV double quad_sum(double v) {  // sum over the 4 lanes of a quad, same value a
 }
 DEV d3 quad_sum3(d3 v) { return mk3(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z)); }
 
+// Schur SYRK of one landmark block from the LDS tile: part `blk` of the 15 upper 16x16 tiles of sum_l c_l w_l w_l^T
+// (cols 73/74 carry b_l and the Cauchy cross-term column) on the FP64 matrix pipe.  Wave w owns tiles w, w+4, w+8,
+// w+12; four landmarks per MFMA: lane (k, c) feeds A[i = c][k] = c_l w_l[16 t + c], B[k][j = c] = w_l[16 u + c]; the
+// accumulator holds D[row = (lane >> 4) + 4 reg][col = lane & 15].
+DEV void schur_block(Slot *S, int blk, int mode, int Nlim, double (*tile)[WLD + 1], const double *lcoef, const double *le) {
+  const int tid = threadIdx.x;
+  {
+    const int wv = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
+    double4_t acc[4];
+    int ct[4], cu[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      acc[j] = double4_t{0, 0, 0, 0};
+      const int ti = wv + 4 * j;  // upper tile index: (0,0..4) (1,1..4) (2,2..4) (3,3..4) (4,4)
+      const int t = ti < 5 ? 0 : ti < 9 ? 1 : ti < 12 ? 2 : ti < 14 ? 3 : 4;
+      const int u = ti - (t * 5 - (t * (t - 1)) / 2) + t;
+      ct[j] = 16 * t + cc, cu[j] = 16 * u + cc;
+    }
+    int rows = Nlim - blk * LM_BLOCK;
+    rows = rows > LM_BLOCK ? LM_BLOCK : rows;
+    for (int s4 = 0; 4 * s4 < rows; s4++) {
+      const int row = 4 * s4 + kk;
+      const double coef = lcoef[row], eb = le[row];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (wv + 4 * j >= NT) continue;  // wave-uniform
+        const double xa = tile[row][ct[j]];
+        double xb = tile[row][cu[j]];
+        if (mode == MODE_SOLVE && cu[j] == COL_K) xb *= eb;  // b/D2 * e  -> z2 column
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(coef * xa, xb, acc[j], 0, 0, 0);
+      }
+    }
+    double *out = S->schur_part + (size_t)blk * SCHUR_LEN;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (wv + 4 * j >= NT) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) out[(wv + 4 * j) * 256 + r * 64 + lane] = acc[j][r];
+    }
+  }
+}
+
+// A solve repeated with a new mu on an unchanged linearization (do_schur without do_lin): only the Schur weights
+// change.  The block's W rows come back from HBM into the tile and the SYRK is redone.
+DEV void lin_schur_only_role(Slot *S, int blk, double *lds) {
+  double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
+  double *lcoef = lds + LM_BLOCK * (WLD + 1) + 64, *le = lcoef + LM_BLOCK;
+  const int tid = threadIdx.x;
+  const double *Wb = S->W + (size_t)blk * LM_BLOCK * WLD;
+  for (int e = tid; e < LM_BLOCK * WLD; e += LIN_THREADS) tile[e / WLD][e % WLD] = Wb[e];
+  if (tid < LM_BLOCK) {
+    const int l = blk * LM_BLOCK + tid;
+    double cf = 0.0, eb = 0.0;
+    if (l < S->N) {
+      const double sc = S->scale_l[l], s2a = sc * sc * S->a[l];
+      const double D2 = fmin(fmax(s2a, 1e-6), 1e32);
+      eb = s2a + S->tr.mu * D2;  // e-block + lm_diagonal^2
+      const double einv = 1.0 / eb;
+      cf = sc * sc * einv;
+      S->einv_l[l] = einv;
+    }
+    lcoef[tid] = cf, le[tid] = eb;
+  }
+  __syncthreads();
+  schur_block(S, blk, MODE_SOLVE, S->N, tile, lcoef, le);
+}
+
 // Landmark role: 64 landmarks per workgroup, 4 lanes per landmark (lane q takes the observations 1+q, 5+q, 9+q of the
 // track), so the dependent chain per lane is a quarter of the track.  The 80-wide row w_l is built in an LDS tile and
 // leaves as whole 512-byte lines.
 DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *red = lds + LM_BLOCK * (WLD + 1);
+  double *lcoef = red + 64, *le = lcoef + LM_BLOCK;  // Schur weight c_l and e-block of the block's landmarks
   const int tid = threadIdx.x, lml = tid >> 2, q = tid & 3;
   const TRState *tr = &S->tr;
   const int cur = tr->cur;
@@ -183,6 +250,7 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
   const int est_ex = is_marg(mode) ? 1 : S->est_ex;  // ResidualBlockInfo::Evaluate asks for every Jacobian
   const double td = S->x[cur].td;
   for (int e = tid; e < LM_BLOCK * (WLD + 1); e += LIN_THREADS) lds[e] = 0.0;
+  if (tid < 2 * LM_BLOCK) lcoef[tid] = 0.0;
   __syncthreads();
   double a = 0, b = 0, cost = 0, lam = 1.0, wtd = 0;
   d3 wPi = mk3(0, 0, 0), wTi = wPi, wTic = wPi, wTx = wPi;
@@ -254,6 +322,15 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
       const double v = gr / dg;
       asv2 = s * s * a * v * v;
       tile[lml][COL_K] = b / D2;
+      // Schur weight: e-block + lm_diagonal^2 (k_schur restates this when only mu changes)
+      const double s2a = s * s * a;
+      const double eb = s2a + tr->mu * D2, einv = 1.0 / eb;
+      le[lml] = eb, lcoef[lml] = s * s * einv;
+      S->einv_l[l] = einv;
+    } else {
+      const double cf = (a > 1e-8) ? 1.0 / a : 0.0;  // eps of marginalization_factor.h:70 on the diagonal block
+      le[lml] = a, lcoef[lml] = cf;
+      S->einv_l[l] = cf;
     }
     S->a[l] = a;
     S->b[l] = b;
@@ -280,6 +357,7 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
   }
   double *Wb = S->W + (size_t)blk * LM_BLOCK * WLD;
   for (int e = tid; e < LM_BLOCK * WLD; e += LIN_THREADS) Wb[e] = tile[e / WLD][e % WLD];
+  schur_block(S, blk, mode, Nlim, tile, lcoef, le);
 }
 
 // Gram role: one chunk (<= 64 observations of one frame pair) per WAVE, four chunks per workgroup; the waves never
@@ -484,16 +562,19 @@ DEV void lin_prior_role(Slot *S, int mode, double *lds) {
 __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode, int gLm, int gCh) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
-  if (tr->done || !tr->do_lin) return;
+  const int do_lin = tr->do_lin, do_schur = tr->do_schur;
+  if (tr->done || (!do_lin && !do_schur)) return;
   __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLm, gCh); each slot uses its own counts
   int b = blockIdx.x;
   if (b < gLm) {
     if (b >= S->nLmBlocks) return;
     if (is_marg(mode) && b * LM_BLOCK >= marg_plan(S, mode)->N0) return;
-    lin_landmark_role(S, b, mode, lds);
+    if (do_lin) lin_landmark_role(S, b, mode, lds);
+    else lin_schur_only_role(S, b, lds);
     return;
   }
+  if (!do_lin) return;
   b -= gLm;
   if (b < gCh) {  // gCh workgroups of 4 chunks
     lin_gram_role(S, b, mode, lds);
@@ -505,70 +586,6 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t strid
     return;
   }
   lin_prior_role(S, mode, lds);
-}
-
-// ---------------------------------------------------------------------------
-// k_schur: grid (nSchurParts, batch) x 64.  Sc = sum_l c_l w_l w_l^T over the 80-wide rows
-// (cols 73/74 carry b_l and the Cauchy cross-term column), upper 15 tiles of 16x16, on the
-// FP64 matrix pipe.  Lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the
-// accumulator holds D[row = (l>>4) + 4*reg][col = l&15].
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_schur(char *base, size_t stride, int mode) {
-  Slot *S = SLOT(base, stride);
-  const TRState *tr = &S->tr;
-  if (tr->done || !tr->do_schur) return;
-  const int lane = threadIdx.x, kk = lane >> 4, cc = lane & 15;
-  const int part = blockIdx.x;
-  const int Nlim = is_marg(mode) ? marg_plan(S, mode)->N0 : S->N;
-  const double mu = tr->mu;
-  double4_t acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++) acc[t] = double4_t{0, 0, 0, 0};
-  const int lm = S->schur_lm;
-  const int l0 = part * lm;
-  for (int s = 0; s < lm / 4; s++) {
-    if (l0 + 4 * s >= Nlim) break;
-    const int l = l0 + 4 * s + kk;
-    double coef = 0.0, e = 0.0;
-    double x[5] = {0, 0, 0, 0, 0};
-    if (l < Nlim) {
-      const double a = S->a[l];
-      if (is_marg(mode)) {
-        e = a;
-        coef = (a > 1e-8) ? 1.0 / a : 0.0;  // eps of marginalization_factor.h:70 on the diagonal block
-        if (cc == 0) S->einv_l[l] = coef;
-      } else {
-        const double sc = S->scale_l[l];
-        const double s2a = sc * sc * a;
-        const double D2 = fmin(fmax(s2a, 1e-6), 1e32);
-        e = s2a + mu * D2;  // e-block + lm_diagonal^2
-        const double einv = 1.0 / e;
-        coef = sc * sc * einv;
-        if (cc == 0) S->einv_l[l] = einv;
-      }
-      const double *row = S->W + (size_t)l * WLD + cc;
-#pragma unroll
-      for (int t = 0; t < 5; t++) x[t] = row[16 * t];
-    }
-    double bx4 = x[4];
-    if (mode == MODE_SOLVE && cc == (COL_K - 64)) bx4 = x[4] * e;  // b/D2 * e  -> z2 column
-    int ti = 0;
-#pragma unroll
-    for (int t = 0; t < 5; t++) {
-      const double at = coef * x[t];
-#pragma unroll
-      for (int u = t; u < 5; u++) {
-        const double bu = (u == 4) ? bx4 : x[u];
-        acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bu, acc[ti], 0, 0, 0);
-        ti++;
-      }
-    }
-  }
-  double *out = S->schur_part + (size_t)part * SCHUR_LEN;
-#pragma unroll
-  for (int t = 0; t < NT; t++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) out[t * 256 + r * 64 + lane] = acc[t][r];
 }
 
 // element (R, Cc) of the reduced 80x80 accumulator, R <= Cc
@@ -648,16 +665,15 @@ DEV double gram_gather(const Slot *S, int e, int mode) {
 }
 
 // ---------------------------------------------------------------------------
-// k_presum: grid (NPAIR + PRE_SCHUR_BLOCKS + 1, batch) x 256 — only launched for large windows, where one thread of
+// k_presum: grid (NPAIR + 15 * groups + 1, batch) x 256, groups = ceil(parts / PRE_GROUP) — only launched for large windows, where one thread of
 // k_sum would otherwise walk thousands of partials.  First level of the fixed-order reductions:
 //   [0, NPAIR)            Gram chunks of one frame pair -> pairG[pair]
 //   [NPAIR, +25*G)        Schur SYRK partials in groups of PRE_GROUP, in place (the sum lands in the group's first part)
 //   last                  landmark scalar partials -> lm_sum
 // ---------------------------------------------------------------------------
 constexpr int PRE_GROUP = 32;
-constexpr int PRE_GROUPS = (SCHUR_PARTS_MAX + PRE_GROUP - 1) / PRE_GROUP + 1;
-constexpr int PRE_SCHUR_BLOCKS = (SCHUR_LEN / 256) * PRE_GROUPS;
-__global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int mode) {
+__global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int mode, int groups) {
+  const int PRE_SCHUR_BLOCKS = (SCHUR_LEN / 256) * groups;
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   if (tr->done) return;

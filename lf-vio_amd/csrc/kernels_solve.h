@@ -814,7 +814,7 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
   const int lane = threadIdx.x;
   // Everything the kernel needs from the slot header in ONE batch of loads, before the first branch: a load issued
   // behind a branch waits a full memory round trip (~0.6 us) of its own, and this kernel is nothing but such a chain.
-  TRHead t = *static_cast<const TRHead *>(tr);
+  TRHead t = *reinterpret_cast<const TRHead *>(tr);
   const int sharded = S->sharded, max_iter = S->max_iter, nLmBlocks = S->nLmBlocks;
   const double *cost_part = S->cost_part;
   const double pc = lane < 11 ? S->pose_cost[lane] : 0.0;
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
     }
   }
   if (finished) {  // the converged iteration is not pushed (Minimize() returns before Finalize)
-    *static_cast<TRHead *>(trg) = t;
+    *reinterpret_cast<TRHead *>(trg) = t;
     return;
   }
   // FinalizeIterationAndCheckIfMinimizerCanContinue
@@ -936,5 +936,5 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
   }
   (void)gradient_tolerance;
   t.iteration++;
-  *static_cast<TRHead *>(trg) = t;
+  *reinterpret_cast<TRHead *>(trg) = t;
 }

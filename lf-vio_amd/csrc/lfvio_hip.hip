@@ -46,7 +46,7 @@ Layout make_layout(int maxN, int maxM) {
   L.maxM = maxM;
   L.capLmBlocks = std::max(1, (maxN + LM_BLOCK - 1) / LM_BLOCK);
   L.capChunks = 64 + maxM / CHUNK_MAX;
-  L.capSchurParts = std::min(SCHUR_PARTS_MAX, std::max(1, (maxN + SCHUR_LM_MIN - 1) / SCHUR_LM_MIN)) + 1;
+  L.capSchurParts = L.capLmBlocks + 1;
   size_t o = align_up(sizeof(Slot), 256);
   auto take = [&](size_t bytes) {
     size_t r = o;
@@ -344,12 +344,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->pair_chunk0[NPAIR] = nChunks;
   S->nChunks = nChunks;
   S->nLmBlocks = (N + LM_BLOCK - 1) / LM_BLOCK;
-  {
-    int lm = SCHUR_LM_MIN;
-    if ((N + lm - 1) / lm > SCHUR_PARTS_MAX) lm = ((N + SCHUR_PARTS_MAX - 1) / SCHUR_PARTS_MAX + 3) / 4 * 4;
-    S->schur_lm = lm;
-    S->nSchurParts = (N + lm - 1) / lm;
-  }
+  S->schur_lm = SCHUR_LM;  // one part per landmark block: k_lin forms it from its LDS tile
+  S->nSchurParts = S->nLmBlocks;
   info.gLm = S->nLmBlocks, info.gCh = nChunks, info.gSc = S->nSchurParts;
   // ---- gather lists of k_sum: which Gram entries (chunk or, for large windows, frame pair; local index of the
   //      20 x 20 block [Pi th_i Pj th_j tic th_ic td | r]) add up to each packed H_pp / g_p entry.  Units ascend, so the
@@ -483,14 +479,14 @@ void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
 void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const size_t st = c->L.total;
   const int pre = (g.ch > PRE_CHUNK_LIMIT || g.sc > 4 * PRE_GROUP) ? 1 : 0;
-  if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + PRE_SCHUR_BLOCKS + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode);
+  const int groups = (g.sc + PRE_GROUP - 1) / PRE_GROUP;
+  if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + (SCHUR_LEN / 256) * groups + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, groups);
   hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre);
 }
 
 void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const size_t st = c->L.total;
   launch_lin(c, count, g, mode);
-  hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, mode);
   launch_sum(c, count, g, mode);
   if (mode == MODE_SOLVE) {
     hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
@@ -739,7 +735,6 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   const Grid g = grid_for(c, 1);
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, 1).lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
   launch_lin(c, 1, g, MODE_SOLVE);
-  hipLaunchKernelGGL(k_schur, dim3(g.sc, 1), dim3(64), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
   launch_sum(c, 1, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total);
   HIPCHK(c, hipGetLastError());
@@ -768,6 +763,47 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   return LFVIO_OK;
 }
 
+// The mu-retry path (do_schur without do_lin: k_lin's landmark blocks redo only the Schur SYRK from the stored W rows)
+// against a full linearization at the same mu.  Returns the largest absolute difference of the Schur sums (expected 0).
+int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, double *max_abs_diff) {
+  if (!c || !in || !max_abs_diff) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = reserve(c, 1, in->num_landmarks, in->num_observations);
+  if (rc) return rc;
+  if ((rc = upload_window(c, 0, in))) return rc;
+  const Grid g = grid_for(c, 1);
+  char *d = c->d_base;
+  const size_t o_tr = offsetof(Slot, tr);
+  auto poke_int = [&](size_t off, int v) { return hipMemcpy(d + o_tr + off, &v, sizeof v, hipMemcpyHostToDevice); };
+  auto run = [&](int do_lin, std::vector<double> &out) -> int {
+    HIPCHK(c, hipMemcpy(d + o_tr + offsetof(TRState, mu), &mu, sizeof mu, hipMemcpyHostToDevice));
+    HIPCHK(c, poke_int(offsetof(TRState, do_lin), do_lin));
+    HIPCHK(c, poke_int(offsetof(TRState, do_schur), 1));
+    launch_lin(c, 1, g, MODE_SOLVE);
+    launch_sum(c, 1, g, MODE_SOLVE);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out.resize(SCHUR_LEN);
+    HIPCHK(c, hipMemcpy(out.data(), d + c->L.xch + sizeof(double) * XOFF_S, sizeof(double) * SCHUR_LEN, hipMemcpyDeviceToHost));
+    return LFVIO_OK;
+  };
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<double> first, repeat, full;
+  const double mu1 = mu;
+  mu = 1e-8;
+  if ((rc = run(1, first))) return rc;   // ordinary first pass (fixes the Jacobi scaling: k_solve does that, so run it)
+  hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  mu = mu1;
+  if ((rc = run(0, repeat))) return rc;  // Schur only, new mu
+  if ((rc = run(1, full))) return rc;    // everything again at the new mu
+  double m = 0, ref = 0;
+  for (int i = 0; i < SCHUR_LEN; i++) m = std::max(m, std::fabs(repeat[i] - full[i])), ref = std::max(ref, std::fabs(full[i] - first[i]));
+  *max_abs_diff = m;
+  return ref > 0 ? LFVIO_OK : LFVIO_ERR_ARG;  // the new mu must have changed the sums, or the check proves nothing
+}
+
 // Post-Schur system A', b' of the last marginalization of slot 0 (n x n, n).
 int lfvio_debug_marg_system(lfvio_ctx *c, int n, double *A, double *b) {
   if (!c || !c->d_base) return LFVIO_ERR_ARG;
@@ -786,7 +822,7 @@ int lfvio_debug_read_clocks(lfvio_ctx *c, long long *out32) {
 }
 
 // Average duration (ms) of `reps` launches of one pipeline kernel on slots [0, count), measured with
-// HIP events on the context's own stream.  which: 0 k_lin, 1 k_schur, 2 k_sum, 3 k_solve.
+// HIP events on the context's own stream.  which: 0 k_lin (with the Schur SYRK of the landmark blocks), 2 k_sum, 3 k_solve.
 // The slots must hold an uploaded window; the trust-region flags are re-armed by k_setup first.
 int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double *avg_ms) {
   if (!c || !c->d_base || count <= 0 || count > c->batch || reps <= 0) return LFVIO_ERR_ARG;
@@ -799,13 +835,11 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
   // one full linearization so that every kernel has valid inputs
   launch_lin(c, count, g, MODE_SOLVE);
-  hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE);
   launch_sum(c, count, g, MODE_SOLVE);
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
       case 0: launch_lin(c, count, g, MODE_SOLVE); break;
-      case 1: hipLaunchKernelGGL(k_schur, dim3(g.sc, count), dim3(64), 0, c->stream, c->d_base, st, MODE_SOLVE); break;
       case 2: launch_sum(c, count, g, MODE_SOLVE); break;  // k_presum + k_sum for large windows
       default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st); break;
     }

@@ -51,6 +51,13 @@ class Engine:
         self._check(self.lib.lfvio_marginalize(self.ctx, C.byref(win.c()), flag, C.byref(prior)), "lfvio_marginalize")
         return prior
 
+    def schur_repeat(self, win, mu):
+        """Largest |difference| between the Schur sums of the mu-retry path and of a full re-linearization (expected 0)."""
+        d = np.zeros(1)
+        self.lib.lfvio_debug_schur_repeat.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_double, _dp]
+        self._check(self.lib.lfvio_debug_schur_repeat(self.ctx, C.byref(win.c()), float(mu), _p(d)), "lfvio_debug_schur_repeat")
+        return float(d[0])
+
     def marg_system(self, n):
         A = np.zeros((n, n))
         b = np.zeros(n)

@@ -205,6 +205,13 @@ def test_edge_cases(eng, oracle):
     check_solution(eng.solve(w1), oracle.solve(w1), w1)
 
 
+@pytest.mark.parametrize("seed,n,mu", [(0, 300, 1e-3), (5, 65, 1e-5), (8, 3000, 1e-2)])
+def test_mu_retry_path_equals_full_relinearization(eng, seed, n, mu):
+    """A solve repeated with a larger mu on the stored linearization (Ceres: linear solver failure / invalid step) only
+    redoes the Schur SYRK from the stored W rows; it must give exactly what a full re-linearization at that mu gives."""
+    assert eng.schur_repeat(synth.make_window(seed, n), mu) == 0.0
+
+
 def test_large_window_invariants(eng):
     """N = 20 000 (beyond what the dense oracle handles comfortably): size-independent properties."""
     w = synth.make_window(21, 20000)
