@@ -227,17 +227,21 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       double *cbw = colbuf + (k2 & 1) * 176;                                                             \
       if (!(d > 0.0)) bad = true;                                                                        \
       const double dinv = fast_rsqrt(d);                                                                 \
-      _Pragma("unroll") for (int a = KB; a < 11; a++) {                                                  \
-        const int i = trow + 16 * a;                                                                     \
+      /* only tile row KB straddles the pivot; rows beyond KP hold exact zeros and need no mask */        \
+      {                                                                                                  \
         double v = 0.0;                                                                                  \
-        if (i > k2 && i <= KP) {                                                                         \
-          m[a][KB] *= dinv;                                                                              \
-          v = m[a][KB];                                                                                  \
-        } else if (i == k2) {                                                                            \
-          m[a][KB] = d * dinv;                                                                           \
+        if (trow > fk) {                                                                                 \
+          m[KB][KB] *= dinv;                                                                             \
+          v = m[KB][KB];                                                                                 \
+        } else if (trow == fk) {                                                                         \
+          m[KB][KB] = d * dinv;                                                                          \
           invd[k2] = dinv;                                                                               \
         }                                                                                                \
-        cbw[i] = v;                                                                                      \
+        cbw[trow + 16 * (KB)] = v;                                                                       \
+      }                                                                                                  \
+      _Pragma("unroll") for (int a = (KB) + 1; a < 11; a++) {                                            \
+        m[a][KB] *= dinv;                                                                                \
+        cbw[trow + 16 * a] = m[a][KB];                                                                   \
       }                                                                                                  \
     }                                                                                                    \
   } while (0)
