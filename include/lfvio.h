@@ -218,7 +218,10 @@ void *lfvio_stream(lfvio_ctx *ctx);
  *     if (lfvio_shard_candidate(ctx) == 1) all_reduce(buf[scalar_offset : len]); // 128 B
  *     lfvio_shard_decide(ctx, &state);   // identical decision on every rank, no broadcast
  *   }
- *   lfvio_shard_finish(ctx, &sol);       // pose-side state replicated; inv_depth: own range only
+ *   if (lfvio_shard_marg_linearize(ctx, flag) == 1) all_reduce(buf[0 : len]);   // optional: the next prior
+ *   lfvio_shard_marg_finish(ctx, flag, &prior);   // identical on every rank (estimator.cpp:833-1005)
+ *   lfvio_shard_finish(ctx, &sol);       // pose-side state replicated; inv_depth: own range only;
+ *                                        // after the marginalization calls: the state after double2vector()
  */
 int lfvio_shard_begin(lfvio_ctx *ctx, const LfvioWindow *in, int lm_begin, int lm_end, int add_pose_side);
 int lfvio_shard_exchange_len(void);
@@ -229,6 +232,8 @@ int lfvio_shard_solve(lfvio_ctx *ctx);
 int lfvio_shard_candidate(lfvio_ctx *ctx);
 /* *state: 0 = linearize next, 1 = step rejected (only a new candidate), 2 = terminated */
 int lfvio_shard_decide(lfvio_ctx *ctx, int *state);
+int lfvio_shard_marg_linearize(lfvio_ctx *ctx, int flag);
+int lfvio_shard_marg_finish(lfvio_ctx *ctx, int flag, LfvioPrior *out);
 int lfvio_shard_finish(lfvio_ctx *ctx, LfvioSolution *out);
 
 #ifdef __cplusplus

@@ -842,6 +842,7 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
       }
       sc[XS_COST] = cost;
       sc[XS_G2] = S->lm_sum[1], sc[XS_ASV2] = S->lm_sum[2], sc[XS_LAM2] = S->lm_sum[3], sc[XS_BMAX] = S->lm_sum[4];
+      if (is_marg(mode)) sc[XS_N0] = (double)marg_plan(S, mode)->N0;  // landmarks this rank eliminates
     }
   }
 }

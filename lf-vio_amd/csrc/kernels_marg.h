@@ -457,7 +457,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   __syncthreads();
   // eliminate the frame-0 landmarks: H -= sum c_l w_l w_l^T, g -= sum c_l b_l w_l
   const double *Sc = S->schur_sum;
-  if (mp->N0 > 0) {
+  if (mp->N0 > 0 || S->sharded) {  // sharded: the all-reduced sums hold the other ranks' landmarks
     for (int e = tid; e < KC * (KC + 1) / 2; e += MARG_THREADS) {
       int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
       while ((r + 1) * (r + 2) / 2 <= e) r++;
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   STAMP(S, 15);
   if (tid == 0) {
     out->valid = 1;
-    out->m = m15 + mp->N0;
+    out->m = m15 + (S->sharded ? (int)(S->xch[XOFF_C + XS_N0] + 0.5) : mp->N0);
     out->n = n;
     out->num_blocks = mp->nb;
   }

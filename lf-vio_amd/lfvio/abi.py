@@ -279,7 +279,8 @@ HIP_SYMBOLS = [
     "lfvio_batch_reserve", "lfvio_batch_upload", "lfvio_batch_optimize", "lfvio_batch_optimize_async",
     "lfvio_batch_sync", "lfvio_batch_download", "lfvio_stream",
     "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_scalar_offset", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
-    "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_finish",
+    "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_marg_linearize", "lfvio_shard_marg_finish",
+    "lfvio_shard_finish",
 ]
 
 
@@ -325,6 +326,8 @@ def load_hip_library(path=None):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.lfvio_shard_decide.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.lfvio_shard_finish.argtypes = [C.c_void_p, C.POINTER(SolutionC)]
+    lib.lfvio_shard_marg_linearize.argtypes = [C.c_void_p, C.c_int]
+    lib.lfvio_shard_marg_finish.argtypes = [C.c_void_p, C.c_int, C.POINTER(Prior)]
     return lib
 
 

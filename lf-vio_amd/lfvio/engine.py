@@ -129,6 +129,17 @@ class Engine:
         self._check(self.lib.lfvio_shard_decide(self.ctx, C.byref(st)), "shard_decide")
         return st.value
 
+    def shard_marginalize_linearize(self, flag):
+        rc = self.lib.lfvio_shard_marg_linearize(self.ctx, int(flag))
+        if rc < 0:
+            self._check(rc, "shard_marg_linearize")
+        return rc
+
+    def shard_marginalize_finish(self, flag):
+        prior = abi.Prior()
+        self._check(self.lib.lfvio_shard_marg_finish(self.ctx, int(flag), C.byref(prior)), "shard_marg_finish")
+        return prior
+
     def shard_finish(self, n_landmarks_total):
         sol = abi.Solution(n_landmarks_total)
         self._check(self.lib.lfvio_shard_finish(self.ctx, C.byref(sol.c)), "shard_finish")

@@ -41,10 +41,12 @@ def exchange_tensor(engine):
     return t, soff
 
 
-def solve_sharded(engine, win, rank, world, all_reduce):
+def solve_sharded(engine, win, rank, world, all_reduce, marg_flag=None):
     """Run the sharded trust-region loop.  all_reduce(tensor) must sum `tensor` in place over the ranks
-    (torch.distributed.all_reduce on the RCCL backend).  Returns the solution; inv_depth is filled for the
-    local landmark range only (use gather_inv_depth to assemble all)."""
+    (torch.distributed.all_reduce on the RCCL backend).  Returns (solution, (begin, end)) — inv_depth is filled for
+    the local landmark range only — or, with marg_flag (abi.MARGIN_OLD / MARGIN_SECOND_NEW), the whole
+    optimization(): (solution after the gauge fix, (begin, end), next prior); the marginalization costs one more
+    all-reduce of the exchange buffer and every rank ends up with the identical prior."""
     ranges = partition_landmarks(win.obs_offset, world)
     b, e = ranges[rank]
     engine.shard_begin(win, b, e, add_pose_side=(rank == 0))
@@ -62,4 +64,9 @@ def solve_sharded(engine, win, rank, world, all_reduce):
         guard += 1
         if guard > 4 * (win.max_num_iterations + 8):
             raise RuntimeError("sharded loop did not terminate")
-    return engine.shard_finish(win.N), (b, e)
+    if marg_flag is None:
+        return engine.shard_finish(win.N), (b, e)
+    if engine.shard_marginalize_linearize(marg_flag) == 1:
+        all_reduce(buf)
+    prior = engine.shard_marginalize_finish(marg_flag)
+    return engine.shard_finish(win.N), (b, e), prior

@@ -109,6 +109,7 @@ def test_two_contexts_emulate_ranks_on_one_gpu(oracle, world):
     w = synth.make_window_with_prior(4, 300, lambda x, f: oracle.optimize(x, f))[0]
     ref = Engine(0)
     want = ref.solve(w)
+    want_opt, want_prior = ref.optimize(w, abi.MARGIN_OLD)  # solve -> gauge fix -> marginalization on one GPU
     ref.close()
     engs = [Engine(0) for _ in range(world)]
     ranges = partition_landmarks(w.obs_offset, world)
@@ -139,7 +140,24 @@ def test_two_contexts_emulate_ranks_on_one_gpu(oracle, world):
         assert len(set(states)) == 1  # identical decision on every rank
         guard += 1
         assert guard < 64
-    sols = [e.shard_finish(w.N) for e in engs]
+    # ---- marginalization of the sharded window: one more all-reduce, identical prior on every rank
+    rcs = [e.shard_marginalize_linearize(abi.MARGIN_OLD) for e in engs]
+    assert rcs == [1] * world
+    all_reduce([b for b, _ in bufs])
+    priors = [e.shard_marginalize_finish(abi.MARGIN_OLD) for e in engs]
+    for p in priors:
+        assert (p.valid, p.m, p.n, p.num_blocks) == (1, want_prior.m, want_prior.n, want_prior.num_blocks)
+        assert p.block_list() == want_prior.block_list()
+        assert np.array_equal(p.J(), priors[0].J()) and np.array_equal(p.r(), priors[0].r())
+    J, r, Jw, rw = priors[0].J(), priors[0].r(), want_prior.J(), want_prior.r()
+    Aw = Jw.T @ Jw
+    assert np.abs(J.T @ J - Aw).max() < 1e-6 * np.abs(Aw).max()
+    assert np.abs(J.T @ r - Jw.T @ rw).max() < 1e-4 * np.abs(Jw.T @ rw).max()
+    for i in range(priors[0].num_blocks):
+        assert np.abs(priors[0].x0(i) - want_prior.x0(i)).max() < 1e-6
+    sols = [e.shard_finish(w.N) for e in engs]  # the state after the gauge fix now
+    assert np.abs(sols[0].pose - want_opt.pose).max() < 1e-6 * max(1.0, np.abs(want_opt.pose).max())
+    want = want_opt
     lam = np.zeros(w.N)
     for r, s in enumerate(sols):
         b, e = ranges[r]
