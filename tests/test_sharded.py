@@ -100,14 +100,16 @@ def test_shards_sum_to_the_whole_window_gloo(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_two_contexts_emulate_ranks_on_one_gpu(oracle, world):
+@pytest.mark.parametrize("world,n", [(2, 300), (3, 300), (2, 20000)])  # 20000: the two-level reductions under sharding
+def test_two_contexts_emulate_ranks_on_one_gpu(oracle, world, n):
     import torch
     from lfvio.engine import Engine
     from lfvio.sharded import exchange_tensor
 
-    w = synth.make_window_with_prior(4, 300, lambda x, f: oracle.optimize(x, f))[0]
     ref = Engine(0)
+    # the warm-up step that produces the prior: the oracle where its dense marginalization reaches, the GPU path beyond
+    warm = (lambda x, f: oracle.optimize(x, f)) if n <= 1000 else (lambda x, f: ref.optimize(x, f))
+    w = synth.make_window_with_prior(4, n, warm)[0]
     want = ref.solve(w)
     want_opt, want_prior = ref.optimize(w, abi.MARGIN_OLD)  # solve -> gauge fix -> marginalization on one GPU
     ref.close()
