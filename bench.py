@@ -38,6 +38,28 @@ def algorithmic_bytes(win):
     return 68 * (M - N) + 88 * N
 
 
+def pmc_traffic(workload):
+    """HBM bytes per k_lin launch from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r*/pmc_summary.md, written by tools/collect_profiles.py): FETCH_SIZE + WRITE_SIZE, reported in KB.
+    None when no summary covers the workload (the counters cannot be collected from inside the timed process)."""
+    import glob
+    import re
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.md")), reverse=True):
+        section = None
+        for line in open(path):
+            m = re.match(r"## (\S+)", line)
+            if m:
+                section = m.group(1)
+            elif section == workload and line.startswith("| k_lin |"):
+                cells = [c.strip() for c in line.strip().strip("|").split("|")]
+                try:
+                    return (float(cells[2]) + float(cells[3])) * 1024.0, os.path.relpath(path, ROOT)
+                except ValueError:
+                    return None, None
+    return None, None
+
+
 def cpu_baseline(win, flag, target_seconds=12.0):
     """Single-thread CPU restatement (oracle/, kind 'port') of the same optimization() on the same window.
 
@@ -164,8 +186,10 @@ def main():
     lin_ms = eng.time_kernel(0, batch, reps)
     bytes_per_launch = sum(algorithmic_bytes(w) for w in wins)
     achieved = bytes_per_launch / (lin_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(args.workload)
     roofline = dict(bound="hbm", kernel="k_lin (visual residual/Jacobian sweep: landmark rows + Schur SYRK, Gram chunks, IMU, prior)",
-                    achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                    traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_us=lin_ms * 1e3,
                     note="latency-bound at N=300 (0.12 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep")
     extra = dict(k_sum_us=eng.time_kernel(2, batch, reps) * 1e3, k_solve_us=eng.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
