@@ -92,12 +92,24 @@ def cpu_baseline(win, flag, target_seconds=12.0):
             break
     n = len(laps)
     laps = np.array(laps) * 1e3
+    # variant with the reference's NUM_THREADS = 4 in marginalize() (marginalization_factor.h:13): same sums, four threads
+    mt = ""
+    if full:
+        ob.set_marg_threads(4)
+        one()
+        t1 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t1 < 3.0:
+            one()
+            k += 1
+        mt = f"; with 4-thread marginalize(): {k / (time.perf_counter() - t1):.1f} solves/s"
+        ob.set_marg_threads(1)
     what = "optimization() calls" if full else "trust-region solves WITHOUT the marginalization step (CPU upper bound)"
     return dict(value=n / el, unit="solves/s", cores=1, kind="port",
                 sample=f"{n} {what} on the same window ({win.N} landmarks, {win.M} observations), "
                        f"single thread, host cores available: {os.cpu_count()}; "
                        f"ms per call median/p95 = {np.median(laps):.2f}/{np.percentile(laps, 95):.2f}; "
-                       f"mean ms solve/gauge/marg = {parts[0] / n * 1e3:.2f}/{parts[1] / n * 1e3:.3f}/{parts[2] / n * 1e3:.2f}")
+                       f"mean ms solve/gauge/marg = {parts[0] / n * 1e3:.2f}/{parts[1] / n * 1e3:.3f}/{parts[2] / n * 1e3:.2f}" + mt)
 
 
 def main():

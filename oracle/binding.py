@@ -158,3 +158,10 @@ def sym_eig(A):
     V = np.zeros((n, n))
     lib().oracle_sym_eig(_p(A), n, _p(d), _p(V))
     return d, V
+
+
+def set_marg_threads(n):
+    """4: marginalize() builds A, b on four threads like the reference's ThreadsConstructA (bit-identical sums); 1: serial."""
+    L = lib()
+    L.oracle_set_marg_threads.argtypes = [C.c_int]
+    return L.oracle_set_marg_threads(int(n))

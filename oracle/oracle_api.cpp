@@ -147,6 +147,12 @@ int oracle_optimize(const LfvioWindow *w, int flag, LfvioSolution *sol, LfvioPri
   return rc;
 }
 
+// 4: the Jacobian products of marginalize() run on four threads like the reference's pthreads (timing variant); 1: serial
+int oracle_set_marg_threads(int n) {
+  g_marg_threads = n >= 4 ? 4 : 1;
+  return g_marg_threads;
+}
+
 int oracle_sym_eig(const double *A, int n, double *d, double *V) {
   sym_eig(A, n, d, V);
   return 0;

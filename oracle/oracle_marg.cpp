@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <map>
+#include <thread>
 
 #include "oracle_solver.h"
 
@@ -45,6 +46,8 @@ inline const double *state_block(const State &x, LfvioBlockId id) {
 }
 
 }  // namespace
+
+int g_marg_threads = 1;  // NUM_THREADS of marginalization_factor.h:13 when set to 4 (timing variant of the CPU baseline)
 
 int marginalize(const LfvioWindow &w, int flag, LfvioPrior *out, std::vector<double> *A_out, std::vector<double> *b_out) {
   Problem pb(w);
@@ -204,23 +207,34 @@ int marginalize(const LfvioWindow &w, int flag, LfvioPrior *out, std::vector<dou
   const int NT = 4;
   std::vector<std::vector<double>> At(NT, std::vector<double>((size_t)pos * pos, 0.0));
   std::vector<std::vector<double>> bt(NT, std::vector<double>(pos, 0.0));
-  for (size_t fi = 0; fi < factors.size(); fi++) {
-    const Factor &f = factors[fi];
-    std::vector<double> &Aa = At[fi % NT];
-    std::vector<double> &ba = bt[fi % NT];
-    const int nc = (int)f.cols.size();
-    for (int c1 = 0; c1 < nc; c1++) {
-      if (f.cols[c1] < 0) continue;
-      double g = 0;
-      for (int rr = 0; rr < f.nres; rr++) g += f.J[(size_t)rr * nc + c1] * f.r[rr];
-      ba[f.cols[c1]] += g;
-      for (int c2 = 0; c2 < nc; c2++) {
-        if (f.cols[c2] < 0) continue;
-        double s = 0;
-        for (int rr = 0; rr < f.nres; rr++) s += f.J[(size_t)rr * nc + c1] * f.J[(size_t)rr * nc + c2];
-        Aa[(size_t)f.cols[c1] * pos + f.cols[c2]] += s;
+  // accumulator t takes factors t, t+4, ... in order, so running the four on their own threads (the reference's
+  // pthreads; g_marg_threads = 4) gives bit-identical sums to running them one after the other (= 1, the default)
+  auto construct = [&](int t) {
+    std::vector<double> &Aa = At[t];
+    std::vector<double> &ba = bt[t];
+    for (size_t fi = t; fi < factors.size(); fi += NT) {
+      const Factor &f = factors[fi];
+      const int nc = (int)f.cols.size();
+      for (int c1 = 0; c1 < nc; c1++) {
+        if (f.cols[c1] < 0) continue;
+        double g = 0;
+        for (int rr = 0; rr < f.nres; rr++) g += f.J[(size_t)rr * nc + c1] * f.r[rr];
+        ba[f.cols[c1]] += g;
+        for (int c2 = 0; c2 < nc; c2++) {
+          if (f.cols[c2] < 0) continue;
+          double s = 0;
+          for (int rr = 0; rr < f.nres; rr++) s += f.J[(size_t)rr * nc + c1] * f.J[(size_t)rr * nc + c2];
+          Aa[(size_t)f.cols[c1] * pos + f.cols[c2]] += s;
+        }
       }
     }
+  };
+  if (g_marg_threads >= NT) {
+    std::thread th[NT];
+    for (int t = 0; t < NT; t++) th[t] = std::thread(construct, t);
+    for (int t = 0; t < NT; t++) th[t].join();
+  } else {
+    for (int t = 0; t < NT; t++) construct(t);
   }
   std::vector<double> A((size_t)pos * pos, 0.0), b(pos, 0.0);
   for (int t = NT - 1; t >= 0; t--) {

@@ -65,5 +65,6 @@ void gauge_fix(const State &pre, State *post);
 
 // A', b' (n x n, n) are optional outputs (post-Schur, pre-factorization).
 int marginalize(const LfvioWindow &w, int flag, LfvioPrior *out, std::vector<double> *A_out, std::vector<double> *b_out);
+extern int g_marg_threads;  // 1 (default) or 4 = NUM_THREADS of the reference's ThreadsConstructA; same sums either way
 
 }  // namespace orc
