@@ -411,6 +411,13 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   }
   plan_marg(w, LFVIO_MARGIN_OLD, N0, kmax0, S->pair_chunk0[11], true, &S->marg[0]);
   plan_marg(w, LFVIO_MARGIN_SECOND_NEW, 0, 0, 0, true, &S->marg[1]);
+  for (int f = 0; f < 2; f++)
+    if (S->marg[f].valid && (S->marg[f].n > 76 || S->marg[f].m15 + S->marg[f].n > 92)) {
+      // k_marg_solve keeps the dense system in LDS: sized for what the reference's own marginalization produces
+      // (10 poses + ex + td + one speed/bias = 76 kept, 15 dropped), not for an arbitrary hand-made prior
+      c->err = "prior keeps more than 76 tangent dimensions";
+      return LFVIO_ERR_ARG;
+    }
   // ---- device pointers
   S->lm_start.set(S, L.lm_start), S->lm_cnt.set(S, L.lm_cnt), S->lm_obs0.set(S, L.lm_obs0), S->lm_perm.set(S, L.lm_perm);
   S->lam0.set(S, L.lam0);
