@@ -180,8 +180,7 @@ struct Slot {
   GP<double2> rotlog;               // [JLOG_STEPS][JLOG_LD] (cos, sin) of every Jacobi step of the n x n eigen-problem
   GP<double> eig_aux;               // eigenvalues[96] | sorted b'[96] | (int) diagonal-sort permutation[96]
   double scale_p[KP], diag_p[KP], grad_p[KP], gn_p[KP], step_p[KP];
-  double uc_grad[WLD], uc_gn[WLD], uc_y[WLD];
-  double z1[WLD], z2[WLD];
+  double uc_grad[WLD], uc_gn[WLD];  // camera-side Cauchy / Gauss-Newton directions (unscaled), zero-padded to WLD
   long long dbg[32];
   double jtrace[32];             // off/diag mass per Jacobi sweep (instrumentation)             // shader-clock stamps (bring-up instrumentation)
   int eig_steps, eig_pad;        // Jacobi steps logged in rotlog

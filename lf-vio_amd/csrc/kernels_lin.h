@@ -595,7 +595,6 @@ DEV int schur_index(int R, int Cc) {
   const int row = R & 15, col = Cc & 15;
   return tile * 256 + (row >> 2) * 64 + ((row & 3) << 4) + col;
 }
-DEV double schur_get(const double *Sc, int r, int c) { return r <= c ? Sc[schur_index(r, c)] : Sc[schur_index(c, r)]; }
 
 // ---------------------------------------------------------------------------
 // k_sum: grid (HPP_BLOCKS + SCHUR_LEN/256 + 1, batch) x 256   (pre = 1: second level, after k_presum)
@@ -609,19 +608,6 @@ DEV double schur_get(const double *Sc, int r, int c) { return r <= c ? Sc[schur_
 constexpr int HPP_ITEMS = PACKED + KP;
 constexpr int HPP_BLOCKS = (HPP_ITEMS + 255) / 256;
 
-// frame block of a camera-side column: 0..10 pose, 11 ex, 12 td; lc = index inside the block
-DEV void cam_block(int c, int &f, int &lc) {
-  if (c < 66) {
-    f = c / 6;
-    lc = c - 6 * f;
-  } else if (c < 72) {
-    f = 11;
-    lc = c - 66;
-  } else {
-    f = 12;
-    lc = 0;
-  }
-}
 // IMU factor f sees tangent column c as local column (0..29) or -1
 DEV int imu_local(int c, int f) {
   if (c < 66) {

@@ -34,27 +34,6 @@ DEV double block_max(double v, double *scratch, int tid) {
   return s;
 }
 
-// sum over the packed lower triangle of  w_ij H_ij (x_i y_j + x_j y_i) / 2  = x^T H y
-// (each thread walks entries e = tid, tid + T, ...; (i, j) advance incrementally)
-DEV double packed_bilinear(const double *H, const double *x, const double *y, int tid, int nthreads) {
-  double s = 0;
-  int i = 0, j = tid;
-  while (j > i) {
-    j -= (i + 1);
-    i++;
-  }
-  for (int e = tid; e < PACKED; e += nthreads) {
-    const double h = H[e];
-    s = fma(h, (i == j) ? x[i] * y[i] : (x[i] * y[j] + x[j] * y[i]), s);
-    j += nthreads;
-    while (j > i) {
-      j -= (i + 1);
-      i++;
-    }
-  }
-  return s;
-}
-
 // ---------------------------------------------------------------------------
 // k_solve: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS.
 // Input: H_pp (packed) and g_p assembled by k_sum, Schur sums, landmark scalars.
