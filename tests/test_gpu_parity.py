@@ -210,6 +210,37 @@ def test_sequence_of_windows_tracks_the_oracle(eng, oracle):
         st = synth.continue_state(scene, k + 1, sol.pose, sol.speed_bias, sol.ex_pose, sol.td, rng)
 
 
+def test_randomized_sweep_against_the_oracle(eng, oracle):
+    """60 random (seed, size, flags, max_iterations, marginalization flag, with / without prior) combinations of the whole
+    optimization() — the cases tools/fuzz_parity.py draws.  Tiny windows sit close to the conditioning limits of the
+    algorithm itself, hence the slightly wider bars on inverse depths and on the prior; a prior whose information is
+    pure cancellation noise (no frame-0 landmark, no input prior: a lone IMU factor marginalized) is not compared."""
+    rng = np.random.default_rng(20260928)
+    for case in range(60):
+        seed = int(rng.integers(0, 10_000))
+        n = int(rng.choice([1, 2, 5, 9, 17, 33, 64, 65, 128, 300]))
+        kw = dict(estimate_extrinsic=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)),
+                  tr=float(rng.choice([0.0, 0.02])), max_num_iterations=int(rng.choice([1, 3, 8, 12])))
+        flag = int(rng.choice([abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW]))
+        if rng.integers(0, 2):
+            w = synth.make_window_with_prior(seed, n, lambda x, f: oracle.optimize(x, f), **kw)[0]
+        else:
+            w = synth.make_window(seed, n, **kw)
+        rs, rp = oracle.optimize(w, flag)
+        gs, gp = eng.optimize(w, flag)
+        tag = (case, seed, n, kw, flag)
+        assert (gs.c.num_iterations, gs.c.termination) == (rs.c.num_iterations, rs.c.termination), tag
+        assert np.abs(gs.pose - rs.pose).max() < 1e-6 * max(1.0, np.abs(rs.pose).max()), tag
+        assert np.abs(gs.speed_bias - rs.speed_bias).max() < 1e-6, tag
+        assert rel(gs.lam, rs.lam) < 1e-5, tag
+        assert gp.valid == rp.valid, tag
+        if rp.valid == 1:
+            assert (gp.m, gp.n, gp.num_blocks) == (rp.m, rp.n, rp.num_blocks) and gp.block_list() == rp.block_list(), tag
+            Ar = rp.J().T @ rp.J()
+            if np.abs(Ar).max() > 1.0:
+                assert rel(gp.J().T @ gp.J(), Ar) < 1e-4, tag
+
+
 def test_batched_windows_match_single(eng, oracle):
     wins = [synth.make_window(100 + s, 120 + 37 * s) for s in range(5)]
     eng.batch_reserve(5, max(w.N for w in wins), max(w.M for w in wins))

@@ -1,0 +1,23 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from lfvio import abi, synth
+from lfvio.engine import Engine
+from oracle import binding as ob
+import np_ref
+eng = Engine(0)
+seed, n = int(sys.argv[1]), int(sys.argv[2])
+kw = dict(estimate_extrinsic=int(sys.argv[3]), estimate_td=int(sys.argv[4]), tr=float(sys.argv[5]), max_num_iterations=int(sys.argv[6]))
+w = synth.make_window(seed, n, **kw)
+sol, _ = ob.optimize(w, abi.MARGIN_OLD)
+w2 = abi.apply_solution(w, sol)
+ref, Aref, bref = ob.marginalize(w2, abi.MARGIN_OLD, want_Ab=True)
+p = eng.marginalize(w2, abi.MARGIN_OLD)
+A, b = eng.marg_system(p.n)
+Aref = np.array(Aref).reshape(ref.n, ref.n)
+print("start frames", w.start_frame, "m", ref.m, p.m, "n", ref.n, p.n)
+print("A' diff max", np.abs(A - Aref).max(), "max |A'|", np.abs(Aref).max())
+d = np.abs(A - Aref); i, j = np.unravel_index(d.argmax(), d.shape); print("worst entry", i, j, A[i, j], Aref[i, j])
+lin = ob.linearize(w2)
+print("a_l:", lin["a"])

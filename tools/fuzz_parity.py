@@ -1,0 +1,53 @@
+"""Randomized parity sweep: GPU optimization() against the oracle over many seeds / sizes / flags (bring-up tool).
+Prints the cases that violate the parity bar of tests/test_gpu_parity.py."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd"))
+import numpy as np
+from lfvio import abi, synth
+from lfvio.engine import Engine
+from oracle import binding as ob
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+eng = Engine(0)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(20260928)
+bad, t0 = [], time.time()
+for case in range(K):
+    seed = int(rng.integers(0, 10_000))
+    n = int(rng.choice([1, 2, 5, 9, 17, 33, 64, 65, 128, 300, 301, 700]))
+    kw = dict(estimate_extrinsic=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)),
+              tr=float(rng.choice([0.0, 0.02])), max_num_iterations=int(rng.choice([1, 3, 8, 12])))
+    flag = int(rng.choice([abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW]))
+    with_prior = bool(rng.integers(0, 2))
+    try:
+        if with_prior:
+            w = synth.make_window_with_prior(seed, n, lambda x, f: ob.optimize(x, f), **kw)[0]
+        else:
+            w = synth.make_window(seed, n, **kw)
+        rs, rp = ob.optimize(w, flag)
+        gs, gp = eng.optimize(w, flag)
+        why = []
+        if gs.c.num_iterations != rs.c.num_iterations or gs.c.termination != rs.c.termination:
+            why.append(f"iterations {gs.c.num_iterations}/{rs.c.num_iterations} termination {gs.c.termination}/{rs.c.termination}")
+        if np.abs(gs.pose - rs.pose).max() > 1e-6 * max(1.0, np.abs(rs.pose).max()): why.append("pose %.2e" % np.abs(gs.pose - rs.pose).max())
+        if np.abs(gs.speed_bias - rs.speed_bias).max() > 1e-6: why.append("sb %.2e" % np.abs(gs.speed_bias - rs.speed_bias).max())
+        if w.N and rel(gs.lam, rs.lam) > 1e-6: why.append("lam %.2e" % rel(gs.lam, rs.lam))
+        if gp.valid != rp.valid: why.append(f"prior valid {gp.valid}/{rp.valid}")
+        elif rp.valid == 1:
+            if (gp.m, gp.n, gp.num_blocks) != (rp.m, rp.n, rp.num_blocks) or gp.block_list() != rp.block_list(): why.append("prior structure")
+            else:
+                Jg, Jr = gp.J(), rp.J()
+                Ar = Jr.T @ Jr
+                # a window without frame-0 landmarks and without a prior marginalizes a lone IMU factor: A' is pure
+                # cancellation noise (|A'| ~ 1e-5 from terms of 1e6) in the reference as well; nothing to compare then
+                if np.abs(Ar).max() > 1.0 and rel(Jg.T @ Jg, Ar) > 1e-5: why.append("prior A %.2e (|A| %.1e)" % (rel(Jg.T @ Jg, Ar), np.abs(Ar).max()))
+        if why: bad.append((case, seed, n, kw, flag, with_prior, why))
+    except Exception as e:  # noqa: BLE001
+        bad.append((case, seed, n, kw, flag, with_prior, ["exception " + repr(e)[:200]]))
+print(f"{K} cases in {time.time() - t0:.1f} s, {len(bad)} outside the parity bar")
+for b in bad[:40]:
+    print(b)
