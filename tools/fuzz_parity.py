@@ -18,7 +18,7 @@ rng = np.random.default_rng(20260928)
 bad, t0 = [], time.time()
 for case in range(K):
     seed = int(rng.integers(0, 10_000))
-    n = int(rng.choice([1, 2, 5, 9, 17, 33, 64, 65, 128, 300, 301, 700]))
+    n = int(rng.choice([int(x) for x in os.environ["FUZZ_N"].split(",")])) if os.environ.get("FUZZ_N") else int(rng.choice([1, 2, 5, 9, 17, 33, 64, 65, 128, 300, 301, 700]))
     kw = dict(estimate_extrinsic=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)),
               tr=float(rng.choice([0.0, 0.02])), max_num_iterations=int(rng.choice([1, 3, 8, 12])))
     flag = int(rng.choice([abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW]))
