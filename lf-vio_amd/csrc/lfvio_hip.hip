@@ -352,44 +352,40 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   //      marginalization's subset (pairs (0, j)) is a prefix of every list.
   {
     S->pre_gram = nChunks > PRE_CHUNK_LIMIT ? 1 : 0;
-    static thread_local std::vector<std::vector<int>> lists;
-    lists.assign(PACKED + KP, {});
     auto col = [](int l, int i, int j) { return l < 6 ? 6 * i + l : l < 12 ? 6 * j + (l - 6) : l < 18 ? 66 + (l - 12) : 72; };
     const int units = S->pre_gram ? NPAIR : nChunks;
-    for (int u = 0; u < units; u++) {
-      const int p = S->pre_gram ? u : chunk_pair[u];
-      if (S->pre_gram && S->pair_chunk0[p + 1] == S->pair_chunk0[p]) continue;
-      const int i = p / 11, j = p % 11;
-      for (int lp = 0; lp < 19; lp++)
-        for (int lq = lp; lq < 20; lq++) {
-          const int cp = col(lp, i, j), g20 = lp * 20 - (lp * (lp - 1)) / 2 + (lq - lp);
-          int e;
-          if (lq == 19) {
-            e = PACKED + cp;
-          } else {
-            const int cq = col(lq, i, j);
-            e = cq * (cq + 1) / 2 + cp;  // cp <= cq: the local order follows the tangent order (i < j < ex < td)
-          }
-          lists[e].push_back(u * NGP + g20);
-        }
-    }
     int *sum_off = (int *)(h + L.sum_off), *sum_end_marg = (int *)(h + L.sum_end_marg), *sum_items = (int *)(h + L.sum_items);
     const int marg_units = S->pre_gram ? 11 : S->pair_chunk0[11];  // pairs (0, j) / their chunks
-    int pos = 0;
-    for (int e = 0; e < PACKED + KP; e++) {
-      sum_off[e] = pos;
-      int nm = 0;
-      for (int it : lists[e]) {
-        if (pos >= SUM_ITEMS_CAP) {
-          c->err = "gather list overflow";
-          return LFVIO_ERR_ARG;
+    // counting sort by destination entry, two passes over (unit, local entry): count, then place in ascending unit order
+    static thread_local std::vector<int> cursor;
+    cursor.assign(PACKED + KP + 1, 0);
+    auto for_each_item = [&](auto &&fn) {
+      for (int u = 0; u < units; u++) {
+        const int p = S->pre_gram ? u : chunk_pair[u];
+        if (S->pre_gram && S->pair_chunk0[p + 1] == S->pair_chunk0[p]) continue;
+        const int i = p / 11, j = p % 11;
+        for (int lp = 0; lp < 19; lp++) {
+          const int cp = col(lp, i, j);
+          for (int lq = lp; lq < 20; lq++) {
+            // cp <= cq: the local order follows the tangent order (i < j < ex < td); lq = 19 is the residual column
+            const int e = lq == 19 ? PACKED + cp : col(lq, i, j) * (col(lq, i, j) + 1) / 2 + cp;
+            fn(e, u, u * NGP + lp * 20 - (lp * (lp - 1)) / 2 + (lq - lp));
+          }
         }
-        sum_items[pos++] = it;
-        if (it / NGP < marg_units) nm++;
       }
-      sum_end_marg[e] = sum_off[e] + nm;
+    };
+    for_each_item([&](int e, int, int) { cursor[e + 1]++; });
+    for (int e = 0; e < PACKED + KP; e++) cursor[e + 1] += cursor[e];
+    if (cursor[PACKED + KP] > SUM_ITEMS_CAP) {
+      c->err = "gather list overflow";
+      return LFVIO_ERR_ARG;
     }
-    sum_off[PACKED + KP] = pos;
+    for (int e = 0; e <= PACKED + KP; e++) sum_off[e] = cursor[e];
+    for (int e = 0; e < PACKED + KP; e++) sum_end_marg[e] = sum_off[e];
+    for_each_item([&](int e, int u, int item) {
+      sum_items[cursor[e]++] = item;
+      if (u < marg_units) sum_end_marg[e]++;
+    });
   }
   // ---- prior
   info.has_in_prior = pr != nullptr;

@@ -383,6 +383,38 @@ void Estimator::optimization() {
   LfvioWindow w;
   packWindow(&w);
   std::vector<double> lam(w.num_landmarks > 0 ? w.num_landmarks : 1);
+  const bool second_new_needed =
+      marginalization_flag == MARGIN_SECOND_NEW && last_marginalization_info && last_marginalization_info->valid;
+  const bool marginalize = marginalization_flag == MARGIN_OLD || second_new_needed;
+  if (fused) {
+    // One upload: solve (:810-825), the gauge fix of double2vector() (:532-626) and the marginalization (:833-1005) run
+    // back to back on the device; the state that comes back is the one double2vector() would have produced, so the call
+    // below re-applies it to an already re-anchored state (a rotation by zero yaw and a zero shift).
+    const int flag = marginalization_flag == MARGIN_OLD ? LFVIO_MARGIN_OLD : LFVIO_MARGIN_SECOND_NEW;
+    LfvioPrior *next = marginalize ? new LfvioPrior() : nullptr;
+    last_summary.inv_depth = lam.data();
+    last_status = lfvio_batch_reserve(gpu, 1, w.num_landmarks, w.num_observations);
+    if (last_status == LFVIO_OK) last_status = lfvio_batch_upload(gpu, 0, &w);
+    if (last_status == LFVIO_OK) last_status = lfvio_batch_optimize(gpu, 1, flag);
+    if (last_status == LFVIO_OK) last_status = lfvio_batch_download(gpu, 0, &last_summary, next);
+    last_summary.inv_depth = nullptr;
+    if (last_status != LFVIO_OK) {
+      delete next;
+      return;
+    }
+    std::memcpy(para_Pose, last_summary.para_pose, sizeof para_Pose);
+    std::memcpy(para_SpeedBias, last_summary.para_speed_bias, sizeof para_SpeedBias);
+    std::memcpy(para_Ex_Pose[0], last_summary.para_ex_pose, sizeof para_Ex_Pose[0]);
+    if (ESTIMATE_TD) para_Td[0][0] = last_summary.para_td;
+    for (int i = 0; i < w.num_landmarks; i++) para_Feature[i] = lam[i];
+    double2vector();  // :830
+    if (next) {
+      delete last_marginalization_info;  // :935-938
+      last_marginalization_info = next;
+    }
+    return;
+  }
+  // The literal two-call flow of the reference: solve, double2vector() on the host, vector2double(), marginalize.
   last_summary.inv_depth = lam.data();
   last_status = lfvio_solve(gpu, &w, &last_summary);  // :810-825
   last_summary.inv_depth = nullptr;
@@ -396,9 +428,7 @@ void Estimator::optimization() {
 
   // :833-1005 — both branches start with vector2double() and differ only in the factor set, which the
   // library derives from the flag
-  const bool second_new_needed =
-      marginalization_flag == MARGIN_SECOND_NEW && last_marginalization_info && last_marginalization_info->valid;
-  if (marginalization_flag == MARGIN_OLD || second_new_needed) {
+  if (marginalize) {
     vector2double();
     packWindow(&w);
     LfvioPrior *next = new LfvioPrior();

@@ -157,6 +157,9 @@ class Estimator {
   LfvioSolution last_summary;
   int last_status = 0;
   lfvio_ctx *gpu = nullptr;
+  // true: one upload, solve -> gauge fix -> marginalization on the device (lfvio_batch_* on one slot);
+  // false: the literal flow, lfvio_solve / host double2vector() / lfvio_marginalize (two uploads)
+  bool fused = true;
 
   // pack para_* + features + pre-integrations + prior into the ABI POD (buffers live in `scratch_`)
   void packWindow(LfvioWindow *w);

@@ -133,6 +133,9 @@ int lfvio_host_get_prior(void *h, LfvioPrior *out) {
   return 1;
 }
 
+// 1 (default): one upload, everything on the device; 0: the literal lfvio_solve / double2vector / lfvio_marginalize flow
+void lfvio_host_set_fused(void *h, int on) { ((Estimator *)h)->fused = on != 0; }
+
 int lfvio_host_optimization(void *h) {
   Estimator *e = (Estimator *)h;
   e->optimization();

@@ -104,8 +104,10 @@ class HostEstimator:
         self.L.lfvio_host_get_depths(self.h, _p(d))
         return d[:n]
 
-    def optimization(self, flag):
+    def optimization(self, flag, fused=True):
         self.L.lfvio_host_set_flag(self.h, flag)
+        self.L.lfvio_host_set_fused.argtypes = [C.c_void_p, C.c_int]
+        self.L.lfvio_host_set_fused(self.h, int(fused))
         return self.L.lfvio_host_optimization(self.h)
 
     def prior(self):

@@ -94,12 +94,15 @@ def test_repropagate_is_idempotent(host):
 
 
 @pytest.mark.gpu
-def test_host_optimization_end_to_end(host, oracle):
-    """Estimator::optimization() of the mirror (host C++ -> C-ABI -> HIP) against the oracle, two frames in a row."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_host_optimization_end_to_end(host, oracle, fused):
+    """Estimator::optimization() of the mirror (host C++ -> C-ABI -> HIP) against the oracle, two frames in a row;
+    fused: one upload and the whole call on the device; not fused: the reference's literal solve / double2vector /
+    marginalize sequence with the gauge fix on the host."""
     win, warm = synth.make_window_with_prior(2, 200, lambda w, f: oracle.optimize(w, f))
     for w in (warm, win):
         host.load_window(w)
-        assert host.optimization(abi.MARGIN_OLD) == 0
+        assert host.optimization(abi.MARGIN_OLD, fused=fused) == 0
         ref_sol, ref_prior = oracle.optimize(w, abi.MARGIN_OLD)
         host.L.lfvio_host_vector2double(host.h)
         pose, sb, ex, td, feat = host.para(w.N)

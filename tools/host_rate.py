@@ -9,10 +9,12 @@ eng = Engine(0)  # (loads torch's HIP runtime first, see abi.load_hip_library)
 from lfvio.host import HostEstimator
 w = synth.make_window_with_prior(0, 300, lambda x, f: eng.optimize(x, f))[0]
 h = HostEstimator()
-for _ in range(5):
-    h.load_window(w); assert h.optimization(abi.MARGIN_OLD) == 0
-K, t = 50, 0.0
-for _ in range(K):
-    h.load_window(w)  # the same input state every time (load is not timed)
-    t0 = time.perf_counter(); assert h.optimization(abi.MARGIN_OLD) == 0; t += time.perf_counter() - t0
-print(f"host mirror Estimator::optimization(), N=300 with prior: {t / K * 1e3:.3f} ms per call = {K / t:.1f} calls/s")
+for fused in (True, False):
+    for _ in range(5):
+        h.load_window(w); assert h.optimization(abi.MARGIN_OLD, fused=fused) == 0
+    K, t = 50, 0.0
+    for _ in range(K):
+        h.load_window(w)  # the same input state every time (load is not timed)
+        t0 = time.perf_counter(); assert h.optimization(abi.MARGIN_OLD, fused=fused) == 0; t += time.perf_counter() - t0
+    print(f"host mirror Estimator::optimization(), N=300 with prior, {'one upload (fused)' if fused else 'two-call flow'}: "
+          f"{t / K * 1e3:.3f} ms per call = {K / t:.1f} calls/s")
