@@ -206,6 +206,32 @@ int lfvio_batch_download(lfvio_ctx *ctx, int slot, LfvioSolution *sol, LfvioPrio
 /* the context's HIP stream (hipStream_t) for event timing by the caller */
 void *lfvio_stream(lfvio_ctx *ctx);
 
+/* ---- the landmark-parallel steps either side of optimization() ------------------------
+ * lfvio_triangulate: FeatureManager::triangulate (feature_manager.cpp:199-253).  For every landmark with
+ * estimated_depth <= 0 (the caller lists only landmarks with used_num >= 2 && start_frame < WINDOW_SIZE - 2, in the
+ * CSR form of LfvioWindow): the 2k x 4 system of the k observations in the frame of the first one, its right singular
+ * vector of the smallest singular value v (the reference: Eigen::JacobiSVD, ComputeThinV, last column),
+ * depth = (v[0:3] / v[3]) . point_0, replaced by init_depth when negative.  Landmarks with estimated_depth > 0 are
+ * left alone.  estimated_depth is read and written in place. */
+typedef struct {
+  int num_landmarks, num_observations;
+  const int *start_frame;   /* [N] */
+  const int *obs_offset;    /* [N + 1] */
+  const double *obs_point;  /* [M][3]  FeaturePerFrame::point as stored (normalized inside, used raw in the dot product) */
+  double Ps[LFVIO_NUM_FRAMES][3];
+  double Rs[LFVIO_NUM_FRAMES][9]; /* row-major */
+  double tic[3], ric[9];
+  double init_depth;              /* INIT_DEPTH, parameters.cpp:116 */
+} LfvioTriangulateIn;
+int lfvio_triangulate(lfvio_ctx *ctx, const LfvioTriangulateIn *in, double *estimated_depth);
+
+/* lfvio_shift_depth: the arithmetic of FeatureManager::removeBackShiftDepth (feature_manager.cpp:271-310) for the n
+ * landmarks that started in the marginalized frame and keep >= 2 observations: uv_i is the erased first observation,
+ * depth <- || new_R^T (marg_R (uv_i * depth) + marg_P - new_P) ||, or init_depth when that is not > 0.
+ * (Erasing observations / features and start_frame-- stay list bookkeeping on the host.) */
+int lfvio_shift_depth(lfvio_ctx *ctx, int n, const double *uv_i /* [n][3] */, const double marg_R[9], const double marg_P[3],
+                      const double new_R[9], const double new_P[3], double init_depth, double *estimated_depth /* [n] */);
+
 /* ---- landmark-sharded API (multi-GPU) ------------------------
  * Every rank passes the same window but linearizes only landmarks [lm_begin, lm_end) (caller order);
  * IMU factors and the prior are added on the rank(s) with add_pose_side != 0 — exactly one rank.

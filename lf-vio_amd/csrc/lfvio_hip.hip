@@ -16,6 +16,7 @@
 #include "../../include/lfvio.h"
 #include "../../include/lfvio_debug.h"
 #include "kernels_marg.h"
+#include "kernels_feat.h"
 
 #define HIPCHK(ctx, call)                                                                      \
   do {                                                                                         \
@@ -98,6 +99,8 @@ struct SlotHostInfo {
 struct lfvio_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  char *d_feat = nullptr;  // scratch of lfvio_triangulate / lfvio_shift_depth (grow-only)
+  size_t feat_bytes = 0;
   std::string err;
   int batch = 0;
   Layout L;
@@ -644,6 +647,7 @@ void lfvio_destroy(lfvio_ctx *c) {
   (void)hipSetDevice(c->device);
   destroy_graph(c);
   if (c->d_base) (void)hipFree(c->d_base);
+  if (c->d_feat) (void)hipFree(c->d_feat);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_down) (void)hipHostFree(c->h_down);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -725,6 +729,82 @@ int lfvio_batch_download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior 
   if (sol && (rc = download_solution(c, slot, sol))) return rc;
   if (prior && (rc = download_prior(c, slot, prior))) return rc;
   return rc;
+}
+
+// ---- the landmark-parallel steps either side of optimization()
+static int feat_reserve(lfvio_ctx *c, size_t bytes) {
+  if (bytes <= c->feat_bytes) return LFVIO_OK;
+  if (c->d_feat) (void)hipFree(c->d_feat);
+  c->d_feat = nullptr, c->feat_bytes = 0;
+  bytes = align_up(bytes + bytes / 4, 4096);
+  if (hipMalloc(&c->d_feat, bytes) != hipSuccess) {
+    c->err = "out of device memory (feature scratch)";
+    return LFVIO_ERR_DEVICE;
+  }
+  c->feat_bytes = bytes;
+  return LFVIO_OK;
+}
+
+int lfvio_triangulate(lfvio_ctx *c, const LfvioTriangulateIn *in, double *estimated_depth) {
+  if (!c || !in || in->num_landmarks < 0 || in->num_observations < 0) return LFVIO_ERR_ARG;
+  const int N = in->num_landmarks, M = in->num_observations;
+  if (N == 0) return LFVIO_OK;
+  if (!estimated_depth || !in->start_frame || !in->obs_offset || !in->obs_point || in->obs_offset[0] != 0 || in->obs_offset[N] != M) {
+    c->err = "triangulate: null arrays or obs_offset is not a CSR over num_observations";
+    return LFVIO_ERR_ARG;
+  }
+  for (int l = 0; l < N; l++) {
+    const int k = in->obs_offset[l + 1] - in->obs_offset[l], s = in->start_frame[l];
+    if (k < 2 || s < 0 || s + k > LFVIO_NUM_FRAMES) {
+      c->err = "triangulate: landmark with fewer than 2 observations or a track leaving the window";
+      return LFVIO_ERR_ARG;
+    }
+  }
+  (void)hipSetDevice(c->device);
+  const size_t oF = 0, oS = align_up(sizeof(FeatFrames), 256), oO = align_up(oS + (size_t)N * 4, 256),
+               oP = align_up(oO + (size_t)(N + 1) * 4, 256), oD = align_up(oP + (size_t)M * 24, 256), total = oD + (size_t)N * 8;
+  int rc = feat_reserve(c, total);
+  if (rc) return rc;
+  FeatFrames F;
+  std::memcpy(F.Ps, in->Ps, sizeof F.Ps), std::memcpy(F.Rs, in->Rs, sizeof F.Rs);
+  std::memcpy(F.tic, in->tic, sizeof F.tic), std::memcpy(F.ric, in->ric, sizeof F.ric);
+  F.init_depth = in->init_depth;
+  char *d = c->d_feat;
+  HIPCHK(c, hipMemcpyAsync(d + oF, &F, sizeof F, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + oS, in->start_frame, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + oO, in->obs_offset, (size_t)(N + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + oP, in->obs_point, (size_t)M * 24, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + oD, estimated_depth, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_triangulate, dim3((N + TRI_THREADS - 1) / TRI_THREADS), dim3(TRI_THREADS), 0, c->stream, (const FeatFrames *)(d + oF), N,
+                     (const int *)(d + oS), (const int *)(d + oO), (const double *)(d + oP), (double *)(d + oD));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(estimated_depth, d + oD, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // F and the caller's arrays are pageable: done before returning
+  return LFVIO_OK;
+}
+
+int lfvio_shift_depth(lfvio_ctx *c, int n, const double *uv_i, const double marg_R[9], const double marg_P[3], const double new_R[9],
+                      const double new_P[3], double init_depth, double *estimated_depth) {
+  if (!c || n < 0) return LFVIO_ERR_ARG;
+  if (n == 0) return LFVIO_OK;
+  if (!uv_i || !marg_R || !marg_P || !new_R || !new_P || !estimated_depth) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  const size_t oT = 0, oU = 256, oD = align_up(oU + (size_t)n * 24, 256), total = oD + (size_t)n * 8;
+  int rc = feat_reserve(c, total);
+  if (rc) return rc;
+  double T[25];
+  std::memcpy(T, marg_R, 72), std::memcpy(T + 9, marg_P, 24), std::memcpy(T + 12, new_R, 72), std::memcpy(T + 21, new_P, 24);
+  T[24] = init_depth;
+  char *d = c->d_feat;
+  HIPCHK(c, hipMemcpyAsync(d + oT, T, sizeof T, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + oU, uv_i, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + oD, estimated_depth, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_shift_depth, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const double *)(d + oU), (const double *)(d + oT),
+                     (double *)(d + oD));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(estimated_depth, d + oD, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LFVIO_OK;
 }
 
 // ---- debug / parity hooks (include/lfvio_debug.h)

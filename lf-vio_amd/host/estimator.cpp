@@ -10,6 +10,7 @@ namespace lfvio {
 
 double ACC_N = 0.02, ACC_W = 0.04, GYR_N = 0.01, GYR_W = 0.001;  // config/mindvision/mindvision.yaml:138-141
 Vector3d G{0.0, 0.0, 9.81007};                                     // :142
+double INIT_DEPTH = 5.0;                                           // parameters.cpp:116
 double SOLVER_TIME = 0.04;                                         // :133
 int NUM_ITERATIONS = 8;                                            // :134
 int ESTIMATE_EXTRINSIC = 1, ESTIMATE_TD = 1;                       // :83, :151
@@ -205,6 +206,120 @@ VectorXd FeatureManager::getDepthVector() {
   }
   return dep_vec;
 }
+// feature_manager.cpp:199-253.  The per-landmark 2k x 4 SVD runs on the device; the inclusion rule and the in-place
+// update of estimated_depth are the reference's.
+void FeatureManager::triangulate(Vector3d Ps[], Vector3d tic[], Matrix3d ric[]) {
+  last_status = LFVIO_OK;
+  std::vector<FeaturePerId *> sel;
+  std::vector<int> start, off(1, 0);
+  std::vector<double> pts, depth;
+  for (auto &it_per_id : feature) {
+    it_per_id.used_num = (int)it_per_id.feature_per_frame.size();
+    if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
+    if (it_per_id.estimated_depth > 0) continue;
+    sel.push_back(&it_per_id);
+    start.push_back(it_per_id.start_frame);
+    for (auto &f : it_per_id.feature_per_frame) pts.push_back(f.point.x()), pts.push_back(f.point.y()), pts.push_back(f.point.z());
+    off.push_back((int)pts.size() / 3);
+    depth.push_back(it_per_id.estimated_depth);
+  }
+  if (sel.empty()) return;
+  if (!gpu || !Rs) {
+    last_status = LFVIO_ERR_ARG;
+    return;
+  }
+  if (!*gpu) *gpu = lfvio_create(0);
+  if (!*gpu) {
+    last_status = LFVIO_ERR_DEVICE;  // no fallback
+    return;
+  }
+  LfvioTriangulateIn in;
+  in.num_landmarks = (int)sel.size(), in.num_observations = (int)pts.size() / 3;
+  in.start_frame = start.data(), in.obs_offset = off.data(), in.obs_point = pts.data();
+  for (int f = 0; f <= WINDOW_SIZE; f++)
+    for (int i = 0; i < 3; i++) {
+      in.Ps[f][i] = Ps[f](i);
+      for (int j = 0; j < 3; j++) in.Rs[f][3 * i + j] = Rs[f](i, j);
+    }
+  for (int i = 0; i < 3; i++) {
+    in.tic[i] = tic[0](i);
+    for (int j = 0; j < 3; j++) in.ric[3 * i + j] = ric[0](i, j);
+  }
+  in.init_depth = INIT_DEPTH;
+  last_status = lfvio_triangulate(*gpu, &in, depth.data());
+  if (last_status != LFVIO_OK) return;
+  for (size_t k = 0; k < sel.size(); k++) sel[k]->estimated_depth = depth[k];
+}
+
+// feature_manager.cpp:271-310
+void FeatureManager::removeBackShiftDepth(Matrix3d marg_R, Vector3d marg_P, Matrix3d new_R, Vector3d new_P) {
+  last_status = LFVIO_OK;
+  std::vector<FeaturePerId *> sel;
+  std::vector<double> uv, depth;
+  for (auto it = feature.begin(), it_next = feature.begin(); it != feature.end(); it = it_next) {
+    it_next++;
+    if (it->start_frame != 0) {
+      it->start_frame--;
+    } else {
+      const Vector3d uv_i = it->feature_per_frame[0].point;
+      it->feature_per_frame.erase(it->feature_per_frame.begin());
+      if (it->feature_per_frame.size() < 2) {
+        feature.erase(it);
+        continue;
+      }
+      sel.push_back(&*it);
+      uv.push_back(uv_i.x()), uv.push_back(uv_i.y()), uv.push_back(uv_i.z());
+      depth.push_back(it->estimated_depth);
+    }
+  }
+  if (sel.empty()) return;
+  if (!gpu) {
+    last_status = LFVIO_ERR_ARG;
+    return;
+  }
+  if (!*gpu) *gpu = lfvio_create(0);
+  if (!*gpu) {
+    last_status = LFVIO_ERR_DEVICE;
+    return;
+  }
+  double mR[9], nR[9], mP[3], nP[3];
+  for (int i = 0; i < 3; i++) {
+    mP[i] = marg_P(i), nP[i] = new_P(i);
+    for (int j = 0; j < 3; j++) mR[3 * i + j] = marg_R(i, j), nR[3 * i + j] = new_R(i, j);
+  }
+  last_status = lfvio_shift_depth(*gpu, (int)sel.size(), uv.data(), mR, mP, nR, nP, INIT_DEPTH, depth.data());
+  if (last_status != LFVIO_OK) return;
+  for (size_t k = 0; k < sel.size(); k++) sel[k]->estimated_depth = depth[k];
+}
+
+// feature_manager.cpp:312-330
+void FeatureManager::removeBack() {
+  for (auto it = feature.begin(), it_next = feature.begin(); it != feature.end(); it = it_next) {
+    it_next++;
+    if (it->start_frame != 0) {
+      it->start_frame--;
+    } else {
+      it->feature_per_frame.erase(it->feature_per_frame.begin());
+      if (it->feature_per_frame.size() == 0) feature.erase(it);
+    }
+  }
+}
+
+// feature_manager.cpp:332-351
+void FeatureManager::removeFront(int frame_count) {
+  for (auto it = feature.begin(), it_next = feature.begin(); it != feature.end(); it = it_next) {
+    it_next++;
+    if (it->start_frame == frame_count) {
+      it->start_frame--;
+    } else {
+      const int j = WINDOW_SIZE - 1 - it->start_frame;
+      if (it->endFrame() < frame_count - 1) continue;
+      it->feature_per_frame.erase(it->feature_per_frame.begin() + j);
+      if (it->feature_per_frame.size() == 0) feature.erase(it);
+    }
+  }
+}
+
 FeaturePerId &FeatureManager::addFeature(int feature_id, int start_frame) {
   feature.emplace_back(feature_id, start_frame);
   return feature.back();
@@ -213,6 +328,7 @@ FeaturePerId &FeatureManager::addFeature(int feature_id, int start_frame) {
 // ---------------------------------------------------------------- Estimator
 Estimator::Estimator() {
   for (int i = 0; i <= WINDOW_SIZE; i++) pre_integrations[i] = nullptr;
+  f_manager.Rs = Rs, f_manager.gpu = &gpu;  // FeatureManager f_manager{Rs} (estimator.cpp:6)
   clearState();
 }
 Estimator::~Estimator() {

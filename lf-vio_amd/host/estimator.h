@@ -27,6 +27,7 @@ const int NUM_OF_F = 1000;  // the reference's para_Feature capacity (unchecked 
 extern double ACC_N, ACC_W, GYR_N, GYR_W;
 extern Vector3d G;
 extern double SOLVER_TIME;
+extern double INIT_DEPTH;
 extern int NUM_ITERATIONS;
 extern int ESTIMATE_EXTRINSIC, ESTIMATE_TD;
 extern double TD, TR, ROW, COL;
@@ -109,10 +110,18 @@ class FeatureManager {
   void clearDepth(const VectorXd &x);
   void removeFailures();
   VectorXd getDepthVector();
-  // window bookkeeping (addFeatureCheckParallax / triangulate / removeBack*) is SURVEY §8f "next";
-  // addFeature() is the minimal producer the mirror needs.
+  // SURVEY §8f rank 2 (feature_manager.cpp:199-253, 271-351): the landmark-parallel arithmetic runs behind
+  // lfvio_triangulate / lfvio_shift_depth, the std::list surgery stays here
+  void triangulate(Vector3d Ps[], Vector3d tic[], Matrix3d ric[]);
+  void removeBackShiftDepth(Matrix3d marg_R, Vector3d marg_P, Matrix3d new_R, Vector3d new_P);
+  void removeBack();
+  void removeFront(int frame_count);
+  // addFeatureCheckParallax (keyframe policy) is SURVEY §8f rank 4; addFeature() is the minimal producer the mirror needs.
   FeaturePerId &addFeature(int feature_id, int start_frame);
   std::list<FeaturePerId> feature;
+  const Matrix3d *Rs = nullptr;  // the estimator's Rs[] (FeatureManager(Matrix3d _Rs[]), feature_manager.cpp:13)
+  lfvio_ctx **gpu = nullptr;     // the estimator's device context (created on first use)
+  int last_status = 0;
 };
 
 // ---- estimator.h

@@ -66,6 +66,39 @@ void lfvio_host_add_feature(void *h, int id, int start_frame, int n, const doubl
   f.estimated_depth = estimated_depth;
 }
 
+// FeatureManager::triangulate with the estimator's own Ps / tic / ric (estimator.cpp:473)
+int lfvio_host_triangulate(void *h) {
+  Estimator *e = (Estimator *)h;
+  e->f_manager.triangulate(e->Ps, e->tic, e->ric);
+  return e->f_manager.last_status;
+}
+// FeatureManager::removeBackShiftDepth with the arguments slideWindowOld() forms (estimator.cpp:1120-1127): the
+// marginalized frame's pose is passed in (back_R0, back_P0), the new frame 0 is the estimator's
+int lfvio_host_remove_back_shift_depth(void *h, const double *back_R0, const double *back_P0) {
+  Estimator *e = (Estimator *)h;
+  Matrix3d bR;
+  setM(bR, back_R0);
+  const Vector3d bP(back_P0[0], back_P0[1], back_P0[2]);
+  const Matrix3d R0 = bR * e->ric[0], R1 = e->Rs[0] * e->ric[0];
+  const Vector3d P0 = bP + bR * e->tic[0], P1 = e->Ps[0] + e->Rs[0] * e->tic[0];
+  e->f_manager.removeBackShiftDepth(R0, P0, R1, P1);
+  return e->f_manager.last_status;
+}
+void lfvio_host_set_depths(void *h, const double *d, int n) {
+  int k = 0;
+  for (auto &f : ((Estimator *)h)->f_manager.feature)
+    if (k < n) f.estimated_depth = d[k++];
+}
+int lfvio_host_num_features(void *h) { return (int)((Estimator *)h)->f_manager.feature.size(); }
+// (feature_id, start_frame, number of observations, estimated_depth) of every feature in list order
+void lfvio_host_list_features(void *h, int *ids, int *start, int *count, double *depth) {
+  int k = 0;
+  for (auto &f : ((Estimator *)h)->f_manager.feature) {
+    ids[k] = f.feature_id, start[k] = f.start_frame, count[k] = (int)f.feature_per_frame.size(), depth[k] = f.estimated_depth;
+    k++;
+  }
+}
+
 int lfvio_host_feature_count(void *h) { return ((Estimator *)h)->f_manager.getFeatureCount(); }
 void lfvio_host_get_depths(void *h, double *out) {
   Estimator *e = (Estimator *)h;

@@ -274,13 +274,62 @@ def apply_solution(win, sol):
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIP_LIB_PATH = os.path.join(PKG_DIR, "liblfvio_hip.so")
 
+class TriangulateInC(C.Structure):
+    """LfvioTriangulateIn (include/lfvio.h)."""
+    _fields_ = [
+        ("num_landmarks", C.c_int),
+        ("num_observations", C.c_int),
+        ("start_frame", C.POINTER(C.c_int)),
+        ("obs_offset", C.POINTER(C.c_int)),
+        ("obs_point", C.POINTER(C.c_double)),
+        ("Ps", (C.c_double * 3) * NUM_FRAMES),
+        ("Rs", (C.c_double * 9) * NUM_FRAMES),
+        ("tic", C.c_double * 3),
+        ("ric", C.c_double * 9),
+        ("init_depth", C.c_double),
+    ]
+
+
+class TriangulateIn:
+    """Inputs of FeatureManager::triangulate taken from a window: frame poses (Ps, Rs), extrinsics, the landmark CSR and
+    the stored observation points.  Keeps the numpy arrays alive for the ctypes view."""
+
+    def __init__(self, win, Rs=None, ric=None, init_depth=5.0):
+        from . import synth  # quaternion helpers
+
+        self.start_frame = np.ascontiguousarray(win.start_frame, dtype=np.int32)
+        self.obs_offset = np.ascontiguousarray(win.obs_offset, dtype=np.int32)
+        self.obs_point = np.ascontiguousarray(win.obs_point, dtype=np.float64).reshape(-1, 3)
+        self.Ps = np.ascontiguousarray(win.pose[:, :3], dtype=np.float64)
+        self.Rs = np.stack([synth.pose_R(win.pose[f]) for f in range(NUM_FRAMES)]) if Rs is None else np.asarray(Rs, float)
+        self.tic = np.ascontiguousarray(win.ex_pose[:3], dtype=np.float64)
+        self.ric = synth.pose_R(win.ex_pose) if ric is None else np.asarray(ric, float)
+        self.init_depth = float(init_depth)
+        c = TriangulateInC()
+        c.num_landmarks, c.num_observations = len(self.start_frame), len(self.obs_point)
+        c.start_frame = self.start_frame.ctypes.data_as(C.POINTER(C.c_int))
+        c.obs_offset = self.obs_offset.ctypes.data_as(C.POINTER(C.c_int))
+        c.obs_point = self.obs_point.ctypes.data_as(C.POINTER(C.c_double))
+        for f in range(NUM_FRAMES):
+            for k in range(3):
+                c.Ps[f][k] = self.Ps[f, k]
+            for k in range(9):
+                c.Rs[f][k] = self.Rs[f].reshape(9)[k]
+        for k in range(3):
+            c.tic[k] = self.tic[k]
+        for k in range(9):
+            c.ric[k] = self.ric.reshape(9)[k]
+        c.init_depth = self.init_depth
+        self.c = c
+
+
 HIP_SYMBOLS = [
     "lfvio_create", "lfvio_destroy", "lfvio_last_error", "lfvio_version", "lfvio_solve", "lfvio_marginalize",
     "lfvio_batch_reserve", "lfvio_batch_upload", "lfvio_batch_optimize", "lfvio_batch_optimize_async",
     "lfvio_batch_sync", "lfvio_batch_download", "lfvio_stream",
     "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_scalar_offset", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
     "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_marg_linearize", "lfvio_shard_marg_finish",
-    "lfvio_shard_finish",
+    "lfvio_shard_finish", "lfvio_triangulate", "lfvio_shift_depth",
 ]
 
 
@@ -326,6 +375,9 @@ def load_hip_library(path=None):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.lfvio_shard_decide.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.lfvio_shard_finish.argtypes = [C.c_void_p, C.POINTER(SolutionC)]
+    _dp = C.POINTER(C.c_double)
+    lib.lfvio_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangulateInC), _dp]
+    lib.lfvio_shift_depth.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]
     lib.lfvio_shard_marg_linearize.argtypes = [C.c_void_p, C.c_int]
     lib.lfvio_shard_marg_finish.argtypes = [C.c_void_p, C.c_int, C.POINTER(Prior)]
     return lib

@@ -103,6 +103,22 @@ class Engine:
         self.batch_optimize(1, flag)
         return self.batch_download(0, win.N)
 
+    # ---- SURVEY §8f rank 2
+    def triangulate(self, tin, depth):
+        """FeatureManager::triangulate on abi.TriangulateIn; returns the updated copy of `depth`."""
+        d = np.ascontiguousarray(depth, dtype=np.float64).copy()
+        self._check(self.lib.lfvio_triangulate(self.ctx, C.byref(tin.c), _p(d)), "lfvio_triangulate")
+        return d
+
+    def shift_depth(self, uv_i, marg_R, marg_P, new_R, new_P, init_depth, depth):
+        """Depth arithmetic of FeatureManager::removeBackShiftDepth; returns the updated copy of `depth`."""
+        uv = np.ascontiguousarray(uv_i, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(depth, dtype=np.float64).copy()
+        a = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in (marg_R, marg_P, new_R, new_P)]
+        self._check(self.lib.lfvio_shift_depth(self.ctx, len(d), _p(uv), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), float(init_depth), _p(d)),
+                    "lfvio_shift_depth")
+        return d
+
     def time_kernel(self, which, count, reps):
         ms = np.zeros(1)
         self._check(self.lib.lfvio_debug_time_kernel(self.ctx, which, count, reps, _p(ms)), "time_kernel")

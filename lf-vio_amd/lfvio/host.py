@@ -44,6 +44,13 @@ class HostEstimator:
         L.lfvio_host_set_prior.argtypes = [C.c_void_p, C.POINTER(abi.Prior)]
         L.lfvio_host_get_prior.argtypes = [C.c_void_p, C.POINTER(abi.Prior)]
         L.lfvio_host_optimization.argtypes = [C.c_void_p]
+        L.lfvio_host_set_fused.argtypes = [C.c_void_p, C.c_int]
+        ip = C.POINTER(C.c_int)
+        L.lfvio_host_triangulate.argtypes = [C.c_void_p]
+        L.lfvio_host_remove_back_shift_depth.argtypes = [C.c_void_p, _dp, _dp]
+        L.lfvio_host_num_features.argtypes = [C.c_void_p]
+        L.lfvio_host_list_features.argtypes = [C.c_void_p, ip, ip, ip, _dp]
+        L.lfvio_host_set_depths.argtypes = [C.c_void_p, _dp, C.c_int]
         L.lfvio_host_last_iterations.argtypes = [C.c_void_p]
         L.lfvio_host_last_cost.argtypes = [C.c_void_p]
         L.lfvio_host_last_cost.restype = C.c_double
@@ -79,6 +86,27 @@ class HostEstimator:
                                       _p(_f(accs)), _p(_f(gyrs)))
         self.L.lfvio_host_set_prior(self.h, C.byref(win.prior) if win.prior is not None else None)
 
+    # ---- SURVEY §8f rank 2
+    def set_depths(self, depth):
+        """estimated_depth of every feature in list order (the order load_window() added them)."""
+        d = _f(depth)
+        self.L.lfvio_host_set_depths(self.h, _p(d), len(d))
+
+    def triangulate(self):
+        return self.L.lfvio_host_triangulate(self.h)
+
+    def remove_back_shift_depth(self, back_R0, back_P0):
+        return self.L.lfvio_host_remove_back_shift_depth(self.h, _p(_f(back_R0)), _p(_f(back_P0)))
+
+    def features(self):
+        """(feature_id, start_frame, observation count, estimated_depth) arrays in list order."""
+        n = self.L.lfvio_host_num_features(self.h)
+        ids, st, cnt = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        dep = np.zeros(n)
+        ip = C.POINTER(C.c_int)
+        self.L.lfvio_host_list_features(self.h, ids.ctypes.data_as(ip), st.ctypes.data_as(ip), cnt.ctypes.data_as(ip), _p(dep))
+        return ids, st, cnt, dep
+
     def pack(self):
         w = abi.WindowC()
         self.L.lfvio_host_pack(self.h, C.byref(w))
@@ -106,7 +134,6 @@ class HostEstimator:
 
     def optimization(self, flag, fused=True):
         self.L.lfvio_host_set_flag(self.h, flag)
-        self.L.lfvio_host_set_fused.argtypes = [C.c_void_p, C.c_int]
         self.L.lfvio_host_set_fused(self.h, int(fused))
         return self.L.lfvio_host_optimization(self.h)
 

@@ -46,6 +46,8 @@ def lib():
                                               C.c_double, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp,
                                               C.c_double, C.c_double] + [_dp] * 6)
         L.oracle_sym_eig.argtypes = [_dp, C.c_int, _dp, _dp]
+        L.oracle_triangulate.argtypes = [C.POINTER(abi.TriangulateInC), _dp]
+        L.oracle_shift_depth.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]
         L.oracle_sizeof.argtypes = [C.c_int]
         assert L.oracle_sizeof(0) == C.sizeof(abi.WindowC), "LfvioWindow layout mismatch"
         assert L.oracle_sizeof(1) == C.sizeof(abi.SolutionC), "LfvioSolution layout mismatch"
@@ -165,3 +167,20 @@ def set_marg_threads(n):
     L = lib()
     L.oracle_set_marg_threads.argtypes = [C.c_int]
     return L.oracle_set_marg_threads(int(n))
+
+
+def triangulate(tin, depth):
+    """FeatureManager::triangulate on abi.TriangulateIn; depth: estimated_depth per landmark (<= 0: to be triangulated).
+    Returns the updated copy."""
+    d = np.ascontiguousarray(depth, dtype=np.float64).copy()
+    lib().oracle_triangulate(C.byref(tin.c), _p(d))
+    return d
+
+
+def shift_depth(uv_i, marg_R, marg_P, new_R, new_P, init_depth, depth):
+    """Depth arithmetic of FeatureManager::removeBackShiftDepth; returns the updated copy."""
+    uv = np.ascontiguousarray(uv_i, dtype=np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(depth, dtype=np.float64).copy()
+    a = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in (marg_R, marg_P, new_R, new_P)]
+    lib().oracle_shift_depth(len(d), _p(uv), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), float(init_depth), _p(d))
+    return d

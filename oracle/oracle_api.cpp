@@ -153,6 +153,17 @@ int oracle_set_marg_threads(int n) {
   return g_marg_threads;
 }
 
+int oracle_triangulate(const LfvioTriangulateIn *in, double *depth) {
+  triangulate(*in, depth);
+  return 0;
+}
+
+int oracle_shift_depth(int n, const double *uv_i, const double *marg_R, const double *marg_P, const double *new_R,
+                       const double *new_P, double init_depth, double *depth) {
+  shift_depth(n, uv_i, marg_R, marg_P, new_R, new_P, init_depth, depth);
+  return 0;
+}
+
 int oracle_sym_eig(const double *A, int n, double *d, double *V) {
   sym_eig(A, n, d, V);
   return 0;

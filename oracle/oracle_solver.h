@@ -65,6 +65,9 @@ void gauge_fix(const State &pre, State *post);
 
 // A', b' (n x n, n) are optional outputs (post-Schur, pre-factorization).
 int marginalize(const LfvioWindow &w, int flag, LfvioPrior *out, std::vector<double> *A_out, std::vector<double> *b_out);
+void triangulate(const LfvioTriangulateIn &in, double *depth);
+void shift_depth(int n, const double *uv_i, const double *marg_R, const double *marg_P, const double *new_R, const double *new_P,
+                 double init_depth, double *depth);
 extern int g_marg_threads;  // 1 (default) or 4 = NUM_THREADS of the reference's ThreadsConstructA; same sums either way
 
 }  // namespace orc

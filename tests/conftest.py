@@ -25,3 +25,13 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    """One library context (lfvio_create) per test module; GPU tests only."""
+    from lfvio.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()

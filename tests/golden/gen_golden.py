@@ -110,8 +110,32 @@ def gen_chained(name, seed, n):
     return gen_window(name, seed, n, kf0=1, scene=scene, prior=prior, init_state=nxt)
 
 
+def gen_feature(name, seed, n):
+    """SURVEY §8f rank 2: inputs and numpy results of FeatureManager::triangulate and removeBackShiftDepth."""
+    w = synth.make_window(seed, n)
+    tin = abi.TriangulateIn(w)
+    rng = np.random.default_rng([seed, 31337])
+    depth_in = -np.ones(w.N)
+    keep = rng.random(w.N) < 0.25
+    depth_in[keep] = rng.uniform(1.0, 9.0, size=int(keep.sum()))  # already triangulated: must come back untouched
+    depth_out = nr.triangulate(tin.start_frame, tin.obs_offset, tin.obs_point, tin.Ps, tin.Rs, tin.tic, tin.ric, depth_in)
+    # removeBackShiftDepth for the landmarks that start in frame 0: marginalized frame 0 -> new frame 0 (old frame 1)
+    sel = np.flatnonzero(np.asarray(w.start_frame) == 0)
+    uv = tin.obs_point[np.asarray(tin.obs_offset)[sel]]
+    d0 = rng.uniform(0.5, 12.0, size=len(sel))
+    d0[:2] = 0.0  # range 0 -> INIT_DEPTH only if the transformed point is the origin; kept as an ordinary case
+    mR, mP = tin.Rs[0] @ tin.ric, tin.Ps[0] + tin.Rs[0] @ tin.tic  # estimator.cpp:1120-1127
+    nR, nP = tin.Rs[1] @ tin.ric, tin.Ps[1] + tin.Rs[1] @ tin.tic
+    shifted = nr.shift_depth(uv, mR, mP, nR, nP, d0)
+    np.savez_compressed(os.path.join(HERE, name), seed=seed, n=n, start_frame=tin.start_frame, obs_offset=tin.obs_offset,
+                        obs_point=tin.obs_point, Ps=tin.Ps, Rs=tin.Rs, tic=tin.tic, ric=tin.ric, depth_in=depth_in,
+                        depth_out=depth_out, sh_uv=uv, sh_marg_R=mR, sh_marg_P=mP, sh_new_R=nR, sh_new_P=nP, sh_in=d0,
+                        sh_out=shifted)
+
+
 if __name__ == "__main__":
     gen_factors()
+    gen_feature("feature_n120.npz", 105, 120)
     gen_window("window_n24.npz", 101, 24)
     gen_chained("window_n24_prior.npz", 104, 24)
     gen_window("window_n24_notd_noex.npz", 102, 24, estimate_td=0, estimate_extrinsic=0)

@@ -663,3 +663,38 @@ def gauge_fix(pre_pose0, st):
     st.ex[3:7] = [qe[1], qe[2], qe[3], qe[0]]
     st.lam = 1.0 / (1.0 / st.lam)
     return st
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# FeatureManager::triangulate / removeBackShiftDepth, independently of oracle/ (numpy.linalg.svd)
+# ---------------------------------------------------------------------------------------------------------------
+def triangulate(start_frame, obs_offset, obs_point, Ps, Rs, tic, ric, depth, init_depth=5.0):
+    """feature_manager.cpp:199-253."""
+    depth = np.array(depth, dtype=float)
+    for l in range(len(start_frame)):
+        if depth[l] > 0:
+            continue
+        i, o0, k = int(start_frame[l]), int(obs_offset[l]), int(obs_offset[l + 1] - obs_offset[l])
+        t0, R0 = Ps[i] + Rs[i] @ tic, Rs[i] @ ric
+        rows = []
+        for o in range(k):
+            j = i + o
+            t1, R1 = Ps[j] + Rs[j] @ tic, Rs[j] @ ric
+            t, R = R0.T @ (t1 - t0), R0.T @ R1
+            P = np.hstack([R.T, (-R.T @ t)[:, None]])
+            f = obs_point[o0 + o] / np.linalg.norm(obs_point[o0 + o])
+            rows += [f[0] * P[2] - f[2] * P[0], f[1] * P[2] - f[2] * P[1]]
+        v = np.linalg.svd(np.array(rows))[2][-1]
+        d = float((v[:3] / v[3]) @ obs_point[o0])
+        depth[l] = d if d >= 0 else init_depth
+    return depth
+
+
+def shift_depth(uv_i, marg_R, marg_P, new_R, new_P, depth, init_depth=5.0):
+    """feature_manager.cpp:291-299."""
+    out = []
+    for u, d in zip(np.asarray(uv_i, float).reshape(-1, 3), depth):
+        pj = new_R.T @ (marg_R @ (u * d) + marg_P - new_P)
+        r = float(np.linalg.norm(pj))
+        out.append(r if r > 0 else init_depth)
+    return np.array(out)

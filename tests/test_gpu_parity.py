@@ -18,15 +18,6 @@ from lfvio import abi, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
-    from lfvio.engine import Engine
-
-    e = Engine(0)
-    yield e
-    e.close()
-
-
 def rel(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
 

@@ -113,3 +113,45 @@ def test_host_optimization_end_to_end(host, oracle, fused):
         assert p.block_list() == ref_prior.block_list()
         J, Jr = p.J(), ref_prior.J()
         assert np.abs(J.T @ J - Jr.T @ Jr).max() < 1e-5 * np.abs(Jr.T @ Jr).max()
+
+
+@pytest.mark.gpu
+def test_feature_manager_triangulate_and_shift(host, oracle):
+    """SURVEY §8f rank 2 through the mirror: FeatureManager::triangulate() (inclusion rule, in-place update) and
+    removeBackShiftDepth() (list surgery on the host, depth arithmetic on the device) against the oracle."""
+    w = synth.make_window(11, 150)
+    host.load_window(w)
+    d0 = -np.ones(w.N)
+    d0[::4] = 1.0 / w.inv_depth[::4]  # already triangulated
+    host.set_depths(d0)
+    assert host.triangulate() == 0
+    ids, st, cnt, dep = host.features()
+    tin = abi.TriangulateIn(w)
+    want = oracle.triangulate(tin, d0)
+    late = np.asarray(w.start_frame) >= 8  # start_frame < WINDOW_SIZE - 2 is the inclusion rule (:203)
+    want[late] = d0[late]
+    assert np.array_equal(ids, np.arange(w.N)) and np.abs(dep - want).max() < 1e-9 * np.abs(want).max()
+    assert np.array_equal(dep[::4], d0[::4])
+    # slideWindowOld(): frame 0 is marginalized, the estimator's Rs/Ps already hold the shifted window (here: frame 1 of
+    # the window plays the new frame 0, like estimator.cpp:1120-1127 after the swap loop)
+    back_R0, back_P0 = synth.pose_R(w.pose[0]), w.pose[0, :3]
+    shifted = w.copy(pose=np.vstack([w.pose[1:], w.pose[-1:]]))
+    shifted.raw_imu = w.raw_imu  # (not part of the ABI window: the mirror's IMU buffers, irrelevant here)
+    host.load_window(shifted)  # state arrays of the slid window; features reloaded with the original start frames
+    host.set_depths(dep)
+    assert host.remove_back_shift_depth(back_R0, back_P0) == 0
+    ids2, st2, cnt2, dep2 = host.features()
+    start = np.asarray(w.start_frame)
+    k = np.diff(np.asarray(w.obs_offset))
+    survive = (start != 0) | (k - 1 >= 2)
+    assert np.array_equal(ids2, np.arange(w.N)[survive])
+    assert np.array_equal(st2, np.where(start[survive] != 0, start[survive] - 1, 0))
+    assert np.array_equal(cnt2, np.where(start[survive] != 0, k[survive], k[survive] - 1))
+    moved = (start == 0) & (k - 1 >= 2)
+    ric, tic = synth.pose_R(w.ex_pose), w.ex_pose[:3]
+    R0, P0 = back_R0 @ ric, back_P0 + back_R0 @ tic
+    R1, P1 = synth.pose_R(w.pose[1]) @ ric, w.pose[1, :3] + synth.pose_R(w.pose[1]) @ tic
+    uv = w.obs_point[np.asarray(w.obs_offset)[:-1][moved]]
+    want2 = dep.copy()
+    want2[moved] = oracle.shift_depth(uv, R0, P0, R1, P1, 5.0, dep[moved])
+    assert np.abs(dep2 - want2[survive]).max() < 1e-12 * np.abs(want2).max()
