@@ -2,8 +2,7 @@
 //
 //   k_triangulate : FeatureManager::triangulate            feature_manager.cpp:199-253
 //   k_shift_depth : FeatureManager::removeBackShiftDepth   feature_manager.cpp:271-310 (the depth arithmetic)
-// One thread per landmark.  The 2k x 4 system (k <= 11 observations) lives in LDS, one column of 64 lanes per matrix
-// entry, so the row loops of the one-sided Jacobi SVD run without scratch memory and without bank conflicts.
+// One thread per landmark.
 #pragma once
 #include "dev_math.h"
 
@@ -26,11 +25,11 @@ DEV m33 mT(const m33 &a) {
   return r;
 }
 
-// grid ceil(N / 64) x 64
+// grid ceil(N / 64) x 64.  The 2k x 4 system (k <= 11) stays in registers: every loop over rows / observations is fully
+// unrolled to the maximum and predicated on the landmark's own count, so there is no indexed private array.
 __global__ __launch_bounds__(TRI_THREADS) void k_triangulate(const FeatFrames *F, int N, const int *start_frame, const int *obs_offset,
                                                             const double *obs_point, double *depth) {
-  __shared__ double A[TRI_ROWS * 4][TRI_THREADS];  // entry (row, col) of lane's matrix at A[4 row + col][lane]
-  const int lane = threadIdx.x, l = blockIdx.x * TRI_THREADS + lane;
+  const int l = blockIdx.x * TRI_THREADS + threadIdx.x;
   if (l >= N) return;
   if (depth[l] > 0.0) return;  // :207
   const int imu_i = start_frame[l], o0 = obs_offset[l], k = obs_offset[l + 1] - o0;
@@ -38,26 +37,32 @@ __global__ __launch_bounds__(TRI_THREADS) void k_triangulate(const FeatFrames *F
   const d3 tic = ld3(F->tic);
   const d3 t0 = ld3(F->Ps[imu_i]) + mul(ldm(F->Rs[imu_i]), tic);  // :216
   const m33 R0T = mT(mm(ldm(F->Rs[imu_i]), ric));
-  for (int o = 0; o < k; o++) {
-    const int imu_j = imu_i + o;
-    const d3 t1 = ld3(F->Ps[imu_j]) + mul(ldm(F->Rs[imu_j]), tic);
-    const m33 R1 = mm(ldm(F->Rs[imu_j]), ric);
-    const d3 t = mul(R0T, t1 - t0);
-    const m33 Rt = mT(mm(R0T, R1));  // P = [R^T | -R^T t]
-    const d3 mt = -1.0 * mul(Rt, t);
-    const d3 p = ld3(obs_point + 3 * (size_t)(o0 + o));
-    const double pn = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
-    const d3 f = mk3(p.x / pn, p.y / pn, p.z / pn);  // :235  normalized()
-    const double P3[4] = {mt.x, mt.y, mt.z, 0.0};
+  double A[TRI_ROWS][4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const double p0 = c < 3 ? Rt.a[c] : P3[0], p1 = c < 3 ? Rt.a[3 + c] : P3[1], p2 = c < 3 ? Rt.a[6 + c] : P3[2];
-      A[4 * (2 * o) + c][lane] = f.x * p2 - f.z * p0;      // :236
-      A[4 * (2 * o + 1) + c][lane] = f.y * p2 - f.z * p1;  // :237
+  for (int o = 0; o < LFVIO_NUM_FRAMES; o++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) A[2 * o][c] = A[2 * o + 1][c] = 0.0;
+    if (o < k) {
+      const int imu_j = imu_i + o;
+      const d3 t1 = ld3(F->Ps[imu_j]) + mul(ldm(F->Rs[imu_j]), tic);
+      const m33 R1 = mm(ldm(F->Rs[imu_j]), ric);
+      const d3 t = mul(R0T, t1 - t0);
+      const m33 Rt = mT(mm(R0T, R1));  // P = [R^T | -R^T t]
+      const d3 mt = -1.0 * mul(Rt, t);
+      const d3 p = ld3(obs_point + 3 * (size_t)(o0 + o));
+      const double pn = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+      const d3 f = mk3(p.x / pn, p.y / pn, p.z / pn);  // :235  normalized()
+      const double P0[4] = {Rt.a[0], Rt.a[1], Rt.a[2], mt.x}, P1[4] = {Rt.a[3], Rt.a[4], Rt.a[5], mt.y},
+                   P2[4] = {Rt.a[6], Rt.a[7], Rt.a[8], mt.z};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        A[2 * o][c] = f.x * P2[c] - f.z * P0[c];      // :236
+        A[2 * o + 1][c] = f.y * P2[c] - f.z * P1[c];  // :237
+      }
     }
   }
-  // one-sided Jacobi SVD of the 2k x 4 matrix: orthogonalize the columns, accumulate V
-  const int rows = 2 * k;
+  // one-sided Jacobi SVD of the 2k x 4 matrix: orthogonalize the columns, accumulate V.  Rows beyond 2k are zero and
+  // add exact zeros to the sums, so the arithmetic is the one of a 2k-row loop.
   double V[4][4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -70,25 +75,28 @@ __global__ __launch_bounds__(TRI_THREADS) void k_triangulate(const FeatFrames *F
 #pragma unroll
       for (int q = p + 1; q < 4; q++) {
         double al = 0, be = 0, ga = 0;
-        for (int r = 0; r < rows; r++) {
-          const double x = A[4 * r + p][lane], y = A[4 * r + q][lane];
+#pragma unroll
+        for (int r = 0; r < TRI_ROWS; r++) {
+          const double x = A[r][p], y = A[r][q];
           al += x * x, be += y * y, ga += x * y;
         }
-        if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
-        rotated = true;
-        const double zeta = (be - al) / (2.0 * ga);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-        for (int r = 0; r < rows; r++) {
-          const double x = A[4 * r + p][lane], y = A[4 * r + q][lane];
-          A[4 * r + p][lane] = c * x - s * y;
-          A[4 * r + q][lane] = s * x + c * y;
-        }
+        if (!(ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be))) {
+          rotated = true;
+          const double zeta = (be - al) / (2.0 * ga);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const double x = V[r][p], y = V[r][q];
-          V[r][p] = c * x - s * y;
-          V[r][q] = s * x + c * y;
+          for (int r = 0; r < TRI_ROWS; r++) {
+            const double x = A[r][p], y = A[r][q];
+            A[r][p] = c * x - s * y;
+            A[r][q] = s * x + c * y;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const double x = V[r][p], y = V[r][q];
+            V[r][p] = c * x - s * y;
+            V[r][q] = s * x + c * y;
+          }
         }
       }
     if (!rotated) break;
@@ -98,12 +106,13 @@ __global__ __launch_bounds__(TRI_THREADS) void k_triangulate(const FeatFrames *F
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     double n2 = 0;
-    for (int r = 0; r < rows; r++) n2 += A[4 * r + c][lane] * A[4 * r + c][lane];
+#pragma unroll
+    for (int r = 0; r < TRI_ROWS; r++) n2 += A[r][c] * A[r][c];
     if (c == 0 || n2 < bn) bn = n2, v0 = V[0][c], v1 = V[1][c], v2 = V[2][c], v3 = V[3][c];
   }
-  const d3 X = mk3(v0 / v3, v1 / v3, v2 / v3);      // :246
+  const d3 X = mk3(v0 / v3, v1 / v3, v2 / v3);         // :246
   double d = dot(X, ld3(obs_point + 3 * (size_t)o0));  // :247
-  if (d < 0) d = F->init_depth;                      // :249-252
+  if (d < 0) d = F->init_depth;                         // :249-252
   depth[l] = d;
 }
 
