@@ -24,6 +24,25 @@ DEV double block_sum(double v, double *scratch, int tid) {
   for (int w = 0; w < SOLVE_THREADS / 64; w++) s += scratch[w];
   return s;
 }
+// several sums at once: one pair of barriers for all of them (same association as block_sum: butterfly inside the wave,
+// then the four wave totals in order)
+template <int NV>
+DEV void block_sum_n(double (&v)[NV], double *scratch, int tid) {
+#pragma unroll
+  for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) scratch[(tid >> 6) * NV + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    double s = 0;
+    for (int w = 0; w < SOLVE_THREADS / 64; w++) s += scratch[w * NV + k];
+    v[k] = s;
+  }
+}
 DEV double block_max(double v, double *scratch, int tid) {
   v = wave_max(v);
   __syncthreads();
@@ -173,9 +192,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       gs = gr[tid] * gr[tid];
       if (tid < KC) cross = Sc[schur_index(tid, COL_K)] * Gd[tid];  // z2 . G_c
     }
-    const double q_gg = block_sum(qgg_part, scratch, tid);
-    const double gsq = block_sum(gs, scratch, tid);
-    const double cr = block_sum(cross, scratch, tid);
+    double sums[3] = {qgg_part, gs, cross};
+    block_sum_n(sums, scratch, tid);
+    const double q_gg = sums[0], gsq = sums[1], cr = sums[2];
     if (tid == 0) {
       const double Jg2 = q_gg + 2.0 * cr + ls[2];
       const double gtot = gsq + ls[1];
@@ -416,12 +435,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       gG = g[tid] * Gd[tid];
       gN = g[tid] * yv[tid];
     }
-    gn2 = block_sum(gn2, scratch, tid);
-    ggn = block_sum(ggn, scratch, tid);
-    gG = block_sum(gG, scratch, tid);
-    gN = block_sum(gN, scratch, tid);
-    qgn = block_sum(qgn, scratch, tid);
-    qnn = block_sum(qnn, scratch, tid);
+    double sums[6] = {gn2, ggn, gG, gN, qgn, qnn};
+    block_sum_n(sums, scratch, tid);
+    gn2 = sums[0], ggn = sums[1], gG = sums[2], gN = sums[3], qgn = sums[4], qnn = sums[5];
     STAMP(S, 7);
     if (tid == 0) {
       tr->q[Q_GN_SQ] = gn2;
