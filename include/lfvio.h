@@ -232,6 +232,22 @@ int lfvio_triangulate(lfvio_ctx *ctx, const LfvioTriangulateIn *in, double *esti
 int lfvio_shift_depth(lfvio_ctx *ctx, int n, const double *uv_i /* [n][3] */, const double marg_R[9], const double marg_P[3],
                       const double new_R[9], const double new_P[3], double init_depth, double *estimated_depth /* [n] */);
 
+/* lfvio_preintegrate: IntegrationBase::push_back / propagate / midPointIntegration (factor/integration_base.h:29-158) for
+ * num_intervals independent keyframe intervals at once — the ten of a window after a bias update (repropagate(),
+ * integration_base.h:41-52, called from Estimator::double2vector / solveGyroscopeBias), or one interval as frames arrive.
+ * Each interval is the constructor arguments (acc_0, gyr_0, linearized_ba, linearized_bg, integration_base.h:15-27) plus its
+ * buffered samples dt_buf / acc_buf / gyr_buf; noise = {ACC_N, GYR_N, ACC_W, GYR_W} (parameters.cpp:94-97).  out[k] is
+ * what LfvioWindow::imu[k] takes: delta_p/q/v, sum_dt, jacobian and covariance after the last sample.  An interval with
+ * no samples returns the constructor state (identity jacobian, zero covariance). */
+typedef struct {
+  int num_samples;
+  const double *dt;  /* [num_samples]    */
+  const double *acc; /* [num_samples][3] */
+  const double *gyr; /* [num_samples][3] */
+  double acc_0[3], gyr_0[3], linearized_ba[3], linearized_bg[3];
+} LfvioImuInterval;
+int lfvio_preintegrate(lfvio_ctx *ctx, int num_intervals, const LfvioImuInterval *in, const double noise[4], LfvioPreintegration *out);
+
 /* ---- landmark-sharded API (multi-GPU) ------------------------
  * Every rank passes the same window but linearizes only landmarks [lm_begin, lm_end) (caller order);
  * IMU factors and the prior are added on the rank(s) with add_pose_side != 0 — exactly one rank.

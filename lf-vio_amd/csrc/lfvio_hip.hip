@@ -101,6 +101,7 @@ struct lfvio_ctx {
   hipStream_t stream = nullptr;
   char *d_feat = nullptr;  // scratch of lfvio_triangulate / lfvio_shift_depth (grow-only)
   size_t feat_bytes = 0;
+  std::vector<char> feat_stage;  // host staging of lfvio_preintegrate (one packed copy)
   std::string err;
   int batch = 0;
   Layout L;
@@ -803,6 +804,52 @@ int lfvio_shift_depth(lfvio_ctx *c, int n, const double *uv_i, const double marg
                      (double *)(d + oD));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(estimated_depth, d + oD, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LFVIO_OK;
+}
+
+int lfvio_preintegrate(lfvio_ctx *c, int num_intervals, const LfvioImuInterval *in, const double noise[4], LfvioPreintegration *out) {
+  if (!c || num_intervals < 0) return LFVIO_ERR_ARG;
+  if (num_intervals == 0) return LFVIO_OK;
+  if (!in || !noise || !out) return LFVIO_ERR_ARG;
+  size_t S = 0;
+  for (int k = 0; k < num_intervals; k++) {
+    if (in[k].num_samples < 0 || (in[k].num_samples > 0 && (!in[k].dt || !in[k].acc || !in[k].gyr))) {
+      c->err = "preintegrate: interval with a negative sample count or null sample arrays";
+      return LFVIO_ERR_ARG;
+    }
+    S += (size_t)in[k].num_samples;
+  }
+  (void)hipSetDevice(c->device);
+  const size_t K = (size_t)num_intervals;
+  const size_t oJ = 0, oN = align_up(K * sizeof(ImuJob), 256), oT = oN + 256, oA = align_up(oT + S * 8, 256), oG = align_up(oA + S * 24, 256),
+               oO = align_up(oG + S * 24, 256), total = oO + K * sizeof(LfvioPreintegration);
+  int rc = feat_reserve(c, total);
+  if (rc) return rc;
+  // one packed staging buffer -> one host-to-device copy
+  c->feat_stage.resize(oO);
+  char *h = c->feat_stage.data();
+  size_t off = 0;
+  for (int k = 0; k < num_intervals; k++) {
+    ImuJob *jb = (ImuJob *)(h + oJ) + k;
+    const size_t n = (size_t)in[k].num_samples;
+    jb->n = (int)n, jb->off = (int)off;
+    std::memcpy(jb->acc_0, in[k].acc_0, 24), std::memcpy(jb->gyr_0, in[k].gyr_0, 24);
+    std::memcpy(jb->ba, in[k].linearized_ba, 24), std::memcpy(jb->bg, in[k].linearized_bg, 24);
+    if (n) {
+      std::memcpy(h + oT + off * 8, in[k].dt, n * 8);
+      std::memcpy(h + oA + off * 24, in[k].acc, n * 24);
+      std::memcpy(h + oG + off * 24, in[k].gyr, n * 24);
+    }
+    off += n;
+  }
+  std::memcpy(h + oN, noise, 32);
+  char *d = c->d_feat;
+  HIPCHK(c, hipMemcpyAsync(d, h, oO, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_preintegrate, dim3(num_intervals), dim3(256), 0, c->stream, (const ImuJob *)(d + oJ), (const double *)(d + oT),
+                     (const double *)(d + oA), (const double *)(d + oG), (const double *)(d + oN), (LfvioPreintegration *)(d + oO));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out, d + oO, K * sizeof(LfvioPreintegration), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LFVIO_OK;
 }

@@ -57,6 +57,19 @@ class Preintegration(C.Structure):
     ]
 
 
+class ImuIntervalC(C.Structure):
+    _fields_ = [
+        ("num_samples", C.c_int),
+        ("dt", C.POINTER(C.c_double)),
+        ("acc", C.POINTER(C.c_double)),
+        ("gyr", C.POINTER(C.c_double)),
+        ("acc_0", C.c_double * 3),
+        ("gyr_0", C.c_double * 3),
+        ("linearized_ba", C.c_double * 3),
+        ("linearized_bg", C.c_double * 3),
+    ]
+
+
 class Prior(C.Structure):
     _fields_ = [
         ("valid", C.c_int),
@@ -329,7 +342,7 @@ HIP_SYMBOLS = [
     "lfvio_batch_sync", "lfvio_batch_download", "lfvio_stream",
     "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_scalar_offset", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
     "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_marg_linearize", "lfvio_shard_marg_finish",
-    "lfvio_shard_finish", "lfvio_triangulate", "lfvio_shift_depth",
+    "lfvio_shard_finish", "lfvio_triangulate", "lfvio_shift_depth", "lfvio_preintegrate",
 ]
 
 
@@ -378,6 +391,7 @@ def load_hip_library(path=None):
     _dp = C.POINTER(C.c_double)
     lib.lfvio_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangulateInC), _dp]
     lib.lfvio_shift_depth.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp]
+    lib.lfvio_preintegrate.argtypes = [C.c_void_p, C.c_int, C.POINTER(ImuIntervalC), _dp, C.POINTER(Preintegration)]
     lib.lfvio_shard_marg_linearize.argtypes = [C.c_void_p, C.c_int]
     lib.lfvio_shard_marg_finish.argtypes = [C.c_void_p, C.c_int, C.POINTER(Prior)]
     return lib

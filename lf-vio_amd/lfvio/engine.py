@@ -119,6 +119,25 @@ class Engine:
                     "lfvio_shift_depth")
         return d
 
+    def preintegrate(self, intervals, noise):
+        """IntegrationBase over a list of (linearized_ba, linearized_bg, acc_0, gyr_0, dt[], acc[][3], gyr[][3]) intervals
+        (the tuple order of synth.Window.raw_imu); returns a list of abi.Preintegration."""
+        K = len(intervals)
+        arr = (abi.ImuIntervalC * max(K, 1))()
+        keep = []
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        for k, (ba, bg, a0, g0, dts, accs, gyrs) in enumerate(intervals):
+            dts, accs, gyrs = f(dts).reshape(-1), f(accs).reshape(-1, 3), f(gyrs).reshape(-1, 3)
+            keep.append((dts, accs, gyrs))
+            arr[k].num_samples = len(dts)
+            arr[k].dt, arr[k].acc, arr[k].gyr = _p(dts), _p(accs), _p(gyrs)
+            for name, v in (("acc_0", a0), ("gyr_0", g0), ("linearized_ba", ba), ("linearized_bg", bg)):
+                setattr(arr[k], name, (C.c_double * 3)(*[float(x) for x in v]))
+        out = (abi.Preintegration * max(K, 1))()
+        nz = f(noise)
+        self._check(self.lib.lfvio_preintegrate(self.ctx, K, arr, _p(nz), out), "lfvio_preintegrate")
+        return [out[k] for k in range(K)]
+
     def time_kernel(self, which, count, reps):
         ms = np.zeros(1)
         self._check(self.lib.lfvio_debug_time_kernel(self.ctx, which, count, reps, _p(ms)), "time_kernel")
