@@ -846,7 +846,7 @@ int lfvio_preintegrate(lfvio_ctx *c, int num_intervals, const LfvioImuInterval *
   std::memcpy(h + oN, noise, 32);
   char *d = c->d_feat;
   HIPCHK(c, hipMemcpyAsync(d, h, oO, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_preintegrate, dim3(num_intervals), dim3(256), 0, c->stream, (const ImuJob *)(d + oJ), (const double *)(d + oT),
+  hipLaunchKernelGGL(k_preintegrate, dim3(num_intervals), dim3(PRE_THREADS), 0, c->stream, (const ImuJob *)(d + oJ), (const double *)(d + oT),
                      (const double *)(d + oA), (const double *)(d + oG), (const double *)(d + oN), (LfvioPreintegration *)(d + oO));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(out, d + oO, K * sizeof(LfvioPreintegration), hipMemcpyDeviceToHost, c->stream));

@@ -485,6 +485,53 @@ void Estimator::packWindow(LfvioWindow *w) {
   w->prior = last_marginalization_info;
 }
 
+// `for (i <= WINDOW_SIZE) pre_integrations[i]->repropagate(ba[i], bg[i])` (estimator.cpp:403-406; IntegrationBase::repropagate,
+// integration_base.h:38-52) with the propagation of all intervals on the device: each IntegrationBase ends in the state
+// its own repropagate() would leave (delta_*, jacobian, covariance, sum_dt, acc_0 / gyr_0 = the last buffered sample).
+void Estimator::repropagateWindow(const Vector3d ba[(WINDOW_SIZE + 1)], const Vector3d bg[(WINDOW_SIZE + 1)]) {
+  if (!gpu) gpu = lfvio_create(0);
+  if (!gpu) {
+    last_status = LFVIO_ERR_DEVICE;  // no fallback
+    return;
+  }
+  std::vector<LfvioImuInterval> in;
+  std::vector<int> which;
+  std::vector<std::vector<double>> acc, gyr;
+  for (int i = 0; i <= WINDOW_SIZE; i++) {
+    IntegrationBase *p = pre_integrations[i];
+    if (!p) continue;
+    const size_t n = p->dt_buf.size();
+    acc.emplace_back(3 * n), gyr.emplace_back(3 * n);
+    for (size_t k = 0; k < n; k++)
+      for (int d = 0; d < 3; d++) acc.back()[3 * k + d] = p->acc_buf[k](d), gyr.back()[3 * k + d] = p->gyr_buf[k](d);
+    LfvioImuInterval iv;
+    iv.num_samples = (int)n;
+    iv.dt = p->dt_buf.data();
+    for (int d = 0; d < 3; d++)
+      iv.acc_0[d] = p->linearized_acc(d), iv.gyr_0[d] = p->linearized_gyr(d), iv.linearized_ba[d] = ba[i](d), iv.linearized_bg[d] = bg[i](d);
+    in.push_back(iv), which.push_back(i);
+  }
+  for (size_t k = 0; k < in.size(); k++) in[k].acc = acc[k].data(), in[k].gyr = gyr[k].data();
+  std::vector<LfvioPreintegration> out(in.size());
+  const double noise[4] = {ACC_N, GYR_N, ACC_W, GYR_W};
+  last_status = lfvio_preintegrate(gpu, (int)in.size(), in.data(), noise, out.data());
+  if (last_status != LFVIO_OK) return;
+  for (size_t k = 0; k < in.size(); k++) {
+    IntegrationBase *p = pre_integrations[which[k]];
+    const LfvioPreintegration &o = out[k];
+    p->sum_dt = o.sum_dt;
+    p->delta_p = Vector3d(o.delta_p[0], o.delta_p[1], o.delta_p[2]);
+    p->delta_q = Quaterniond(o.delta_q[3], o.delta_q[0], o.delta_q[1], o.delta_q[2]);
+    p->delta_v = Vector3d(o.delta_v[0], o.delta_v[1], o.delta_v[2]);
+    p->linearized_ba = ba[which[k]], p->linearized_bg = bg[which[k]];
+    for (int r = 0; r < 15; r++)
+      for (int c = 0; c < 15; c++) p->jacobian(r, c) = o.jacobian[15 * r + c], p->covariance(r, c) = o.covariance[15 * r + c];
+    const size_t n = p->dt_buf.size();
+    p->acc_0 = n ? p->acc_buf[n - 1] : p->linearized_acc, p->gyr_0 = n ? p->gyr_buf[n - 1] : p->linearized_gyr;
+    if (n) p->dt = p->dt_buf[n - 1], p->acc_1 = p->acc_buf[n - 1], p->gyr_1 = p->gyr_buf[n - 1];
+  }
+}
+
 // Estimator::optimization(), estimator.cpp:676-1009, over the C-ABI:
 //   vector2double -> [ceres::Solve := lfvio_solve] -> double2vector
 //   -> vector2double -> [MarginalizationInfo := lfvio_marginalize] -> new prior

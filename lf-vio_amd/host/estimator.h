@@ -132,6 +132,9 @@ class Estimator {
   void setParameter();
   void clearState();
   void optimization();
+  // the batched repropagate of visualInitialAlign (estimator.cpp:403-406): every pre_integrations[i] redone from its
+  // buffers with new linearization biases, all intervals in ONE lfvio_preintegrate call; status in last_status
+  void repropagateWindow(const Vector3d ba[(WINDOW_SIZE + 1)], const Vector3d bg[(WINDOW_SIZE + 1)]);
   void vector2double();
   void double2vector();
 

@@ -123,6 +123,15 @@ void lfvio_host_repropagate(void *h, int frame, const double *ba, const double *
   if (e->pre_integrations[frame]) e->pre_integrations[frame]->repropagate(Vector3d(ba[0], ba[1], ba[2]), Vector3d(bg[0], bg[1], bg[2]));
 }
 
+// ba, bg: [WINDOW_SIZE + 1][3]; returns Estimator::last_status
+int lfvio_host_repropagate_window(void *h, const double *ba, const double *bg) {
+  Estimator *e = (Estimator *)h;
+  Vector3d a[WINDOW_SIZE + 1], g[WINDOW_SIZE + 1];
+  for (int i = 0; i <= WINDOW_SIZE; i++) a[i] = Vector3d(ba[3 * i], ba[3 * i + 1], ba[3 * i + 2]), g[i] = Vector3d(bg[3 * i], bg[3 * i + 1], bg[3 * i + 2]);
+  e->repropagateWindow(a, g);
+  return e->last_status;
+}
+
 void lfvio_host_vector2double(void *h) { ((Estimator *)h)->vector2double(); }
 void lfvio_host_double2vector(void *h) { ((Estimator *)h)->double2vector(); }
 

@@ -35,6 +35,7 @@ class HostEstimator:
         L.lfvio_host_get_depths.argtypes = [C.c_void_p, _dp]
         L.lfvio_host_set_imu.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp]
         L.lfvio_host_repropagate.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.lfvio_host_repropagate_window.argtypes = [C.c_void_p, _dp, _dp]
         L.lfvio_host_vector2double.argtypes = [C.c_void_p]
         L.lfvio_host_double2vector.argtypes = [C.c_void_p]
         L.lfvio_host_get_para.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
@@ -85,6 +86,12 @@ class HostEstimator:
             self.L.lfvio_host_set_imu(self.h, i + 1, _p(_f(a0)), _p(_f(g0)), _p(_f(ba)), _p(_f(bg)), len(dts), _p(_f(dts)),
                                       _p(_f(accs)), _p(_f(gyrs)))
         self.L.lfvio_host_set_prior(self.h, C.byref(win.prior) if win.prior is not None else None)
+
+    # ---- SURVEY §8f rank 3
+    def repropagate_window(self, ba, bg):
+        """Estimator::repropagateWindow: every pre_integrations[i] redone on the device with biases ba[i], bg[i] ([11][3])."""
+        ba, bg = _f(ba).reshape(11, 3), _f(bg).reshape(11, 3)
+        return self.L.lfvio_host_repropagate_window(self.h, _p(ba), _p(bg))
 
     # ---- SURVEY §8f rank 2
     def set_depths(self, depth):

@@ -155,3 +155,29 @@ def test_feature_manager_triangulate_and_shift(host, oracle):
     want2 = dep.copy()
     want2[moved] = oracle.shift_depth(uv, R0, P0, R1, P1, 5.0, dep[moved])
     assert np.abs(dep2 - want2[survive]).max() < 1e-12 * np.abs(want2).max()
+
+
+@pytest.mark.gpu
+def test_repropagate_window_on_device(host):
+    """Estimator::repropagateWindow (one lfvio_preintegrate call for the window) leaves every IntegrationBase where its own
+    host-side repropagate() (integration_base.h:38-52) leaves it — with the biases it had and with new ones."""
+    w = synth.make_window(8, 10)
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(1)
+    for trial in range(2):
+        host.load_window(w)
+        ba, bg = np.zeros((11, 3)), np.zeros((11, 3))
+        for i in range(10):
+            ba[i + 1], bg[i + 1] = w.raw_imu[i][0], w.raw_imu[i][1]
+        if trial:
+            ba += rng.normal(0, 0.02, ba.shape)
+            bg += rng.normal(0, 0.005, bg.shape)
+        for i in range(1, 11):
+            host.L.lfvio_host_repropagate(host.h, i, ba[i].ctypes.data_as(dp), bg[i].ctypes.data_as(dp))
+        want = [abi.preint_to_array(host.pack().imu[k]) for k in range(10)]
+        host.load_window(w)
+        assert host.repropagate_window(ba, bg) == 0
+        got = [abi.preint_to_array(host.pack().imu[k]) for k in range(10)]
+        for k in range(10):
+            for lo, hi, tol in ((0, 17, 1e-13), (17, 242, 1e-12), (242, 467, 1e-12)):
+                assert np.abs(got[k][lo:hi] - want[k][lo:hi]).max() <= tol * np.abs(want[k][lo:hi]).max(), (trial, k, lo)
