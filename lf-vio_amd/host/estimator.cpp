@@ -2,6 +2,7 @@
 // /root/reference/vins_estimator/src.
 #include "estimator.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -15,6 +16,7 @@ double SOLVER_TIME = 0.04;                                         // :133
 int NUM_ITERATIONS = 8;                                            // :134
 int ESTIMATE_EXTRINSIC = 1, ESTIMATE_TD = 1;                       // :83, :151
 double TD = -0.008, TR = 0.0, ROW = 960, COL = 1280;
+double MIN_PARALLAX = 10.0 / FOCAL_LENGTH;                         // keyframe_parallax: 10.0, parameters.cpp:56-57
 
 // ---------------------------------------------------------------- Utility (utility.h:66-113)
 Vector3d Utility::R2ypr(const Matrix3d &R) {
@@ -320,6 +322,43 @@ void FeatureManager::removeFront(int frame_count) {
   }
 }
 
+// feature_manager.cpp:45-95 — appends the frame's observations and decides keyframe (true -> MARGIN_OLD) or not
+bool FeatureManager::addFeatureCheckParallax(int frame_count, const ImageMap &image, double td) {
+  double parallax_sum = 0;
+  int parallax_num = 0;
+  last_track_num = 0;
+  for (auto &id_pts : image) {
+    FeaturePerFrame f_per_fra(id_pts.second[0].second.a, td);
+    int feature_id = id_pts.first;
+    auto it = std::find_if(feature.begin(), feature.end(), [feature_id](const FeaturePerId &it) { return it.feature_id == feature_id; });
+    if (it == feature.end()) {
+      feature.push_back(FeaturePerId(feature_id, frame_count));
+      feature.back().feature_per_frame.push_back(f_per_fra);
+    } else if (it->feature_id == feature_id) {
+      it->feature_per_frame.push_back(f_per_fra);
+      last_track_num++;
+    }
+  }
+  if (frame_count < 2 || last_track_num < 20) return true;
+  for (auto &it_per_id : feature) {
+    if (it_per_id.start_frame <= frame_count - 2 && it_per_id.start_frame + int(it_per_id.feature_per_frame.size()) - 1 >= frame_count - 1) {
+      parallax_sum += compensatedParallax2(it_per_id, frame_count);
+      parallax_num++;
+    }
+  }
+  if (parallax_num == 0) return true;
+  return parallax_sum / parallax_num >= MIN_PARALLAX;
+}
+// feature_manager.cpp:353-369 — the angle between the bearings of the second and third last frame (x 10), uncompensated
+double FeatureManager::compensatedParallax2(const FeaturePerId &it_per_id, int frame_count) {
+  const FeaturePerFrame &frame_i = it_per_id.feature_per_frame[frame_count - 2 - it_per_id.start_frame];
+  const FeaturePerFrame &frame_j = it_per_id.feature_per_frame[frame_count - 1 - it_per_id.start_frame];
+  Vector3d p_j = frame_j.point;
+  Vector3d p_i = frame_i.point;
+  double p_i_comp = p_i.dot(p_j);
+  return acos(p_i_comp) * 10;
+}
+
 FeaturePerId &FeatureManager::addFeature(int feature_id, int start_frame) {
   feature.emplace_back(feature_id, start_frame);
   return feature.back();
@@ -354,10 +393,207 @@ void Estimator::clearState() {  // estimator.cpp:23-84 (subset owned by the mirr
     ric[i] = Matrix3d::Identity();
   }
   td = TD;
+  for (int i = 0; i < WINDOW_SIZE + 1; i++) {
+    dt_buf[i].clear();
+    linear_acceleration_buf[i].clear();
+    angular_velocity_buf[i].clear();
+    Headers[i] = 0;
+  }
+  solver_flag = INITIAL;
+  first_imu = false;
+  sum_of_back = 0;
+  sum_of_front = 0;
+  frame_count = 0;
+  initial_timestamp = 0;
   delete last_marginalization_info;
   last_marginalization_info = nullptr;
   f_manager.clearState();
   failure_occur = 0;
+}
+
+// estimator.cpp:86-120
+void Estimator::processIMU(double dt, const Vector3d &linear_acceleration, const Vector3d &angular_velocity) {
+  if (!first_imu) {
+    first_imu = true;
+    acc_0 = linear_acceleration;
+    gyr_0 = angular_velocity;
+  }
+  if (!pre_integrations[frame_count]) pre_integrations[frame_count] = new IntegrationBase{acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]};
+  if (frame_count != 0) {
+    pre_integrations[frame_count]->push_back(dt, linear_acceleration, angular_velocity);
+    // tmp_pre_integration (:100) only feeds all_image_frame, i.e. initialStructure(): not kept
+    dt_buf[frame_count].push_back(dt);
+    linear_acceleration_buf[frame_count].push_back(linear_acceleration);
+    angular_velocity_buf[frame_count].push_back(angular_velocity);
+    int j = frame_count;
+    Vector3d un_acc_0 = Rs[j] * (acc_0 - Bas[j]) - g;
+    Vector3d un_gyr = 0.5 * (gyr_0 + angular_velocity) - Bgs[j];
+    Rs[j] = Rs[j] * Utility::deltaQ(un_gyr * dt).toRotationMatrix();
+    Vector3d un_acc_1 = Rs[j] * (linear_acceleration - Bas[j]) - g;
+    Vector3d un_acc = 0.5 * (un_acc_0 + un_acc_1);
+    Ps[j] += dt * Vs[j] + 0.5 * dt * dt * un_acc;
+    Vs[j] += dt * un_acc;
+  }
+  acc_0 = linear_acceleration;
+  gyr_0 = angular_velocity;
+}
+
+// estimator.cpp:122-220 without the ROS logging, all_image_frame / tmp_pre_integration (inputs of initialStructure) and
+// the ESTIMATE_EXTRINSIC == 2 rotation calibration (init-only)
+void Estimator::processImage(const ImageMap &image, double header_stamp) {
+  if (f_manager.addFeatureCheckParallax(frame_count, image, td))
+    marginalization_flag = MARGIN_OLD;
+  else
+    marginalization_flag = MARGIN_SECOND_NEW;
+  Headers[frame_count] = header_stamp;
+  if (solver_flag == INITIAL) {
+    if (frame_count == WINDOW_SIZE) {
+      bool result = false;
+      if (ESTIMATE_EXTRINSIC != 2 && (header_stamp - initial_timestamp) > 0.1) {
+        result = initialStructure();
+        initial_timestamp = header_stamp;
+      }
+      if (result) {
+        solver_flag = NON_LINEAR;
+        solveOdometry();
+        slideWindow();
+        f_manager.removeFailures();
+        last_R = Rs[WINDOW_SIZE];
+        last_P = Ps[WINDOW_SIZE];
+        last_R0 = Rs[0];
+        last_P0 = Ps[0];
+      } else
+        slideWindow();
+    } else
+      frame_count++;
+  } else {
+    solveOdometry();
+    if (failureDetection()) {
+      failure_occur = 1;
+      clearState();
+      setParameter();
+      return;
+    }
+    slideWindow();
+    f_manager.removeFailures();
+    key_poses.clear();
+    for (int i = 0; i <= WINDOW_SIZE; i++) key_poses.push_back(Ps[i]);
+    last_R = Rs[WINDOW_SIZE];
+    last_P = Ps[WINDOW_SIZE];
+    last_R0 = Rs[0];
+    last_P0 = Ps[0];
+  }
+}
+
+// Stand-in for initialStructure() + visualInitialAlign() (estimator.cpp:222-473): the window state comes from the
+// `bootstrap` record; what visualInitialAlign does with it afterwards is kept — every interval is re-propagated with its
+// new gyroscope bias and a zero accelerometer bias (:403-406; here on the device, one call) and g is taken over (:445).
+bool Estimator::initialStructure() {
+  if (!bootstrap.valid) return false;
+  for (int i = 0; i <= WINDOW_SIZE; i++) {
+    Ps[i] = bootstrap.Ps[i], Rs[i] = bootstrap.Rs[i], Vs[i] = bootstrap.Vs[i];
+    Bas[i] = bootstrap.Bas[i], Bgs[i] = bootstrap.Bgs[i];
+  }
+  g = bootstrap.g;
+  Vector3d zero[(WINDOW_SIZE + 1)];
+  repropagateWindow(zero, Bgs);
+  if (last_status != LFVIO_OK) return false;
+  for (auto &it : f_manager.feature) it.estimated_depth = -1;  // clearDepth(-1), :386-390; triangulated in solveOdometry()
+  return true;
+}
+
+// estimator.cpp:475-486
+void Estimator::solveOdometry() {
+  if (frame_count < WINDOW_SIZE) return;
+  if (solver_flag == NON_LINEAR) {
+    f_manager.triangulate(Ps, tic, ric);
+    optimization();
+  }
+}
+
+// estimator.cpp:628-674 — as shipped: only the gyroscope-bias and the two translation tests return true
+bool Estimator::failureDetection() {
+  if (Bgs[WINDOW_SIZE].norm() > 1.0) return true;
+  Vector3d tmp_P = Ps[WINDOW_SIZE];
+  if ((tmp_P - last_P).norm() > 5) return true;
+  if (std::abs(tmp_P.z() - last_P.z()) > 1) return true;
+  return false;
+}
+
+// estimator.cpp:1011-1131
+void Estimator::slideWindow() {
+  if (marginalization_flag == MARGIN_OLD) {
+    back_R0 = Rs[0];
+    back_P0 = Ps[0];
+    if (frame_count == WINDOW_SIZE) {
+      for (int i = 0; i < WINDOW_SIZE; i++) {
+        std::swap(Rs[i], Rs[i + 1]);
+        std::swap(pre_integrations[i], pre_integrations[i + 1]);
+        dt_buf[i].swap(dt_buf[i + 1]);
+        linear_acceleration_buf[i].swap(linear_acceleration_buf[i + 1]);
+        angular_velocity_buf[i].swap(angular_velocity_buf[i + 1]);
+        Headers[i] = Headers[i + 1];
+        std::swap(Ps[i], Ps[i + 1]);
+        std::swap(Vs[i], Vs[i + 1]);
+        std::swap(Bas[i], Bas[i + 1]);
+        std::swap(Bgs[i], Bgs[i + 1]);
+      }
+      Headers[WINDOW_SIZE] = Headers[WINDOW_SIZE - 1];
+      Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1];
+      Vs[WINDOW_SIZE] = Vs[WINDOW_SIZE - 1];
+      Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1];
+      Bas[WINDOW_SIZE] = Bas[WINDOW_SIZE - 1];
+      Bgs[WINDOW_SIZE] = Bgs[WINDOW_SIZE - 1];
+      delete pre_integrations[WINDOW_SIZE];
+      pre_integrations[WINDOW_SIZE] = new IntegrationBase{acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]};
+      dt_buf[WINDOW_SIZE].clear();
+      linear_acceleration_buf[WINDOW_SIZE].clear();
+      angular_velocity_buf[WINDOW_SIZE].clear();
+      slideWindowOld();
+    }
+  } else {
+    if (frame_count == WINDOW_SIZE) {
+      for (unsigned int i = 0; i < dt_buf[frame_count].size(); i++) {
+        double tmp_dt = dt_buf[frame_count][i];
+        Vector3d tmp_linear_acceleration = linear_acceleration_buf[frame_count][i];
+        Vector3d tmp_angular_velocity = angular_velocity_buf[frame_count][i];
+        pre_integrations[frame_count - 1]->push_back(tmp_dt, tmp_linear_acceleration, tmp_angular_velocity);
+        dt_buf[frame_count - 1].push_back(tmp_dt);
+        linear_acceleration_buf[frame_count - 1].push_back(tmp_linear_acceleration);
+        angular_velocity_buf[frame_count - 1].push_back(tmp_angular_velocity);
+      }
+      Headers[frame_count - 1] = Headers[frame_count];
+      Ps[frame_count - 1] = Ps[frame_count];
+      Vs[frame_count - 1] = Vs[frame_count];
+      Rs[frame_count - 1] = Rs[frame_count];
+      Bas[frame_count - 1] = Bas[frame_count];
+      Bgs[frame_count - 1] = Bgs[frame_count];
+      delete pre_integrations[WINDOW_SIZE];
+      pre_integrations[WINDOW_SIZE] = new IntegrationBase{acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]};
+      dt_buf[WINDOW_SIZE].clear();
+      linear_acceleration_buf[WINDOW_SIZE].clear();
+      angular_velocity_buf[WINDOW_SIZE].clear();
+      slideWindowNew();
+    }
+  }
+}
+void Estimator::slideWindowNew() {
+  sum_of_front++;
+  f_manager.removeFront(frame_count);
+}
+void Estimator::slideWindowOld() {
+  sum_of_back++;
+  bool shift_depth = solver_flag == NON_LINEAR ? true : false;
+  if (shift_depth) {
+    Matrix3d R0, R1;
+    Vector3d P0, P1;
+    R0 = back_R0 * ric[0];
+    R1 = Rs[0] * ric[0];
+    P0 = back_P0 + back_R0 * tic[0];
+    P1 = Ps[0] + Rs[0] * tic[0];
+    f_manager.removeBackShiftDepth(R0, P0, R1, P1);
+  } else
+    f_manager.removeBack();
 }
 
 void Estimator::vector2double() {  // estimator.cpp:488-530

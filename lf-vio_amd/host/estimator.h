@@ -31,6 +31,7 @@ extern double INIT_DEPTH;
 extern int NUM_ITERATIONS;
 extern int ESTIMATE_EXTRINSIC, ESTIMATE_TD;
 extern double TD, TR, ROW, COL;
+extern double MIN_PARALLAX;  // keyframe_parallax / FOCAL_LENGTH (parameters.cpp:56-57)
 enum SIZE_PARAMETERIZATION { SIZE_POSE = 7, SIZE_SPEEDBIAS = 9, SIZE_FEATURE = 1 };
 enum StateOrder { O_P = 0, O_R = 3, O_V = 6, O_BA = 9, O_BG = 12 };
 
@@ -102,6 +103,10 @@ class FeaturePerId {
   int endFrame() { return start_frame + (int)feature_per_frame.size() - 1; }
 };
 
+// the decoded feature message, estimator_node.cpp:292-312: feature_id -> [(camera_id, x y z u v vx vy vz)]
+typedef Mat<8, 1> Vector8d;
+typedef std::map<int, std::vector<std::pair<int, Vector8d>>> ImageMap;
+
 class FeatureManager {
  public:
   void clearState() { feature.clear(); }
@@ -116,8 +121,11 @@ class FeatureManager {
   void removeBackShiftDepth(Matrix3d marg_R, Vector3d marg_P, Matrix3d new_R, Vector3d new_P);
   void removeBack();
   void removeFront(int frame_count);
-  // addFeatureCheckParallax (keyframe policy) is SURVEY §8f rank 4; addFeature() is the minimal producer the mirror needs.
-  FeaturePerId &addFeature(int feature_id, int start_frame);
+  // SURVEY §8f rank 4 (feature_manager.cpp:45-95, 353-369): the keyframe policy
+  bool addFeatureCheckParallax(int frame_count, const ImageMap &image, double td);
+  double compensatedParallax2(const FeaturePerId &it_per_id, int frame_count);
+  int last_track_num = 0;
+  FeaturePerId &addFeature(int feature_id, int start_frame);  // test / packing helper, not in the reference
   std::list<FeaturePerId> feature;
   const Matrix3d *Rs = nullptr;  // the estimator's Rs[] (FeatureManager(Matrix3d _Rs[]), feature_manager.cpp:13)
   lfvio_ctx **gpu = nullptr;     // the estimator's device context (created on first use)
@@ -137,6 +145,36 @@ class Estimator {
   void repropagateWindow(const Vector3d ba[(WINDOW_SIZE + 1)], const Vector3d bg[(WINDOW_SIZE + 1)]);
   void vector2double();
   void double2vector();
+  // the per-measurement control flow around optimization() (estimator.cpp:86-220, 475-486,
+  // 628-674, 1011-1131).  initialStructure() (SfM + visual-inertial alignment, out of scope) is replaced by a state record
+  // the caller supplies (`bootstrap`); everything after it is the reference's sequence.
+  void processIMU(double dt, const Vector3d &linear_acceleration, const Vector3d &angular_velocity);
+  void processImage(const ImageMap &image, double header_stamp);
+  bool initialStructure();
+  void solveOdometry();
+  void slideWindow();
+  void slideWindowNew();
+  void slideWindowOld();
+  bool failureDetection();
+
+  enum SolverFlag { INITIAL, NON_LINEAR };
+  SolverFlag solver_flag = INITIAL;
+  int frame_count = 0;
+  double Headers[(WINDOW_SIZE + 1)];  // header.stamp.toSec()
+  bool first_imu = false;
+  Vector3d acc_0, gyr_0, g;
+  std::vector<double> dt_buf[(WINDOW_SIZE + 1)];
+  std::vector<Vector3d> linear_acceleration_buf[(WINDOW_SIZE + 1)], angular_velocity_buf[(WINDOW_SIZE + 1)];
+  Matrix3d back_R0, last_R;
+  Vector3d back_P0, last_P;
+  std::vector<Vector3d> key_poses;
+  int sum_of_back = 0, sum_of_front = 0;
+  double initial_timestamp = 0;
+  struct Bootstrap {  // what initialStructure() + visualInitialAlign() leave behind (estimator.cpp:222-473), from outside
+    bool valid = false;
+    Vector3d Ps[(WINDOW_SIZE + 1)], Vs[(WINDOW_SIZE + 1)], Bas[(WINDOW_SIZE + 1)], Bgs[(WINDOW_SIZE + 1)], g;
+    Matrix3d Rs[(WINDOW_SIZE + 1)];
+  } bootstrap;
 
   enum MarginalizationFlag { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };
   MarginalizationFlag marginalization_flag = MARGIN_OLD;

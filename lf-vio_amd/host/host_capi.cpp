@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "estimator.h"
+#include "replay.h"
 
 using namespace lfvio;
 
@@ -130,6 +131,118 @@ int lfvio_host_repropagate_window(void *h, const double *ba, const double *bg) {
   for (int i = 0; i <= WINDOW_SIZE; i++) a[i] = Vector3d(ba[3 * i], ba[3 * i + 1], ba[3 * i + 2]), g[i] = Vector3d(bg[3 * i], bg[3 * i + 1], bg[3 * i + 2]);
   e->repropagateWindow(a, g);
   return e->last_status;
+}
+
+// ---- the control flow around optimization() and the trace replay
+void lfvio_host_set_min_parallax(double keyframe_parallax_px) { MIN_PARALLAX = keyframe_parallax_px / FOCAL_LENGTH; }
+
+void lfvio_host_process_imu(void *h, double dt, const double *acc, const double *gyr) {
+  ((Estimator *)h)->processIMU(dt, Vector3d(acc[0], acc[1], acc[2]), Vector3d(gyr[0], gyr[1], gyr[2]));
+}
+
+// ids[n], pts[n][8] = x y z u v vx vy vz (camera 0); returns Estimator::last_status (or FeatureManager's when that failed)
+int lfvio_host_process_image(void *h, double stamp, int n, const int *ids, const double *pts) {
+  Estimator *e = (Estimator *)h;
+  ImageMap image;
+  for (int i = 0; i < n; i++) {
+    Vector8d v;
+    for (int k = 0; k < 8; k++) v.a[k] = pts[8 * i + k];
+    image[ids[i]].emplace_back(0, v);
+  }
+  e->last_status = LFVIO_OK, e->f_manager.last_status = LFVIO_OK;
+  e->processImage(image, stamp);
+  return e->last_status != LFVIO_OK ? e->last_status : e->f_manager.last_status;
+}
+
+// only the keyframe decision of processImage(): appends the observations, returns 1 for MARGIN_OLD
+int lfvio_host_add_feature_check_parallax(void *h, int frame_count, int n, const int *ids, const double *pts, double td) {
+  Estimator *e = (Estimator *)h;
+  ImageMap image;
+  for (int i = 0; i < n; i++) {
+    Vector8d v;
+    for (int k = 0; k < 8; k++) v.a[k] = pts[8 * i + k];
+    image[ids[i]].emplace_back(0, v);
+  }
+  return e->f_manager.addFeatureCheckParallax(frame_count, image, td) ? 1 : 0;
+}
+
+// Ps Rs Vs Bas Bgs as lfvio_host_set_state, g[3]
+void lfvio_host_set_bootstrap(void *h, const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs, const double *g) {
+  Estimator *e = (Estimator *)h;
+  for (int i = 0; i <= WINDOW_SIZE; i++) {
+    e->bootstrap.Ps[i] = Vector3d(Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2]);
+    e->bootstrap.Vs[i] = Vector3d(Vs[3 * i], Vs[3 * i + 1], Vs[3 * i + 2]);
+    e->bootstrap.Bas[i] = Vector3d(Bas[3 * i], Bas[3 * i + 1], Bas[3 * i + 2]);
+    e->bootstrap.Bgs[i] = Vector3d(Bgs[3 * i], Bgs[3 * i + 1], Bgs[3 * i + 2]);
+    setM(e->bootstrap.Rs[i], Rs + 9 * i);
+  }
+  e->bootstrap.g = Vector3d(g[0], g[1], g[2]);
+  e->bootstrap.valid = true;
+}
+
+// the window is already filled from outside (lfvio_host_set_state / add_feature / set_imu): continue from NON_LINEAR
+void lfvio_host_set_running(void *h, const double *stamps, const double *acc_0, const double *gyr_0, const double *g) {
+  Estimator *e = (Estimator *)h;
+  e->solver_flag = Estimator::NON_LINEAR;
+  e->frame_count = WINDOW_SIZE;
+  e->first_imu = true;
+  for (int i = 0; i <= WINDOW_SIZE; i++) e->Headers[i] = stamps[i];
+  e->acc_0 = Vector3d(acc_0[0], acc_0[1], acc_0[2]), e->gyr_0 = Vector3d(gyr_0[0], gyr_0[1], gyr_0[2]);
+  e->g = Vector3d(g[0], g[1], g[2]);
+  e->last_R = e->Rs[WINDOW_SIZE], e->last_P = e->Ps[WINDOW_SIZE], e->last_R0 = e->Rs[0], e->last_P0 = e->Ps[0];
+}
+
+void lfvio_host_clear_state(void *h) {
+  Estimator *e = (Estimator *)h;
+  e->clearState();
+  e->setParameter();
+  e->bootstrap.valid = false;
+}
+
+void lfvio_host_slide_window(void *h) { ((Estimator *)h)->slideWindow(); }
+int lfvio_host_failure_detection(void *h) { return ((Estimator *)h)->failureDetection() ? 1 : 0; }
+
+// out = {solver_flag, marginalization_flag, frame_count, sum_of_back, sum_of_front, last_track_num, feature count, failure_occur}
+void lfvio_host_get_flow(void *h, int *out) {
+  Estimator *e = (Estimator *)h;
+  out[0] = e->solver_flag, out[1] = e->marginalization_flag, out[2] = e->frame_count, out[3] = e->sum_of_back, out[4] = e->sum_of_front;
+  out[5] = e->f_manager.last_track_num, out[6] = (int)e->f_manager.feature.size(), out[7] = e->failure_occur ? 1 : 0;
+}
+
+// per frame: Headers, number of buffered IMU samples, pre_integrations[i] != nullptr, its sum_dt
+void lfvio_host_get_buffers(void *h, double *stamps, int *num_samples, int *has_pre, double *sum_dt) {
+  Estimator *e = (Estimator *)h;
+  for (int i = 0; i <= WINDOW_SIZE; i++) {
+    stamps[i] = e->Headers[i], num_samples[i] = (int)e->dt_buf[i].size(), has_pre[i] = e->pre_integrations[i] ? 1 : 0;
+    sum_dt[i] = e->pre_integrations[i] ? e->pre_integrations[i]->sum_dt : 0.0;
+  }
+}
+
+// Replays an LFVT trace (host/replay.h) through processIMU / processImage and writes the trajectory file.
+// stats (may be null) = {images, thrown, keyframes, non_keyframes, poses, failures, last_status, iterations}
+int lfvio_host_replay(void *h, const char *trace_path, const char *traj_path, int max_images, int *stats) {
+  Trace trace;
+  if (!trace.load(trace_path)) return -3;
+  ReplayStats st;
+  int rc = replay(*(Estimator *)h, trace, traj_path, max_images, &st);
+  if (stats) std::memcpy(stats, &st, sizeof st);
+  return rc;
+}
+
+// the decode of one feature record, for the wire-format test: fills ids[n], pts[n][8]; returns n
+int lfvio_host_decode_features(const char *trace_path, int image_index, int cap, int *ids, double *pts, double *stamp) {
+  Trace trace;
+  if (!trace.load(trace_path) || image_index < 0 || image_index >= (int)trace.images.size()) return -1;
+  ImageMap m = decodeFeatures(trace.images[image_index]);
+  *stamp = trace.images[image_index].t;
+  int n = 0;
+  for (auto &kv : m) {
+    if (n >= cap) break;
+    ids[n] = kv.first;
+    for (int k = 0; k < 8; k++) pts[8 * n + k] = kv.second[0].second.a[k];
+    n++;
+  }
+  return n;
 }
 
 void lfvio_host_vector2double(void *h) { ((Estimator *)h)->vector2double(); }

@@ -1,0 +1,57 @@
+// replay.h — ROS-free recording of what estimator_node.cpp consumes, and the loop that feeds it to the Estimator
+// (SURVEY §8f rank 1).  A trace is the two topics of the node in arrival order plus what stands in for initialStructure():
+//
+//   file   = "LFVT" u32 version(1)  { u32 type, u32 bytes, payload[bytes] }*          (little-endian, packed)
+//   type 1 = sensor_msgs/Imu          f64 stamp, f64 linear_acceleration[3], f64 angular_velocity[3]   (imu_callback, estimator_node.cpp:136-161)
+//   type 2 = sensor_msgs/PointCloud   f64 stamp, u32 n, n x f32[9]:
+//                                     points[i].{x,y,z} (geometry_msgs/Point32: float32 — the bearing as the tracker
+//                                     published it, feature_tracker_node.cpp:146-151), then channels[0..5].values[i]:
+//                                     id * NUM_OF_CAM + cam, u, v, velocity x, y, z (:152-163; decoded at estimator_node.cpp:292-312)
+//   type 3 = bootstrap                f64 Ps[11][3], Rs[11][9] (row-major), Vs[11][3], Bas[11][3], Bgs[11][3], g[3], tic[3], ric[9], td
+//                                     — the window state initialStructure() + visualInitialAlign() would have produced
+//   type 4 = ground truth (optional)  f64 stamp, p[3], q[4] (x y z w); skipped by the replay, read by tools/ate.py
+//
+// Unknown record types are skipped, so a recorder can add its own.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "estimator.h"
+
+namespace lfvio {
+
+struct TraceImu {
+  double t;
+  Vector3d acc, gyr;
+};
+struct TraceImage {
+  double t;
+  std::vector<float> v;  // n x 9
+  size_t size() const { return v.size() / 9; }
+};
+struct Trace {
+  std::vector<TraceImu> imu;
+  std::vector<TraceImage> images;
+  bool has_bootstrap = false;
+  Estimator::Bootstrap bootstrap;
+  Vector3d tic;
+  Matrix3d ric;
+  double td = 0;
+  std::string error;
+  bool load(const char *path);
+};
+
+struct ReplayStats {
+  int images, thrown, keyframes, non_keyframes, poses, failures, last_status, iterations;
+};
+
+// feature message -> the map processImage() takes (estimator_node.cpp:292-312)
+ImageMap decodeFeatures(const TraceImage &msg);
+
+// getMeasurements() + process() of estimator_node.cpp (:96-134, :206-342) over a loaded trace, single-threaded;
+// after every image in NON_LINEAR state one line of the trajectory file as pubOdometry() writes it
+// (utility/visualization.cpp:173-179).  Returns 0 or a negative error; `stats` may be null.
+int replay(Estimator &estimator, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats);
+
+}  // namespace lfvio

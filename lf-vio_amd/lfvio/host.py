@@ -25,6 +25,7 @@ class HostEstimator:
             raise RuntimeError(f"{HOST_LIB_PATH} not found: run __graft_entry__.build()")
         L = C.CDLL(HOST_LIB_PATH)
         L.lfvio_host_create.restype = C.c_void_p
+        ip = C.POINTER(C.c_int)
         L.lfvio_host_destroy.argtypes = [C.c_void_p]
         L.lfvio_host_set_params.argtypes = [_dp, C.c_int, C.c_int, C.c_int]
         L.lfvio_host_set_state.argtypes = [C.c_void_p] + [_dp] * 7 + [C.c_double]
@@ -36,6 +37,19 @@ class HostEstimator:
         L.lfvio_host_set_imu.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp]
         L.lfvio_host_repropagate.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.lfvio_host_repropagate_window.argtypes = [C.c_void_p, _dp, _dp]
+        L.lfvio_host_set_min_parallax.argtypes = [C.c_double]
+        L.lfvio_host_process_imu.argtypes = [C.c_void_p, C.c_double, _dp, _dp]
+        L.lfvio_host_process_image.argtypes = [C.c_void_p, C.c_double, C.c_int, ip, _dp]
+        L.lfvio_host_add_feature_check_parallax.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, _dp, C.c_double]
+        L.lfvio_host_set_bootstrap.argtypes = [C.c_void_p] + [_dp] * 6
+        L.lfvio_host_set_running.argtypes = [C.c_void_p] + [_dp] * 4
+        L.lfvio_host_clear_state.argtypes = [C.c_void_p]
+        L.lfvio_host_slide_window.argtypes = [C.c_void_p]
+        L.lfvio_host_failure_detection.argtypes = [C.c_void_p]
+        L.lfvio_host_get_flow.argtypes = [C.c_void_p, ip]
+        L.lfvio_host_get_buffers.argtypes = [C.c_void_p, _dp, ip, ip, _dp]
+        L.lfvio_host_replay.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, ip]
+        L.lfvio_host_decode_features.argtypes = [C.c_char_p, C.c_int, C.c_int, ip, _dp, _dp]
         L.lfvio_host_vector2double.argtypes = [C.c_void_p]
         L.lfvio_host_double2vector.argtypes = [C.c_void_p]
         L.lfvio_host_get_para.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
@@ -46,7 +60,6 @@ class HostEstimator:
         L.lfvio_host_get_prior.argtypes = [C.c_void_p, C.POINTER(abi.Prior)]
         L.lfvio_host_optimization.argtypes = [C.c_void_p]
         L.lfvio_host_set_fused.argtypes = [C.c_void_p, C.c_int]
-        ip = C.POINTER(C.c_int)
         L.lfvio_host_triangulate.argtypes = [C.c_void_p]
         L.lfvio_host_remove_back_shift_depth.argtypes = [C.c_void_p, _dp, _dp]
         L.lfvio_host_num_features.argtypes = [C.c_void_p]
@@ -86,6 +99,75 @@ class HostEstimator:
             self.L.lfvio_host_set_imu(self.h, i + 1, _p(_f(a0)), _p(_f(g0)), _p(_f(ba)), _p(_f(bg)), len(dts), _p(_f(dts)),
                                       _p(_f(accs)), _p(_f(gyrs)))
         self.L.lfvio_host_set_prior(self.h, C.byref(win.prior) if win.prior is not None else None)
+
+    # ---- control flow and trace replay
+    FLOW = ("solver_flag", "marginalization_flag", "frame_count", "sum_of_back", "sum_of_front", "last_track_num", "features",
+            "failure_occur")
+
+    def clear_state(self):
+        self.L.lfvio_host_clear_state(self.h)
+
+    def set_min_parallax(self, keyframe_parallax_px):
+        self.L.lfvio_host_set_min_parallax(float(keyframe_parallax_px))
+
+    def process_imu(self, dt, acc, gyr):
+        self.L.lfvio_host_process_imu(self.h, float(dt), _p(_f(acc)), _p(_f(gyr)))
+
+    @staticmethod
+    def _image(ids, pts):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        pts = _f(pts).reshape(len(ids), 8)
+        return ids, pts
+
+    def process_image(self, stamp, ids, pts):
+        """pts[n][8] = x y z u v vx vy vz; returns the status of the device calls inside (0 = ok)."""
+        ids, pts = self._image(ids, pts)
+        return self.L.lfvio_host_process_image(self.h, float(stamp), len(ids), ids.ctypes.data_as(C.POINTER(C.c_int)), _p(pts))
+
+    def add_feature_check_parallax(self, frame_count, ids, pts, td):
+        ids, pts = self._image(ids, pts)
+        return bool(self.L.lfvio_host_add_feature_check_parallax(self.h, frame_count, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int)),
+                                                                 _p(pts), float(td)))
+
+    def set_bootstrap(self, Ps, Rs, Vs, Bas, Bgs, g):
+        a = [_f(x) for x in (Ps, Rs, Vs, Bas, Bgs, g)]
+        self.L.lfvio_host_set_bootstrap(self.h, *[_p(x) for x in a])
+
+    def set_running(self, stamps, acc_0, gyr_0, g):
+        a = [_f(x) for x in (stamps, acc_0, gyr_0, g)]
+        self.L.lfvio_host_set_running(self.h, *[_p(x) for x in a])
+
+    def slide_window(self):
+        self.L.lfvio_host_slide_window(self.h)
+
+    def failure_detection(self):
+        return bool(self.L.lfvio_host_failure_detection(self.h))
+
+    def flow(self):
+        o = np.zeros(8, dtype=np.int32)
+        self.L.lfvio_host_get_flow(self.h, o.ctypes.data_as(C.POINTER(C.c_int)))
+        return dict(zip(self.FLOW, (int(x) for x in o)))
+
+    def buffers(self):
+        st, sd = np.zeros(11), np.zeros(11)
+        ns, hp = np.zeros(11, dtype=np.int32), np.zeros(11, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        self.L.lfvio_host_get_buffers(self.h, _p(st), ns.ctypes.data_as(ip), hp.ctypes.data_as(ip), _p(sd))
+        return dict(stamps=st, num_samples=ns, has_pre=hp, sum_dt=sd)
+
+    STATS = ("images", "thrown", "keyframes", "non_keyframes", "poses", "failures", "last_status", "iterations")
+
+    def replay(self, trace_path, traj_path="", max_images=0):
+        """-> (rc, stats dict); rc 0 ok, -2 a device call failed (stats['last_status']), -3 unreadable trace."""
+        o = np.zeros(8, dtype=np.int32)
+        rc = self.L.lfvio_host_replay(self.h, str(trace_path).encode(), str(traj_path).encode(), int(max_images),
+                                      o.ctypes.data_as(C.POINTER(C.c_int)))
+        return rc, dict(zip(self.STATS, (int(x) for x in o)))
+
+    def decode_features(self, trace_path, image_index, cap=4096):
+        ids, pts, st = np.zeros(cap, dtype=np.int32), np.zeros((cap, 8)), np.zeros(1)
+        n = self.L.lfvio_host_decode_features(str(trace_path).encode(), image_index, cap, ids.ctypes.data_as(C.POINTER(C.c_int)), _p(pts), _p(st))
+        return float(st[0]), ids[:n], pts[:n]
 
     # ---- SURVEY §8f rank 3
     def repropagate_window(self, ba, bg):

@@ -1,0 +1,164 @@
+"""LFVT traces (host/replay.h): the ROS-free recording of the two topics estimator_node.cpp consumes, a writer / reader,
+and a seeded synthetic recording (a tracker's view of a static point cloud along synth.Scene's trajectory).
+
+Plumbing for tests and tools: it produces INPUTS for Estimator::processIMU / processImage and the
+ground truth the ATE tool compares against."""
+import struct
+
+import numpy as np
+
+from . import abi, synth
+
+MAGIC = b"LFVT"
+REC_IMU, REC_FEATURES, REC_BOOTSTRAP, REC_TRUTH = 1, 2, 3, 4
+
+
+class TraceWriter:
+    def __init__(self, path):
+        self.f = open(path, "wb")
+        self.f.write(MAGIC + struct.pack("<I", 1))
+
+    def _rec(self, kind, payload):
+        self.f.write(struct.pack("<II", kind, len(payload)) + payload)
+
+    def imu(self, t, acc, gyr):
+        self._rec(REC_IMU, struct.pack("<7d", t, *acc, *gyr))
+
+    def features(self, t, ids, xyz, u, v, vel):
+        """One sensor_msgs/PointCloud of the tracker: points (float32 bearings) + channels id, u, v, vx, vy, vz (float32)."""
+        n = len(ids)
+        a = np.zeros((n, 9), dtype="<f4")
+        a[:, 0:3] = xyz
+        a[:, 3] = np.asarray(ids, dtype=np.float64) * 1 + 0  # id * NUM_OF_CAM + cam, NUM_OF_CAM = 1
+        a[:, 4], a[:, 5] = u, v
+        a[:, 6:9] = vel
+        self._rec(REC_FEATURES, struct.pack("<dI", t, n) + a.tobytes())
+
+    def bootstrap(self, Ps, Rs, Vs, Bas, Bgs, g, tic, ric, td):
+        d = np.concatenate([np.ravel(Ps), np.ravel(Rs), np.ravel(Vs), np.ravel(Bas), np.ravel(Bgs), np.ravel(g), np.ravel(tic),
+                            np.ravel(ric), [td]]).astype("<f8")
+        assert d.size == 11 * 21 + 3 + 13
+        self._rec(REC_BOOTSTRAP, d.tobytes())
+
+    def truth(self, t, p, q_xyzw):
+        self._rec(REC_TRUTH, struct.pack("<8d", t, *p, *q_xyzw))
+
+    def close(self):
+        self.f.close()
+
+
+def read_trace(path):
+    """-> dict(imu [n,7], images [(t, array[n,9] float32)], bootstrap array or None, truth [n,8])"""
+    out = dict(imu=[], images=[], bootstrap=None, truth=[])
+    with open(path, "rb") as f:
+        head = f.read(8)
+        assert head[:4] == MAGIC and struct.unpack("<I", head[4:])[0] == 1
+        while True:
+            h = f.read(8)
+            if len(h) < 8:
+                break
+            kind, nbytes = struct.unpack("<II", h)
+            p = f.read(nbytes)
+            if kind == REC_IMU:
+                out["imu"].append(struct.unpack("<7d", p))
+            elif kind == REC_FEATURES:
+                t, n = struct.unpack("<dI", p[:12])
+                out["images"].append((t, np.frombuffer(p[12:], dtype="<f4").reshape(n, 9).copy()))
+            elif kind == REC_BOOTSTRAP:
+                out["bootstrap"] = np.frombuffer(p, dtype="<f8").copy()
+            elif kind == REC_TRUTH:
+                out["truth"].append(struct.unpack("<8d", p))
+    out["imu"] = np.array(out["imu"]).reshape(-1, 7)
+    out["truth"] = np.array(out["truth"]).reshape(-1, 8)
+    return out
+
+
+def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset=0.0023, pixel_noise=1.0, boot_noise=(0.02, 0.5)):
+    """Write a synthetic recording of `n_frames` images at 10 Hz with 200 Hz IMU and return what was written.
+
+    A static cloud of `n_points` points in a 2-12 m shell is seen through the 40-120 deg annulus; a point is tracked over
+    a random span of frames and comes back under a new id afterwards, at most `max_cnt` features per image (longest
+    tracks first, like the tracker's mask).  Image k is exposed at t = 0.1 k + cam_offset on the IMU clock and stamped
+    t - TD0, so the estimator interpolates the IMU at image time (estimator_node.cpp:240-258).  The bootstrap record is
+    the truth of the first 11 frames (+) N(0, boot_noise[0] m / boot_noise[1] deg), zero accelerometer bias."""
+    scene = synth.Scene(seed, n_total=n_frames + 2)
+    rng = np.random.default_rng([seed, 104729])
+    traj = scene.traj
+    # world points and their visibility spans
+    d = rng.normal(size=(n_points, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    Xw = d * rng.uniform(2.0, 12.0, size=(n_points, 1))
+    spans = []  # per point: list of (first, last, id)
+    next_id = 0
+    for p in range(n_points):
+        f, s = int(rng.integers(-10, 5)), []
+        while f < n_frames:
+            L = int(rng.integers(3, 26))
+            s.append((f, f + L - 1, next_id))
+            next_id += 1
+            f += L + int(rng.integers(1, 8))
+        spans.append(s)
+
+    def cam_pose(t):
+        return traj.pos(t), traj.R_at(t)
+
+    def bearings(t):
+        P, R = cam_pose(t)
+        Xb = (Xw - P) @ R            # R^T (X - P)
+        Xc = (Xb - synth.TIC) @ synth.RIC
+        return Xc / np.linalg.norm(Xc, axis=1, keepdims=True)
+
+    w = TraceWriter(path)
+    truth, images, flags = [], [], []
+    t_imu = traj.t
+    k_imu = 0
+    first_seen = {}
+    for k in range(n_frames):
+        t_img = synth.KF_DT * k + cam_offset
+        # IMU messages up to and including the first one after the image (arrival order)
+        while k_imu < len(t_imu) and t_imu[k_imu] <= t_img + synth.IMU_DT:
+            w.imu(t_imu[k_imu], scene.acc_m[k_imu], scene.gyr_m[k_imu])
+            k_imu += 1
+        b = bearings(t_img)
+        b_prev = bearings(t_img - synth.KF_DT) if t_img - synth.KF_DT >= 0 else b
+        ang = np.degrees(np.arccos(np.clip(b[:, 2], -1, 1)))
+        cand = []
+        for p in range(n_points):
+            if not (40.0 <= ang[p] <= 120.0):
+                continue
+            for (f0, f1, fid) in spans[p]:
+                if f0 <= k <= f1:
+                    cand.append((first_seen.setdefault(fid, k), fid, p))
+        cand.sort()
+        cand = cand[:max_cnt]
+        ids = np.array([c[1] for c in cand], dtype=np.int64)
+        pts = np.array([c[2] for c in cand], dtype=np.int64)
+        bb = b[pts]
+        noise = rng.normal(0, pixel_noise / 160.0, size=bb.shape)
+        noise -= bb * np.sum(noise * bb, axis=1, keepdims=True)
+        xyz = synth._bearing_f32(bb + noise)
+        vel = (bb - b_prev[pts]) / synth.KF_DT
+        vel[np.array([first_seen[i] == k for i in ids], dtype=bool)] = 0.0  # a new corner has no optical flow yet
+        u = 640.0 + 400.0 * np.arctan2(bb[:, 1], bb[:, 0]) / np.pi
+        v = 480.0 + 380.0 * np.cos(np.arccos(np.clip(bb[:, 2], -1, 1)))
+        stamp = t_img - synth.TD0
+        w.features(stamp, ids, xyz, u, v, vel)
+        P, R = cam_pose(t_img)
+        q = synth.R_to_q(R)  # [w x y z]
+        w.truth(stamp, P, [q[1], q[2], q[3], q[0]])
+        truth.append((stamp, P, R, traj.vel(t_img)))
+        images.append((stamp, ids, xyz.copy(), np.stack([u, v], 1), vel.astype(np.float32).astype(np.float64)))
+        if k == abi.WINDOW_SIZE - 1:  # before the 11th image arrives: what initialStructure() would have produced
+            Ps, Rs, Vs = [], [], []
+            for j in range(abi.NUM_FRAMES):
+                tj = synth.KF_DT * j + cam_offset
+                Pj, Rj = cam_pose(tj)
+                Ps.append(Pj + rng.normal(0, boot_noise[0], 3))
+                Rs.append(Rj @ synth.exp_so3(rng.normal(0, np.deg2rad(boot_noise[1]), 3)))
+                Vs.append(traj.vel(tj) + rng.normal(0, 0.02, 3))
+            Bgs = np.tile(scene.bg + rng.normal(0, 0.0005, 3), (abi.NUM_FRAMES, 1))
+            boot = dict(Ps=np.array(Ps), Rs=np.array(Rs), Vs=np.array(Vs), Bas=np.zeros((abi.NUM_FRAMES, 3)), Bgs=Bgs,
+                        g=np.array([0.0, 0.0, synth.G_NORM]), tic=synth.TIC, ric=synth.RIC, td=synth.TD0)
+            w.bootstrap(**boot)
+    w.close()
+    return dict(scene=scene, truth=truth, images=images, bootstrap=boot, n_ids=next_id)

@@ -1,0 +1,211 @@
+"""SURVEY §8f ranks 4 and 1 — the control flow around optimization() in the host mirror and the trace replay.
+CPU: keyframe policy, processIMU dead reckoning, slideWindow bookkeeping, message synchronisation and the wire decode
+against the plain-Python restatement in flow_ref.py (everything that runs before initialization, i.e. without the solver).
+GPU: a synthetic recording replayed end to end (bootstrap -> triangulate -> optimization -> slideWindow per image) with
+the trajectory file and its ATE against the recording's ground truth."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import flow_ref
+from lfvio import synth, trace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def host():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from lfvio.host import HostEstimator
+
+    h = HostEstimator()
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def stream(tmp_path_factory):
+    p = str(tmp_path_factory.mktemp("trace") / "s7.lfvt")
+    return p, trace.make_stream(p, seed=7, n_frames=24)
+
+
+def fresh(host, parallax_px=10.0):
+    host.clear_state()
+    host.set_min_parallax(parallax_px)
+
+
+def image_arrays(img):
+    stamp, ids, xyz, uv, vel = img
+    return stamp, ids, np.concatenate([xyz, uv.astype(np.float32).astype(np.float64), vel], axis=1)
+
+
+def test_wire_format_roundtrip(host, stream):
+    """feature_tracker_node.cpp:113-178 -> estimator_node.cpp:292-312: float32 points and channels, id = int(value + 0.5)."""
+    path, s = stream
+    rd = trace.read_trace(path)
+    assert len(rd["images"]) == len(s["images"]) and rd["bootstrap"].size == 247 and rd["truth"].shape == (24, 8)
+    for k in (0, 5, 23):
+        stamp, ids, pts = image_arrays(s["images"][k])
+        st, gi, gp = host.decode_features(path, k)
+        order = np.argsort(ids)  # the decoded map iterates by feature id
+        assert st == stamp and np.array_equal(gi, ids[order])
+        assert np.array_equal(gp, pts[order].astype(np.float32).astype(np.float64))
+    assert np.allclose(rd["imu"][1:, 0] - rd["imu"][:-1, 0], synth.IMU_DT)
+
+
+def test_keyframe_policy_vs_restatement(host, stream):
+    """addFeatureCheckParallax over the first 11 frames of a recording, at three thresholds, + the early-out branches."""
+    _, s = stream
+    for px in (2.0, 10.0, 40.0):
+        fresh(host, px)
+        ref = flow_ref.Flow(px / 160.0)
+        got, want = [], []
+        for fc in range(11):
+            _, ids, pts = image_arrays(s["images"][fc])
+            got.append(host.add_feature_check_parallax(fc, ids, pts, synth.TD0))
+            want.append(ref.add_feature_check_parallax(fc, ids, pts))
+            assert host.flow()["last_track_num"] == ref.last_track_num and host.flow()["features"] == len(ref.feature)
+        assert got == want, px
+    assert got[:2] == [True, True] and not all(got)         # frame_count < 2 -> keyframe; 40 px rejects some frames
+    fresh(host, 1e9)
+    _, ids, pts = image_arrays(s["images"][0])
+    for fc in range(4):                                       # fewer than 20 tracked features -> keyframe whatever the parallax
+        assert host.add_feature_check_parallax(fc, ids[:15], pts[:15], 0.0)
+    fresh(host, 1e9)
+    for fc in range(4):                                       # 30 tracked, zero parallax: keyframe only while frame_count < 2
+        assert host.add_feature_check_parallax(fc, ids[:30], pts[:30], 0.0) == (fc < 2)
+
+
+def drive(host, ref, imu, images, upto):
+    """Feed both the mirror and the restatement the way process() would; returns the image indices consumed."""
+    used = []
+    for stamp, idx, calls in flow_ref.sync(imu, [(im[0], None) for im in images], lambda: synth.TD0):
+        if idx >= upto:
+            break
+        for dt, a, g in calls:
+            host.process_imu(dt, a, g)
+            ref.process_imu(dt, a, g)
+        _, ids, pts = image_arrays(images[idx])
+        assert host.process_image(stamp, ids, pts) == 0
+        ref.process_image(ids, pts, stamp)
+        used.append(idx)
+    return used
+
+
+@pytest.mark.parametrize("px", [10.0, 40.0])
+def test_flow_before_initialization_vs_restatement(host, stream, px):
+    """processIMU dead reckoning, frame_count, the MARGIN_OLD / MARGIN_SECOND_NEW window shuffles with removeBack /
+    removeFront, IMU buffers and Headers over 20 images without a bootstrap record (initialStructure() fails -> slideWindow)."""
+    path, s = stream
+    rd = trace.read_trace(path)
+    fresh(host, px)
+    ref = flow_ref.Flow(px / 160.0)
+    used = drive(host, ref, rd["imu"], s["images"], 20)
+    assert len(used) == 20
+    fl, st, bf = host.flow(), host.state(), host.buffers()
+    assert fl["solver_flag"] == 0 and fl["frame_count"] == 10
+    assert (fl["sum_of_back"], fl["sum_of_front"]) == (ref.sum_of_back, ref.sum_of_front) and fl["sum_of_back"] + fl["sum_of_front"] == 10
+    if px > 20:
+        assert fl["sum_of_front"] > 0 and fl["sum_of_back"] > 0
+    assert np.array_equal(bf["stamps"], ref.Headers)
+    assert list(bf["num_samples"]) == [len(b) for b in ref.bufs] and list(bf["has_pre"]) == [int(x) for x in ref.has_pre]
+    assert np.allclose(bf["sum_dt"], [sum(c[0] for c in b) for b in ref.bufs], atol=1e-12)
+    for k, want in (("Ps", ref.Ps), ("Rs", ref.Rs), ("Vs", ref.Vs)):
+        assert np.abs(st[k] - want).max() < 1e-12 * max(1.0, np.abs(want).max()), k
+    ids, start, cnt, _ = host.features()
+    assert [list(a) for a in zip(ids, start, cnt)] == [[f[0], f[1], len(f[2])] for f in ref.feature]
+
+
+def test_replay_synchronisation_equals_manual_drive(host, stream):
+    """lfvio_host_replay (C++ getMeasurements + process loop, IMU interpolated at image time) == the Python-driven calls."""
+    path, s = stream
+    rd = trace.read_trace(path)
+    fresh(host)
+    ref = flow_ref.Flow(10.0 / 160.0)
+    drive(host, ref, rd["imu"], s["images"], 9)       # stops before the 11th image (where the bootstrap would be used)
+    want_b, want_s = host.buffers(), host.state()
+    fresh(host)
+    rc, stats = host.replay(path, "", max_images=9)
+    assert rc == 0 and stats["images"] == 9 and stats["thrown"] == 0 and stats["poses"] == 0
+    got_b, got_s = host.buffers(), host.state()
+    for k in want_b:
+        assert np.array_equal(got_b[k], want_b[k]), k
+    for k in ("Ps", "Rs", "Vs"):
+        assert np.array_equal(got_s[k], want_s[k]), k
+    # every interval spans exactly the image period on the IMU clock: the last sample of each is the interpolated one
+    assert np.allclose(got_b["sum_dt"][1:9], synth.KF_DT, atol=1e-12)
+    assert list(got_b["num_samples"][1:9]) == [21] * 8
+
+
+def test_failure_detection_thresholds(host):
+    """estimator.cpp:628-674 as shipped: gyro bias > 1, jump > 5 m, z jump > 1 m; the commented-out tests do not fire."""
+    w = synth.make_window(3, 10)
+    z3 = np.zeros(3)
+
+    def case(dP=(0, 0, 0), bg=(0, 0, 0), ba=(0, 0, 0)):
+        fresh(host)
+        host.load_window(w)
+        host.set_running(np.arange(11) * 0.1, z3, z3, [0, 0, 9.81])   # last_P = Ps[WINDOW_SIZE]
+        st = host.state()
+        st["Ps"][10] += dP
+        st["Bgs"][10], st["Bas"][10] = bg, ba
+        host.L.lfvio_host_set_state(host.h, *[x.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))
+                                               for x in (st["Ps"], st["Rs"], st["Vs"], st["Bas"], st["Bgs"], st["tic"], st["ric"])], st["td"])
+        return host.failure_detection()
+
+    assert not case()
+    assert case(bg=(0.8, 0.7, 0)) and not case(bg=(0.5, 0.5, 0.5))
+    assert case(dP=(4, 3.1, 0)) and not case(dP=(4, 2.9, 0))
+    assert case(dP=(0, 0, -1.1)) and not case(dP=(0, 0, 0.9))
+    assert not case(ba=(3, 0, 0))        # "big IMU acc bias" only logs (:636-640)
+
+
+@pytest.mark.gpu
+def test_replay_recording_end_to_end(host, tmp_path):
+    """60 images: 10 fill the window, the 11th bootstraps (device re-propagation of the window, triangulation,
+    optimization), then one optimization() + slideWindow per image.  Trajectory file as pubOdometry writes it; ATE."""
+    import ate
+    from lfvio.engine import Engine  # noqa: F401  (torch first: the ROCm wheel brings its own HIP runtime)
+
+    tp, jp = str(tmp_path / "rec.lfvt"), str(tmp_path / "traj.txt")
+    trace.make_stream(tp, seed=3, n_frames=60)
+    fresh(host)
+    rc, st = host.replay(tp, jp)
+    assert rc == 0 and st["last_status"] == 0 and st["failures"] == 0
+    # the last image is only taken if an IMU message newer than stamp + td (the ESTIMATED td) was recorded: 59 or 60
+    n = st["poses"]
+    assert st["images"] in (59, 60) and n == st["images"] - 10 and st["keyframes"] + st["non_keyframes"] == n
+    fl = host.flow()
+    assert fl["solver_flag"] == 1 and fl["frame_count"] == 10
+    lines = open(jp).read().strip().split("\n")
+    assert len(lines) == n
+    for ln in lines[:3]:
+        f = ln.split(" ")
+        assert len(f) == 8 and all(len(x.split(".")[1]) == 12 for x in f)   # fixed, precision(12)
+    a = np.loadtxt(jp)
+    assert np.allclose(np.linalg.norm(a[:, 4:8], axis=1), 1.0, atol=1e-9) and np.allclose(np.diff(a[:, 0]), synth.KF_DT)
+    r = ate.ate(jp, tp)
+    assert r["n"] == n and r["rmse"] < 0.05, r      # 1 px bearing noise, 2 cm / 0.5 deg bootstrap noise
+    assert ate.ate(jp, tp, do_align=False)["rmse"] < 0.15
+
+
+@pytest.mark.gpu
+def test_replay_with_non_keyframes(host, tmp_path):
+    """A 30 px keyframe threshold makes part of the frames non-keyframes: MARGIN_SECOND_NEW marginalization, merged IMU
+    intervals and removeFront run inside the loop."""
+    import ate
+    from lfvio.engine import Engine  # noqa: F401
+
+    tp, jp = str(tmp_path / "rec.lfvt"), str(tmp_path / "traj.txt")
+    trace.make_stream(tp, seed=5, n_frames=50)
+    fresh(host, 30.0)
+    rc, st = host.replay(tp, jp)
+    assert rc == 0 and st["poses"] == st["images"] - 10 and st["images"] in (49, 50)
+    assert st["keyframes"] >= 1 and st["non_keyframes"] >= 1, st
+    assert host.flow()["sum_of_front"] >= st["non_keyframes"]
+    assert ate.ate(jp, tp)["rmse"] < 0.10
