@@ -20,10 +20,12 @@ def _f(a):
 
 
 class HostEstimator:
-    def __init__(self):
-        if not os.path.exists(HOST_LIB_PATH):
-            raise RuntimeError(f"{HOST_LIB_PATH} not found: run __graft_entry__.build()")
-        L = C.CDLL(HOST_LIB_PATH)
+    def __init__(self, lib_path=None):
+        """lib_path: tests pass the oracle-linked build of the same sources (oracle/liblfvio_host_oracle.so) here."""
+        lib_path = lib_path or HOST_LIB_PATH
+        if not os.path.exists(lib_path):
+            raise RuntimeError(f"{lib_path} not found: run __graft_entry__.build()")
+        L = C.CDLL(lib_path)
         L.lfvio_host_create.restype = C.c_void_p
         ip = C.POINTER(C.c_int)
         L.lfvio_host_destroy.argtypes = [C.c_void_p]

@@ -1,0 +1,127 @@
+// abi_shim.cpp — TEST INFRASTRUCTURE ONLY.  The entry points of include/lfvio.h implemented over the CPU oracle, so that
+// the host mirror (lf-vio_amd/host) can be linked against the oracle instead of the HIP library and run its whole loop —
+// processIMU / processImage / triangulate / optimization / slideWindow — on the CPU.  tests/ compare the trajectory the
+// product stack (host mirror + liblfvio_hip.so) writes for a recording with the one this stack writes.  Nothing under
+// lf-vio_amd/ loads this library; the product fails without liblfvio_hip.so.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/lfvio.h"
+
+extern "C" {
+int oracle_solve(const LfvioWindow *w, LfvioSolution *out);
+int oracle_marginalize(const LfvioWindow *w, int flag, LfvioPrior *out, double *A_out, double *b_out);
+int oracle_optimize(const LfvioWindow *w, int flag, LfvioSolution *sol, LfvioPrior *prior_out, double *seconds);
+int oracle_triangulate(const LfvioTriangulateIn *in, double *depth);
+int oracle_shift_depth(int n, const double *uv_i, const double *marg_R, const double *marg_P, const double *new_R, const double *new_P,
+                       double init_depth, double *depth);
+int oracle_preintegrate(const double *acc0, const double *gyr0, const double *ba, const double *bg, int n, const double *dt,
+                        const double *acc, const double *gyr, const double *noise, LfvioPreintegration *out);
+}
+
+namespace {
+struct SlotCopy {  // a window with its arrays owned
+  LfvioWindow w;
+  std::vector<int> start_frame, obs_offset;
+  std::vector<double> inv_depth, point, velocity, cur_td, uv_y, lam_out;
+  LfvioPrior prior_in, prior_out;
+  LfvioSolution sol;
+  bool has_prior_out = false;
+  void set(const LfvioWindow *in) {
+    w = *in;
+    const int N = in->num_landmarks, M = in->num_observations;
+    start_frame.assign(in->start_frame, in->start_frame + N), obs_offset.assign(in->obs_offset, in->obs_offset + N + 1);
+    inv_depth.assign(in->inv_depth, in->inv_depth + N);
+    point.assign(in->obs_point, in->obs_point + 3 * (size_t)M), velocity.assign(in->obs_velocity, in->obs_velocity + 3 * (size_t)M);
+    cur_td.assign(in->obs_cur_td, in->obs_cur_td + M), uv_y.assign(in->obs_uv_y, in->obs_uv_y + M);
+    w.start_frame = start_frame.data(), w.obs_offset = obs_offset.data(), w.inv_depth = inv_depth.data();
+    w.obs_point = point.data(), w.obs_velocity = velocity.data(), w.obs_cur_td = cur_td.data(), w.obs_uv_y = uv_y.data();
+    if (in->prior && in->prior->valid) {
+      prior_in = *in->prior;
+      w.prior = &prior_in;
+    } else
+      w.prior = nullptr;
+    lam_out.assign(N > 0 ? N : 1, 0.0);
+  }
+};
+}  // namespace
+
+struct lfvio_ctx {
+  std::string err;
+  std::vector<SlotCopy> slots;
+};
+
+extern "C" {
+
+lfvio_ctx *lfvio_create(int) { return new lfvio_ctx(); }
+void lfvio_destroy(lfvio_ctx *c) { delete c; }
+const char *lfvio_last_error(const lfvio_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *lfvio_version(void) { return "lfvio C-ABI over the CPU oracle (test infrastructure)"; }
+
+int lfvio_solve(lfvio_ctx *c, const LfvioWindow *in, LfvioSolution *out) {
+  if (!c || !in || !out) return LFVIO_ERR_ARG;
+  return oracle_solve(in, out);
+}
+int lfvio_marginalize(lfvio_ctx *c, const LfvioWindow *in, int flag, LfvioPrior *out) {
+  if (!c || !in || !out) return LFVIO_ERR_ARG;
+  return oracle_marginalize(in, flag, out, nullptr, nullptr);
+}
+int lfvio_batch_reserve(lfvio_ctx *c, int batch, int, int) {
+  if (!c || batch < 1) return LFVIO_ERR_ARG;
+  if ((int)c->slots.size() < batch) c->slots.resize(batch);
+  return LFVIO_OK;
+}
+int lfvio_batch_upload(lfvio_ctx *c, int slot, const LfvioWindow *in) {
+  if (!c || !in || slot < 0 || slot >= (int)c->slots.size()) return LFVIO_ERR_ARG;
+  c->slots[slot].set(in);
+  return LFVIO_OK;
+}
+int lfvio_batch_optimize(lfvio_ctx *c, int count, int marg_flag) {
+  if (!c || count < 0 || count > (int)c->slots.size()) return LFVIO_ERR_ARG;
+  for (int s = 0; s < count; s++) {
+    SlotCopy &S = c->slots[s];
+    S.sol.inv_depth = S.lam_out.data();
+    int rc = oracle_optimize(&S.w, marg_flag, &S.sol, &S.prior_out, nullptr);
+    if (rc != LFVIO_OK) return rc;
+    S.has_prior_out = true;
+  }
+  return LFVIO_OK;
+}
+int lfvio_batch_optimize_async(lfvio_ctx *c, int count, int marg_flag) { return lfvio_batch_optimize(c, count, marg_flag); }
+int lfvio_batch_sync(lfvio_ctx *c) { return c ? LFVIO_OK : LFVIO_ERR_ARG; }
+int lfvio_batch_download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior *prior) {
+  if (!c || slot < 0 || slot >= (int)c->slots.size()) return LFVIO_ERR_ARG;
+  SlotCopy &S = c->slots[slot];
+  if (sol) {
+    double *lam = sol->inv_depth;
+    *sol = S.sol;
+    sol->inv_depth = lam;
+    if (lam) std::memcpy(lam, S.lam_out.data(), sizeof(double) * S.w.num_landmarks);
+  }
+  if (prior && S.has_prior_out) *prior = S.prior_out;
+  return LFVIO_OK;
+}
+void *lfvio_stream(lfvio_ctx *) { return nullptr; }
+
+int lfvio_triangulate(lfvio_ctx *c, const LfvioTriangulateIn *in, double *estimated_depth) {
+  if (!c || !in) return LFVIO_ERR_ARG;
+  if (in->num_landmarks == 0) return LFVIO_OK;
+  return oracle_triangulate(in, estimated_depth);
+}
+int lfvio_shift_depth(lfvio_ctx *c, int n, const double *uv_i, const double marg_R[9], const double marg_P[3], const double new_R[9],
+                      const double new_P[3], double init_depth, double *estimated_depth) {
+  if (!c || n < 0) return LFVIO_ERR_ARG;
+  if (n == 0) return LFVIO_OK;
+  return oracle_shift_depth(n, uv_i, marg_R, marg_P, new_R, new_P, init_depth, estimated_depth);
+}
+int lfvio_preintegrate(lfvio_ctx *c, int num_intervals, const LfvioImuInterval *in, const double noise[4], LfvioPreintegration *out) {
+  if (!c || num_intervals < 0) return LFVIO_ERR_ARG;
+  for (int k = 0; k < num_intervals; k++) {
+    int rc = oracle_preintegrate(in[k].acc_0, in[k].gyr_0, in[k].linearized_ba, in[k].linearized_bg, in[k].num_samples, in[k].dt, in[k].acc,
+                                 in[k].gyr, noise, &out[k]);
+    if (rc != 0) return rc;
+  }
+  return LFVIO_OK;
+}
+}

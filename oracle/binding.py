@@ -24,6 +24,15 @@ def build(force=False):
     return LIB_PATH
 
 
+HOST_ORACLE_LIB_PATH = os.path.join(HERE, "liblfvio_host_oracle.so")
+
+
+def build_host_oracle():
+    """The host mirror's sources linked against the oracle-backed C-ABI (abi_shim.cpp): the whole loop on the CPU."""
+    subprocess.check_call(["make", "-C", HERE, "liblfvio_host_oracle.so"])
+    return HOST_ORACLE_LIB_PATH
+
+
 _lib = None
 
 
