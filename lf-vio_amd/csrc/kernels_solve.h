@@ -11,7 +11,31 @@
 constexpr int SOLVE_THREADS = 256;
 constexpr int NROW = KP + 1;                       // + rhs row (forward substitution fused)
 constexpr int LPACK = NROW * (NROW + 1) / 2;       // 15051
-constexpr size_t SOLVE_LDS = (size_t)(LPACK + 2 * 176 + 8 * KP + 256 + 64 + 11 * 256) * sizeof(double);
+// The reduced system lives in LDS as the lower 16 x 16 tiles of a 176 x 176 matrix (row 172 = rhs row, rows 173..175
+// padding): tile (a, b), a >= b, at tile_id(a, b) * TSZ; inside a tile entry (r, k) sits at 17 r + k.  The row stride of
+// 17 keeps every access pattern of the factorization free of bank conflicts with plain linear addressing (so the
+// offsets fold into the instructions): an MFMA operand load (lane (c, g) reads row c, column g + 4 s), a D-layout
+// store (rows g + 4 r, column c) and a row per lane.
+constexpr int NTL = 11, NTILES = NTL * (NTL + 1) / 2;  // 66
+constexpr int TLD = 17, TSZ = 16 * TLD;                 // 272 doubles per tile
+constexpr int TPACK = NTILES * TSZ;                     // 17952 doubles
+constexpr size_t SOLVE_LDS = (size_t)(TPACK + 256 + 8 * KP + 256 + 64) * sizeof(double);
+__host__ __device__ constexpr int tile_id(int a, int b) { return a * (a + 1) / 2 + b; }
+__host__ __device__ constexpr int tile_a(int t) {
+  int a = 0;
+  while ((a + 1) * (a + 2) / 2 <= t) a++;
+  return a;
+}
+__host__ __device__ constexpr int tile_b(int t) { return t - tile_id(tile_a(t), 0); }
+DEV int tsw(int r, int k) { return r * TLD + k; }
+DEV int lidx(int i, int j) { return tile_id(i >> 4, j >> 4) * TSZ + tsw(i & 15, j & 15); }  // entry (i, j), j <= i
+// lane i of every row of 16 lanes <- lane J of its row (one v_mov_b64_dpp row_newbcast)
+template <int J>
+DEV double row_bcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
+DEV double readlane_f64(double v, int src) {  // src wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+typedef double solve_d4 __attribute__((ext_vector_type(4)));
 
 #define STAMP(S, k) do { if (threadIdx.x == 0) (S)->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -63,9 +87,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   TRState *tr = &S->tr;
   if (tr->done || !tr->do_schur) return;
   const int tid = threadIdx.x;
-  double *Hs = smem;                 // LPACK (H_pp packed, later L packed incl. rhs row)
-  double *colbuf = Hs + LPACK;       // 2 x 176
-  double *g = colbuf + 2 * 176;      // KP
+  double *Hs = smem;                 // TPACK: H_pp, then S, then L as 16 x 16 tiles (rhs row = row 172)
+  double *Ld = Hs + TPACK;           // 16 x 16: the diagonal block just factored, plain, TRANSPOSED (panel solve); later rhs
+  double *g = Ld + 256;              // KP
   double *sc = g + KP;               // scale
   double *dg = sc + KP;              // diagonal_
   double *gr = dg + KP;              // gradient_
@@ -73,24 +97,23 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   double *yv = Gd + KP;              // y, then N direction
   double *hv = yv + KP;              // gauss_newton_step_
   double *invd = hv + KP;            // 1 / L_ii
-  double *scratch = invd + KP;       // 256 (+64 pad), then 11 x 256 inverted diagonal blocks
+  double *scratch = invd + KP;       // 256 (+64 pad)
   const bool est_ex = S->est_ex != 0, est_td = S->est_td != 0;
   auto active = [&](int c) { return (est_ex || c < off_ex() || c >= off_ex() + 6) && (est_td || c != off_td()); };
   STAMP(S, 0);
-  {  // H_pp global -> LDS, 16-byte loads, 4 in flight per thread
-    const double2 *src = (const double2 *)(const double *)S->Hpp;
-    double2 *dst = (double2 *)Hs;
-    constexpr int NV2 = PACKED / 2;
-    for (int e = tid; e < NV2; e += 4 * SOLVE_THREADS) {
-      double2 v0 = src[e], v1, v2, v3;
-      const bool b1 = e + SOLVE_THREADS < NV2, b2 = e + 2 * SOLVE_THREADS < NV2, b3 = e + 3 * SOLVE_THREADS < NV2;
-      if (b1) v1 = src[e + SOLVE_THREADS];
-      if (b2) v2 = src[e + 2 * SOLVE_THREADS];
-      if (b3) v3 = src[e + 3 * SOLVE_THREADS];
-      dst[e] = v0;
-      if (b1) dst[e + SOLVE_THREADS] = v1;
-      if (b2) dst[e + 2 * SOLVE_THREADS] = v2;
-      if (b3) dst[e + 3 * SOLVE_THREADS] = v3;
+  const int er = tid >> 4, ek = tid & 15, esw = tsw(er, ek);  // this thread's entry of every tile
+  {  // H_pp global (packed rows) -> tiles; six independent loads in flight per thread
+    const double *Hg = S->Hpp;
+#pragma unroll
+    for (int t0 = 0; t0 < NTILES; t0 += 6) {
+      double v[6];
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+        const int i = 16 * tile_a(t0 + u) + er, j = 16 * tile_b(t0 + u) + ek;
+        v[u] = (i < KP && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 6; u++) Hs[(t0 + u) * TSZ + esw] = v[u];
     }
     if (tid < KP) g[tid] = S->gp[tid];
   }
@@ -110,7 +133,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   const double mu = tr->mu;
   if (tid < KP) {
     const int i = tid;
-    const double hii = Hs[pidx(i, i)];
+    const double hii = Hs[lidx(i, i)];
     double s;
     if (!tr->scaled) {
       s = 1.0 / (1.0 + sqrt(hii));
@@ -127,63 +150,34 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   }
   __syncthreads();
   STAMP(S, 2);
-  // ---- reduced system in registers: thread (trow, tcol) owns (i, j) = (trow + 16 a, tcol + 16 b);
-  //      the Cauchy-point quadratic form G^T H G is accumulated from the same owned entries.
+  // ---- reduced system, in place:  S = S_p (H_pp - Schur) S_p + mu D^2  and the rhs row; the Cauchy-point quadratic
+  //      form G^T H G is accumulated from the same entries on the way.
   const double *Sc = S->schur_sum;
-  const int trow = tid & 15, tcol = tid >> 4;
+  const int trow = tid & 15, tcol = tid >> 4;  // ownership pattern of the quadratic forms further down
   double qgg_part = 0;
-  {  // pass 1: G^T H G over the owned entries (kept apart from pass 2 to bound register pressure)
-    double gi[11], gj[11];
 #pragma unroll
-    for (int a = 0; a < 11; a++) {
-      const int i = trow + 16 * a, j = tcol + 16 * a;
-      gi[a] = i < KP ? Gd[i] : 0.0;
-      gj[a] = j < KP ? Gd[j] : 0.0;
-    }
-#pragma unroll
-    for (int a = 0; a < 11; a++)
-#pragma unroll
-      for (int b = 0; b <= a; b++) {
-        const int i = trow + 16 * a, j = tcol + 16 * b;
-        if (i < KP && j <= i) {
-          const double h = Hs[i * (i + 1) / 2 + j];
-          qgg_part = fma(h * gi[a], (i == j) ? gj[b] : 2.0 * gj[b], qgg_part);
-        }
+  for (int t = 0; t < NTILES; t++) {
+    const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
+    double *e = &Hs[t * TSZ + esw];
+    double v = 0.0;
+    if (i < KP && j <= i) {
+      double h = *e;
+      qgg_part = fma(h * Gd[i], (i == j) ? Gd[j] : 2.0 * Gd[j], qgg_part);
+      if (active(i) && active(j)) {
+        if (tile_a(t) <= 4 && i < KC) h -= Sc[schur_index(j, i)];  // j <= i < 73
+        v = sc[i] * sc[j] * h;
+        if (i == j) v += mu * dg[i] * dg[i];
+      } else {
+        v = (i == j) ? 1.0 : 0.0;
       }
-  }
-  double m[11][11];
-  {  // pass 2: S = S_p (H_pp - Schur) S_p + mu D^2, rhs row
-    double si[11], sj[11];
-#pragma unroll
-    for (int a = 0; a < 11; a++) {
-      const int i = trow + 16 * a, j = tcol + 16 * a;
-      si[a] = i < KP ? sc[i] : 0.0;
-      sj[a] = j < KP ? sc[j] : 0.0;
-    }
-#pragma unroll
-    for (int a = 0; a < 11; a++)
-#pragma unroll
-      for (int b = 0; b <= a; b++) {
-        const int i = trow + 16 * a, j = tcol + 16 * b;
-        double v = 0.0;
-        if (i < KP && j <= i) {
-          if (active(i) && active(j)) {
-            double h = Hs[i * (i + 1) / 2 + j];
-            if (i < KC) h -= Sc[schur_index(j, i)];  // j <= i < 73
-            v = si[a] * sj[b] * h;
-            if (i == j) v += mu * dg[i] * dg[i];
-          } else {
-            v = (i == j) ? 1.0 : 0.0;
-          }
-        } else if (i == KP && j < KP) {
-          if (active(j)) {
-            double r = g[j];
-            if (j < KC) r -= Sc[schur_index(j, COL_B)];  // z1
-            v = sj[b] * r;
-          }
-        }
-        m[a][b] = v;
+    } else if (tile_a(t) == NTL - 1 && i == KP && j < KP) {
+      if (active(j)) {
+        double r = g[j];
+        if (j < KC) r -= Sc[schur_index(j, COL_B)];  // z1
+        v = sc[j] * r;
       }
+    }
+    *e = v;
   }
   // ---- Cauchy point: alpha = ||gradient_||^2 / ||J (gradient_/diagonal_)||^2
   {
@@ -204,148 +198,177 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       tr->q[Q_GRAD_SQ] = gsq;
     }
   }
-  __syncthreads();  // Hs may now be overwritten
+  __syncthreads();
   STAMP(S, 3);
 
-  // ---- right-looking Cholesky with one column of look-ahead, one barrier per pivot.
-  // Column k+1 is brought up to date first, its owners (16 lanes of one wave) scale it and publish it, and only then
-  // is the rest of the rank-1 update of pivot k applied: the rsqrt / scale / LDS-write chain of the next pivot runs
-  // while the other three waves are still in their trailing update.
+  // ---- blocked right-looking Cholesky, 11 block columns of 16.  Per block column:
+  //   F  wave 0 factors the diagonal tile, one ROW per lane, fully unrolled: pivot and column entries travel by
+  //      v_readlane, the update uses the raw column (a_ik a_jk / d_k: the reciprocal runs beside the broadcasts), the
+  //      columns are scaled by 1/sqrt(d_k) once at the end;
+  //   P  the rows below solve  x L_kk^T = a  — one thread per row, L_kk read from a plain copy with uniform addresses;
+  //   U  the trailing tiles take  A_ij -= L_ik L_jk^T  on the FP64 matrix pipe (4 v_mfma_f64_16x16x4_f64 per tile),
+  //      tiles dealt round-robin to the four waves; operands and accumulators go straight between LDS and the MFMA
+  //      register layouts.
+  // The rhs row rides along as row 12 of block row 10 (never a pivot), which is the forward substitution.
   bool bad = !(mu < 1.0);  // ComputeGaussNewtonStep: `while (mu_ < max_mu_)` — no attempt at mu >= 1
-  // scale column k (tile column KB of the register tile, lane group kk) by 1/sqrt(pivot) and publish it; the column
-  // buffer is written for EVERY row of the owner (zero outside (k, KP]) so that readers load it unconditionally
-#define FACTOR_COLUMN(KB, kk_, k_)                                                                       \
-  do {                                                                                                   \
-    const int fk = (kk_), k2 = (k_);                                                                     \
-    const int src = ((fk & 3) << 4) | fk; /* the diagonal lives in this lane of wave fk >> 2 */          \
-    const double dd = m[KB][KB];                                                                         \
-    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dd), src),                \
-                                      __builtin_amdgcn_readlane(__double2loint(dd), src));               \
-    if (tcol == fk) {                                                                                    \
-      double *cbw = colbuf + (k2 & 1) * 176;                                                             \
-      if (!(d > 0.0)) bad = true;                                                                        \
-      const double dinv = fast_rsqrt(d);                                                                 \
-      /* only tile row KB straddles the pivot; rows beyond KP hold exact zeros and need no mask */        \
-      {                                                                                                  \
-        double v = 0.0;                                                                                  \
-        if (trow > fk) {                                                                                 \
-          m[KB][KB] *= dinv;                                                                             \
-          v = m[KB][KB];                                                                                 \
-        } else if (trow == fk) {                                                                         \
-          m[KB][KB] = d * dinv;                                                                          \
-          invd[k2] = dinv;                                                                               \
-        }                                                                                                \
-        cbw[trow + 16 * (KB)] = v;                                                                       \
-      }                                                                                                  \
-      _Pragma("unroll") for (int a = (KB) + 1; a < 11; a++) {                                            \
-        m[a][KB] *= dinv;                                                                                \
-        cbw[trow + 16 * a] = m[a][KB];                                                                   \
-      }                                                                                                  \
-    }                                                                                                    \
-  } while (0)
-#define LOAD_COLUMN(KB, k_)                                              \
-  do {                                                                   \
-    const double *cbr = colbuf + ((k_) & 1) * 176;                       \
-    _Pragma("unroll") for (int a = KB; a < 11; a++) {                    \
-      li[a] = cbr[trow + 16 * a];                                        \
-      lj[a] = cbr[tcol + 16 * a];                                        \
-    }                                                                    \
-  } while (0)
-  FACTOR_COLUMN(0, 0, 0);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave in an SGPR: scalar loop control below
+  // F: factor diagonal tile kb in wave 0, one ROW per lane
+  auto factor = [&](int kb) {
+    const int nb = kb < NTL - 1 ? 16 : KP - 16 * (NTL - 1);  // pivots in this block column (12 in the last)
+    double *Td = Hs + tile_id(kb, kb) * TSZ;
+    const int row = lane & 15;
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) a[j] = j <= row ? Td[tsw(row, j)] : 0.0;
+    double mydiag = 1.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < nb) {
+        const double d = readlane_f64(a[k], k);
+        if (!(d > 0.0)) bad = true;
+        if (row == k) mydiag = d;
+        const double f = row > k ? a[k] * fast_rcp(d) : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < 16; j++) a[j] = fma(-f, readlane_f64(a[k], j), a[j]);
+      }
+    }
+    const double myrs = fast_rsqrt(mydiag);
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const double rsj = readlane_f64(myrs, j);
+        double v = 0.0;
+        if (j < nb) v = j < row ? a[j] * rsj : (j == row ? mydiag * myrs : 0.0);
+        Td[tsw(row, j)] = v;
+      }
+      if (lane < nb) invd[16 * kb + lane] = myrs;
+    }
+  };
+  // U: tiles [first, first + count) of the enumeration (ti, tj), kb < tj <= ti, every `step`-th; four tiles in flight
+  auto update = [&](int kb, int first, int step, int last) {
+    const int c = lane & 15, gq = lane >> 4, offA = c * TLD + gq, offC = gq * TLD + c;
+    int ti = kb + 1, tj = kb + 1, u = 0;
+    auto advance = [&](int n) {
+      for (int q = 0; q < n; q++, u++)
+        if (++tj > ti) ti++, tj = kb + 1;
+    };
+    advance(first);
+    while (u < last) {
+      double av[4][4], bv[4][4];
+      solve_d4 cv[4];
+      double *Tc[4];
+      int nt = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        Tc[t] = nullptr;
+        if (u < last) {
+          const double *Ta = Hs + tile_id(ti, kb) * TSZ + offA, *Tb = Hs + tile_id(tj, kb) * TSZ + offA;
+          Tc[t] = Hs + tile_id(ti, tj) * TSZ + offC;
+#pragma unroll
+          for (int q = 0; q < 4; q++) av[t][q] = Ta[4 * q], bv[t][q] = Tb[4 * q], cv[t][q] = Tc[t][4 * TLD * q];
+          nt = t + 1;
+          advance(step);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        if (t < nt) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) cv[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[t][q], bv[t][q], cv[t], 0, 0, 0);
+        }
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        if (t < nt) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) Tc[t][4 * TLD * r] = cv[t][r];
+        }
+    }
+  };
+  if (wave == 0) factor(0);
   __syncthreads();
+  for (int kb = 0; kb < NTL - 1; kb++) {
+    {  // P: the rows below solve x L_kk^T = a, one thread per row
+      const int ta = kb + 1 + (tid >> 4), r = tid & 15;
+      if (ta < NTL) {
+        double *Tp = Hs + tile_id(ta, kb) * TSZ;
+        const double *Tk = Hs + tile_id(kb, kb) * TSZ;
+        double x[16];
 #pragma unroll
-  for (int kb = 0; kb < 11; kb++) {
-    // pivots whose successor column sits in the same tile column kb
-#pragma nounroll
-    for (int kk = 0; kk < 15; kk++) {
-      const int k = kb * 16 + kk;
-      if (k >= KP) break;
-      double li[11], lj[11];
-      LOAD_COLUMN(kb, k);
+        for (int j = 0; j < 16; j++) x[j] = Tp[tsw(r, j)];
 #pragma unroll
-      for (int a = kb; a < 11; a++) m[a][kb] = fma(-li[a], lj[kb], m[a][kb]);
-      if (k + 1 < KP) FACTOR_COLUMN(kb, kk + 1, k + 1);
+        for (int j = 0; j < 16; j++) {
+          x[j] *= invd[16 * kb + j];
 #pragma unroll
-      for (int a = kb + 1; a < 11; a++)
+          for (int t = j + 1; t < 16; t++) x[t] = fma(-x[j], Tk[tsw(t, j)], x[t]);  // uniform addresses
+        }
 #pragma unroll
-        for (int b = kb + 1; b <= a; b++) m[a][b] = fma(-li[a], lj[b], m[a][b]);
-      __syncthreads();
+        for (int j = 0; j < 16; j++) Tp[tsw(r, j)] = x[j];
+      }
     }
-    // last pivot of the tile column: its successor opens tile column kb + 1
-    if (kb < 10) {
-      const int k = kb * 16 + 15;
-      double li[11], lj[11];
-      LOAD_COLUMN(kb, k);
-#pragma unroll
-      for (int a = kb + 1; a < 11; a++) m[a][kb + 1] = fma(-li[a], lj[kb + 1], m[a][kb + 1]);
-      FACTOR_COLUMN(kb + 1 < 11 ? kb + 1 : 10, 0, k + 1);
-#pragma unroll
-      for (int a = kb; a < 11; a++) m[a][kb] = fma(-li[a], lj[kb], m[a][kb]);
-#pragma unroll
-      for (int a = kb + 2; a < 11; a++)
-#pragma unroll
-        for (int b = kb + 2; b <= a; b++) m[a][b] = fma(-li[a], lj[b], m[a][b]);
-      __syncthreads();
+    __syncthreads();
+    {  // U with look-ahead: wave 0 updates the next diagonal tile first and factors it while waves 1..3 update the rest
+      const int m = NTL - 1 - kb, ntiles = m * (m + 1) / 2;
+      if (wave == 0) {
+        update(kb, 0, 1, 1);
+        factor(kb + 1);
+      } else {
+        update(kb, wave, 3, ntiles);
+      }
     }
+    __syncthreads();
   }
-#undef FACTOR_COLUMN
-#undef LOAD_COLUMN
   STAMP(S, 4);
   {
     double f = bad ? 1.0 : 0.0;
     f = block_max(f, scratch, tid);
     bad = f > 0.0;
   }
-  // ---- L (and z = row KP) to LDS, packed
-#pragma unroll
-  for (int a = 0; a < 11; a++)
-#pragma unroll
-    for (int b = 0; b <= a; b++) {
-      const int i = trow + 16 * a, j = tcol + 16 * b;
-      if (i <= KP && j <= i && j < KP) Hs[i * (i + 1) / 2 + j] = m[a][b];
-    }
-  __syncthreads();
   STAMP(S, 5);
   // ---- blocked back-substitution  L^T y = z  (11 diagonal blocks of 16):
-  //   1. every diagonal block L_kk is inverted up front, all blocks in parallel (one thread per column);
+  //   1. every diagonal block L_kk is inverted up front, all blocks in parallel (one thread per column), in place;
   //   2. going from the last block to the first, y_k = L_kk^-T (z_k - sum_{m>k} L_mk^T y_m): the sum is a
   //      dense 16 x (rows below) product done by all threads, the solve is a 16x16 mat-vec — 11 short
   //      steps instead of 172 dependent ones.
-  double *Binv = scratch + 320;  // 11 x 256, after the (256 + 64) scratch area
   {
     const int blk = tid >> 4, c = tid & 15;  // thread -> (diagonal block, column)
-    if (blk < 11) {
-      const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
-      double x[16];
+    double x[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) x[r] = 0.0;
+    for (int r = 0; r < 16; r++) x[r] = 0.0;
+    if (blk < NTL) {
+      const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
+      const double *Tk = Hs + tile_id(blk, blk) * TSZ;
       // column c of X = L_kk^-1 by forward substitution: X[r][c] = (delta_rc - sum_{t<r} L[r][t] X[t][c]) / L[r][r]
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         if (r < nb && c < nb && r >= c) {
           double s = (r == c) ? 1.0 : 0.0;
-          const int rb = (o + r) * (o + r + 1) / 2 + o;
 #pragma unroll
           for (int t = 0; t < 16; t++)
-            if (t < r && t >= c) s = fma(-Hs[rb + t], x[t], s);
+            if (t < r && t >= c) s = fma(-Tk[tsw(r, t)], x[t], s);
           x[r] = s * invd[o + r];
         }
       }
+    }
+    // the rhs row of the last diagonal tile is z of block 10: keep it before the tile is overwritten
+    if (tid < 16) Ld[tid] = Hs[tile_id(NTL - 1, NTL - 1) * TSZ + tsw(KP & 15, tid)];
+    __syncthreads();
+    if (blk < NTL) {
+      double *Tk = Hs + tile_id(blk, blk) * TSZ;  // now the inverse, plain row-major
 #pragma unroll
-      for (int r = 0; r < 16; r++) Binv[blk * 256 + r * 16 + c] = x[r];
+      for (int r = 0; r < 16; r++) Tk[r * 16 + c] = x[r];
     }
   }
   __syncthreads();
   {
-    const int zbase = KP * (KP + 1) / 2;
-    double *rhs = colbuf;  // 16 entries, reused
-    for (int blk = 10; blk >= 0; blk--) {
+    double *rhs = Ld + 16;  // 16 entries
+    for (int blk = NTL - 1; blk >= 0; blk--) {
       const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
+      const double *Binv = Hs + tile_id(blk, blk) * TSZ;
       // partial sums: thread (c = tid & 15, part = tid >> 4) covers rows o+16+part, +16, ...
       const int c = tid & 15, part = tid >> 4;
       double acc = 0.0;
       if (c < nb)
-        for (int i = o + 16 + part; i < KP; i += 16) acc = fma(Hs[i * (i + 1) / 2 + o + c], yv[i], acc);
+        for (int i = o + 16 + part; i < KP; i += 16) acc = fma(Hs[lidx(i, o + c)], yv[i], acc);
       // reduce the 16 parts of each column (parts live in different 16-lane groups -> LDS)
       scratch[part * 16 + c] = acc;
       __syncthreads();
@@ -353,14 +376,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
         double s = 0;
 #pragma unroll
         for (int p2 = 0; p2 < 16; p2++) s += scratch[p2 * 16 + tid];
-        rhs[tid] = (tid < nb) ? Hs[zbase + o + tid] - s : 0.0;
+        const double z = blk == NTL - 1 ? Ld[tid] : Hs[lidx(KP, o + tid)];
+        rhs[tid] = (tid < nb) ? z - s : 0.0;
       }
       __syncthreads();
       // y_k = L_kk^-T rhs : y[c] = sum_r Binv[r][c] rhs[r]
       if (tid < 16 && tid < nb) {
         double s = 0;
 #pragma unroll
-        for (int r = 0; r < 16; r++) s = fma(Binv[blk * 256 + r * 16 + tid], rhs[r], s);
+        for (int r = 0; r < 16; r++) s = fma(Binv[r * 16 + tid], rhs[r], s);
         yv[o + tid] = s;
       }
       __syncthreads();
