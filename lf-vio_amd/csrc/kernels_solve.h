@@ -102,19 +102,19 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   auto active = [&](int c) { return (est_ex || c < off_ex() || c >= off_ex() + 6) && (est_td || c != off_td()); };
   STAMP(S, 0);
   const int er = tid >> 4, ek = tid & 15, esw = tsw(er, ek);  // this thread's entry of every tile
-  {  // H_pp global (packed rows) -> tiles; six independent loads in flight per thread
+  // This thread's entry (er, ek) of every lower tile: H_pp stays in these registers for the whole kernel — the reduced
+  // system is built from them and the quadratic forms G^T H G, G^T H N, N^T H N are taken from them, so H_pp is read once.
+  double hreg[NTILES];
+  {
     const double *Hg = S->Hpp;
 #pragma unroll
-    for (int t0 = 0; t0 < NTILES; t0 += 6) {
-      double v[6];
-#pragma unroll
-      for (int u = 0; u < 6; u++) {
-        const int i = 16 * tile_a(t0 + u) + er, j = 16 * tile_b(t0 + u) + ek;
-        v[u] = (i < KP && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 6; u++) Hs[(t0 + u) * TSZ + esw] = v[u];
+    for (int t = 0; t < NTILES; t++) {
+      const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
+      hreg[t] = (i < KP && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
     }
+#pragma unroll
+    for (int a = 0; a < NTL; a++)
+      if (er == ek && 16 * a + er < KP) hv[16 * a + er] = hreg[tile_id(a, a)];  // the diagonal, for the scaling below
     if (tid < KP) g[tid] = S->gp[tid];
   }
   // landmark-side scalars: local sums, or the all-reduced totals of the sharded mode
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   const double mu = tr->mu;
   if (tid < KP) {
     const int i = tid;
-    const double hii = Hs[lidx(i, i)];
+    const double hii = hv[i];
     double s;
     if (!tr->scaled) {
       s = 1.0 / (1.0 + sqrt(hii));
@@ -153,31 +153,41 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   // ---- reduced system, in place:  S = S_p (H_pp - Schur) S_p + mu D^2  and the rhs row; the Cauchy-point quadratic
   //      form G^T H G is accumulated from the same entries on the way.
   const double *Sc = S->schur_sum;
-  const int trow = tid & 15, tcol = tid >> 4;  // ownership pattern of the quadratic forms further down
   double qgg_part = 0;
+  {
+    // per-thread slices of the vectors: row index 16 a + er, column index 16 b + ek
+    double Gi[NTL], Gj[NTL], si[NTL], sj[NTL];
+    bool ai[NTL], aj[NTL];
 #pragma unroll
-  for (int t = 0; t < NTILES; t++) {
-    const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
-    double *e = &Hs[t * TSZ + esw];
-    double v = 0.0;
-    if (i < KP && j <= i) {
-      double h = *e;
-      qgg_part = fma(h * Gd[i], (i == j) ? Gd[j] : 2.0 * Gd[j], qgg_part);
-      if (active(i) && active(j)) {
-        if (tile_a(t) <= 4 && i < KC) h -= Sc[schur_index(j, i)];  // j <= i < 73
-        v = sc[i] * sc[j] * h;
-        if (i == j) v += mu * dg[i] * dg[i];
-      } else {
-        v = (i == j) ? 1.0 : 0.0;
-      }
-    } else if (tile_a(t) == NTL - 1 && i == KP && j < KP) {
-      if (active(j)) {
-        double r = g[j];
-        if (j < KC) r -= Sc[schur_index(j, COL_B)];  // z1
-        v = sc[j] * r;
-      }
+    for (int a = 0; a < NTL; a++) {
+      const int i = 16 * a + er, j = 16 * a + ek;
+      Gi[a] = i < KP ? Gd[i] : 0.0, si[a] = i < KP ? sc[i] : 0.0, ai[a] = i < KP && active(i);
+      Gj[a] = j < KP ? Gd[j] : 0.0, sj[a] = j < KP ? sc[j] : 0.0, aj[a] = j < KP && active(j);
     }
-    *e = v;
+#pragma unroll
+    for (int t = 0; t < NTILES; t++) {
+      const int a = tile_a(t), b = tile_b(t);
+      const int i = 16 * a + er, j = 16 * b + ek;
+      double v = 0.0;
+      if (i < KP && j <= i) {
+        double h = hreg[t];
+        qgg_part = fma(h * Gi[a], (i == j) ? Gj[b] : 2.0 * Gj[b], qgg_part);
+        if (ai[a] && aj[b]) {
+          if (a <= 4 && i < KC) h -= Sc[schur_index(j, i)];  // j <= i < 73
+          v = si[a] * sj[b] * h;
+          if (i == j) v += mu * dg[i] * dg[i];
+        } else {
+          v = (i == j) ? 1.0 : 0.0;
+        }
+      } else if (a == NTL - 1 && i == KP && j < KP) {
+        if (aj[b]) {
+          double r = g[j];
+          if (j < KC) r -= Sc[schur_index(j, COL_B)];  // z1
+          v = sj[b] * r;
+        }
+      }
+      Hs[t * TSZ + esw] = v;
+    }
   }
   // ---- Cauchy point: alpha = ||gradient_||^2 / ||J (gradient_/diagonal_)||^2
   {
@@ -324,73 +334,46 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     bad = f > 0.0;
   }
   STAMP(S, 5);
-  // ---- blocked back-substitution  L^T y = z  (11 diagonal blocks of 16):
-  //   1. every diagonal block L_kk is inverted up front, all blocks in parallel (one thread per column), in place;
-  //   2. going from the last block to the first, y_k = L_kk^-T (z_k - sum_{m>k} L_mk^T y_m): the sum is a
-  //      dense 16 x (rows below) product done by all threads, the solve is a 16x16 mat-vec — 11 short
-  //      steps instead of 172 dependent ones.
-  {
-    const int blk = tid >> 4, c = tid & 15;  // thread -> (diagonal block, column)
-    double x[16];
+  // ---- blocked back-substitution  L^T y = z  (11 diagonal blocks of 16), right-looking, from the last block to the
+  //      first: wave 0 solves L_kk^T y_k = z_k inside the wave (lane c keeps z_c and column c of L_kk; y_r travels by
+  //      v_readlane), then every earlier block takes z_j -= L_kj^T y_k at once (thread (j, c): one column of one tile).
+  if (tid < KP) yv[tid] = Hs[lidx(KP, tid)];  // z = the rhs row
+  __syncthreads();
+  auto tri_solve = [&](int blk) {  // wave 0
+    const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16, c = lane & 15;
+    const double *Tk = Hs + tile_id(blk, blk) * TSZ;
+    // state w_c = z_c / L_cc, so that y_r is lane r's state as it stands and a step is one broadcast and one fma
+    const double dinv = invd[o + (c < nb ? c : 0)];
+    double lc[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = 0.0;
-    if (blk < NTL) {
-      const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
-      const double *Tk = Hs + tile_id(blk, blk) * TSZ;
-      // column c of X = L_kk^-1 by forward substitution: X[r][c] = (delta_rc - sum_{t<r} L[r][t] X[t][c]) / L[r][r]
+    for (int r = 0; r < 16; r++) lc[r] = (r > c && r < nb) ? Tk[tsw(r, c)] * dinv : 0.0;
+    double z = c < nb ? yv[o + c] * dinv : 0.0;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        if (r < nb && c < nb && r >= c) {
-          double s = (r == c) ? 1.0 : 0.0;
+    for (int r = 15; r >= 1; r--)
+      if (r < nb) z = fma(-lc[r], readlane_f64(z, r), z);  // lc[r] = 0 for c >= r: lanes r.. keep their value
+    if (lane < nb) yv[o + lane] = z;
+  };
+  auto apply = [&](int blk, int j, int c) {  // z_j[c] -= (L_kj^T y_k)[c]
+    const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
+    const double *Tj = Hs + tile_id(blk, j) * TSZ;
+    double s = yv[16 * j + c];
 #pragma unroll
-          for (int t = 0; t < 16; t++)
-            if (t < r && t >= c) s = fma(-Tk[tsw(r, t)], x[t], s);
-          x[r] = s * invd[o + r];
-        }
-      }
+    for (int r = 0; r < 16; r++)
+      if (r < nb) s = fma(-Tj[tsw(r, c)], yv[o + r], s);
+    yv[16 * j + c] = s;
+  };
+  if (wave == 0) tri_solve(NTL - 1);
+  __syncthreads();
+  for (int blk = NTL - 1; blk >= 1; blk--) {
+    if (wave == 0) {  // look-ahead: the next block to be solved gets its update first
+      if (lane < 16) apply(blk, blk - 1, lane);
+      tri_solve(blk - 1);
+    } else {
+      const int j = (tid - 64) >> 4;
+      if (j < blk - 1) apply(blk, j, tid & 15);
     }
-    // the rhs row of the last diagonal tile is z of block 10: keep it before the tile is overwritten
-    if (tid < 16) Ld[tid] = Hs[tile_id(NTL - 1, NTL - 1) * TSZ + tsw(KP & 15, tid)];
     __syncthreads();
-    if (blk < NTL) {
-      double *Tk = Hs + tile_id(blk, blk) * TSZ;  // now the inverse, plain row-major
-#pragma unroll
-      for (int r = 0; r < 16; r++) Tk[r * 16 + c] = x[r];
-    }
   }
-  __syncthreads();
-  {
-    double *rhs = Ld + 16;  // 16 entries
-    for (int blk = NTL - 1; blk >= 0; blk--) {
-      const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
-      const double *Binv = Hs + tile_id(blk, blk) * TSZ;
-      // partial sums: thread (c = tid & 15, part = tid >> 4) covers rows o+16+part, +16, ...
-      const int c = tid & 15, part = tid >> 4;
-      double acc = 0.0;
-      if (c < nb)
-        for (int i = o + 16 + part; i < KP; i += 16) acc = fma(Hs[lidx(i, o + c)], yv[i], acc);
-      // reduce the 16 parts of each column (parts live in different 16-lane groups -> LDS)
-      scratch[part * 16 + c] = acc;
-      __syncthreads();
-      if (tid < 16) {
-        double s = 0;
-#pragma unroll
-        for (int p2 = 0; p2 < 16; p2++) s += scratch[p2 * 16 + tid];
-        const double z = blk == NTL - 1 ? Ld[tid] : Hs[lidx(KP, o + tid)];
-        rhs[tid] = (tid < nb) ? z - s : 0.0;
-      }
-      __syncthreads();
-      // y_k = L_kk^-T rhs : y[c] = sum_r Binv[r][c] rhs[r]
-      if (tid < 16 && tid < nb) {
-        double s = 0;
-#pragma unroll
-        for (int r = 0; r < 16; r++) s = fma(Binv[r * 16 + tid], rhs[r], s);
-        yv[o + tid] = s;
-      }
-      __syncthreads();
-    }
-  }
-  __syncthreads();
   STAMP(S, 6);
   {
     double f = 0.0;
@@ -422,34 +405,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   if (tid >= KC && tid < WLD) S->uc_grad[tid] = S->uc_gn[tid] = 0.0;
   __syncthreads();
   {
-    // G^T H N and N^T H N from the global copy of H_pp (LDS now holds L): every thread re-reads the
-    // entries it owned (static pattern, all loads independent)
+    // G^T H N and N^T H N from the entries of H_pp this thread has held in registers since the start
     double qgn = 0, qnn = 0;
     {
-      const double *Hg = S->Hpp;
-      double Gi[11], Ni[11], Gj[11], Nj[11];
+      double Gi[NTL], Ni[NTL], Gj[NTL], Nj[NTL];
 #pragma unroll
-      for (int a = 0; a < 11; a++) {
-        const int i = trow + 16 * a, j = tcol + 16 * a;
+      for (int a = 0; a < NTL; a++) {
+        const int i = 16 * a + er, j = 16 * a + ek;
         Gi[a] = i < KP ? Gd[i] : 0.0, Ni[a] = i < KP ? yv[i] : 0.0;
         Gj[a] = j < KP ? Gd[j] : 0.0, Nj[a] = j < KP ? yv[j] : 0.0;
       }
 #pragma unroll
-      for (int a = 0; a < 11; a++)
-#pragma unroll
-        for (int b = 0; b <= a; b++) {
-          const int i = trow + 16 * a, j = tcol + 16 * b;
-          if (i < KP && j <= i) {
-            const double h = Hg[i * (i + 1) / 2 + j];
-            if (i == j) {
-              qgn = fma(h, Gi[a] * Nj[b], qgn);
-              qnn = fma(h, Ni[a] * Nj[b], qnn);
-            } else {
-              qgn = fma(h, Gi[a] * Nj[b] + Ni[a] * Gj[b], qgn);
-              qnn = fma(h, 2.0 * Ni[a] * Nj[b], qnn);
-            }
+      for (int t = 0; t < NTILES; t++) {
+        const int a = tile_a(t), b = tile_b(t);
+        const int i = 16 * a + er, j = 16 * b + ek;
+        if (i < KP && j <= i) {
+          const double h = hreg[t];
+          if (i == j) {
+            qgn = fma(h, Gi[a] * Nj[b], qgn);
+            qnn = fma(h, Ni[a] * Nj[b], qnn);
+          } else {
+            qgn = fma(h, Gi[a] * Nj[b] + Ni[a] * Gj[b], qgn);
+            qnn = fma(h, 2.0 * Ni[a] * Nj[b], qnn);
           }
         }
+      }
     }
     double gn2 = 0, ggn = 0, gG = 0, gN = 0;
     if (tid < KP) {
