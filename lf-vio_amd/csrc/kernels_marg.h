@@ -19,7 +19,9 @@ constexpr int MARG_THREADS = 768;   // 12 waves: one 2x2 block of the 38 x 39 / 
 constexpr int MARG_MAXD = 96;  // 15 dropped + 76 kept, padded
 constexpr int LDN = 80;              // LDS row stride of the n x n (n <= 76) eigen-problem, see jacobi_systolic
 constexpr double JACOBI_TOL = 1e-19;  // off-diagonal mass / diagonal mass at which the n x n Jacobi stops, see jacobi_systolic
-constexpr size_t MARG_LDS = (size_t)17408 * sizeof(double);  // >= LPACK + KP + 64 and >= the eigen-phase carve below
+constexpr size_t MARG_LDS = (size_t)19072 * sizeof(double);  // >= LPACK + KP + 64 and >= the eigen-phase carve below
+constexpr bool EIG_TRIDIAG = true;  // n x n eigen-problem: Householder tridiagonalization + multisection + twisted factorization
+                                    // (eig_tridiag below); false: the systolic Jacobi + k_marg_vecs
 
 __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
@@ -439,6 +441,281 @@ DEV int jacobi_small(double *Am, double *Vm, int n, int tid, int nthreads, doubl
   return sweeps;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The n x n (n <= 76) symmetric eigen-problem of marginalization_factor.cpp:283-291 the way Eigen's SelfAdjointEigenSolver
+// and the oracle's tred2 + tql2 pose it — tridiagonalize, solve the tridiagonal problem, transform back — with the serial
+// QL iteration replaced by two steps that are parallel over the eigenvalues:
+//   1. Householder tridiagonalization  A = Q T Q^T  (LAPACK dsytd2 arithmetic), A full-symmetric in LDS: per column one
+//      wave forms the reflector, eight lanes per row take the product A v, every wave forms w = p - (tau/2)(p.v) v on
+//      the fly for its share of the rank-2 update  A -= v w^T + w v^T; three barriers per column.
+//   2. eigenvalues of T by multisection of the Sturm count: eight lanes per eigenvalue index, nine-fold shrink per
+//      round, 18 rounds from the Gershgorin interval down to the rounding level of T.
+//   3. eigenvectors of T by the twisted factorization (Parlett & Dhillon; LAPACK dlar1v without the relatively robust
+//      representation): one thread per eigenvalue runs the stationary and the progressive quotient-difference recurrence,
+//      twists where |gamma| is smallest and multiplies out from there.  Eigenvalues closer than the rounding level give
+//      parallel vectors; that only happens in the block of noise eigenvalues (|lambda| ~ 1e-6 against ||A'|| ~ 1e6),
+//      whose rows contribute lambda v v^T ~ 1e-6 to J0^T J0 whatever v is.
+//   4. V = Q Z: eight lanes per eigenvector push their column through the reflectors, last to first, and write
+//      J0 = sqrt(S) V^T,  r0 = sqrt(1/S) V^T b'  for the eigenvalues above eps, zero rows for the others.
+// Rows of J0 come out in ascending eigenvalue order, as Eigen returns them.
+// ---------------------------------------------------------------------------------------------------------------
+// cross-lane sums by DPP moves (a few cycles each) instead of ds_bpermute round trips (~100 cycles each)
+template <int CTRL>
+DEV double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+DEV double sum8(double v) {  // over aligned groups of eight lanes; every lane of the group gets the sum
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  return v;
+}
+DEV double wave_sum_dpp(double v) {  // every lane gets the sum over the 64 lanes
+  v = sum8(v);
+  v += dpp_f64<0x140>(v);  // row_mirror: the other half of the row of 16
+  return readlane_f64(v, 0) + readlane_f64(v, 16) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+// Sturm count of T - sigma I (number of eigenvalues below sigma) by the determinant recurrence
+// p_i = (d_i - sigma) p_{i-1} - e_{i-1}^2 p_{i-2}: two dependent flops per row instead of a division.  T is read through
+// the scalar cache (uniform addresses -> s_load, no LDS or vector-memory traffic: every lane of ten waves walks the same
+// 152 numbers 18 times), the signs are shifted into a mask and counted at the end, and the pair is brought back to unit
+// scale every eight rows (one row grows it by at most ||T||^2).
+typedef const __attribute__((address_space(4))) double sdouble;
+DEV int sturm_count(sdouble *Tg /* d[96] | e^2[96], zero-padded */, int n, double sigma) {
+  double pm = 1.0, p = Tg[0] - sigma;
+  unsigned cnt = (unsigned)__double2hiint(p) >> 31;
+  for (int i0 = 1; i0 < n; i0 += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const double pn = fma(Tg[i0 + u] - sigma, p, -Tg[96 + i0 + u - 1] * pm);
+      // a sign change between p_{i-1} and p_i; rows beyond n (d = e^2 = 0 there) are masked out
+      const unsigned ch = (unsigned)(__double2hiint(pn) ^ __double2hiint(p)) >> 31;
+      cnt += (i0 + u < n) ? ch : 0u;
+      pm = p, p = pn;
+    }
+    const int ex = ilogb(fmax(fmax(fabs(p), fabs(pm)), 1e-300));
+    p = ldexp(p, -ex), pm = ldexp(pm, -ex);
+  }
+  return (int)cnt;
+}
+// A: n x n, row stride LDN, full symmetric (destroyed; receives Z, component i of vector m at [i * LDN + m]); b: n;
+// RV: >= n * 76, DM: >= n * LDN, vec: >= 8 * 96 doubles of LDS.  Writes out->linearized_jacobians / _residuals.
+DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, double *DM, double *vec, double *scr, double *Tglob, LfvioPrior *out, double eps, long long *dbg) {
+#define ESTAMP(k) do { if (tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+  ESTAMP(26);
+  const int wave = tid >> 6, lane = tid & 63;
+  double *dd = vec, *ee = vec + 96, *ee2 = vec + 192, *tau = vec + 288, *lam = vec + 384, *pp = vec + 480, *nrm = vec + 576;
+  // ---- 1. tridiagonalization.  Only the lower triangle is read, like Eigen's solver (and tred2) do: mirror it first.
+  for (int i = tid >> 5; i < n; i += MARG_THREADS / 32)
+    for (int j = (tid & 31); j < i; j += 32) A[j * LDN + i] = A[i * LDN + j];
+  if (tid < 96) dd[tid] = 0.0, ee[tid] = 0.0, ee2[tid] = 0.0;
+  __syncthreads();
+  for (int k = 0; k + 2 < n; k++) {
+    const int m = n - k - 1;  // the reflector acts on rows k+1 .. n-1; x = column k below the diagonal = row k right of it
+    // every wave forms the reflector itself (dlarfg): no barrier between this and the product A v
+    const double *xr = A + k * LDN + k + 1;
+    const double x0 = lane < m ? xr[lane] : 0.0, x1 = lane + 64 < m ? xr[lane + 64] : 0.0;
+    const double alpha = readlane_f64(x0, 0);
+    const double ss = wave_sum_dpp((lane > 0 ? x0 * x0 : 0.0) + x1 * x1);
+    double beta = alpha, t = 0.0, scal = 0.0;
+    if (ss > 0.0) {
+      const double nn = alpha * alpha + ss;
+      beta = -copysign(nn * fast_rsqrt(nn), alpha);
+      t = (beta - alpha) * fast_rcp(beta);
+      scal = fast_rcp(alpha - beta);
+    }
+    if (wave == 0) {
+      if (lane < m) RV[k * 76 + lane] = lane == 0 ? 1.0 : x0 * scal;
+      if (lane + 64 < m) RV[k * 76 + lane + 64] = x1 * scal;
+      if (lane == 0) tau[k] = t, ee[k] = beta, dd[k] = A[k * LDN + k];
+    }
+    {  // p = tau A v, eight lanes per row
+      const int i = tid >> 3, l8 = tid & 7;
+      double s = 0.0;
+      if (i < m) {
+        const double *row = A + (k + 1 + i) * LDN + k + 1;
+        for (int j = l8; j < m; j += 8) s = fma(row[j], j == 0 ? 1.0 : xr[j] * scal, s);
+      }
+      s = sum8(s);
+      if (i < m && l8 == 0) pp[i] = t * s;
+    }
+    __syncthreads();
+    {  // w = p - (tau/2)(p.v) v on the fly, A -= v w^T + w v^T
+      const double v0 = lane == 0 ? 1.0 : x0 * scal, v1 = x1 * scal;
+      const double pv = wave_sum_dpp((lane < m ? pp[lane] * v0 : 0.0) + (lane + 64 < m ? pp[lane + 64] * v1 : 0.0));
+      const double K = 0.5 * t * pv;
+      // thread (r, c) of a 24 x 32 grid: columns c, c + 32, c + 64 (their v, w stay in registers), rows r, r + 24, ...
+      const int c0 = tid & 31;
+      double vj[3], wj[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int j = c0 + 32 * q;
+        vj[q] = j == 0 ? 1.0 : (j < m ? xr[j] * scal : 0.0);
+        wj[q] = j < m ? pp[j] - K * vj[q] : 0.0;
+      }
+      for (int i = tid >> 5; i < m; i += MARG_THREADS / 32) {
+        const double vi = i == 0 ? 1.0 : xr[i] * scal, wi = pp[i] - K * vi;
+        double *row = A + (k + 1 + i) * LDN + k + 1;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int j = c0 + 32 * q;
+          if (j < m) row[j] -= vi * wj[q] + wi * vj[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (n >= 2) dd[n - 2] = A[(n - 2) * LDN + n - 2], ee[n - 2] = A[(n - 1) * LDN + n - 2];
+    dd[n - 1] = A[(n - 1) * LDN + n - 1];
+  }
+  __syncthreads();
+  ESTAMP(27);
+  // ---- 2. eigenvalues
+  if (tid < n) ee2[tid] = ee[tid] * ee[tid];
+  if (tid < 96) Tglob[tid] = dd[tid], Tglob[96 + tid] = tid < n ? ee[tid] * ee[tid] : 0.0;
+  __threadfence();
+  {
+    double lo = 1e300, hi = -1e300;
+    if (tid < n) {
+      const double r = (tid > 0 ? fabs(ee[tid - 1]) : 0.0) + (tid + 1 < n ? fabs(ee[tid]) : 0.0);
+      lo = dd[tid] - r, hi = dd[tid] + r;
+    }
+    lo = -wave_max(-lo), hi = wave_max(hi);
+    if (lane == 0) scr[wave] = lo, scr[16 + wave] = hi;
+  }
+  __syncthreads();
+  double gl = fmin(scr[0], scr[1]), gu = fmax(scr[16], scr[17]);  // n <= 76: the first two waves hold everything
+  __builtin_amdgcn_s_dcache_inv();
+  const unsigned long long ta = (unsigned long long)Tglob;
+  unsigned tlo = __builtin_amdgcn_readfirstlane((unsigned)ta), thi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
+  asm volatile("" : "+s"(tlo), "+s"(thi));  // the scalar loads stay behind the barrier above
+  sdouble *Tg = (sdouble *)(((unsigned long long)thi << 32) | tlo);
+  {
+    const double tn = fmax(fabs(gl), fabs(gu)), pivmin = 1e-290;
+    gl -= 2.2e-16 * tn * n + 1e-300, gu += 2.2e-16 * tn * n + 1e-300;
+    // two lanes per eigenvalue (trisection, 34 rounds): 152 threads are three waves, one per SIMD — the recurrence is
+    // bound by instruction issue, so the work is kept small rather than the round count (eight lanes per eigenvalue
+    // need 18 rounds but ten waves)
+    const int m = tid >> 1, l8 = tid & 1;
+    double lo = gl, hi = gu;
+    const int mm = m < n ? m : n - 1;
+    if (tid < 2 * 96)
+      for (int round = 0; round < 34; round++) {
+        const double w = hi - lo;
+        const double sigma = lo + w * (double)(l8 + 1) * (1.0 / 3.0);
+        const int cnt = sturm_count(Tg, n, sigma);
+        int f = cnt <= mm ? 1 : 0;  // eigenvalue mm (0-based, ascending) is >= sigma
+        f += __shfl_xor(f, 1, 64);
+        const double nlo = f == 0 ? lo : lo + w * (double)f * (1.0 / 3.0), nhi = f == 2 ? hi : lo + w * (double)(f + 1) * (1.0 / 3.0);
+        lo = nlo, hi = nhi;
+      }
+    if (m < n && l8 == 0) lam[m] = 0.5 * (lo + hi);
+    __syncthreads();
+    ESTAMP(28);
+    // ---- 3. eigenvectors of T: thread me runs the stationary recurrence (top down) into A, thread 128 + me the
+    //         progressive one (bottom up) into DM
+    if (tid < n) {
+      const int me = tid;
+      const double l = lam[me];
+      double q = dd[0] - l;
+      A[me] = q;
+      for (int i = 1; i < n; i++) {
+        if (fabs(q) < pivmin) q = -pivmin;
+        q = fma(-ee2[i - 1], fast_rcp(q), dd[i] - l);
+        A[i * LDN + me] = q;
+      }
+    } else if (tid >= 128 && tid < 128 + n) {
+      const int me = tid - 128;
+      const double l = lam[me];
+      double q = dd[n - 1] - l;
+      DM[(n - 1) * LDN + me] = q;
+      for (int i = n - 2; i >= 0; i--) {
+        if (fabs(q) < pivmin) q = -pivmin;
+        q = fma(-ee2[i], fast_rcp(q), dd[i] - l);
+        DM[i * LDN + me] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < n) {  // twist where |gamma| is smallest and multiply out
+      const int me = tid;
+      const double l = lam[me];
+      double gmin = 1e300;
+      int kt = 0;
+      for (int i = 0; i < n; i++) {
+        const double g = fabs(A[i * LDN + me] + DM[i * LDN + me] - (dd[i] - l));
+        if (g < gmin) gmin = g, kt = i;
+      }
+      double z = 1.0, nn = 1.0;
+      for (int i = kt - 1; i >= 0; i--) {
+        double dp = A[i * LDN + me];
+        if (fabs(dp) < pivmin) dp = -pivmin;
+        z = -ee[i] * fast_rcp(dp) * z;
+        A[i * LDN + me] = z;
+        nn = fma(z, z, nn);
+      }
+      z = 1.0;
+      A[kt * LDN + me] = 1.0;
+      for (int i = kt + 1; i < n; i++) {
+        double dm = DM[i * LDN + me];
+        if (fabs(dm) < pivmin) dm = -pivmin;
+        z = -ee[i - 1] * fast_rcp(dm) * z;
+        A[i * LDN + me] = z;
+        nn = fma(z, z, nn);
+      }
+      nrm[me] = fast_rsqrt(nn);
+    }
+  }
+  __syncthreads();
+  ESTAMP(29);
+  // ---- 4. V = Q Z and the outputs
+  {
+    const int m = tid >> 3, l8 = tid & 7;
+    const bool live = m < n;
+    const int mm = live ? m : 0;
+    double zz[10];
+    const double sc = nrm[mm];
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+      const int i = l8 + 8 * q;
+      zz[q] = i < n ? A[i * LDN + mm] * sc : 0.0;
+    }
+    for (int k = n - 3; k >= 0; k--) {
+      const double *v = RV + k * 76 - (k + 1);  // v[i] for rows i >= k + 1
+      double vq[10], s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 10; q++) {
+        const int i = l8 + 8 * q;
+        vq[q] = (i > k && i < n) ? v[i] : 0.0;
+        s = fma(vq[q], zz[q], s);
+      }
+      s = sum8(s) * tau[k];
+#pragma unroll
+      for (int q = 0; q < 10; q++) zz[q] = fma(-s, vq[q], zz[q]);
+    }
+    const double l = lam[mm];
+    double rb = 0.0;
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+      const int i = l8 + 8 * q;
+      if (i < n) rb = fma(zz[q], b[i], rb);
+    }
+    rb = sum8(rb);
+    if (live) {
+      const bool keep = l > eps;
+      const double sq = keep ? sqrt(l) : 0.0;
+#pragma unroll
+      for (int q = 0; q < 10; q++) {
+        const int i = l8 + 8 * q;
+        if (i < n) out->linearized_jacobians[m * n + i] = sq * zz[q];
+      }
+      if (l8 == 0) out->linearized_residuals[m] = keep ? rb / sq : 0.0;
+    }
+  }
+}
+
 // grid (1, batch) x 256, dynamic LDS = MARG_LDS
 __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t stride, int flag) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -491,11 +768,13 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   double *Vm = Am + 256;                   // m15 x m15
   double *Ainv = Vm + 256;                 // m15 x m15
   double *Tm = Ainv + 256;                 // n x m15
-  double *Ar = Tm + 80 * 16;               // n x n, row stride LDN
+  double *Ar = smem + 12544;               // n x n, row stride LDN (above everything the tridiagonal path puts below it)
   double *br = Ar + 76 * LDN;              // n
   double2 *cs = (double2 *)(br + 80);      // [2][48] (cos, sin) of the Jacobi rotations, double-buffered
   int *perm = (int *)(cs + 96);            // n ints
   double *scr = (double *)(perm + 96);     // 64
+  // tridiagonal path: reflectors, the progressive recurrence and the small vectors live in the dead A / Tm area
+  double *RV = smem, *vec8 = smem + 5776, *DMs = smem + 5776 + 672;  // 76 x 76, 7 x 96, 76 x LDN: ends at 12528 < 12544
   for (int e = tid; e < D * D; e += MARG_THREADS) A[e] = Ag[e];
   for (int c = tid; c < D; c += MARG_THREADS) bv[c] = Ag[D * D + c];
   __syncthreads();
@@ -549,21 +828,28 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   // The matrix is strongly graded (eigenvalues 1e-6 .. 1e6): cyclic Jacobi converges markedly faster when the
   // diagonal is sorted in decreasing order first (de Rijk), which is a permutation similarity.
   STAMP(S, 13);
-  if (tid < n) {
-    const double di = Ar[tid * LDN + tid];
-    int rank = 0;
-    for (int j = 0; j < n; j++) {
-      const double dj = Ar[j * LDN + j];
-      rank += (dj > di) || (dj == di && j < tid);
+  int sw2 = 0;
+  if (EIG_TRIDIAG) {
+    eig_tridiag(Ar, br, n, tid, RV, DMs, vec8, scr, S->eig_aux, out, 1e-8, S->dbg);
+    if (tid == 0) S->eig_steps = 0;
+  } else {
+    if (tid < n) {
+      const double di = Ar[tid * LDN + tid];
+      int rank = 0;
+      for (int j = 0; j < n; j++) {
+        const double dj = Ar[j * LDN + j];
+        rank += (dj > di) || (dj == di && j < tid);
+      }
+      perm[rank] = tid;
     }
-    perm[rank] = tid;
+    __syncthreads();
+    double *ev = S->eig_aux, *brp = S->eig_aux + 96;
+    int *gperm = (int *)(S->eig_aux + 192);
+    if (tid < n) gperm[tid] = perm[tid], brp[tid] = br[perm[tid]];
+    sw2 = jacobi_systolic(Ar, LDN, perm, V2, LDN, n, tid, MARG_THREADS, cs, scr, S->rotlog, ev, S->jtrace);  // V2 aliases the dead A
+    if (tid == 0) S->eig_steps = sw2 * (n + (n & 1) - 1);
   }
-  __syncthreads();
-  double *ev = S->eig_aux, *brp = S->eig_aux + 96;
-  int *gperm = (int *)(S->eig_aux + 192);
-  if (tid < n) gperm[tid] = perm[tid], brp[tid] = br[perm[tid]];
-  const int sw2 = jacobi_systolic(Ar, LDN, perm, V2, LDN, n, tid, MARG_THREADS, cs, scr, S->rotlog, ev, S->jtrace);  // V2 aliases the dead A
-  if (tid == 0) S->dbg[24] = sw1, S->dbg[25] = sw2, S->eig_steps = sw2 * (n + (n & 1) - 1);
+  if (tid == 0) S->dbg[24] = sw1, S->dbg[25] = sw2;
   STAMP(S, 14);
   // J0 and r0 follow in k_marg_vecs
   // ---- getParameterBlocks + addr_shift

@@ -536,7 +536,7 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone) {
     hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
   launch_iteration(c, count, g, mode);
   hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag);
-  hipLaunchKernelGGL(k_marg_vecs, dim3(MARG_VEC_WGS, count), dim3(256), 0, c->stream, c->d_base, c->L.total, flag);
+  if (!EIG_TRIDIAG) hipLaunchKernelGGL(k_marg_vecs, dim3(MARG_VEC_WGS, count), dim3(256), 0, c->stream, c->d_base, c->L.total, flag);
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
 }

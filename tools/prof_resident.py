@@ -33,6 +33,7 @@ tr = [struct.unpack("d", struct.pack("q", clk[32 + k]))[0] for k in range(32)]
 print("  jacobi off/diag mass per sweep:", ["%.1e" % v for v in tr[:12]])
 
 mn = {11: "gather", 12: "eig15", 13: "schur+store", 14: "sort+eig76", 15: "J0/r0 out"}
+print("eig_tridiag stages (tridiagonalize, eigenvalues, eigenvectors, back-transform + out):", c[27]-c[26], c[28]-c[27], c[29]-c[28], c[14]-c[29])
 print("k_marg_solve phases:", {mn[k]: c[k] - c[k - 1] for k in range(11, 16)})
 
 print("jacobi step segments, cycles/step (angle, barrier1, rotate+store, barrier2, load):", [int(v / max(1, c[25] * 75)) for v in tr[13:18]])
