@@ -142,6 +142,27 @@ def test_replay_synchronisation_equals_manual_drive(host, stream):
     assert list(got_b["num_samples"][1:9]) == [21] * 8
 
 
+def test_replay_rejects_malformed_traces(host, stream, tmp_path):
+    """Unreadable, foreign and truncated recordings are refused (-3) before anything reaches the estimator; unknown
+    record types are skipped."""
+    path, _ = stream
+    raw = open(path, "rb").read()
+    fresh(host)
+    assert host.replay(str(tmp_path / "missing.lfvt"))[0] == -3
+    for name, blob in (("foreign", b"RIFF" + raw[4:]), ("version", raw[:4] + (2).to_bytes(4, "little") + raw[8:]),
+                       ("truncated", raw[: len(raw) // 2 + 3]), ("short_features", raw[:8] + (2).to_bytes(4, "little") + (16).to_bytes(4, "little") + b"\0" * 16)):
+        f = tmp_path / f"{name}.lfvt"
+        f.write_bytes(blob)
+        rc, st = host.replay(str(f))
+        assert rc == -3 and st["images"] == 0, name
+    assert host.flow()["frame_count"] == 0 and host.flow()["features"] == 0
+    # a record type the reader does not know (here 77) is skipped
+    f = tmp_path / "extra.lfvt"
+    f.write_bytes(raw[:8] + (77).to_bytes(4, "little") + (5).to_bytes(4, "little") + b"hello" + raw[8:])
+    rc, st = host.replay(str(f), "", max_images=5)
+    assert rc == 0 and st["images"] == 5
+
+
 def test_failure_detection_thresholds(host):
     """estimator.cpp:628-674 as shipped: gyro bias > 1, jump > 5 m, z jump > 1 m; the commented-out tests do not fire."""
     w = synth.make_window(3, 10)
