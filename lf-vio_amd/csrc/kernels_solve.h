@@ -687,41 +687,49 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
 }
 
 // ---------------------------------------------------------------------------
-// k_cost: grid (nLmBlocks + 10 + 1, batch) x 64 — candidate point:
-//   landmark blocks: lambda_c = lambda + delta_l, cost of every observation at the candidate,
-//                    landmark part of the model cost change and of the norms
+// k_cost<LPT>: grid (nLmBlocks + 10 + 1, batch) x 64 LPT — candidate point:
+//   landmark blocks: lambda_c = lambda + delta_l, cost of every observation at the candidate, landmark part of the model
+//                    cost change and of the norms
 //   IMU / prior blocks: residual-only evaluation at the candidate
+// LPT = lanes per track (and per row of J0 in the prior block).  4: a track of 11 observations is three deep instead of
+// ten — the latency of a single window; 1: a quarter of the waves for the same work — the throughput of a resident batch.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_cost(char *base, size_t stride, int gLm) {
+template <int LPT>
+__global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, int gLm) {
+  constexpr int COST_THREADS = 64 * LPT, NW = LPT;
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   if (tr->done || tr->chol_fail) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cur = tr->cur, nxt = cur ^ 1;
+  __shared__ double red[4 * 8];
   int b = blockIdx.x;
   if (b < gLm) {
     if (b >= S->nLmBlocks) return;
     const Tab *T = &S->tab[nxt];
     const double cg = tr->cg, cn = tr->cn;
     const double td = S->x[nxt].td;
-    const int l = b * LM_BLOCK + lane;
+    const int lml = tid / LPT, q = tid % LPT;
+    const int l = b * LM_BLOCK + lml;
     double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
     if (l < S->N) {
       const double s = S->scale_l[l];
       const double dl = (cg * S->grad_l[l] + cn * S->gn_l[l]) / S->diag_l[l] * s;
       const double lam = S->lam[cur][l];
       const double lc = lam + dl;
-      S->lam[nxt][l] = lc;
-      dn = dl * dl;
-      xn = lc * lc;
-      // model: -(delta.g) - 1/2 delta^T H delta, landmark rows/cols
-      const double wd = cg * S->d1[l] + cn * S->d2[l];  // w_l . delta_c
-      mlin = dl * S->b[l];
-      mquad = 2.0 * dl * wd + S->a[l] * dl * dl;
+      if (q == 0) {
+        S->lam[nxt][l] = lc;
+        dn = dl * dl;
+        xn = lc * lc;
+        // model: -(delta.g) - 1/2 delta^T H delta, landmark rows/cols
+        const double wd = cg * S->d1[l] + cn * S->d2[l];  // w_l . delta_c
+        mlin = dl * S->b[l];
+        mquad = 2.0 * dl * wd + S->a[l] * dl * dl;
+      }
       const int i = S->lm_start[l], k = S->lm_cnt[l], o0 = S->lm_obs0[l];
       ObsPair ob;
       load_obs(S, o0, ob.pi, ob.vi, ob.tdi, ob.rowi);
-      for (int o = 1; o < k; o++) {
+      for (int o = 1 + q; o < k; o += LPT) {
         const int pair = i * 11 + i + o;
         load_obs(S, o0 + o, ob.pj, ob.vj, ob.tdj, ob.rowj);
         cost += 0.5 * visual_cost(ob, lc, td, S->est_td, S->tr_over_row, S->half_row, S->sqrt_info, ldm(T->T[pair]),
@@ -729,9 +737,12 @@ __global__ __launch_bounds__(64) void k_cost(char *base, size_t stride, int gLm)
       }
     }
     cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn);
-    if (lane == 0) {
-      double *p = S->cost_part + (size_t)b * LMS;
-      p[0] = cost, p[1] = mlin, p[2] = mquad, p[3] = dn, p[4] = xn;
+    if (lane == 0) red[wv * 8] = cost, red[wv * 8 + 1] = mlin, red[wv * 8 + 2] = mquad, red[wv * 8 + 3] = dn, red[wv * 8 + 4] = xn;
+    __syncthreads();
+    if (tid < 5) {
+      double v = red[tid];
+      for (int w = 1; w < NW; w++) v += red[8 * w + tid];
+      S->cost_part[(size_t)b * LMS + tid] = v;
     }
     return;
   }
@@ -741,17 +752,19 @@ __global__ __launch_bounds__(64) void k_cost(char *base, size_t stride, int gLm)
     __shared__ double rr[15];
     double c = 0.0;
     if (S->imu_active[b]) {
-      if (lane == 0) imu_raw_residual(&S->imu[b], S->g, x->pose[b], x->sb[b], x->pose[b + 1], x->sb[b + 1], rr);
+      if (tid == 0) imu_raw_residual(&S->imu[b], S->g, x->pose[b], x->sb[b], x->pose[b + 1], x->sb[b + 1], rr);
       __syncthreads();
-      double v = 0;
-      if (lane < 15) {
-        const double *Sq = S->imu_sqrt[b];
-        for (int k = lane; k < 15; k++) v = fma(Sq[lane * 15 + k], rr[k], v);
-        v = v * v;
+      if (wv == 0) {
+        double v = 0;
+        if (lane < 15) {
+          const double *Sq = S->imu_sqrt[b];
+          for (int k = lane; k < 15; k++) v = fma(Sq[lane * 15 + k], rr[k], v);
+          v = v * v;
+        }
+        c = 0.5 * wave_sum(v);
       }
-      c = 0.5 * wave_sum(v);
     }
-    if (lane == 0) S->pose_cost[b] = c;
+    if (tid == 0) S->pose_cost[b] = c;
     return;
   }
   {
@@ -759,17 +772,28 @@ __global__ __launch_bounds__(64) void k_cost(char *base, size_t stride, int gLm)
     double c = 0.0;
     if (S->prior_valid) {
       const int n = S->prior_n;
-      if (lane < S->prior_nb) prior_block_dx(S, x, lane, dx);
+      if (tid < S->prior_nb) prior_block_dx(S, x, tid, dx);
       __syncthreads();
       const double *J = S->prior_J;
-      for (int row = lane; row < n; row += 64) {
-        double s = S->prior_r[row];
-        for (int cc = 0; cc < n; cc++) s = fma(J[row * n + cc], dx[cc], s);
-        c += s * s;
+      constexpr int CW = 76 / LPT;  // n <= 76: LPT lanes per row, CW columns each
+      const int q = tid % LPT, c0 = q * CW;
+      for (int row = tid / LPT; row < n; row += 64) {
+        double s = 0.0;
+        for (int cc = c0; cc < c0 + CW && cc < n; cc++) s = fma(J[row * n + cc], dx[cc], s);
+        if (LPT == 4) s = quad_sum(s);
+        if (q == 0) {
+          s += S->prior_r[row];
+          c += s * s;
+        }
       }
-      c = 0.5 * wave_sum(c);
+      c = wave_sum(c);
+      if (lane == 0) red[wv] = c;
+      __syncthreads();
+      c = red[0];
+      for (int w = 1; w < NW; w++) c += red[w];
+      c *= 0.5;
     }
-    if (lane == 0) S->pose_cost[10] = c;
+    if (tid == 0) S->pose_cost[10] = c;
   }
 }
 
