@@ -99,7 +99,7 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
 // Stops when the off-diagonal mass is below JACOBI_TOL = 1e-19 of the diagonal mass (off/||A|| < 3e-10: the conditioning
 // error of A' itself is ~1e-10, A_mm carries IMU information ~1e10) or stagnates.  What the sweeps beyond that point do
 // is diagonalize the block of noise eigenvalues (|lambda| ~ 1e-6 against ||A|| ~ 2e6: 1e-23 of the mass) — three more
-// sweeps at linear, not quadratic, rate; per-call parity (tools/fuzz_parity.py) and the chained-window deviation
+// sweeps at linear, not quadratic, rate; per-call parity (tests/tools/fuzz_parity.py) and the chained-window deviation
 // (tests/test_flow.py) are the same with 1e-24 and with 1e-19, with 1e-17 the chains start to differ.
 // round-robin pairing of step `step`: slot k rotates (step+k, step-k) mod (np-1), slot 0 pairs the fixed index np-1.
 // q = -1 marks the dummy index of an odd n.  Consecutive slots give consecutive rows / columns (no p<q reordering),

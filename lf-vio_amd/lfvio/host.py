@@ -21,7 +21,8 @@ def _f(a):
 
 class HostEstimator:
     def __init__(self, lib_path=None):
-        """lib_path: tests pass the oracle-linked build of the same sources (oracle/liblfvio_host_oracle.so) here."""
+        """lib_path: another build of the same host sources (the test suite links one against its CPU checker); the
+        default is the product build over liblfvio_hip.so, and there is no fallback if that is missing."""
         lib_path = lib_path or HOST_LIB_PATH
         if not os.path.exists(lib_path):
             raise RuntimeError(f"{lib_path} not found: run __graft_entry__.build()")

@@ -203,7 +203,7 @@ def test_sequence_of_windows_tracks_the_oracle(eng, oracle):
 
 def test_randomized_sweep_against_the_oracle(eng, oracle):
     """60 random (seed, size, flags, max_iterations, marginalization flag, with / without prior) combinations of the whole
-    optimization() — the cases tools/fuzz_parity.py draws.  Tiny windows sit close to the conditioning limits of the
+    optimization() — the cases tests/tools/fuzz_parity.py draws.  Tiny windows sit close to the conditioning limits of the
     algorithm itself, hence the slightly wider bars on inverse depths and on the prior; a prior whose information is
     pure cancellation noise (no frame-0 landmark, no input prior: a lone IMU factor marginalized) is not compared."""
     rng = np.random.default_rng(20260928)

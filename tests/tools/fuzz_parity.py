@@ -1,7 +1,7 @@
 """Randomized parity sweep: GPU optimization() against the oracle over many seeds / sizes / flags (bring-up tool).
 Prints the cases that violate the parity bar of tests/test_gpu_parity.py."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd"))
 import numpy as np
 from lfvio import abi, synth

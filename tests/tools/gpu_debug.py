@@ -1,6 +1,6 @@
 """One-shot GPU diagnostics: HIP path vs oracle, verbose (used during bring-up)."""
 import os, sys, time, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from lfvio import abi, synth

@@ -1,7 +1,7 @@
 """lfvio_preintegrate: whole call (host buffers in / out) for the ten intervals of one window and for a batch of windows,
 beside the CPU oracle; under rocprofv3 --kernel-trace the k_preintegrate rows give the kernel alone."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd"))
 import numpy as np
 from lfvio import abi, synth

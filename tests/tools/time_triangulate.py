@@ -1,6 +1,6 @@
 """lfvio_triangulate at a given window size: whole call (host buffers in / out) and, under rocprofv3, the kernel alone."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd"))
 import numpy as np
 from lfvio import abi, synth
