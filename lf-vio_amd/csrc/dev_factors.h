@@ -130,31 +130,42 @@ DEV void visual_basis(const ObsPair &ob, double lam, double td, int est_td, doub
 
 // Block-cooperative construction of the per-frame / per-pair table for one state.
 // Call with >= 128 threads; contains __syncthreads().
-DEV void build_tab(const FrameState *x, Tab *t, int tid) {
+// Per-frame and per-pair quantities of one linearization point.  poses: 12 x 7 doubles in LDS (pose[0..10], ex_pose);
+// lds: >= 256 doubles of scratch.  The intermediate results travel through LDS (a global write -> barrier -> read by
+// another thread is a full memory round trip each time, and there are two of them), the table itself is written once.
+// Needs >= 121 threads; every thread of the workgroup has to come here (barriers inside).
+DEV void build_tab(const double *poses, Tab *t, int tid, double *lds) {
+  double *R = lds, *P = lds + 99, *ric = lds + 132, *ricT = lds + 141, *tic = lds + 150, *M1 = lds + 153;  // .. 252
   if (tid < 11) {
-    m33 R = q2R(q_from_pose(x->pose[tid]));
-    stm(t->R[tid], R);
-    t->P[tid][0] = x->pose[tid][0], t->P[tid][1] = x->pose[tid][1], t->P[tid][2] = x->pose[tid][2];
+    const double *p = poses + 7 * tid;
+    const m33 r = q2R(q_from_pose(p));
+    stm(R + 9 * tid, r), stm(t->R[tid], r);
+#pragma unroll
+    for (int k = 0; k < 3; k++) P[3 * tid + k] = p[k], t->P[tid][k] = p[k];
   } else if (tid == 11) {
-    m33 ric = q2R(q_from_pose(x->ex));
-    stm(t->ric, ric);
-    stm(t->ricT, tr(ric));
-    t->tic[0] = x->ex[0], t->tic[1] = x->ex[1], t->tic[2] = x->ex[2];
+    const double *p = poses + 77;
+    const m33 r = q2R(q_from_pose(p)), rT = tr(r);
+    stm(ric, r), stm(ricT, rT), stm(t->ric, r), stm(t->ricT, rT);
+#pragma unroll
+    for (int k = 0; k < 3; k++) tic[k] = p[k], t->tic[k] = p[k];
   }
   __syncthreads();
-  if (tid < 11) stm(t->M1[tid], mm(ldm(t->ricT), tr(ldm(t->R[tid]))));
+  if (tid < 11) {
+    const m33 m = mm(ldm(ricT), tr(ldm(R + 9 * tid)));
+    stm(M1 + 9 * tid, m), stm(t->M1[tid], m);
+  }
   __syncthreads();
   if (tid < NPAIR) {
-    int i = tid / 11, j = tid % 11;
+    const int i = tid / 11, j = tid % 11;
     if (i < j) {
-      m33 Ri = ldm(t->R[i]), ric = ldm(t->ric);
-      m33 M2 = mm(ldm(t->M1[j]), Ri);
+      const m33 Ri = ldm(R + 9 * i), rc = ldm(ric);
+      const m33 M2 = mm(ldm(M1 + 9 * j), Ri);
       stm(t->M2[tid], M2);
-      stm(t->T[tid], mm(M2, ric));
-      d3 tic = ld3(t->tic);
-      d3 v = mul(Ri, tic) + ld3(t->P[i]) - ld3(t->P[j]);
-      m33 RjT = tr(ldm(t->R[j]));
-      d3 cc = mul(ldm(t->ricT), mul(RjT, v) - tic);
+      stm(t->T[tid], mm(M2, rc));
+      const d3 tc = ld3(tic);
+      const d3 v = mul(Ri, tc) + ld3(P + 3 * i) - ld3(P + 3 * j);
+      const m33 RjT = tr(ldm(R + 9 * j));
+      const d3 cc = mul(ldm(ricT), mul(RjT, v) - tc);
       t->c[tid][0] = cc.x, t->c[tid][1] = cc.y, t->c[tid][2] = cc.z;
     }
   }

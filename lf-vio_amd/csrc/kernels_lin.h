@@ -50,8 +50,11 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       t->new_point = 0;
       if (mode >= MODE_MARG) t->mu = 0.0;
     }
+    __shared__ double bt[84 + 256];
+    if (tid < 77) bt[tid] = (&S->x0.pose[0][0])[tid];
+    else if (tid < 84) bt[tid] = S->x0.ex[tid - 77];
     __syncthreads();
-    build_tab(&S->x0, &S->tab[0], tid);
+    build_tab(bt, &S->tab[0], tid, bt + 84);
   } else if (blockIdx.x <= LFVIO_WINDOW_SIZE) {
     // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64), hoisted out of the iteration loop:
     // the reference recomputes it in every Evaluate().  One factor per workgroup: Gauss-Jordan with

@@ -74,12 +74,17 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
     qn = R2q(q2R(q_from_pose(x->ex)));  // ric = Quaterniond(para_Ex_Pose).toRotationMatrix(); Quaterniond{ric}
   }
   __syncthreads();
+  __shared__ double bt[84 + 256];  // the re-anchored poses for build_tab, and its scratch
   if (tid < 11) {
-    x->pose[tid][0] = Psi.x, x->pose[tid][1] = Psi.y, x->pose[tid][2] = Psi.z;
-    x->pose[tid][3] = qn.x, x->pose[tid][4] = qn.y, x->pose[tid][5] = qn.z, x->pose[tid][6] = qn.w;
+    const double pn[7] = {Psi.x, Psi.y, Psi.z, qn.x, qn.y, qn.z, qn.w};
+#pragma unroll
+    for (int k = 0; k < 7; k++) x->pose[tid][k] = pn[k], bt[7 * tid + k] = pn[k];
     x->sb[tid][0] = Vsi.x, x->sb[tid][1] = Vsi.y, x->sb[tid][2] = Vsi.z;
   } else if (tid == 11) {
     x->ex[3] = qn.x, x->ex[4] = qn.y, x->ex[5] = qn.z, x->ex[6] = qn.w;
+#pragma unroll
+    for (int k = 0; k < 3; k++) bt[77 + k] = x->ex[k];
+    bt[80] = qn.x, bt[81] = qn.y, bt[82] = qn.z, bt[83] = qn.w;
   }
   __syncthreads();
   if (tid == 0) {
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
     ts->do_schur = 1;
     ts->chol_fail = 0;
   }
-  build_tab(x, &S->tab[ts->cur], tid);
+  build_tab(bt, &S->tab[ts->cur], tid, bt + 84);
 }
 
 // Parallel cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (LDS, ld = n).

@@ -551,30 +551,62 @@ __global__ __launch_bounds__(64) void k_backsub(char *base, size_t stride) {
 __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
-  if (tr->done || tr->chol_fail) return;
   const int tid = threadIdx.x;
-  __shared__ double sh[4], sh2[2];
-  __shared__ double delta[KP];
-  // total norms: pose side (k_solve) + landmark partials (k_backsub)
-  const int do_schur = tr->do_schur;
+  // The kernel is one chain of small dependent steps; a load issued behind a branch or a barrier costs a full memory
+  // round trip (~0.6 us) of its own, so everything that is read — the header, this thread's piece of the state, of the
+  // gradient and of the step vectors, the landmark partials — is requested here in one batch, before the first use.
+  const TRHead t = *reinterpret_cast<const TRHead *>(tr);
+  const int sharded = S->sharded, nLmBlocks = S->nLmBlocks, est_ex = S->est_ex, est_td = S->est_td;
+  const int cur = t.cur, do_schur = t.do_schur;
+  const FrameState *x = &S->x[cur];
+  FrameState *xc = &S->x[cur ^ 1];
+  const double lm4 = sharded ? 0.0 : S->lm_sum[4];
+  const double xg0 = sharded ? S->xch[XOFF_C + XS_GN2] : 0.0, xg1 = sharded ? S->xch[XOFF_C + XS_GGN] : 0.0;
+  double xb[7] = {0, 0, 0, 0, 0, 0, 0}, gpv[6] = {0, 0, 0, 0, 0, 0};
+  const int role = tid < 12 ? 0 : (tid >= 16 && tid < 16 + 99) ? 1 : tid == 120 ? 2 : 3;
+  const int po = tid < 11 ? off_pose(tid) : off_ex();
+  if (role == 0) {
+    const double *src = tid < 11 ? x->pose[tid] : x->ex;
+#pragma unroll
+    for (int k = 0; k < 7; k++) xb[k] = src[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) gpv[k] = S->gp[po + k];
+  } else if (role == 1) {
+    const int e = tid - 16;
+    xb[0] = x->sb[e / 9][e % 9], gpv[0] = S->gp[off_sb(0) + e];
+  } else if (role == 2) {
+    xb[0] = x->td, gpv[0] = S->gp[off_td()];
+  }
+  double vgr[2], vgn[2], vdg[2], vsc[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int i = tid + 128 * q;
+    const bool in = i < KP;
+    vgr[q] = in ? S->grad_p[i] : 0.0, vgn[q] = in ? S->gn_p[i] : 0.0, vdg[q] = in ? S->diag_p[i] : 1.0, vsc[q] = in ? S->scale_p[i] : 0.0;
+  }
   double a = 0, b = 0;
   if (do_schur)
-    for (int k = tid; k < S->nLmBlocks; k += 128) {
+    for (int k = tid; k < nLmBlocks; k += 128) {
       a += S->lm_part[(size_t)k * LMS + 8];
       b += S->lm_part[(size_t)k * LMS + 9];
     }
+  const int last_ok = t.trace_len > 0 ? tr->trace[t.trace_len - 1].step_is_successful : 0;
+  if (t.done || t.chol_fail) return;
+  __shared__ double sh[4], sh2[2];
+  __shared__ double delta[KP];
+  __shared__ double cand[84 + 256];  // candidate poses (pose[0..10], ex) for build_tab, and its scratch
+  // total norms: pose side (k_solve) + landmark partials (k_backsub)
   a = wave_sum(a), b = wave_sum(b);
   if ((tid & 63) == 0) sh[(tid >> 6) * 2] = a, sh[(tid >> 6) * 2 + 1] = b;
   __syncthreads();
   if (tid == 0) {
-    // scalars in one batch of loads; results go back in one batch and reach the other lanes through LDS
-    double gn_sq_total = tr->gn_sq_total, grad_gn_total = tr->grad_gn_total;
-    const double grad_sq_total = tr->grad_sq_total, radius = tr->radius, alpha = tr->alpha;
+    double gn_sq_total = t.gn_sq_total, grad_gn_total = t.grad_gn_total;
+    const double grad_sq_total = t.grad_sq_total, radius = t.radius, alpha = t.alpha;
     if (do_schur) {
       double lgn = sh[0] + sh[2], lgg = sh[1] + sh[3];
-      if (S->sharded) lgn = S->xch[XOFF_C + XS_GN2], lgg = S->xch[XOFF_C + XS_GGN];  // all-reduced (k_xpack 2)
-      gn_sq_total = tr->q[Q_GN_SQ] + lgn;
-      grad_gn_total = tr->q[Q_GRAD_GN] + lgg;
+      if (sharded) lgn = xg0, lgg = xg1;  // all-reduced (k_xpack 2)
+      gn_sq_total = t.q[Q_GN_SQ] + lgn;
+      grad_gn_total = t.q[Q_GRAD_GN] + lgg;
       tr->gn_sq_total = gn_sq_total;
       tr->grad_gn_total = grad_gn_total;
     }
@@ -600,37 +632,31 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
   }
   __syncthreads();
   const double cg = sh2[0], cn = sh2[1];
-  const int cur = tr->cur;
-  const FrameState *x = &S->x[cur];
-  FrameState *xc = &S->x[cur ^ 1];
-  if (tr->new_point) {
+  if (t.new_point) {
     // gradient_max_norm = max |x - Plus(x, -g)| (EvaluateGradientAndJacobian), pose side + landmarks
     double mx = 0;
-    if (tid < 12) {
-      const double *xb = tid < 11 ? x->pose[tid] : x->ex;
-      const int o = tid < 11 ? off_pose(tid) : off_ex();
-      if (tid < 11 || S->est_ex) {
+    if (role == 0) {
+      if (tid < 11 || est_ex) {
         double d[6], xo[7];
-        for (int k = 0; k < 6; k++) d[k] = -S->gp[o + k];
+        for (int k = 0; k < 6; k++) d[k] = -gpv[k];
         pose_plus(xb, d, xo);
         for (int k = 0; k < 7; k++) mx = fmax(mx, fabs(xb[k] - xo[k]));
       }
-    } else if (tid >= 16 && tid < 16 + 99) {
-      mx = fabs(S->gp[off_sb(0) + tid - 16]);
-    } else if (tid == 120 && S->est_td) {
-      mx = fabs(S->gp[off_td()]);
+    } else if (role == 1) {
+      mx = fabs(gpv[0]);
+    } else if (role == 2 && est_td) {
+      mx = fabs(gpv[0]);
     }
     mx = wave_max(mx);
     __syncthreads();
     if ((tid & 63) == 0) sh[tid >> 6] = mx;
     __syncthreads();
     if (tid == 0) {
-      const double gm = fmax(fmax(sh[0], sh[1]), S->sharded ? tr->lm_bmax : S->lm_sum[4]);
+      const double gm = fmax(fmax(sh[0], sh[1]), sharded ? t.lm_bmax : lm4);
       tr->gmax_pose = gm;
-      if (tr->trace_len > 0) {
-        LfvioIterationSummary *last = &tr->trace[tr->trace_len - 1];
-        last->gradient_max_norm = gm;
-        if (last->step_is_successful && gm <= 1e-10) {  // GradientToleranceReached
+      if (t.trace_len > 0) {
+        tr->trace[t.trace_len - 1].gradient_max_norm = gm;
+        if (last_ok && gm <= 1e-10) {  // GradientToleranceReached
           tr->termination = LFVIO_CONVERGENCE;
           tr->done = 1;
         }
@@ -640,50 +666,53 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
     __syncthreads();
   }
   // delta = (step / diagonal_) * scale, step = cg gradient_ + cn gauss_newton_
-  for (int i = tid; i < KP; i += 128) {
-    const double st = (cg * S->grad_p[i] + cn * S->gn_p[i]) / S->diag_p[i];
-    double d = st * S->scale_p[i];
-    if (!col_active(S, i, MODE_SOLVE)) d = 0.0;
-    delta[i] = d;
-    S->step_p[i] = d;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int i = tid + 128 * q;
+    if (i < KP) {
+      double d = (cg * vgr[q] + cn * vgn[q]) / vdg[q] * vsc[q];
+      const bool act = (est_ex || i < off_ex() || i >= off_ex() + 6) && (est_td || i != off_td());
+      if (!act) d = 0.0;
+      delta[i] = d;
+      S->step_p[i] = d;
+    }
   }
   __syncthreads();
   // candidate = Plus(x, delta); ambient step norm and candidate norm, pose side
   double dn = 0, xn = 0;
-  if (tid < 12) {
-    const double *xb = tid < 11 ? x->pose[tid] : x->ex;
+  if (role == 0) {
     double *xo = tid < 11 ? xc->pose[tid] : xc->ex;
-    const int o = tid < 11 ? off_pose(tid) : off_ex();
-    if (tid < 11 || S->est_ex) {
-      pose_plus(xb, delta + o, xo);
-      for (int k = 0; k < 7; k++) dn += (xb[k] - xo[k]) * (xb[k] - xo[k]), xn += xo[k] * xo[k];
+    double xv[7];
+    if (tid < 11 || est_ex) {
+      pose_plus(xb, delta + po, xv);
+      for (int k = 0; k < 7; k++) dn += (xb[k] - xv[k]) * (xb[k] - xv[k]), xn += xv[k] * xv[k];
     } else {
-      for (int k = 0; k < 7; k++) xo[k] = xb[k];
+      for (int k = 0; k < 7; k++) xv[k] = xb[k];
     }
-  } else if (tid >= 16 && tid < 16 + 99) {
+    for (int k = 0; k < 7; k++) xo[k] = xv[k], cand[7 * tid + k] = xv[k];
+  } else if (role == 1) {
     const int e = tid - 16, f = e / 9, k = e % 9;
-    const double v = x->sb[f][k] + delta[off_sb(f) + k];
+    const double v = xb[0] + delta[off_sb(f) + k];
     xc->sb[f][k] = v;
-    dn = (v - x->sb[f][k]) * (v - x->sb[f][k]);
+    dn = (v - xb[0]) * (v - xb[0]);
     xn = v * v;
-  } else if (tid == 120) {
-    double v = x->td;
-    if (S->est_td) {
-      v = x->td + delta[off_td()];
-      dn = (v - x->td) * (v - x->td);
+  } else if (role == 2) {
+    double v = xb[0];
+    if (est_td) {
+      v = xb[0] + delta[off_td()];
+      dn = (v - xb[0]) * (v - xb[0]);
       xn = v * v;
     }
     xc->td = v;
   }
   dn = wave_sum(dn), xn = wave_sum(xn);
-  __syncthreads();
   if ((tid & 63) == 0) sh[(tid >> 6) * 2] = dn, sh[(tid >> 6) * 2 + 1] = xn;
   __syncthreads();
   if (tid == 0) {
     tr->step_sq_pose = sh[0] + sh[2];
     tr->xn2_pose_cand = sh[1] + sh[3];
   }
-  build_tab(xc, &S->tab[cur ^ 1], tid);
+  build_tab(cand, &S->tab[cur ^ 1], tid, cand + 84);
 }
 
 // ---------------------------------------------------------------------------
