@@ -728,15 +728,17 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
   constexpr int COST_THREADS = 64 * LPT, NW = LPT;
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
-  if (tr->done || tr->chol_fail) return;
+  // header fields in one batch of loads, before the first branch (a load behind a branch is a round trip of its own)
+  const int done = tr->done, chol_fail = tr->chol_fail, cur = tr->cur;
+  const double cg = tr->cg, cn = tr->cn;
+  if (done || chol_fail) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int cur = tr->cur, nxt = cur ^ 1;
+  const int nxt = cur ^ 1;
   __shared__ double red[4 * 8];
   int b = blockIdx.x;
   if (b < gLm) {
     if (b >= S->nLmBlocks) return;
     const Tab *T = &S->tab[nxt];
-    const double cg = tr->cg, cn = tr->cn;
     const double td = S->x[nxt].td;
     const int lml = tid / LPT, q = tid % LPT;
     const int l = b * LM_BLOCK + lml;
@@ -758,11 +760,36 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
       const int i = S->lm_start[l], k = S->lm_cnt[l], o0 = S->lm_obs0[l];
       ObsPair ob;
       load_obs(S, o0, ob.pi, ob.vi, ob.tdi, ob.rowi);
-      for (int o = 1 + q; o < k; o += LPT) {
-        const int pair = i * 11 + i + o;
-        load_obs(S, o0 + o, ob.pj, ob.vj, ob.tdj, ob.rowj);
-        cost += 0.5 * visual_cost(ob, lc, td, S->est_td, S->tr_over_row, S->half_row, S->sqrt_info, ldm(T->T[pair]),
-                                  ld3(T->c[pair]));
+      if (LPT == 4) {
+        // at most three observations per lane (tracks are <= 11 long): all of them and their pair tables are requested
+        // before the first residual is formed
+        ObsPair obq[3];
+        m33 Tq[3];
+        d3 cq[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int o = 1 + q + 4 * u;
+          if (o < k) {
+            const int pair = i * 11 + i + o;
+            load_obs(S, o0 + o, obq[u].pj, obq[u].vj, obq[u].tdj, obq[u].rowj);
+            Tq[u] = ldm(T->T[pair]), cq[u] = ld3(T->c[pair]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int o = 1 + q + 4 * u;
+          if (o < k) {
+            obq[u].pi = ob.pi, obq[u].vi = ob.vi, obq[u].tdi = ob.tdi, obq[u].rowi = ob.rowi;
+            cost += 0.5 * visual_cost(obq[u], lc, td, S->est_td, S->tr_over_row, S->half_row, S->sqrt_info, Tq[u], cq[u]);
+          }
+        }
+      } else {
+        for (int o = 1 + q; o < k; o += LPT) {
+          const int pair = i * 11 + i + o;
+          load_obs(S, o0 + o, ob.pj, ob.vj, ob.tdj, ob.rowj);
+          cost += 0.5 * visual_cost(ob, lc, td, S->est_td, S->tr_over_row, S->half_row, S->sqrt_info, ldm(T->T[pair]),
+                                    ld3(T->c[pair]));
+        }
       }
     }
     cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn);
