@@ -108,6 +108,13 @@ struct TRState {
   LfvioIterationSummary trace[LFVIO_MAX_TRACE];
 };
 
+// the eight int flags at the head of the int block of TRHead, fetched with ONE load: the guards at the top of every
+// kernel of the loop test two or three of them, and each separate (dependent, short-circuited) load is a memory round trip
+struct __attribute__((aligned(8))) TRFlags {
+  int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled;
+};
+__device__ __forceinline__ TRFlags tr_flags(const TRState *tr) { return *reinterpret_cast<const TRFlags *>(&tr->iteration); }
+
 struct MargPlan {  // structure of the marginalization, computed on the host at upload
   int valid;       // 0: nothing to do (MARGIN_SECOND_NEW without a prior touching Pose[9])
   int m15;         // dropped pose-side dims (15 for MARGIN_OLD, 6 for SECOND_NEW)

@@ -565,8 +565,9 @@ DEV void lin_prior_role(Slot *S, int mode, double *lds) {
 __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode, int gLm, int gCh) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
-  const int do_lin = tr->do_lin, do_schur = tr->do_schur;
-  if (tr->done || (!do_lin && !do_schur)) return;
+  const TRFlags fl = tr_flags(tr);
+  const int do_lin = fl.do_lin, do_schur = fl.do_schur;
+  if (fl.done | (!do_lin & !do_schur)) return;
   __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLm, gCh); each slot uses its own counts
   int b = blockIdx.x;
@@ -665,7 +666,10 @@ __global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int m
   const int PRE_SCHUR_BLOCKS = (SCHUR_LEN / 256) * groups;
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
-  if (tr->done) return;
+  {
+    const TRFlags fl = tr_flags(tr);
+    if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
+  }
   const int tid = threadIdx.x;
   int b = blockIdx.x;
   if (b < NPAIR) {
@@ -733,7 +737,10 @@ __global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int m
 __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode, int pre) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
-  if (tr->done) return;
+  {
+    const TRFlags fl = tr_flags(tr);
+    if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
+  }
   const int tid = threadIdx.x;
   int b = blockIdx.x;
   if (b < HPP_BLOCKS) {

@@ -85,7 +85,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
-  if (tr->done || !tr->do_schur) return;
+  {
+    const TRFlags fl = tr_flags(tr);
+    if (fl.done | !fl.do_schur) return;
+  }
   const int tid = threadIdx.x;
   double *Hs = smem;                 // TPACK: H_pp, then S, then L as 16 x 16 tiles (rhs row = row 172)
   double *Ld = Hs + TPACK;           // 16 x 16: the diagonal block just factored, plain, TRANSPOSED (panel solve); later rhs
@@ -504,7 +507,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
 __global__ __launch_bounds__(64) void k_backsub(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
-  if (tr->done || !tr->do_schur || tr->chol_fail) return;
+  {
+    const TRFlags fl = tr_flags(tr);
+    if (fl.done | !fl.do_schur | fl.chol_fail) return;
+  }
   __shared__ double ug[WLD], un[WLD];
   const int lane = threadIdx.x;
   for (int c = lane; c < WLD; c += 64) ug[c] = S->uc_grad[c], un[c] = S->uc_gn[c];
@@ -729,9 +735,10 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   // header fields in one batch of loads, before the first branch (a load behind a branch is a round trip of its own)
-  const int done = tr->done, chol_fail = tr->chol_fail, cur = tr->cur;
+  const TRFlags fl = tr_flags(tr);
+  const int cur = fl.cur;
   const double cg = tr->cg, cn = tr->cn;
-  if (done || chol_fail) return;
+  if (fl.done | fl.chol_fail) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nxt = cur ^ 1;
   __shared__ double red[4 * 8];

@@ -54,6 +54,24 @@ def main():
                 for row in rows:
                     row[0] = short(row[0])
                     wr.writerow(row)
+        # 2b. the captured graph launches every kernel of the trust-region loop in every pass; passes that have nothing
+        #     to do return at once, so the plain average of the statistics mixes two populations.  From the same trace:
+        #     the launches that did the work (longer than a quarter of the longest) and the ones that returned early.
+        for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+            dur = defaultdict(list)
+            for r_ in csv.DictReader(open(f)):
+                dur[short(r_["Kernel_Name"])].append(int(r_["End_Timestamp"]) - int(r_["Start_Timestamp"]))
+            lines = ["# launches of the same rocprofv3 --kernel-trace run, split at a quarter of the longest launch of each kernel", "",
+                     "| kernel | launches | working launches | mean us | early returns | mean us |", "|---|---|---|---|---|---|"]
+            for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+                if k.startswith("__amd"):
+                    continue
+                thr = 0.25 * max(v)
+                act = [x for x in v if x >= thr]
+                idle = [x for x in v if x < thr]
+                lines.append(f"| {k} | {len(v)} | {len(act)} | {sum(act) / max(len(act), 1) / 1e3:.2f} | {len(idle)} | "
+                             f"{sum(idle) / max(len(idle), 1) / 1e3:.2f} |")
+            open(os.path.join(OUT, f"bench_{w}_launches.md"), "w").write("\n".join(lines) + "\n")
     # 3. PMC passes (window300 and window100k)
     md = ["# PMC summary — rocprofv3 --pmc, separate passes, values per launch (mean over launches)", "",
           "FETCH_SIZE / WRITE_SIZE are KB as rocprofv3 reports them.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide",
