@@ -554,10 +554,14 @@ __global__ __launch_bounds__(64) void k_backsub(char *base, size_t stride) {
 // k_dogleg: grid (1, batch) x 128 — ComputeTraditionalDoglegStep, candidate pose-side state,
 // per-pair table of the candidate.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
+// inline_backsub != 0 (windows of at most DOGLEG_INLINE_BLOCKS landmark blocks, launched with DOGLEG_INLINE_THREADS):
+// the landmark part of the Gauss-Newton step (k_backsub) is formed here, one landmark per thread, and that launch is left
+// out of the pass — at this size a kernel is a few microseconds of launch and first-load latency whatever it does.
+constexpr int DOGLEG_INLINE_BLOCKS = 5, DOGLEG_INLINE_THREADS = 64 * DOGLEG_INLINE_BLOCKS;
+__global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, size_t stride, int inline_backsub) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
   // The kernel is one chain of small dependent steps; a load issued behind a branch or a barrier costs a full memory
   // round trip (~0.6 us) of its own, so everything that is read — the header, this thread's piece of the state, of the
   // gradient and of the step vectors, the landmark partials — is requested here in one batch, before the first use.
@@ -586,21 +590,54 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
   double vgr[2], vgn[2], vdg[2], vsc[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const int i = tid + 128 * q;
+    const int i = tid + nthr * q;
     const bool in = i < KP;
     vgr[q] = in ? S->grad_p[i] : 0.0, vgn[q] = in ? S->gn_p[i] : 0.0, vdg[q] = in ? S->diag_p[i] : 1.0, vsc[q] = in ? S->scale_p[i] : 0.0;
   }
   double a = 0, b = 0;
-  if (do_schur)
-    for (int k = tid; k < nLmBlocks; k += 128) {
+  if (do_schur && !inline_backsub)
+    for (int k = tid; k < nLmBlocks; k += nthr) {
       a += S->lm_part[(size_t)k * LMS + 8];
       b += S->lm_part[(size_t)k * LMS + 9];
     }
   const int last_ok = t.trace_len > 0 ? tr->trace[t.trace_len - 1].step_is_successful : 0;
   if (t.done || t.chol_fail) return;
-  __shared__ double sh[4], sh2[2];
+  __shared__ double sh[2 * DOGLEG_INLINE_BLOCKS], sh2[2];
   __shared__ double delta[KP];
   __shared__ double cand[84 + 256];  // candidate poses (pose[0..10], ex) for build_tab, and its scratch
+  if (do_schur && inline_backsub) {
+    // k_backsub, one landmark per thread:  y_l = (s_l b_l - s_l w_l . (S_c y_c)) / e_l,  gauss_newton_l = -diagonal_l y_l,
+    // and the two dot products w_l . G_c, w_l . N_c every dogleg interpolant needs
+    double *ug = cand, *un = cand + WLD;
+    for (int c = tid; c < WLD; c += nthr) ug[c] = S->uc_grad[c], un[c] = S->uc_gn[c];
+    __syncthreads();
+    const int l = tid;
+    if (l < S->N) {
+      const double *w = S->W + (size_t)l * WLD;
+      const int lo = 6 * S->lm_start[l], hi = lo + 6 * S->lm_cnt[l];
+      double d1 = 0, d2 = 0;
+      for (int c = lo; c < hi; c++) {
+        const double wc = w[c];
+        d1 = fma(wc, ug[c], d1);
+        d2 = fma(wc, un[c], d2);
+      }
+#pragma unroll
+      for (int c = 66; c < KC; c++) {
+        const double wc = w[c];
+        d1 = fma(wc, ug[c], d1);
+        d2 = fma(wc, un[c], d2);
+      }
+      const double s = S->scale_l[l];
+      const double y = (s * S->b[l] + s * d2) * S->einv_l[l];
+      const double gn = -S->diag_l[l] * y;
+      S->gn_l[l] = gn;
+      S->d1[l] = d1;
+      S->d2[l] = d2;
+      a = gn * gn;
+      b = S->grad_l[l] * gn;
+    }
+    __syncthreads();  // ug / un alias cand
+  }
   // total norms: pose side (k_solve) + landmark partials (k_backsub)
   a = wave_sum(a), b = wave_sum(b);
   if ((tid & 63) == 0) sh[(tid >> 6) * 2] = a, sh[(tid >> 6) * 2 + 1] = b;
@@ -609,7 +646,8 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
     double gn_sq_total = t.gn_sq_total, grad_gn_total = t.grad_gn_total;
     const double grad_sq_total = t.grad_sq_total, radius = t.radius, alpha = t.alpha;
     if (do_schur) {
-      double lgn = sh[0] + sh[2], lgg = sh[1] + sh[3];
+      double lgn = 0, lgg = 0;
+      for (int w = 0; w < nwv; w++) lgn += sh[2 * w], lgg += sh[2 * w + 1];
       if (sharded) lgn = xg0, lgg = xg1;  // all-reduced (k_xpack 2)
       gn_sq_total = t.q[Q_GN_SQ] + lgn;
       grad_gn_total = t.q[Q_GRAD_GN] + lgg;
@@ -658,7 +696,8 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
     if ((tid & 63) == 0) sh[tid >> 6] = mx;
     __syncthreads();
     if (tid == 0) {
-      const double gm = fmax(fmax(sh[0], sh[1]), sharded ? t.lm_bmax : lm4);
+      double gm = sharded ? t.lm_bmax : lm4;
+      for (int w = 0; w < nwv; w++) gm = fmax(gm, sh[w]);
       tr->gmax_pose = gm;
       if (t.trace_len > 0) {
         tr->trace[t.trace_len - 1].gradient_max_norm = gm;
@@ -674,7 +713,7 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
   // delta = (step / diagonal_) * scale, step = cg gradient_ + cn gauss_newton_
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const int i = tid + 128 * q;
+    const int i = tid + nthr * q;
     if (i < KP) {
       double d = (cg * vgr[q] + cn * vgn[q]) / vdg[q] * vsc[q];
       const bool act = (est_ex || i < off_ex() || i >= off_ex() + 6) && (est_td || i != off_td());
@@ -715,8 +754,10 @@ __global__ __launch_bounds__(128) void k_dogleg(char *base, size_t stride) {
   if ((tid & 63) == 0) sh[(tid >> 6) * 2] = dn, sh[(tid >> 6) * 2 + 1] = xn;
   __syncthreads();
   if (tid == 0) {
-    tr->step_sq_pose = sh[0] + sh[2];
-    tr->xn2_pose_cand = sh[1] + sh[3];
+    double sdn = 0, sxn = 0;
+    for (int w = 0; w < nwv; w++) sdn += sh[2 * w], sxn += sh[2 * w + 1];
+    tr->step_sq_pose = sdn;
+    tr->xn2_pose_cand = sxn;
   }
   build_tab(cand, &S->tab[cur ^ 1], tid, cand + 84);
 }

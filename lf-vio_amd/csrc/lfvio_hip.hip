@@ -497,8 +497,10 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
   launch_sum(c, count, g, mode);
   if (mode == MODE_SOLVE) {
     hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
-    hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
-    hipLaunchKernelGGL(k_dogleg, dim3(1, count), dim3(128), 0, c->stream, c->d_base, st);
+    // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
+    const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
+    if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
+    hipLaunchKernelGGL(k_dogleg, dim3(1, count), dim3(inl ? DOGLEG_INLINE_THREADS : 128), 0, c->stream, c->d_base, st, inl ? 1 : 0);
     // four lanes per track while the GPU has room for the extra waves (latency of few windows), one when a batch fills it
     if ((size_t)count * (g.lm + LFVIO_WINDOW_SIZE + 1) <= 512)
       hipLaunchKernelGGL(k_cost<4>, dim3(g.lm + LFVIO_WINDOW_SIZE + 1, count), dim3(256), 0, c->stream, c->d_base, st, g.lm);
