@@ -88,6 +88,11 @@ enum {
 // The scalar part of the trust-region state.  TRHead and TRState share it as a common initial sequence, so the single-lane
 // bookkeeping kernels can copy it to registers in one batch of loads (reinterpret_cast<TRHead *>) while Slot stays a
 // standard-layout type for offsetof on the host.
+// Speculative trust-region candidates (small windows): the radii Ceres tries after rejected steps are known in advance
+// (radius / 2 each time), so one pass can evaluate the step for radius, radius / 2, radius / 4 and k_decide walks through
+// them in Ceres' order.  Candidate 0 lives in x[cur ^ 1] / tab[cur ^ 1] / lam[cur ^ 1] as always, candidates 1, 2 in
+// the *E slots and are copied over when one of them is the accepted step.
+constexpr int SPEC_EXTRA = 2, SPEC_MAX_LM = 320;
 #define TR_HEAD_FIELDS \
   double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha; \
   double cg, cn; \
@@ -98,7 +103,9 @@ enum {
   double initial_cost; \
   double q[Q_COUNT]; \
   int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled; \
-  int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, new_point;
+  int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, new_point; \
+  int spec_n, spec_pad_; \
+  double cgE[SPEC_EXTRA], cnE[SPEC_EXTRA], snE[SPEC_EXTRA], step_sqE[SPEC_EXTRA], xn2E[SPEC_EXTRA];
 struct TRHead {
   TR_HEAD_FIELDS
 };
@@ -170,6 +177,11 @@ struct Slot {
   TRState tr;                    // directly after x[]: one small D2H copy fetches state + trace
   Tab tab[2];
   GP<double> lam[2];
+  FrameState xE[SPEC_EXTRA];     // speculative candidates 1, 2 (see SPEC_EXTRA)
+  Tab tabE[SPEC_EXTRA];
+  GP<double> lamE[SPEC_EXTRA];      // SPEC_MAX_LM each
+  GP<double> cost_partE;            // SPEC_EXTRA * (SPEC_MAX_LM / 64) * LMS
+  double pose_costE[SPEC_EXTRA][16];
   double imu_sqrt[LFVIO_WINDOW_SIZE][225];
   GP<double> prior_A;               // n*n  (J0^T J0)
   double prior_b0[KP];           // J0^T r0

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       t->skip_step = 0;
       t->error = 0;
       t->new_point = 0;
+      t->spec_n = 1;
       if (mode >= MODE_MARG) t->mu = 0.0;
     }
     __shared__ double bt[84 + 256];

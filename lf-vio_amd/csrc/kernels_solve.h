@@ -558,7 +558,28 @@ __global__ __launch_bounds__(64) void k_backsub(char *base, size_t stride) {
 // the landmark part of the Gauss-Newton step (k_backsub) is formed here, one landmark per thread, and that launch is left
 // out of the pass — at this size a kernel is a few microseconds of launch and first-load latency whatever it does.
 constexpr int DOGLEG_INLINE_BLOCKS = 5, DOGLEG_INLINE_THREADS = 64 * DOGLEG_INLINE_BLOCKS;
-__global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, size_t stride, int inline_backsub) {
+// ComputeTraditionalDoglegStep for one radius: step = cg * gradient_ + cn * gauss_newton_, ||step|| = sn
+DEV void dogleg_coeffs(double grad_sq_total, double gn_sq_total, double grad_gn_total, double alpha, double radius, double &cg, double &cn,
+                       double &sn) {
+  const double gradient_norm = sqrt(grad_sq_total), gauss_newton_norm = sqrt(gn_sq_total);
+  if (gauss_newton_norm <= radius) {  // Case 1
+    cg = 0.0, cn = 1.0, sn = gauss_newton_norm;
+  } else if (gradient_norm * alpha >= radius) {  // Case 2
+    cg = -(radius / gradient_norm), cn = 0.0, sn = radius;
+  } else {  // Case 3
+    const double b_dot_a = -alpha * grad_gn_total;
+    const double a_squared_norm = (alpha * gradient_norm) * (alpha * gradient_norm);
+    const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gauss_newton_norm * gauss_newton_norm;
+    const double c = b_dot_a - a_squared_norm;
+    const double d = sqrt(c * c + b_minus_a_squared_norm * (radius * radius - a_squared_norm));
+    const double beta = (c <= 0) ? (d - c) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d + c);
+    cg = -alpha * (1.0 - beta), cn = beta;
+    // ||cg g + cn n||
+    sn = sqrt(cg * cg * grad_sq_total + 2.0 * cg * cn * grad_gn_total + cn * cn * gn_sq_total);
+  }
+}
+// spec: number of candidates to prepare (1, or 1 + SPEC_EXTRA for small windows): candidate z is the step for radius / 2^z
+__global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, size_t stride, int inline_backsub, int spec) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
@@ -602,7 +623,7 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
     }
   const int last_ok = t.trace_len > 0 ? tr->trace[t.trace_len - 1].step_is_successful : 0;
   if (t.done || t.chol_fail) return;
-  __shared__ double sh[2 * DOGLEG_INLINE_BLOCKS], sh2[2];
+  __shared__ double sh[2 * DOGLEG_INLINE_BLOCKS], sh2[2 * (1 + SPEC_EXTRA)];
   __shared__ double delta[KP];
   __shared__ double cand[84 + 256];  // candidate poses (pose[0..10], ex) for build_tab, and its scratch
   if (do_schur && inline_backsub) {
@@ -654,28 +675,16 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
       tr->gn_sq_total = gn_sq_total;
       tr->grad_gn_total = grad_gn_total;
     }
-    const double gradient_norm = sqrt(grad_sq_total), gauss_newton_norm = sqrt(gn_sq_total);
-    double cg, cn, sn;
-    if (gauss_newton_norm <= radius) {  // Case 1
-      cg = 0.0, cn = 1.0, sn = gauss_newton_norm;
-    } else if (gradient_norm * alpha >= radius) {  // Case 2
-      cg = -(radius / gradient_norm), cn = 0.0, sn = radius;
-    } else {  // Case 3
-      const double b_dot_a = -alpha * grad_gn_total;
-      const double a_squared_norm = (alpha * gradient_norm) * (alpha * gradient_norm);
-      const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gauss_newton_norm * gauss_newton_norm;
-      const double c = b_dot_a - a_squared_norm;
-      const double d = sqrt(c * c + b_minus_a_squared_norm * (radius * radius - a_squared_norm));
-      const double beta = (c <= 0) ? (d - c) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d + c);
-      cg = -alpha * (1.0 - beta), cn = beta;
-      // ||cg g + cn n||
-      sn = sqrt(cg * cg * grad_sq_total + 2.0 * cg * cn * grad_gn_total + cn * cn * gn_sq_total);
+    for (int z = 0; z < spec; z++) {
+      double cg, cn, sn;
+      dogleg_coeffs(grad_sq_total, gn_sq_total, grad_gn_total, alpha, ldexp(radius, -z), cg, cn, sn);
+      if (z == 0) tr->cg = cg, tr->cn = cn, tr->dogleg_step_norm = sn;
+      else tr->cgE[z - 1] = cg, tr->cnE[z - 1] = cn, tr->snE[z - 1] = sn;
+      sh2[2 * z] = cg, sh2[2 * z + 1] = cn;
     }
-    tr->cg = cg, tr->cn = cn, tr->dogleg_step_norm = sn;
-    sh2[0] = cg, sh2[1] = cn;
+    tr->spec_n = spec;
   }
   __syncthreads();
-  const double cg = sh2[0], cn = sh2[1];
   if (t.new_point) {
     // gradient_max_norm = max |x - Plus(x, -g)| (EvaluateGradientAndJacobian), pose side + landmarks
     double mx = 0;
@@ -710,56 +719,60 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
     }
     __syncthreads();
   }
-  // delta = (step / diagonal_) * scale, step = cg gradient_ + cn gauss_newton_
+  for (int z = 0; z < spec; z++) {
+    const double cg = sh2[2 * z], cn = sh2[2 * z + 1];
+    FrameState *xz = z == 0 ? xc : &S->xE[z - 1];
+    // delta = (step / diagonal_) * scale, step = cg gradient_ + cn gauss_newton_
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int i = tid + nthr * q;
-    if (i < KP) {
-      double d = (cg * vgr[q] + cn * vgn[q]) / vdg[q] * vsc[q];
-      const bool act = (est_ex || i < off_ex() || i >= off_ex() + 6) && (est_td || i != off_td());
-      if (!act) d = 0.0;
-      delta[i] = d;
-      S->step_p[i] = d;
+    for (int q = 0; q < 2; q++) {
+      const int i = tid + nthr * q;
+      if (i < KP) {
+        double d = (cg * vgr[q] + cn * vgn[q]) / vdg[q] * vsc[q];
+        const bool act = (est_ex || i < off_ex() || i >= off_ex() + 6) && (est_td || i != off_td());
+        if (!act) d = 0.0;
+        delta[i] = d;
+        if (z == 0) S->step_p[i] = d;
+      }
     }
-  }
-  __syncthreads();
-  // candidate = Plus(x, delta); ambient step norm and candidate norm, pose side
-  double dn = 0, xn = 0;
-  if (role == 0) {
-    double *xo = tid < 11 ? xc->pose[tid] : xc->ex;
-    double xv[7];
-    if (tid < 11 || est_ex) {
-      pose_plus(xb, delta + po, xv);
-      for (int k = 0; k < 7; k++) dn += (xb[k] - xv[k]) * (xb[k] - xv[k]), xn += xv[k] * xv[k];
-    } else {
-      for (int k = 0; k < 7; k++) xv[k] = xb[k];
-    }
-    for (int k = 0; k < 7; k++) xo[k] = xv[k], cand[7 * tid + k] = xv[k];
-  } else if (role == 1) {
-    const int e = tid - 16, f = e / 9, k = e % 9;
-    const double v = xb[0] + delta[off_sb(f) + k];
-    xc->sb[f][k] = v;
-    dn = (v - xb[0]) * (v - xb[0]);
-    xn = v * v;
-  } else if (role == 2) {
-    double v = xb[0];
-    if (est_td) {
-      v = xb[0] + delta[off_td()];
+    __syncthreads();
+    // candidate = Plus(x, delta); ambient step norm and candidate norm, pose side
+    double dn = 0, xn = 0;
+    if (role == 0) {
+      double *xo = tid < 11 ? xz->pose[tid] : xz->ex;
+      double xv[7];
+      if (tid < 11 || est_ex) {
+        pose_plus(xb, delta + po, xv);
+        for (int k = 0; k < 7; k++) dn += (xb[k] - xv[k]) * (xb[k] - xv[k]), xn += xv[k] * xv[k];
+      } else {
+        for (int k = 0; k < 7; k++) xv[k] = xb[k];
+      }
+      for (int k = 0; k < 7; k++) xo[k] = xv[k], cand[7 * tid + k] = xv[k];
+    } else if (role == 1) {
+      const int e = tid - 16, f = e / 9, k = e % 9;
+      const double v = xb[0] + delta[off_sb(f) + k];
+      xz->sb[f][k] = v;
       dn = (v - xb[0]) * (v - xb[0]);
       xn = v * v;
+    } else if (role == 2) {
+      double v = xb[0];
+      if (est_td) {
+        v = xb[0] + delta[off_td()];
+        dn = (v - xb[0]) * (v - xb[0]);
+        xn = v * v;
+      }
+      xz->td = v;
     }
-    xc->td = v;
+    dn = wave_sum(dn), xn = wave_sum(xn);
+    if ((tid & 63) == 0) sh[(tid >> 6) * 2] = dn, sh[(tid >> 6) * 2 + 1] = xn;
+    __syncthreads();
+    if (tid == 0) {
+      double sdn = 0, sxn = 0;
+      for (int w = 0; w < nwv; w++) sdn += sh[2 * w], sxn += sh[2 * w + 1];
+      if (z == 0) tr->step_sq_pose = sdn, tr->xn2_pose_cand = sxn;
+      else tr->step_sqE[z - 1] = sdn, tr->xn2E[z - 1] = sxn;
+    }
+    build_tab(cand, z == 0 ? &S->tab[cur ^ 1] : &S->tabE[z - 1], tid, cand + 84);  // ends on a barrier: delta / sh / cand are free again
   }
-  dn = wave_sum(dn), xn = wave_sum(xn);
-  if ((tid & 63) == 0) sh[(tid >> 6) * 2] = dn, sh[(tid >> 6) * 2 + 1] = xn;
-  __syncthreads();
-  if (tid == 0) {
-    double sdn = 0, sxn = 0;
-    for (int w = 0; w < nwv; w++) sdn += sh[2 * w], sxn += sh[2 * w + 1];
-    tr->step_sq_pose = sdn;
-    tr->xn2_pose_cand = sxn;
-  }
-  build_tab(cand, &S->tab[cur ^ 1], tid, cand + 84);
 }
 
 // ---------------------------------------------------------------------------
@@ -771,23 +784,30 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
 // ten — the latency of a single window; 1: a quarter of the waves for the same work — the throughput of a resident batch.
 // ---------------------------------------------------------------------------
 template <int LPT>
-__global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, int gLm) {
+__global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, int gLm, int spec) {
   constexpr int COST_THREADS = 64 * LPT, NW = LPT;
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   // header fields in one batch of loads, before the first branch (a load behind a branch is a round trip of its own)
   const TRFlags fl = tr_flags(tr);
   const int cur = fl.cur;
-  const double cg = tr->cg, cn = tr->cn;
+  // candidate z of the pass: blocks [z * nb, (z + 1) * nb) of the grid, nb = gLm + 10 + 1 (spec = 1: the one candidate)
+  const int nb = gLm + LFVIO_WINDOW_SIZE + 1;
+  const int z = spec > 1 ? (int)blockIdx.x / nb : 0;
+  const double cg = z == 0 ? tr->cg : tr->cgE[z > 0 ? z - 1 : 0], cn = z == 0 ? tr->cn : tr->cnE[z > 0 ? z - 1 : 0];
   if (fl.done | fl.chol_fail) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nxt = cur ^ 1;
+  const Tab *T = z == 0 ? &S->tab[nxt] : &S->tabE[z - 1];
+  const FrameState *x = z == 0 ? &S->x[nxt] : &S->xE[z - 1];
+  double *lam_out = z == 0 ? (double *)S->lam[nxt] : (double *)S->lamE[z - 1];
+  double *cost_part = z == 0 ? (double *)S->cost_part : (double *)S->cost_partE + (size_t)(z - 1) * (SPEC_MAX_LM / 64) * LMS;
+  double *pose_cost = z == 0 ? S->pose_cost : S->pose_costE[z - 1];
   __shared__ double red[4 * 8];
-  int b = blockIdx.x;
+  int b = (int)blockIdx.x - z * nb;
   if (b < gLm) {
     if (b >= S->nLmBlocks) return;
-    const Tab *T = &S->tab[nxt];
-    const double td = S->x[nxt].td;
+    const double td = x->td;
     const int lml = tid / LPT, q = tid % LPT;
     const int l = b * LM_BLOCK + lml;
     double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
@@ -797,7 +817,7 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
       const double lam = S->lam[cur][l];
       const double lc = lam + dl;
       if (q == 0) {
-        S->lam[nxt][l] = lc;
+        lam_out[l] = lc;
         dn = dl * dl;
         xn = lc * lc;
         // model: -(delta.g) - 1/2 delta^T H delta, landmark rows/cols
@@ -846,12 +866,11 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
     if (tid < 5) {
       double v = red[tid];
       for (int w = 1; w < NW; w++) v += red[8 * w + tid];
-      S->cost_part[(size_t)b * LMS + tid] = v;
+      cost_part[(size_t)b * LMS + tid] = v;
     }
     return;
   }
   b -= gLm;
-  const FrameState *x = &S->x[nxt];
   if (b < LFVIO_WINDOW_SIZE) {
     __shared__ double rr[15];
     double c = 0.0;
@@ -868,7 +887,7 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
         c = 0.5 * wave_sum(v);
       }
     }
-    if (tid == 0) S->pose_cost[b] = c;
+    if (tid == 0) pose_cost[b] = c;
     return;
   }
   {
@@ -897,7 +916,7 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
       for (int w = 1; w < NW; w++) c += red[w];
       c *= 0.5;
     }
-    if (tid == 0) S->pose_cost[10] = c;
+    if (tid == 0) pose_cost[10] = c;
   }
 }
 
@@ -937,7 +956,10 @@ __global__ __launch_bounds__(64) void k_xpack(char *base, size_t stride, int whi
 }
 
 // ---------------------------------------------------------------------------
-// k_decide: grid (1, batch) x 64 — TrustRegionMinimizer bookkeeping for one iteration.
+// k_decide: grid (1, batch) x 64 — TrustRegionMinimizer bookkeeping.  One iteration per evaluated candidate: the pass holds
+// tr->spec_n of them (the steps for radius, radius / 2, radius / 4), and they are taken in that order exactly as Ceres would
+// meet them — a rejected step halves the radius and the next candidate is the step for that radius; the walk stops at the
+// first accepted, invalid or terminating one.  An accepted candidate beyond the first is copied into the regular slot.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
@@ -946,9 +968,10 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
   // Everything the kernel needs from the slot header in ONE batch of loads, before the first branch: a load issued
   // behind a branch waits a full memory round trip (~0.6 us) of its own, and this kernel is nothing but such a chain.
   TRHead t = *reinterpret_cast<const TRHead *>(tr);
-  const int sharded = S->sharded, max_iter = S->max_iter, nLmBlocks = S->nLmBlocks;
-  const double *cost_part = S->cost_part;
-  const double pc = lane < 11 ? S->pose_cost[lane] : 0.0;
+  const int sharded = S->sharded, max_iter = S->max_iter, nLmBlocks = S->nLmBlocks, nlm = S->N;
+  const int cur0 = t.cur;
+  __shared__ int acc_z;
+  if (lane == 0) acc_z = 0;
   if (t.done) return;
   if (t.chol_fail) {
     // retry the Gauss-Newton solve with the larger mu; LINEAR_SOLVER_FAILURE once mu >= max_mu
@@ -962,110 +985,133 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
       return;
     }
   }
-  double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
-  if (!t.chol_fail) {
-    for (int k = lane; k < nLmBlocks; k += 64) {
-      const double *p = cost_part + (size_t)k * LMS;
-      cost += p[0], mlin += p[1], mquad += p[2], dn += p[3], xn += p[4];
-    }
-    cost += pc;
-    cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn);
-    if (sharded) {  // all-reduced by the caller after k_xpack 3
-      const double *sc = S->xch + XOFF_C;
-      cost = sc[XS_CCOST], mlin = sc[XS_MLIN], mquad = sc[XS_MQUAD], dn = sc[XS_DN], xn = sc[XS_XN];
+  const int K = t.chol_fail ? 1 : (t.spec_n < 1 ? 1 : (t.spec_n > 1 + SPEC_EXTRA ? 1 + SPEC_EXTRA : t.spec_n));
+  double cost[1 + SPEC_EXTRA], mlin[1 + SPEC_EXTRA], mquad[1 + SPEC_EXTRA], dn[1 + SPEC_EXTRA], xn[1 + SPEC_EXTRA];
+#pragma unroll
+  for (int z = 0; z < 1 + SPEC_EXTRA; z++) {
+    cost[z] = mlin[z] = mquad[z] = dn[z] = xn[z] = 0.0;
+    if (!t.chol_fail && z < K) {
+      const double *cp = z == 0 ? (const double *)S->cost_part : (const double *)S->cost_partE + (size_t)(z - 1) * (SPEC_MAX_LM / 64) * LMS;
+      const double *pcz = z == 0 ? S->pose_cost : S->pose_costE[z > 0 ? z - 1 : 0];
+      double c = 0, l = 0, q = 0, d = 0, x = 0;
+      for (int k = lane; k < nLmBlocks; k += 64) {
+        const double *p = cp + (size_t)k * LMS;
+        c += p[0], l += p[1], q += p[2], d += p[3], x += p[4];
+      }
+      if (lane < 11) c += pcz[lane];
+      cost[z] = wave_sum(c), mlin[z] = wave_sum(l), mquad[z] = wave_sum(q), dn[z] = wave_sum(d), xn[z] = wave_sum(x);
     }
   }
-  if (lane != 0) return;
-  TRState *trg = tr;
-  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-  const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
-  LfvioIterationSummary it;
-  it.cost = t.x_cost, it.cost_change = 0, it.gradient_max_norm = 0, it.step_norm = 0, it.relative_decrease = 0;
-  it.step_is_valid = 0, it.step_is_successful = 0;
-  bool finished = false;
-  bool step_valid = false;
-  double model_cost_change = 0;
-  if (!t.chol_fail) {
-    // model_cost_change = -(J step)^T (r + J step / 2) = -delta.g - 1/2 delta^T H delta
-    const double cg = t.cg, cn = t.cn;
-    // unscaled pose direction delta_p = cg' G + cn' N where gradient_/diagonal_*scale = G, gn/diag*scale = N
-    const double lin = cg * t.q[Q_gG] + cn * t.q[Q_gN] + mlin;
-    const double quad = cg * cg * t.q[Q_GG] + 2.0 * cg * cn * t.q[Q_GN] + cn * cn * t.q[Q_NN] + mquad;
-    model_cost_change = -lin - 0.5 * quad;
-    step_valid = model_cost_change > 0.0;
+  if (sharded && !t.chol_fail) {  // all-reduced by the caller after k_xpack 3 (one candidate)
+    const double *sc = S->xch + XOFF_C;
+    cost[0] = sc[XS_CCOST], mlin[0] = sc[XS_MLIN], mquad[0] = sc[XS_MQUAD], dn[0] = sc[XS_DN], xn[0] = sc[XS_XN];
   }
-  t.model_cost_change = model_cost_change;
-  it.step_is_valid = step_valid ? 1 : 0;
-  if (!step_valid) {
-    // HandleInvalidStep
-    if (++t.consec_invalid >= 5) {
-      t.termination = LFVIO_FAILURE;
-      t.done = 1;
-      finished = true;
-    } else {
-      t.mu *= 10.0;  // StepIsInvalid
-      t.chol_fail = 0;
-      t.do_lin = sharded ? 1 : 0;  // sharded: the exchange buffers were reduced in place, rebuild them
-      t.do_schur = 1;
-    }
-  } else {
-    t.consec_invalid = 0;
-    const double candidate_cost = isfinite(cost) ? cost : 1.79769313486231570815e+308;
-    t.cand_cost = candidate_cost;
-    it.step_norm = sqrt(t.step_sq_pose + dn);
-    if (it.step_norm <= parameter_tolerance * (t.x_norm + parameter_tolerance)) {
-      t.termination = LFVIO_CONVERGENCE;
-      t.done = 1;
-      finished = true;
-    } else {
-      it.cost_change = t.x_cost - candidate_cost;
-      if (fabs(it.cost_change) <= function_tolerance * t.x_cost) {
-        t.termination = LFVIO_CONVERGENCE;
-        t.done = 1;
-        finished = true;
-      } else {
-        it.relative_decrease = it.cost_change / model_cost_change;
-        if (it.relative_decrease > min_relative_decrease) {
-          // HandleSuccessfulStep: x <- candidate; the next k_lin re-evaluates cost/gradient there
-          t.cur ^= 1;
-          t.x_norm = sqrt(t.xn2_pose_cand + xn);
-          it.step_is_successful = 1;
-          it.cost = candidate_cost;  // replaced by the re-evaluated x_cost when the trace is read
-          if (it.relative_decrease < 0.25) t.radius *= 0.5;
-          if (it.relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * t.dogleg_step_norm);
-          t.mu = fmax(1e-8, 2.0 * t.mu / 10.0);
-          t.do_lin = 1;
-          t.do_schur = 1;
-          t.x_cost = candidate_cost;
+  if (lane == 0) {
+    TRState *trg = tr;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
+    (void)gradient_tolerance;
+    for (int z = 0; z < K; z++) {
+      const double cgz = z == 0 ? t.cg : t.cgE[z - 1], cnz = z == 0 ? t.cn : t.cnE[z - 1];
+      const double snz = z == 0 ? t.dogleg_step_norm : t.snE[z - 1];
+      const double step_sq = z == 0 ? t.step_sq_pose : t.step_sqE[z - 1], xn2c = z == 0 ? t.xn2_pose_cand : t.xn2E[z - 1];
+      LfvioIterationSummary it;
+      it.cost = t.x_cost, it.cost_change = 0, it.gradient_max_norm = 0, it.step_norm = 0, it.relative_decrease = 0;
+      it.step_is_valid = 0, it.step_is_successful = 0;
+      bool finished = false, go_on = false;
+      bool step_valid = false;
+      double model_cost_change = 0;
+      if (!t.chol_fail) {
+        // model_cost_change = -(J step)^T (r + J step / 2) = -delta.g - 1/2 delta^T H delta
+        // unscaled pose direction delta_p = cg' G + cn' N where gradient_/diagonal_*scale = G, gn/diag*scale = N
+        const double lin = cgz * t.q[Q_gG] + cnz * t.q[Q_gN] + mlin[z];
+        const double quad = cgz * cgz * t.q[Q_GG] + 2.0 * cgz * cnz * t.q[Q_GN] + cnz * cnz * t.q[Q_NN] + mquad[z];
+        model_cost_change = -lin - 0.5 * quad;
+        step_valid = model_cost_change > 0.0;
+      }
+      t.model_cost_change = model_cost_change;
+      it.step_is_valid = step_valid ? 1 : 0;
+      if (!step_valid) {
+        // HandleInvalidStep
+        if (++t.consec_invalid >= 5) {
+          t.termination = LFVIO_FAILURE;
+          t.done = 1;
+          finished = true;
         } else {
-          // HandleUnsuccessfulStep / StepRejected
-          t.radius *= 0.5;
-          t.do_lin = 0;
-          t.do_schur = 0;
-          it.cost = candidate_cost;
+          t.mu *= 10.0;  // StepIsInvalid
+          t.chol_fail = 0;
+          t.do_lin = sharded ? 1 : 0;  // sharded: the exchange buffers were reduced in place, rebuild them
+          t.do_schur = 1;
+        }
+      } else {
+        t.consec_invalid = 0;
+        const double candidate_cost = isfinite(cost[z]) ? cost[z] : 1.79769313486231570815e+308;
+        t.cand_cost = candidate_cost;
+        it.step_norm = sqrt(step_sq + dn[z]);
+        if (it.step_norm <= parameter_tolerance * (t.x_norm + parameter_tolerance)) {
+          t.termination = LFVIO_CONVERGENCE;
+          t.done = 1;
+          finished = true;
+        } else {
+          it.cost_change = t.x_cost - candidate_cost;
+          if (fabs(it.cost_change) <= function_tolerance * t.x_cost) {
+            t.termination = LFVIO_CONVERGENCE;
+            t.done = 1;
+            finished = true;
+          } else {
+            it.relative_decrease = it.cost_change / model_cost_change;
+            if (it.relative_decrease > min_relative_decrease) {
+              // HandleSuccessfulStep: x <- candidate; the next k_lin re-evaluates cost/gradient there
+              t.cur ^= 1;
+              acc_z = z;
+              t.x_norm = sqrt(xn2c + xn[z]);
+              it.step_is_successful = 1;
+              it.cost = candidate_cost;  // replaced by the re-evaluated x_cost when the trace is read
+              if (it.relative_decrease < 0.25) t.radius *= 0.5;
+              if (it.relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * snz);
+              t.mu = fmax(1e-8, 2.0 * t.mu / 10.0);
+              t.do_lin = 1;
+              t.do_schur = 1;
+              t.x_cost = candidate_cost;
+            } else {
+              // HandleUnsuccessfulStep / StepRejected: the next candidate is the step for the halved radius
+              t.radius *= 0.5;
+              t.do_lin = 0;
+              t.do_schur = 0;
+              it.cost = candidate_cost;
+              go_on = true;
+            }
+          }
         }
       }
+      if (finished) break;  // the converged iteration is not pushed (Minimize() returns before Finalize)
+      // FinalizeIterationAndCheckIfMinimizerCanContinue
+      if (it.step_is_successful)
+        t.num_succ++;
+      else
+        t.num_unsucc++;
+      it.trust_region_radius = t.radius;
+      if (t.trace_len < LFVIO_MAX_TRACE) trg->trace[t.trace_len++] = it;
+      if (t.iteration >= max_iter) {
+        t.termination = LFVIO_NO_CONVERGENCE;
+        t.done = 1;
+      } else if (t.radius <= min_trust_region_radius) {
+        t.termination = LFVIO_CONVERGENCE;
+        t.done = 1;
+      }
+      t.iteration++;
+      if (!go_on || t.done) break;
     }
-  }
-  if (finished) {  // the converged iteration is not pushed (Minimize() returns before Finalize)
     *reinterpret_cast<TRHead *>(trg) = t;
-    return;
   }
-  // FinalizeIterationAndCheckIfMinimizerCanContinue
-  if (it.step_is_successful)
-    t.num_succ++;
-  else
-    t.num_unsucc++;
-  it.trust_region_radius = t.radius;
-  if (t.trace_len < LFVIO_MAX_TRACE) trg->trace[t.trace_len++] = it;
-  if (t.iteration >= max_iter) {
-    t.termination = LFVIO_NO_CONVERGENCE;
-    t.done = 1;
-  } else if (t.radius <= min_trust_region_radius) {
-    t.termination = LFVIO_CONVERGENCE;
-    t.done = 1;
+  __syncthreads();
+  const int az = acc_z;
+  if (az > 0) {  // the accepted step is a speculative candidate: bring it into the slot x[cur ^ 1] stood for
+    const int dst = cur0 ^ 1;
+    const double *xs = (const double *)&S->xE[az - 1], *ts = (const double *)&S->tabE[az - 1], *ls = S->lamE[az - 1];
+    double *xd = (double *)&S->x[dst], *td = (double *)&S->tab[dst], *ld = S->lam[dst];
+    for (int k = lane; k < (int)(sizeof(FrameState) / 8); k += 64) xd[k] = xs[k];
+    for (int k = lane; k < (int)(sizeof(Tab) / 8); k += 64) td[k] = ts[k];
+    for (int k = lane; k < nlm; k += 64) ld[k] = ls[k];
   }
-  (void)gradient_tolerance;
-  t.iteration++;
-  *reinterpret_cast<TRHead *>(trg) = t;
 }

@@ -37,7 +37,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   size_t in_begin = 0, in_end = 0, total = 0;
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
-  size_t lam[2], prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
+  size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
       xch, lm_part, cost_part, imu_out, mscr, rotlog, eig_aux;
 };
 
@@ -68,6 +68,8 @@ Layout make_layout(int maxN, int maxM) {
   L.sum_items = take((size_t)SUM_ITEMS_CAP * 4);
   L.in_end = o;
   L.lam[0] = take(LB * 8), L.lam[1] = take(LB * 8);
+  for (int k = 0; k < SPEC_EXTRA; k++) L.lamE[k] = take((size_t)SPEC_MAX_LM * 8);
+  L.cost_partE = take((size_t)SPEC_EXTRA * (SPEC_MAX_LM / 64) * LMS * 8);
   L.prior_A = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
   L.a = take(LB * 8), L.b = take(LB * 8), L.W = take(LB * WLD * 8);
   L.scale_l = take(LB * 8), L.grad_l = take(LB * 8), L.gn_l = take(LB * 8), L.diag_l = take(LB * 8);
@@ -113,6 +115,10 @@ struct lfvio_ctx {
   // cached graph of the solve loop
   hipGraphExec_t graph = nullptr;
   int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0;
+  // cached graph of one chunk of passes (synchronous entry points: the loop is launched chunk by chunk)
+  hipGraphExec_t chunk = nullptr, chunk0 = nullptr, tail[3] = {nullptr, nullptr, nullptr};  // chunk0: k_setup + chunk; tail[flag]: gauge + marginalization
+  int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
+  int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   bool use_graph = true;
   // landmark-sharded mode (multi-GPU)
   bool shard_active = false;
@@ -127,6 +133,13 @@ void destroy_graph(lfvio_ctx *c) {
     (void)hipGraphExecDestroy(c->graph);
     c->graph = nullptr;
   }
+  if (c->chunk) {
+    (void)hipGraphExecDestroy(c->chunk);
+    c->chunk = nullptr;
+  }
+  if (c->chunk0) (void)hipGraphExecDestroy(c->chunk0), c->chunk0 = nullptr;
+  for (auto &t : c->tail)
+    if (t) (void)hipGraphExecDestroy(t), t = nullptr;
 }
 
 int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
@@ -434,6 +447,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     Slot W;
     std::memset(&W, 0, sizeof W);
     W.lam[0].set(&W, L.lam[0]), W.lam[1].set(&W, L.lam[1]);
+    for (int k = 0; k < SPEC_EXTRA; k++) W.lamE[k].set(&W, L.lamE[k]);
+    W.cost_partE.set(&W, L.cost_partE);
     W.prior_A.set(&W, L.prior_A);
     W.a.set(&W, L.a), W.b.set(&W, L.b), W.W.set(&W, L.W);
     W.scale_l.set(&W, L.scale_l), W.grad_l.set(&W, L.grad_l), W.gn_l.set(&W, L.gn_l);
@@ -447,7 +462,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     W.rotlog.set(&W, L.rotlog), W.eig_aux.set(&W, L.eig_aux);
     // field-by-field so that only pointer members are touched
 #define PUTP(field) HIPCHK(c, hipMemcpyAsync(d + offsetof(Slot, field), &W.field, sizeof W.field, hipMemcpyHostToDevice, c->stream))
-    PUTP(lam);
+    PUTP(lam); PUTP(lamE); PUTP(cost_partE);
     PUTP(prior_A);
     PUTP(a); PUTP(b); PUTP(W); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
     PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(xch); PUTP(gp); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out);
@@ -491,7 +506,8 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre);
 }
 
-void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
+// speculate: small windows evaluate the steps for radius, radius / 2, radius / 4 in every pass (dev_types.h, SPEC_EXTRA)
+void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool speculate = false) {
   const size_t st = c->L.total;
   launch_lin(c, count, g, mode);
   launch_sum(c, count, g, mode);
@@ -499,26 +515,70 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode) {
     hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
+    const int spec = speculate && inl ? 1 + SPEC_EXTRA : 1;
     if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
-    hipLaunchKernelGGL(k_dogleg, dim3(1, count), dim3(inl ? DOGLEG_INLINE_THREADS : 128), 0, c->stream, c->d_base, st, inl ? 1 : 0);
+    hipLaunchKernelGGL(k_dogleg, dim3(1, count), dim3(inl ? DOGLEG_INLINE_THREADS : 128), 0, c->stream, c->d_base, st, inl ? 1 : 0, spec);
     // four lanes per track while the GPU has room for the extra waves (latency of few windows), one when a batch fills it
-    if ((size_t)count * (g.lm + LFVIO_WINDOW_SIZE + 1) <= 512)
-      hipLaunchKernelGGL(k_cost<4>, dim3(g.lm + LFVIO_WINDOW_SIZE + 1, count), dim3(256), 0, c->stream, c->d_base, st, g.lm);
+    const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
+    if ((size_t)count * nb <= 512)
+      hipLaunchKernelGGL(k_cost<4>, dim3(spec * nb, count), dim3(256), 0, c->stream, c->d_base, st, g.lm, spec);
     else
-      hipLaunchKernelGGL(k_cost<1>, dim3(g.lm + LFVIO_WINDOW_SIZE + 1, count), dim3(64), 0, c->stream, c->d_base, st, g.lm);
+      hipLaunchKernelGGL(k_cost<1>, dim3(spec * nb, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, spec);
     hipLaunchKernelGGL(k_decide, dim3(1, count), dim3(64), 0, c->stream, c->d_base, st);
   }
 }
 
+__global__ void k_pending(char *base, size_t stride, int count, int *out) {
+  int n = 0;
+  for (int s = threadIdx.x; s < count; s += 64) n += ((const Slot *)(base + (size_t)s * stride))->tr.done ? 0 : 1;
+  n = __reduce_add_sync(~0ull, n);
+  if (threadIdx.x == 0) *out = n;
+}
+
 // Enqueue the trust-region loop for slots [0, count): max_iter Ceres iterations plus spare
 // passes for mu-retries (a failed Cholesky consumes a pass but not an iteration).
-int enqueue_solve(lfvio_ctx *c, int count, int max_iter) {
+//   adaptive = false: the whole loop as one static graph, nothing but enqueues (lfvio_batch_optimize_async).
+//   adaptive = true (synchronous entry points): the passes go out in chunks of SOLVE_CHUNK and the host reads the number
+//     of unfinished slots in between.  A pass costs its ~30 us of launches and first loads whether or not the loop is
+//     already done, and with the speculative candidates of small windows nine iterations are four passes, not twelve.
+constexpr int SOLVE_CHUNK = 4;
+int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive) {
   const Grid g = grid_for(c, count);
   const int passes = std::max(max_iter, 0) + 4;
+  if (adaptive && c->use_graph) {
+    const bool speculate = (size_t)count * (g.lm + LFVIO_WINDOW_SIZE + 1) <= 512;
+    if (!c->d_pending) {
+      HIPCHK(c, hipMalloc((void **)&c->d_pending, 256));
+      HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
+    }
+    if (!c->chunk || c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate) {
+      destroy_graph(c);
+      for (int first = 0; first < 2; first++) {
+        hipGraph_t graph;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        if (first)
+          hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+        for (int it = 0; it < SOLVE_CHUNK; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate);
+        hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending);
+        HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
+        HIPCHK(c, hipGraphInstantiate(first ? &c->chunk0 : &c->chunk, graph, nullptr, nullptr, 0));
+        HIPCHK(c, hipGraphDestroy(graph));
+      }
+      c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate;
+    }
+    for (int done_passes = 0; done_passes < passes; done_passes += SOLVE_CHUNK) {
+      HIPCHK(c, hipGraphLaunch(done_passes == 0 ? c->chunk0 : c->chunk, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (*c->h_pending == 0) break;
+    }
+    HIPCHK(c, hipGetLastError());
+    return LFVIO_OK;
+  }
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
   if (c->use_graph) {
     if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes) {
-      destroy_graph(c);
+      if (c->graph) (void)hipGraphExecDestroy(c->graph), c->graph = nullptr;
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE);
@@ -657,6 +717,8 @@ void lfvio_destroy(lfvio_ctx *c) {
   if (c->d_feat) (void)hipFree(c->d_feat);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_down) (void)hipHostFree(c->h_down);
+  if (c->d_pending) (void)hipFree(c->d_pending);
+  if (c->h_pending) (void)hipHostFree(c->h_pending);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -670,7 +732,7 @@ int lfvio_solve(lfvio_ctx *c, const LfvioWindow *in, LfvioSolution *out) {
   int rc = reserve(c, 1, in->num_landmarks, in->num_observations);
   if (rc) return rc;
   if ((rc = upload_window(c, 0, in))) return rc;
-  if ((rc = enqueue_solve(c, 1, in->max_num_iterations))) return rc;
+  if ((rc = enqueue_solve(c, 1, in->max_num_iterations, true))) return rc;
   return download_solution(c, 0, out);
 }
 
@@ -700,22 +762,37 @@ int lfvio_batch_upload(lfvio_ctx *c, int slot, const LfvioWindow *in) {
   return upload_window(c, slot, in);
 }
 
-int lfvio_batch_optimize_async(lfvio_ctx *c, int count, int marg_flag) {
+static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adaptive) {
   if (!c || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
-  int max_iter = 0;
   // every slot carries its own max_iter on the device; the pass count follows the largest
-  max_iter = 8;
+  const int max_iter = 8;
   for (int s = 0; s < count; s++)
     if (!c->info[s].uploaded) {
       c->err = "slot not uploaded";
       return LFVIO_ERR_ARG;
     }
-  int rc = enqueue_solve(c, count, max_iter);
+  int rc = enqueue_solve(c, count, max_iter, adaptive);
   if (rc) return rc;
+  if (adaptive && c->use_graph && marg_flag >= 0 && marg_flag < 3) {  // gauge fix + marginalization as one graph launch
+    if (!c->tail[marg_flag]) {
+      hipGraph_t graph;
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total);
+      rc = enqueue_marg(c, count, marg_flag, false);
+      HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
+      if (rc) return rc;
+      HIPCHK(c, hipGraphInstantiate(&c->tail[marg_flag], graph, nullptr, nullptr, 0));
+      HIPCHK(c, hipGraphDestroy(graph));
+    }
+    HIPCHK(c, hipGraphLaunch(c->tail[marg_flag], c->stream));
+    return LFVIO_OK;
+  }
   hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total);
   return enqueue_marg(c, count, marg_flag, false);
 }
+
+int lfvio_batch_optimize_async(lfvio_ctx *c, int count, int marg_flag) { return batch_optimize_impl(c, count, marg_flag, false); }
 
 int lfvio_batch_sync(lfvio_ctx *c) {
   if (!c) return LFVIO_ERR_ARG;
@@ -724,7 +801,7 @@ int lfvio_batch_sync(lfvio_ctx *c) {
 }
 
 int lfvio_batch_optimize(lfvio_ctx *c, int count, int marg_flag) {
-  int rc = lfvio_batch_optimize_async(c, count, marg_flag);
+  int rc = batch_optimize_impl(c, count, marg_flag, true);
   if (rc) return rc;
   return lfvio_batch_sync(c);
 }
