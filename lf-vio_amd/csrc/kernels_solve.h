@@ -578,11 +578,15 @@ DEV void dogleg_coeffs(double grad_sq_total, double gn_sq_total, double grad_gn_
     sn = sqrt(cg * cg * grad_sq_total + 2.0 * cg * cn * grad_gn_total + cn * cn * gn_sq_total);
   }
 }
-// spec: number of candidates to prepare (1, or 1 + SPEC_EXTRA for small windows): candidate z is the step for radius / 2^z
+// spec: number of candidates to prepare (1, or 1 + SPEC_EXTRA for small windows): candidate z is the step for radius / 2^z.
+// Launched with grid.x = spec: workgroup z prepares candidate z (each one repeats the short common part — the kernel is
+// a latency chain, three of them side by side cost what one costs); workgroup 0 alone writes what is shared.
 __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, size_t stride, int inline_backsub, int spec) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
+  const bool first = blockIdx.x == 0;
+  const int z_lo = gridDim.x > 1 ? blockIdx.x : 0, z_hi = gridDim.x > 1 ? blockIdx.x + 1 : spec;
   // The kernel is one chain of small dependent steps; a load issued behind a branch or a barrier costs a full memory
   // round trip (~0.6 us) of its own, so everything that is read — the header, this thread's piece of the state, of the
   // gradient and of the step vectors, the landmark partials — is requested here in one batch, before the first use.
@@ -651,9 +655,11 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
       const double s = S->scale_l[l];
       const double y = (s * S->b[l] + s * d2) * S->einv_l[l];
       const double gn = -S->diag_l[l] * y;
-      S->gn_l[l] = gn;
-      S->d1[l] = d1;
-      S->d2[l] = d2;
+      if (first) {
+        S->gn_l[l] = gn;
+        S->d1[l] = d1;
+        S->d2[l] = d2;
+      }
       a = gn * gn;
       b = S->grad_l[l] * gn;
     }
@@ -672,20 +678,22 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
       if (sharded) lgn = xg0, lgg = xg1;  // all-reduced (k_xpack 2)
       gn_sq_total = t.q[Q_GN_SQ] + lgn;
       grad_gn_total = t.q[Q_GRAD_GN] + lgg;
-      tr->gn_sq_total = gn_sq_total;
-      tr->grad_gn_total = grad_gn_total;
+      if (first) {
+        tr->gn_sq_total = gn_sq_total;
+        tr->grad_gn_total = grad_gn_total;
+      }
     }
-    for (int z = 0; z < spec; z++) {
+    for (int z = z_lo; z < z_hi; z++) {
       double cg, cn, sn;
       dogleg_coeffs(grad_sq_total, gn_sq_total, grad_gn_total, alpha, ldexp(radius, -z), cg, cn, sn);
       if (z == 0) tr->cg = cg, tr->cn = cn, tr->dogleg_step_norm = sn;
       else tr->cgE[z - 1] = cg, tr->cnE[z - 1] = cn, tr->snE[z - 1] = sn;
       sh2[2 * z] = cg, sh2[2 * z + 1] = cn;
     }
-    tr->spec_n = spec;
+    if (first) tr->spec_n = spec;
   }
   __syncthreads();
-  if (t.new_point) {
+  if (t.new_point && first) {
     // gradient_max_norm = max |x - Plus(x, -g)| (EvaluateGradientAndJacobian), pose side + landmarks
     double mx = 0;
     if (role == 0) {
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
     }
     __syncthreads();
   }
-  for (int z = 0; z < spec; z++) {
+  for (int z = z_lo; z < z_hi; z++) {
     const double cg = sh2[2 * z], cn = sh2[2 * z + 1];
     FrameState *xz = z == 0 ? xc : &S->xE[z - 1];
     // delta = (step / diagonal_) * scale, step = cg gradient_ + cn gauss_newton_

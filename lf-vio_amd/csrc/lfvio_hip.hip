@@ -517,7 +517,7 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
     const int spec = speculate && inl ? 1 + SPEC_EXTRA : 1;
     if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
-    hipLaunchKernelGGL(k_dogleg, dim3(1, count), dim3(inl ? DOGLEG_INLINE_THREADS : 128), 0, c->stream, c->d_base, st, inl ? 1 : 0, spec);
+    hipLaunchKernelGGL(k_dogleg, dim3(spec, count), dim3(inl ? DOGLEG_INLINE_THREADS : 128), 0, c->stream, c->d_base, st, inl ? 1 : 0, spec);
     // four lanes per track while the GPU has room for the extra waves (latency of few windows), one when a batch fills it
     const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
     if ((size_t)count * nb <= 512)
