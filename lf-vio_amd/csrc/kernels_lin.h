@@ -62,49 +62,52 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     // partial pivoting on [cov | I] in LDS, then a 15x15 column Cholesky of the inverse.
     const int f = blockIdx.x - 1;
     if (!S->imu_active[f]) return;
-    __shared__ double M[15][31];
+    // The elimination ping-pongs between two copies of [cov | I]: every thread reads what it needs of the old matrix
+    // (pivot row p, its own source row with the swap applied by index), normalizes its pivot-row entry itself and writes
+    // the new entry into the other copy — the arithmetic of swap / scale / eliminate, one barrier per pivot instead of six.
+    __shared__ double Mb[2][15][31];
     __shared__ double L[15][16];
     __shared__ double col[16];
     for (int e = tid; e < 225; e += 256) {
       int r = e / 15, c = e % 15;
-      M[r][c] = S->imu[f].covariance[e];
-      M[r][15 + c] = (r == c) ? 1.0 : 0.0;
+      Mb[0][r][c] = S->imu[f].covariance[e];
+      Mb[0][r][15 + c] = (r == c) ? 1.0 : 0.0;
     }
     __syncthreads();
+    const int r1 = tid / 30, c1 = tid % 30;
+    const int t2 = tid + 256, r2 = t2 / 30, c2 = t2 % 30;
     for (int k = 0; k < 15; k++) {
+      const double(*Mo)[31] = Mb[k & 1];
+      double(*Mn)[31] = Mb[(k & 1) ^ 1];
+      // the whole column in one batch of loads (a loop over r >= k waits for every load in turn)
+      double colk[15];
+#pragma unroll
+      for (int r = 0; r < 15; r++) colk[r] = Mo[r][k];
       int p = k;
-      double best = fabs(M[k][k]);
-      for (int r = k + 1; r < 15; r++) {
-        double v = fabs(M[r][k]);
-        if (v > best) best = v, p = r;
+      double best = -1.0, piv = 0.0;
+#pragma unroll
+      for (int r = 0; r < 15; r++) {
+        const double v = fabs(colk[r]);
+        if (r >= k && v > best) best = v, p = r, piv = colk[r];
       }
-      __syncthreads();
-      if (p != k && tid < 30) {
-        double t = M[k][tid];
-        M[k][tid] = M[p][tid];
-        M[p][tid] = t;
-      }
-      __syncthreads();
-      const double piv = M[k][k];
-      __syncthreads();
-      if (tid < 30) M[k][tid] /= piv;
-      __syncthreads();
-      // rows r != k: thread (r, c) <- M[r][c] - M[r][k] M[k][c]; the column of factors is read before it is overwritten
-      const int r = tid / 30, c = tid % 30;
-      double fac = 0, mk = 0, cur = 0;
-      if (tid < 450) fac = M[r][k], mk = M[k][c], cur = M[r][c];
-      double fac2 = 0, mk2 = 0, cur2 = 0;
-      const int t2 = tid + 256, r2 = t2 / 30, c2 = t2 % 30;
-      if (t2 < 450) fac2 = M[r2][k], mk2 = M[k][c2], cur2 = M[r2][c2];
-      __syncthreads();
-      if (r != k) M[r][c] = cur - fac * mk;
-      if (t2 < 450 && r2 != k) M[r2][c2] = cur2 - fac2 * mk2;
+      // row r of the swapped matrix is row src(r) of the old one
+      auto entry = [&](int r, int c) {
+        const double mk = Mo[p][c] / piv;
+        if (r == k) return mk;
+        const int sr = r == p ? k : r;
+        return Mo[sr][c] - Mo[sr][k] * mk;
+      };
+      if (tid < 450) Mn[r1][c1] = entry(r1, c1);
+      if (t2 < 450) Mn[r2][c2] = entry(r2, c2);
       __syncthreads();
     }
+    const double(*M)[31] = Mb[1];  // 15 pivots: the result is in copy 1
     bool ok = true;
+#pragma unroll
     for (int j = 0; j < 15; j++) {
       if (tid >= j && tid < 15) {
         double t = M[tid][15 + j];
+#pragma unroll
         for (int k = 0; k < j; k++) t -= L[tid][k] * L[j][k];
         col[tid] = t;
       }
@@ -129,19 +132,40 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     if (!S->prior_valid) return;
     const int n = S->prior_n;
     const int part = blockIdx.x - (LFVIO_WINDOW_SIZE + 1);
+    // J0 goes through LDS in slabs of rows (all of it for the usual n = 76): one batch of independent loads instead of
+    // a dependent load per term.  A thread owns up to PRIOR_EPT entries of A' (n <= 172: 29 584 entries over 4 096 threads).
+    constexpr int PRIOR_SLAB = 6016, PRIOR_EPT = 8;
+    __shared__ double Js[PRIOR_SLAB + LFVIO_MAX_PRIOR_DIM];
     const double *J = S->prior_J;
-    for (int e = part * 256 + tid; e < n * n; e += 256 * SETUP_PRIOR_WGS) {
-      int r = e / n, c = e % n;
-      double s = 0;
-      for (int k = 0; k < n; k++) s = fma(J[k * n + r], J[k * n + c], s);
-      S->prior_A[e] = s;
-    }
-    if (part == 0)
-      for (int c = tid; c < n; c += 256) {
-        double s = 0;
-        for (int k = 0; k < n; k++) s = fma(J[k * n + c], S->prior_r[k], s);
-        S->prior_b0[c] = s;
+    const int rows_per = PRIOR_SLAB / n;
+    double acc[PRIOR_EPT], accb = 0;
+#pragma unroll
+    for (int q = 0; q < PRIOR_EPT; q++) acc[q] = 0;
+    for (int k0 = 0; k0 < n; k0 += rows_per) {
+      const int nk = min(rows_per, n - k0);
+      __syncthreads();
+      for (int e = tid; e < nk * n; e += 256) Js[e] = J[k0 * n + e];
+      for (int e = tid; e < nk; e += 256) Js[PRIOR_SLAB + e] = S->prior_r[k0 + e];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < PRIOR_EPT; q++) {
+        const int e = part * 256 + tid + q * 256 * SETUP_PRIOR_WGS;
+        if (e < n * n) {
+          const int r = e / n, c = e % n;
+          double s = acc[q];
+          for (int k = 0; k < nk; k++) s = fma(Js[k * n + r], Js[k * n + c], s);
+          acc[q] = s;
+        }
       }
+      if (part == 0 && tid < n)
+        for (int k = 0; k < nk; k++) accb = fma(Js[k * n + tid], Js[PRIOR_SLAB + k], accb);
+    }
+#pragma unroll
+    for (int q = 0; q < PRIOR_EPT; q++) {
+      const int e = part * 256 + tid + q * 256 * SETUP_PRIOR_WGS;
+      if (e < n * n) S->prior_A[e] = acc[q];
+    }
+    if (part == 0 && tid < n) S->prior_b0[tid] = accb;
   }
 }
 

@@ -1054,6 +1054,10 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     switch (which) {
       case 0: launch_lin(c, count, g, MODE_SOLVE); break;
       case 2: launch_sum(c, count, g, MODE_SOLVE); break;  // k_presum + k_sum for large windows
+      case 4: case 5: case 6: case 7: {  // k_setup by role: state + table | + IMU sqrt_info | + prior J0^T J0 | + inverse depths
+        const int gx = which == 4 ? 1 : which == 5 ? 1 + LFVIO_WINDOW_SIZE : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
+        hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
+      } break;
       default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st); break;
     }
   }
