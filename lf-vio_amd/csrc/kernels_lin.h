@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     const int part = blockIdx.x - (LFVIO_WINDOW_SIZE + 1);
     // J0 goes through LDS in slabs of rows (all of it for the usual n = 76): one batch of independent loads instead of
     // a dependent load per term.  A thread owns up to PRIOR_EPT entries of A' (n <= 172: 29 584 entries over 4 096 threads).
-    constexpr int PRIOR_SLAB = 6016, PRIOR_EPT = 8;
+    constexpr int PRIOR_SLAB = 2048, PRIOR_EPT = 8;  // 16 KB: k_setup keeps 5 workgroups per CU for resident batches
     __shared__ double Js[PRIOR_SLAB + LFVIO_MAX_PRIOR_DIM];
     const double *J = S->prior_J;
     const int rows_per = PRIOR_SLAB / n;
