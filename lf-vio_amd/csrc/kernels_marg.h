@@ -735,36 +735,13 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     return;
   }
   STAMP(S, 10);
-  double *Hs = smem;            // PACKED, then reused: A (D x D), V (n x n), ...
-  double *g = Hs + LPACK;       // KP
-  double *scratch = g + KP;     // 64
-  for (int e = tid; e < PACKED; e += MARG_THREADS) Hs[e] = S->Hpp[e];
-  for (int c = tid; c < KP; c += MARG_THREADS) g[c] = S->gp[c];
-  __syncthreads();
-  // eliminate the frame-0 landmarks: H -= sum c_l w_l w_l^T, g -= sum c_l b_l w_l
+  // ---- the dense system over the present blocks, D = m15 + n, straight from the packed pose-side Hessian: entry
+  // (a, b) of A is H(r, c) of the tangent columns the plan maps there, minus the frame-0 landmarks' Schur sums
+  // (H -= sum c_l w_l w_l^T, g -= sum c_l b_l w_l) where both columns are pose / extrinsic / td columns
   const double *Sc = S->schur_sum;
-  if (mp->N0 > 0 || S->sharded) {  // sharded: the all-reduced sums hold the other ranks' landmarks
-    for (int e = tid; e < KC * (KC + 1) / 2; e += MARG_THREADS) {
-      int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-      while ((r + 1) * (r + 2) / 2 <= e) r++;
-      while (r * (r + 1) / 2 > e) r--;
-      const int c = e - r * (r + 1) / 2;
-      Hs[e] -= Sc[schur_index(c, r)];
-    }
-    for (int c = tid; c < KC; c += MARG_THREADS) g[c] -= Sc[schur_index(c, COL_B)];
-  }
-  __syncthreads();
-  // ---- gather the dense system over the present blocks: D = m15 + n
+  const bool sub = mp->N0 > 0 || S->sharded;  // sharded: the all-reduced sums hold the other ranks' landmarks
   const int m15 = mp->m15, n = mp->n, D = m15 + n;
-  double *Ag = S->mscr;  // global scratch, D x D + D
-  for (int e = tid; e < KP * KP; e += MARG_THREADS) {
-    const int r = e / KP, c = e % KP;
-    const int ar = mp->col[r], ac = mp->col[c];
-    if (ar >= 0 && ac >= 0) Ag[ar * D + ac] = Hs[pidx(r, c)];
-  }
-  for (int c = tid; c < KP; c += MARG_THREADS)
-    if (mp->col[c] >= 0) Ag[D * D + mp->col[c]] = g[c];
-  __syncthreads();
+  double *Ag = S->mscr;  // global scratch: A', b' are kept there for parity checks
   // LDS re-use (16.7k doubles): A dies once A' is formed, so the second eigenvector matrix aliases it
   double *A = smem;                        // D x D           (<= 92*92 = 8464)
   double *V2 = smem;                       // n x n (row stride LDN), aliases A after the Schur step
@@ -776,12 +753,28 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   double *Ar = smem + 12544;               // n x n, row stride LDN (above everything the tridiagonal path puts below it)
   double *br = Ar + 76 * LDN;              // n
   double2 *cs = (double2 *)(br + 80);      // [2][48] (cos, sin) of the Jacobi rotations, double-buffered
-  int *perm = (int *)(cs + 96);            // n ints
+  int *perm = (int *)(cs + 96);            // n ints; first the inverse of the plan's column map
   double *scr = (double *)(perm + 96);     // 64
   // tridiagonal path: reflectors, the progressive recurrence and the small vectors live in the dead A / Tm area
   double *RV = smem, *vec8 = smem + 5776, *DMs = smem + 5776 + 672;  // 76 x 76, 7 x 96, 76 x LDN: ends at 12528 < 12544
-  for (int e = tid; e < D * D; e += MARG_THREADS) A[e] = Ag[e];
-  for (int c = tid; c < D; c += MARG_THREADS) bv[c] = Ag[D * D + c];
+  for (int c = tid; c < KP; c += MARG_THREADS) {
+    const int a = mp->col[c];
+    if (a >= 0) perm[a] = c;
+  }
+  __syncthreads();
+  for (int e = tid; e < D * D; e += MARG_THREADS) {
+    const int r = perm[e / D], c = perm[e % D];
+    const int hi = max(r, c), lo = min(r, c);
+    double v = S->Hpp[hi * (hi + 1) / 2 + lo];
+    if (sub && hi < KC) v -= Sc[schur_index(lo, hi)];
+    A[e] = v;
+  }
+  for (int a = tid; a < D; a += MARG_THREADS) {
+    const int c = perm[a];
+    double v = S->gp[c];
+    if (sub && c < KC) v -= Sc[schur_index(c, COL_B)];
+    bv[a] = v;
+  }
   __syncthreads();
   STAMP(S, 11);
   // ---- A_mm pseudo-inverse by eigen-decomposition (marginalization_factor.cpp:267-272)
