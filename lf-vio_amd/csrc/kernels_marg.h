@@ -96,6 +96,51 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
   build_tab(bt, &S->tab[ts->cur], tid, bt + 84);
 }
 
+// Inverse of a symmetric positive-definite m x m (m <= 15) matrix by ONE wave, everything in registers: lane i holds
+// row i (identity beyond m), Cholesky column by column (pivot and column entries broadcast with v_readlane), then
+// L^-1 one column per lane by forward substitution and X = L^-T L^-1.  Returns true when the factorization went through
+// AND every eigenvalue of the matrix is provably above `floor` (lambda_min = 1 / lambda_max(X) >= 1 / ||X||_F): only then
+// is X the pseudo-inverse the reference forms from the eigen-decomposition (marginalization_factor.cpp:267-272), and the
+// caller may skip that decomposition.  Called by the 64 lanes of one wave; Xout (m x m) is written either way.
+DEV bool spd_inverse_wave(const double *Am, double *Xout, int m, int lane, double floor) {
+  double a[15];
+#pragma unroll
+  for (int j = 0; j < 15; j++) a[j] = (lane < m && j < m) ? Am[lane * m + j] : (lane == j ? 1.0 : 0.0);
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 15; j++) {
+    const double d = readlane_f64(a[j], j);
+    ok = ok && (d > 0.0);
+    const double s = sqrt(d);
+    const double l = lane == j ? s : a[j] / s;
+    a[j] = l;
+#pragma unroll
+    for (int c = j + 1; c < 15; c++) a[c] -= l * readlane_f64(l, c);
+  }
+  double diag = 1.0;
+#pragma unroll
+  for (int j = 0; j < 15; j++) diag = lane == j ? a[j] : diag;
+  const double dinv = 1.0 / diag;
+  double y[15];  // y[i] = (L^-1)[i][lane]
+#pragma unroll
+  for (int i = 0; i < 15; i++) {
+    double t = lane == i ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; k++) t -= readlane_f64(a[k], i) * y[k];
+    y[i] = t * readlane_f64(dinv, i);
+  }
+  double fro = 0;
+#pragma unroll
+  for (int r = 0; r < 15; r++) {
+    double x = 0;
+#pragma unroll
+    for (int i = r; i < 15; i++) x = fma(readlane_f64(y[i], r), y[i], x);
+    if (lane < m && r < m) Xout[r * m + lane] = x, fro += x * x;
+  }
+  fro = wave_sum(fro);
+  return ok && fro * floor * floor < 1.0;  // NaN compares false
+}
+
 // Parallel cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (LDS, ld = n).
 // On exit diag(A) holds the eigenvalues and the columns of V (LDS, ld = n) the eigenvectors.
 // Round-robin ordering: np/2 disjoint rotations per step, np-1 steps per sweep; every 2x2 block
@@ -722,8 +767,9 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
 }
 
 // grid (1, batch) x 256, dynamic LDS = MARG_LDS
-__global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t stride, int flag) {
+__global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t stride, int flag_bits) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int flag = flag_bits & 255, force_eig = flag_bits >> 8;  // bit 8: debug, see lfvio_debug_force_eig
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const MargPlan *mp = &S->marg[flag];
@@ -783,19 +829,30 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     Am[e] = 0.5 * (A[r * D + c] + A[c * D + r]);
   }
   __syncthreads();
-  const int sw1 = jacobi_small(Am, Vm, m15, tid, MARG_THREADS, Tm, cs, scr);  // Tm (n x m15) is free until the Schur step
-  __syncthreads();
+  // Positive definite with every eigenvalue far above eps (the usual case): the pseudo-inverse IS the inverse, one wave
+  // forms it by Cholesky in a few microseconds; otherwise the eigen-decomposition decides which directions survive.
   const double eps = 1e-8;
-  for (int e = tid; e < m15 * m15; e += MARG_THREADS) {
-    const int r = e / m15, c = e % m15;
-    double s = 0;
-    for (int k = 0; k < m15; k++) {
-      const double ev = Am[k * m15 + k];
-      if (ev > eps) s += Vm[r * m15 + k] * (1.0 / ev) * Vm[c * m15 + k];
-    }
-    Ainv[e] = s;
+  __shared__ int spd_fast;
+  if (tid < 64) {
+    const bool fast = m15 <= 15 && !force_eig && spd_inverse_wave(Am, Ainv, m15, tid, 1e3 * eps);
+    if (tid == 0) spd_fast = fast ? 1 : 0;
   }
   __syncthreads();
+  int sw1 = 0;
+  if (!spd_fast) {
+    sw1 = jacobi_small(Am, Vm, m15, tid, MARG_THREADS, Tm, cs, scr);  // Tm (n x m15) is free until the Schur step
+    __syncthreads();
+    for (int e = tid; e < m15 * m15; e += MARG_THREADS) {
+      const int r = e / m15, c = e % m15;
+      double s = 0;
+      for (int k = 0; k < m15; k++) {
+        const double ev = Am[k * m15 + k];
+        if (ev > eps) s += Vm[r * m15 + k] * (1.0 / ev) * Vm[c * m15 + k];
+      }
+      Ainv[e] = s;
+    }
+    __syncthreads();
+  }
   STAMP(S, 12);
   // ---- A' = Arr - Arm Amm^+ Amr, b' = brr - Arm Amm^+ bmm  (:275-281)
   for (int e = tid; e < n * m15; e += MARG_THREADS) {

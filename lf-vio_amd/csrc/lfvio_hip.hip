@@ -120,6 +120,7 @@ struct lfvio_ctx {
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   bool use_graph = true;
+  bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
   // landmark-sharded mode (multi-GPU)
   bool shard_active = false;
   int shard_begin = 0, shard_end = 0, shard_state = 0;
@@ -601,7 +602,7 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone) {
   if (standalone)
     hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
   launch_iteration(c, count, g, mode);
-  hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag);
+  hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag | (c->force_eig ? 256 : 0));
   if (!EIG_TRIDIAG) hipLaunchKernelGGL(k_marg_vecs, dim3(MARG_VEC_WGS, count), dim3(256), 0, c->stream, c->d_base, c->L.total, flag);
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
@@ -1068,6 +1069,13 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   *avg_ms = (double)ms / reps;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  return LFVIO_OK;
+}
+
+int lfvio_debug_force_eig(lfvio_ctx *c, int on) {
+  if (!c) return LFVIO_ERR_ARG;
+  c->force_eig = on != 0;
+  destroy_graph(c);  // the flag is a kernel argument of the captured launches
   return LFVIO_OK;
 }
 

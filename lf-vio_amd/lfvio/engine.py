@@ -18,6 +18,7 @@ class Engine:
         self.lib.lfvio_debug_linearize.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), _dp, _dp, _dp, _dp, _dp, _dp]
         self.lib.lfvio_debug_marg_system.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         self.lib.lfvio_debug_set_graph.argtypes = [C.c_void_p, C.c_int]
+        self.lib.lfvio_debug_force_eig.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
         self.ctx = self.lib.lfvio_create(device)
         if not self.ctx:
@@ -40,6 +41,9 @@ class Engine:
 
     def set_graph(self, on):
         self.lib.lfvio_debug_set_graph(self.ctx, int(on))
+
+    def force_eig(self, on):
+        self.lib.lfvio_debug_force_eig(self.ctx, int(on))
 
     def solve(self, win):
         sol = abi.Solution(win.N)

@@ -143,6 +143,30 @@ def test_marginalize_with_prior_and_second_new(eng, oracle):
     assert q.valid == 0
 
 
+def test_pseudo_inverse_paths_agree(eng, oracle):
+    """The pseudo-inverse of the dropped block comes from a Cholesky factorization when every eigenvalue is provably
+    above eps and from the eigen-decomposition otherwise (marginalization_factor.cpp:267-272); with the second path forced,
+    both must meet the oracle and each other — with and without an incoming prior, for both marginalization flags."""
+    w = synth.make_window(12, 400)
+    sol, prior = oracle.optimize(w, abi.MARGIN_OLD)
+    for win in (abi.apply_solution(w, sol), abi.apply_solution(w, sol).copy(prior=prior)):
+        for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
+            ref, Aref, bref = oracle.marginalize(win, flag, want_Ab=True)
+            if ref.valid != 1:
+                continue
+            got = []
+            for forced in (False, True):
+                eng.force_eig(forced)
+                try:
+                    p = eng.marginalize(win, flag)
+                    A, b = eng.marg_system(p.n)
+                finally:
+                    eng.force_eig(False)
+                check_prior(p, ref, A, b, Aref, bref)
+                got.append(A)
+            assert rel(got[0], got[1]) < 1e-9
+
+
 def test_full_optimization_chain(eng, oracle):
     """optimization() end to end, twice in a row (warm-up window -> BASELINE window with prior)."""
     win, warm = synth.make_window_with_prior(0, 300, lambda w, f: oracle.optimize(w, f))
