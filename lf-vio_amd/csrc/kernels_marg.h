@@ -557,16 +557,39 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
   ESTAMP(26);
   const int wave = tid >> 6, lane = tid & 63;
   double *dd = vec, *ee = vec + 96, *ee2 = vec + 192, *tau = vec + 288, *lam = vec + 384, *pp = vec + 480, *nrm = vec + 576;
-  // ---- 1. tridiagonalization.  Only the lower triangle is read, like Eigen's solver (and tred2) do: mirror it first.
-  for (int i = tid >> 5; i < n; i += MARG_THREADS / 32)
-    for (int j = (tid & 31); j < i; j += 32) A[j * LDN + i] = A[i * LDN + j];
+  // ---- 1. tridiagonalization, the matrix in registers: thread (r0, c0) of a 48 x 16 grid owns A[r0 + 48 i][c0 + 16 q]
+  // (i < 2, q < 5; both triangles, like the LDS version it replaces — that one spent its time on the LDS pipe, reading
+  // and writing the trailing matrix once per column).  LDS carries only vectors: the current row (double-buffered, published
+  // by its owners after the update), p = tau A v, the reflectors.  A row sits in one DPP row of 16 lanes, so the
+  // products A v and p.v are reduced with four DPP steps.  Only the lower triangle of the input is read, like Eigen's
+  // solver (and tred2) do.
+  const int r0 = tid >> 4, c0 = tid & 15;
+  double ar[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      const int R = r0 + 48 * i, C = c0 + 16 * q;
+      ar[i][q] = (R < n && C < n) ? A[max(R, C) * LDN + min(R, C)] : 0.0;
+    }
+  double *xrow0 = lam, *xrow1 = nrm;  // free until the eigenvalue search
   if (tid < 96) dd[tid] = 0.0, ee[tid] = 0.0, ee2[tid] = 0.0;
   __syncthreads();
+  if (r0 == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      const int C = c0 + 16 * q;
+      if (C < n) xrow0[C] = ar[0][q];
+      if (C == 0) dd[0] = ar[0][q];
+    }
+  }
+  __syncthreads();
   for (int k = 0; k + 2 < n; k++) {
-    const int m = n - k - 1;  // the reflector acts on rows k+1 .. n-1; x = column k below the diagonal = row k right of it
+    const int m = n - k - 1;  // the reflector acts on rows / columns k+1 .. n-1; x = row k right of the diagonal
+    const double *xr = (k & 1) ? xrow1 : xrow0;
+    double *xn = (k & 1) ? xrow0 : xrow1;
     // every wave forms the reflector itself (dlarfg): no barrier between this and the product A v
-    const double *xr = A + k * LDN + k + 1;
-    const double x0 = lane < m ? xr[lane] : 0.0, x1 = lane + 64 < m ? xr[lane + 64] : 0.0;
+    const double x0 = lane < m ? xr[k + 1 + lane] : 0.0, x1 = lane + 64 < m ? xr[k + 1 + lane + 64] : 0.0;
     const double alpha = readlane_f64(x0, 0);
     const double ss = wave_sum_dpp((lane > 0 ? x0 * x0 : 0.0) + x1 * x1);
     double beta = alpha, t = 0.0, scal = 0.0;
@@ -579,47 +602,67 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
     if (wave == 0) {
       if (lane < m) RV[k * 76 + lane] = lane == 0 ? 1.0 : x0 * scal;
       if (lane + 64 < m) RV[k * 76 + lane + 64] = x1 * scal;
-      if (lane == 0) tau[k] = t, ee[k] = beta, dd[k] = A[k * LDN + k];
+      if (lane == 0) tau[k] = t, ee[k] = beta;
     }
-    {  // p = tau A v, eight lanes per row
-      const int i = tid >> 3, l8 = tid & 7;
-      double s = 0.0;
-      if (i < m) {
-        const double *row = A + (k + 1 + i) * LDN + k + 1;
-        for (int j = l8; j < m; j += 8) s = fma(row[j], j == 0 ? 1.0 : xr[j] * scal, s);
-      }
-      s = sum8(s);
-      if (i < m && l8 == 0) pp[i] = t * s;
+    double vj[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      const int C = c0 + 16 * q;
+      vj[q] = C == k + 1 ? 1.0 : ((C > k + 1 && C < n) ? xr[C] * scal : 0.0);
+    }
+    // p = tau A v
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int R = r0 + 48 * i;
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 5; q++) sacc = fma(ar[i][q], vj[q], sacc);
+      sacc = sum8(sacc);
+      sacc += dpp_f64<0x140>(sacc);  // row_mirror: the other eight lanes of the row of 16
+      if (c0 == 0 && R > k && R < n) pp[R] = t * sacc;
     }
     __syncthreads();
     {  // w = p - (tau/2)(p.v) v on the fly, A -= v w^T + w v^T
-      const double v0 = lane == 0 ? 1.0 : x0 * scal, v1 = x1 * scal;
-      const double pv = wave_sum_dpp((lane < m ? pp[lane] * v0 : 0.0) + (lane + 64 < m ? pp[lane + 64] * v1 : 0.0));
-      const double K = 0.5 * t * pv;
-      // thread (r, c) of a 24 x 32 grid: columns c, c + 32, c + 64 (their v, w stay in registers), rows r, r + 24, ...
-      const int c0 = tid & 31;
-      double vj[3], wj[3];
+      double wj[5], pvs = 0.0;
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int j = c0 + 32 * q;
-        vj[q] = j == 0 ? 1.0 : (j < m ? xr[j] * scal : 0.0);
-        wj[q] = j < m ? pp[j] - K * vj[q] : 0.0;
+      for (int q = 0; q < 5; q++) {
+        const int C = c0 + 16 * q;
+        wj[q] = (C > k && C < n) ? pp[C] : 0.0;
+        pvs = fma(wj[q], vj[q], pvs);
       }
-      for (int i = tid >> 5; i < m; i += MARG_THREADS / 32) {
-        const double vi = i == 0 ? 1.0 : xr[i] * scal, wi = pp[i] - K * vi;
-        double *row = A + (k + 1 + i) * LDN + k + 1;
+      pvs = sum8(pvs);
+      pvs += dpp_f64<0x140>(pvs);
+      const double K = 0.5 * t * pvs;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const int j = c0 + 32 * q;
-          if (j < m) row[j] -= vi * wj[q] + wi * vj[q];
+      for (int q = 0; q < 5; q++) wj[q] -= K * vj[q];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int R = r0 + 48 * i;
+        if (R > k && R < n) {
+          const double vi = R == k + 1 ? 1.0 : xr[R] * scal, wi = pp[R] - K * vi;
+#pragma unroll
+          for (int q = 0; q < 5; q++) ar[i][q] -= vi * wj[q] + wi * vj[q];
+        }
+        if (R == k + 1) {  // the next row: publish it, and its diagonal entry
+#pragma unroll
+          for (int q = 0; q < 5; q++) {
+            const int C = c0 + 16 * q;
+            if (C < n) xn[C] = ar[i][q];
+            if (C == k + 1) dd[k + 1] = ar[i][q];
+          }
         }
       }
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    if (n >= 2) dd[n - 2] = A[(n - 2) * LDN + n - 2], ee[n - 2] = A[(n - 1) * LDN + n - 2];
-    dd[n - 1] = A[(n - 1) * LDN + n - 1];
+  {  // the last 2 x 2 block: row n-2 is the last one published
+    const double *xl = ((n - 2) & 1) ? xrow1 : xrow0;
+    if (tid == 0 && n >= 2) ee[n - 2] = xl[n - 1];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int q = 0; q < 5; q++)
+        if (r0 + 48 * i == n - 1 && c0 + 16 * q == n - 1) dd[n - 1] = ar[i][q];
   }
   __syncthreads();
   ESTAMP(27);
