@@ -558,10 +558,12 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
   const int wave = tid >> 6, lane = tid & 63;
   double *dd = vec, *ee = vec + 96, *ee2 = vec + 192, *tau = vec + 288, *lam = vec + 384, *pp = vec + 480, *nrm = vec + 576;
   // ---- 1. tridiagonalization, the matrix in registers: thread (r0, c0) of a 48 x 16 grid owns A[r0 + 48 i][c0 + 16 q]
-  // (i < 2, q < 5; both triangles, like the LDS version it replaces — that one spent its time on the LDS pipe, reading
-  // and writing the trailing matrix once per column).  LDS carries only vectors: the current row (double-buffered, published
-  // by its owners after the update), p = tau A v, the reflectors.  A row sits in one DPP row of 16 lanes, so the
-  // products A v and p.v are reduced with four DPP steps.  Only the lower triangle of the input is read, like Eigen's
+  // (i < 2, q < 5; both triangles).  LDS carries only vectors: the reflector v of the current column (normalized and
+  // zero up to the diagonal, so nothing downstream needs a mask), p = tau A v, the reflectors for the back-transformation.
+  // A row sits in one DPP row of 16 lanes: A v, p.v and the norm of the next reflector are reduced with four DPP steps.
+  // The step is bound by instruction issue (three waves per SIMD, FP64 and DPP at four cycles each), so nothing is
+  // computed twice: the 16 lanes that own row k+1 form the NEXT reflector (dlarfg) right after they have updated that
+  // row, inside the update phase — two barriers per column.  Only the lower triangle of the input is read, like Eigen's
   // solver (and tred2) do.
   const int r0 = tid >> 4, c0 = tid & 15;
   double ar[2][5];
@@ -572,26 +574,26 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
       const int R = r0 + 48 * i, C = c0 + 16 * q;
       ar[i][q] = (R < n && C < n) ? A[max(R, C) * LDN + min(R, C)] : 0.0;
     }
-  double *xrow0 = lam, *xrow1 = nrm;  // free until the eigenvalue search
-  if (tid < 96) dd[tid] = 0.0, ee[tid] = 0.0, ee2[tid] = 0.0;
+  double *vb0 = lam, *vb1 = nrm;  // free until the eigenvalue search
+  if (tid < 96) dd[tid] = 0.0, ee[tid] = 0.0, ee2[tid] = 0.0, tau[tid] = 0.0, vb0[tid] = 0.0, vb1[tid] = 0.0;  // v stays zero beyond n
   __syncthreads();
-  if (r0 == 0) {
+  // called by the 16 lanes that own row kk once that row is final: d[kk], and the reflector of column kk (or the last e)
+  auto finish_row = [&](int kk, const double(&row)[5]) {
+    double *vb = (kk & 1) ? vb1 : vb0;
+    double a_part = 0.0, ss_part = 0.0;
 #pragma unroll
     for (int q = 0; q < 5; q++) {
       const int C = c0 + 16 * q;
-      if (C < n) xrow0[C] = ar[0][q];
-      if (C == 0) dd[0] = ar[0][q];
+      if (C == kk) dd[kk] = row[q];
+      if (C == kk + 1) a_part = row[q];
+      if (C > kk + 1 && C < n) ss_part = fma(row[q], row[q], ss_part);
     }
-  }
-  __syncthreads();
-  for (int k = 0; k + 2 < n; k++) {
-    const int m = n - k - 1;  // the reflector acts on rows / columns k+1 .. n-1; x = row k right of the diagonal
-    const double *xr = (k & 1) ? xrow1 : xrow0;
-    double *xn = (k & 1) ? xrow0 : xrow1;
-    // every wave forms the reflector itself (dlarfg): no barrier between this and the product A v
-    const double x0 = lane < m ? xr[k + 1 + lane] : 0.0, x1 = lane + 64 < m ? xr[k + 1 + lane + 64] : 0.0;
-    const double alpha = readlane_f64(x0, 0);
-    const double ss = wave_sum_dpp((lane > 0 ? x0 * x0 : 0.0) + x1 * x1);
+    if (kk + 2 >= n) {
+      if (kk == n - 2 && c0 == ((n - 1) & 15)) ee[kk] = a_part;
+      return;
+    }
+    a_part = sum8(a_part), ss_part = sum8(ss_part);
+    const double alpha = a_part + dpp_f64<0x140>(a_part), ss = ss_part + dpp_f64<0x140>(ss_part);
     double beta = alpha, t = 0.0, scal = 0.0;
     if (ss > 0.0) {
       const double nn = alpha * alpha + ss;
@@ -599,37 +601,53 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
       t = (beta - alpha) * fast_rcp(beta);
       scal = fast_rcp(alpha - beta);
     }
-    if (wave == 0) {
-      if (lane < m) RV[k * 76 + lane] = lane == 0 ? 1.0 : x0 * scal;
-      if (lane + 64 < m) RV[k * 76 + lane + 64] = x1 * scal;
-      if (lane == 0) tau[k] = t, ee[k] = beta;
-    }
-    double vj[5];
 #pragma unroll
     for (int q = 0; q < 5; q++) {
       const int C = c0 + 16 * q;
-      vj[q] = C == k + 1 ? 1.0 : ((C > k + 1 && C < n) ? xr[C] * scal : 0.0);
+      const double v = C == kk + 1 ? 1.0 : ((C > kk + 1 && C < n) ? row[q] * scal : 0.0);
+      vb[C] = v;
+      if (C > kk && C < n) RV[kk * 76 + C - kk - 1] = v;
     }
-    // p = tau A v
+    if (c0 == 0) tau[kk] = t, ee[kk] = beta;
+  };
+  if (r0 == 0) finish_row(0, ar[0]);
+  __syncthreads();
+  for (int k = 0; k + 2 < n; k++) {
+    const double *vb = (k & 1) ? vb1 : vb0;
+    const double t = tau[k];
+    double vj[5];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int R = r0 + 48 * i;
-      double sacc = 0.0;
+    for (int q = 0; q < 5; q++) vj[q] = vb[c0 + 16 * q];
+    {  // p = tau A v (zero for the rows that are done)
+      double sacc[2];
 #pragma unroll
-      for (int q = 0; q < 5; q++) sacc = fma(ar[i][q], vj[q], sacc);
-      sacc = sum8(sacc);
-      sacc += dpp_f64<0x140>(sacc);  // row_mirror: the other eight lanes of the row of 16
-      if (c0 == 0 && R > k && R < n) pp[R] = t * sacc;
+      for (int i = 0; i < 2; i++) {
+        sacc[i] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) sacc[i] = fma(ar[i][q], vj[q], sacc[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) sacc[i] += dpp_f64<0xB1>(sacc[i]);
+#pragma unroll
+      for (int i = 0; i < 2; i++) sacc[i] += dpp_f64<0x4E>(sacc[i]);
+#pragma unroll
+      for (int i = 0; i < 2; i++) sacc[i] += dpp_f64<0x141>(sacc[i]);
+#pragma unroll
+      for (int i = 0; i < 2; i++) sacc[i] += dpp_f64<0x140>(sacc[i]);
+      if (c0 == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) pp[r0 + 48 * i] = r0 + 48 * i > k ? t * sacc[i] : 0.0;
+      }
     }
     __syncthreads();
-    {  // w = p - (tau/2)(p.v) v on the fly, A -= v w^T + w v^T
-      double wj[5], pvs = 0.0;
+    {  // w = p - (tau/2)(p.v) v on the fly, A -= v w^T + w v^T; v and p are zero outside k+1 .. n-1
+      double wj[5], vi[2], wi[2], pvs = 0.0;
 #pragma unroll
-      for (int q = 0; q < 5; q++) {
-        const int C = c0 + 16 * q;
-        wj[q] = (C > k && C < n) ? pp[C] : 0.0;
-        pvs = fma(wj[q], vj[q], pvs);
-      }
+      for (int q = 0; q < 5; q++) wj[q] = pp[c0 + 16 * q];
+#pragma unroll
+      for (int i = 0; i < 2; i++) vi[i] = vb[r0 + 48 * i], wi[i] = pp[r0 + 48 * i];
+#pragma unroll
+      for (int q = 0; q < 5; q++) pvs = fma(wj[q], vj[q], pvs);
       pvs = sum8(pvs);
       pvs += dpp_f64<0x140>(pvs);
       const double K = 0.5 * t * pvs;
@@ -637,33 +655,19 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
       for (int q = 0; q < 5; q++) wj[q] -= K * vj[q];
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        const int R = r0 + 48 * i;
-        if (R > k && R < n) {
-          const double vi = R == k + 1 ? 1.0 : xr[R] * scal, wi = pp[R] - K * vi;
+        wi[i] -= K * vi[i];
 #pragma unroll
-          for (int q = 0; q < 5; q++) ar[i][q] -= vi * wj[q] + wi * vj[q];
-        }
-        if (R == k + 1) {  // the next row: publish it, and its diagonal entry
-#pragma unroll
-          for (int q = 0; q < 5; q++) {
-            const int C = c0 + 16 * q;
-            if (C < n) xn[C] = ar[i][q];
-            if (C == k + 1) dd[k + 1] = ar[i][q];
-          }
-        }
+        for (int q = 0; q < 5; q++) ar[i][q] -= vi[i] * wj[q] + wi[i] * vj[q];
       }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+        if (r0 + 48 * i == k + 1) finish_row(k + 1, ar[i]);
     }
     __syncthreads();
   }
-  {  // the last 2 x 2 block: row n-2 is the last one published
-    const double *xl = ((n - 2) & 1) ? xrow1 : xrow0;
-    if (tid == 0 && n >= 2) ee[n - 2] = xl[n - 1];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int q = 0; q < 5; q++)
-        if (r0 + 48 * i == n - 1 && c0 + 16 * q == n - 1) dd[n - 1] = ar[i][q];
-  }
+  for (int i = 0; i < 2; i++)
+    if (r0 + 48 * i == n - 1) finish_row(n - 1, ar[i]);
   __syncthreads();
   ESTAMP(27);
   // ---- 2. eigenvalues
