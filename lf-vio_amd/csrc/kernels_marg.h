@@ -533,18 +533,21 @@ DEV double wave_sum_dpp(double v) {  // every lane gets the sum over the 64 lane
 // 152 numbers 18 times), the signs are shifted into a mask and counted at the end, and the pair is brought back to unit
 // scale every eight rows (one row grows it by at most ||T||^2).
 typedef const __attribute__((address_space(4))) double sdouble;
-DEV int sturm_count(sdouble *Tg /* d[96] | e^2[96], zero-padded */, int n, double sigma) {
+DEV int sturm_count(sdouble *Tg /* d[96] | e^2[96]; beyond n: d above every shift, e^2 = 0 */, int n, double sigma) {
+  // five instructions per row: d - sigma, e^2 p_{i-2}, the fma, and the sign change shifted into a word that is
+  // counted once per 16 rows.  Rows beyond n keep the sign (d - sigma > 0, e^2 = 0), so they need no mask; the pair is
+  // brought back to unit scale every 16 rows (one row grows it by at most 2 ||T|| + 1).
   double pm = 1.0, p = Tg[0] - sigma;
   unsigned cnt = (unsigned)__double2hiint(p) >> 31;
-  for (int i0 = 1; i0 < n; i0 += 8) {
+  for (int i0 = 1; i0 < n; i0 += 16) {
+    unsigned bits = 0;
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 16; u++) {
       const double pn = fma(Tg[i0 + u] - sigma, p, -Tg[96 + i0 + u - 1] * pm);
-      // a sign change between p_{i-1} and p_i; rows beyond n (d = e^2 = 0 there) are masked out
-      const unsigned ch = (unsigned)(__double2hiint(pn) ^ __double2hiint(p)) >> 31;
-      cnt += (i0 + u < n) ? ch : 0u;
+      bits = __builtin_amdgcn_alignbit(bits, (unsigned)(__double2hiint(pn) ^ __double2hiint(p)), 31);
       pm = p, p = pn;
     }
+    cnt += __builtin_popcount(bits);
     const int ex = ilogb(fmax(fmax(fabs(p), fabs(pm)), 1e-300));
     p = ldexp(p, -ex), pm = ldexp(pm, -ex);
   }
@@ -672,8 +675,6 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
   ESTAMP(27);
   // ---- 2. eigenvalues
   if (tid < n) ee2[tid] = ee[tid] * ee[tid];
-  if (tid < 96) Tglob[tid] = dd[tid], Tglob[96 + tid] = tid < n ? ee[tid] * ee[tid] : 0.0;
-  __threadfence();
   {
     double lo = 1e300, hi = -1e300;
     if (tid < n) {
@@ -685,31 +686,39 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
   }
   __syncthreads();
   double gl = fmin(scr[0], scr[1]), gu = fmax(scr[16], scr[17]);  // n <= 76: the first two waves hold everything
+  {
+    const double tn = fmax(fabs(gl), fabs(gu));
+    gl -= 2.2e-16 * tn * n + 1e-300, gu += 2.2e-16 * tn * n + 1e-300;
+  }
+  // T for the scalar loads; the rows that pad n to the unroll length sit above every shift and are decoupled
+  if (tid < 96) Tglob[tid] = tid < n ? dd[tid] : gu + 1.0, Tglob[96 + tid] = tid + 1 < n ? ee[tid] * ee[tid] : 0.0;
+  __threadfence();
+  __syncthreads();
   __builtin_amdgcn_s_dcache_inv();
   const unsigned long long ta = (unsigned long long)Tglob;
   unsigned tlo = __builtin_amdgcn_readfirstlane((unsigned)ta), thi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
   asm volatile("" : "+s"(tlo), "+s"(thi));  // the scalar loads stay behind the barrier above
   sdouble *Tg = (sdouble *)(((unsigned long long)thi << 32) | tlo);
   {
-    const double tn = fmax(fabs(gl), fabs(gu)), pivmin = 1e-290;
-    gl -= 2.2e-16 * tn * n + 1e-300, gu += 2.2e-16 * tn * n + 1e-300;
-    // two lanes per eigenvalue (trisection, 34 rounds): 152 threads are three waves, one per SIMD — the recurrence is
-    // bound by instruction issue, so the work is kept small rather than the round count (eight lanes per eigenvalue
-    // need 18 rounds but ten waves)
-    const int m = tid >> 1, l8 = tid & 1;
+    const double pivmin = 1e-290;
+    // three lanes per eigenvalue (quadrisection, 27 rounds), 21 eigenvalues per wave: four waves, one per SIMD — the
+    // recurrence is bound by instruction issue, so the work is kept small rather than the round count (eight lanes per
+    // eigenvalue need 18 rounds but ten waves)
+    const int g3 = lane == 63 ? 20 : lane / 3, l8 = lane == 63 ? 3 : lane - 3 * g3;  // lane 63 rides along with group 20
+    const int m = wave * 21 + g3;
     double lo = gl, hi = gu;
     const int mm = m < n ? m : n - 1;
-    if (tid < 2 * 96)
-      for (int round = 0; round < 34; round++) {
+    if (tid < 256)
+      for (int round = 0; round < 27; round++) {
         const double w = hi - lo;
-        const double sigma = lo + w * (double)(l8 + 1) * (1.0 / 3.0);
+        const double sigma = lo + w * (double)(l8 < 3 ? l8 + 1 : 1) * 0.25;
         const int cnt = sturm_count(Tg, n, sigma);
-        int f = cnt <= mm ? 1 : 0;  // eigenvalue mm (0-based, ascending) is >= sigma
-        f += __shfl_xor(f, 1, 64);
-        const double nlo = f == 0 ? lo : lo + w * (double)f * (1.0 / 3.0), nhi = f == 2 ? hi : lo + w * (double)(f + 1) * (1.0 / 3.0);
+        const int f1 = cnt <= mm ? 1 : 0;  // eigenvalue mm (0-based, ascending) is >= sigma
+        const int f = __shfl(f1, 3 * g3, 64) + __shfl(f1, 3 * g3 + 1, 64) + __shfl(f1, 3 * g3 + 2, 64);
+        const double nlo = f == 0 ? lo : lo + w * (double)f * 0.25, nhi = f == 3 ? hi : lo + w * (double)(f + 1) * 0.25;
         lo = nlo, hi = nhi;
       }
-    if (m < n && l8 == 0) lam[m] = 0.5 * (lo + hi);
+    if (tid < 256 && m < n && l8 == 0) lam[m] = 0.5 * (lo + hi);
     __syncthreads();
     ESTAMP(28);
     // ---- 3. eigenvectors of T: thread me runs the stationary recurrence (top down) into A, thread 128 + me the
