@@ -120,6 +120,22 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       if (er == ek && 16 * a + er < KP) hv[16 * a + er] = hreg[tile_id(a, a)];  // the diagonal, for the scaling below
     if (tid < KP) g[tid] = S->gp[tid];
   }
+  // the Schur sums this thread will subtract, requested with everything else (a load behind the branches of the build
+  // loop below waits a memory round trip of its own): entry (er, ek) of the 15 pose-side tiles, the rhs column, z2
+  double sreg[15], srhs[5], scross = 0.0;
+  {
+    const double *Sg = S->schur_sum;
+    int n15 = 0;
+#pragma unroll
+    for (int t = 0; t < NTILES; t++)
+      if (tile_a(t) <= 4) {
+        const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
+        sreg[n15++] = Sg[schur_index(min(i, j), max(i, j))];
+      }
+#pragma unroll
+    for (int b = 0; b < 5; b++) srhs[b] = Sg[schur_index(16 * b + ek, COL_B)];
+    if (tid < KC) scross = Sg[schur_index(tid, COL_K)];
+  }
   // landmark-side scalars: local sums, or the all-reduced totals of the sharded mode
   const double *ls = S->sharded ? S->xch + XOFF_C : S->lm_sum;
   if (tr->do_lin && tid == 0) {
@@ -155,9 +171,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   STAMP(S, 2);
   // ---- reduced system, in place:  S = S_p (H_pp - Schur) S_p + mu D^2  and the rhs row; the Cauchy-point quadratic
   //      form G^T H G is accumulated from the same entries on the way.
-  const double *Sc = S->schur_sum;
   double qgg_part = 0;
   {
+    int n15 = 0;
     // per-thread slices of the vectors: row index 16 a + er, column index 16 b + ek
     double Gi[NTL], Gj[NTL], si[NTL], sj[NTL];
     bool ai[NTL], aj[NTL];
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
         double h = hreg[t];
         qgg_part = fma(h * Gi[a], (i == j) ? Gj[b] : 2.0 * Gj[b], qgg_part);
         if (ai[a] && aj[b]) {
-          if (a <= 4 && i < KC) h -= Sc[schur_index(j, i)];  // j <= i < 73
+          if (a <= 4 && i < KC) h -= sreg[a <= 4 ? n15 : 0];  // j <= i < 73
           v = si[a] * sj[b] * h;
           if (i == j) v += mu * dg[i] * dg[i];
         } else {
@@ -185,11 +201,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       } else if (a == NTL - 1 && i == KP && j < KP) {
         if (aj[b]) {
           double r = g[j];
-          if (j < KC) r -= Sc[schur_index(j, COL_B)];  // z1
+          if (j < KC) r -= srhs[b < 5 ? b : 0];  // z1
           v = sj[b] * r;
         }
       }
       Hs[t * TSZ + esw] = v;
+      if (a <= 4) n15++;
     }
   }
   // ---- Cauchy point: alpha = ||gradient_||^2 / ||J (gradient_/diagonal_)||^2
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     double gs = 0, cross = 0;
     if (tid < KP) {
       gs = gr[tid] * gr[tid];
-      if (tid < KC) cross = Sc[schur_index(tid, COL_K)] * Gd[tid];  // z2 . G_c
+      if (tid < KC) cross = scross * Gd[tid];  // z2 . G_c
     }
     double sums[3] = {qgg_part, gs, cross};
     block_sum_n(sums, scratch, tid);
