@@ -27,6 +27,9 @@ int lfvio_debug_set_graph(lfvio_ctx *ctx, int on);
 /* on != 0: the pseudo-inverse of the dropped block always comes from its eigen-decomposition (marginalization_factor.cpp:267-272);
    default: from a Cholesky factorization when every eigenvalue is provably far above eps, from the eigen-decomposition otherwise. */
 int lfvio_debug_force_eig(lfvio_ctx *ctx, int on);
+/* graph launches the last synchronous solve loop needed (1: every window was done within the first chunk of passes,
+   and gauge fix + marginalization ran in the same graph) */
+int lfvio_debug_last_chunks(lfvio_ctx *ctx);
 #ifdef __cplusplus
 }
 #endif

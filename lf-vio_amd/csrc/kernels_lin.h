@@ -11,6 +11,12 @@
 
 constexpr int MODE_SOLVE = 0;
 constexpr int MODE_MARG = 1;        // MODE_MARG + flag: 1 = MARGIN_OLD, 2 = MARGIN_SECOND_NEW
+// The synchronous entry points put gauge fix + marginalization into the same graph as the first chunk of solve passes.
+// Those launches carry MODE_GATED and act on a slot only once its solve is done and its marginalization has not run yet
+// (Slot::tail_state: 0 not run, 2 finished); they leave `done` set, so later solve passes skip the slot.  Nothing a
+// gated kernel tests is written before the last of them (k_marg_solve) ends.
+constexpr int MODE_GATED = 16;
+DEV bool tail_gate(const Slot *S, int done) { return done && S->tail_state == 0; }
 DEV bool is_marg(int mode) { return mode >= MODE_MARG; }
 DEV const MargPlan *marg_plan(const Slot *S, int mode) { return &S->marg[mode - MODE_MARG]; }
 
@@ -49,6 +55,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       t->error = 0;
       t->new_point = 0;
       t->spec_n = 1;
+      S->tail_state = 0;
       if (mode >= MODE_MARG) t->mu = 0.0;
     }
     __shared__ double bt[84 + 256];
@@ -587,12 +594,17 @@ DEV void lin_prior_role(Slot *S, int mode, double *lds) {
   }
 }
 
-__global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode, int gLm, int gCh) {
+// mode_bits: the mode, plus MODE_GATED for the marginalization sweep that rides behind the solve passes in the same graph
+// (see tail_gate)
+__global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode_bits, int gLm, int gCh) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
+  const int mode = mode_bits & (MODE_GATED - 1);
   const TRFlags fl = tr_flags(tr);
   const int do_lin = fl.do_lin, do_schur = fl.do_schur;
-  if (fl.done | (!do_lin & !do_schur)) return;
+  if (mode_bits & MODE_GATED) {
+    if (!tail_gate(S, fl.done)) return;
+  } else if (fl.done | (!do_lin & !do_schur)) return;
   __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLm, gCh); each slot uses its own counts
   int b = blockIdx.x;
@@ -687,13 +699,16 @@ DEV double gram_gather(const Slot *S, int e, int mode) {
 //   last                  landmark scalar partials -> lm_sum
 // ---------------------------------------------------------------------------
 constexpr int PRE_GROUP = 32;
-__global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int mode, int groups) {
+__global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int mode_bits, int groups) {
   const int PRE_SCHUR_BLOCKS = (SCHUR_LEN / 256) * groups;
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
+  const int mode = mode_bits & (MODE_GATED - 1);
   {
     const TRFlags fl = tr_flags(tr);
-    if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
+    if (mode_bits & MODE_GATED) {
+      if (!tail_gate(S, fl.done)) return;
+    } else if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
   }
   const int tid = threadIdx.x;
   int b = blockIdx.x;
@@ -759,12 +774,15 @@ __global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int m
   if (tid < 5) S->lm_sum[tid] = red[tid][0];
 }
 
-__global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode, int pre) {
+__global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode_bits, int pre) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
+  const int mode = mode_bits & (MODE_GATED - 1);
   {
     const TRFlags fl = tr_flags(tr);
-    if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
+    if (mode_bits & MODE_GATED) {
+      if (!tail_gate(S, fl.done)) return;
+    } else if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
   }
   const int tid = threadIdx.x;
   int b = blockIdx.x;

@@ -23,10 +23,11 @@ constexpr size_t MARG_LDS = (size_t)19072 * sizeof(double);  // >= LPACK + KP + 
 constexpr bool EIG_TRIDIAG = true;  // n x n eigen-problem: Householder tridiagonalization + multisection + twisted factorization
                                     // (eig_tridiag below); false: the systolic Jacobi + k_marg_vecs
 
-__global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
+__global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int gated) {
   Slot *S = SLOT(base, stride);
   TRState *ts = &S->tr;
   const int tid = threadIdx.x;
+  if (gated && !tail_gate(S, ts->done)) return;
   if (blockIdx.x > 0) {
     // setDepth / getDepthVector round trip (feature_manager.cpp:148,191), 128 landmarks per workgroup
     const int l = (blockIdx.x - 1) * 128 + tid;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride) {
   }
   __syncthreads();
   if (tid == 0) {
-    ts->done = 0;
+    if (!gated) ts->done = 0;  // gated: `done` stays, the gated sweep that follows tests it like this kernel did
     ts->do_lin = 1;
     ts->do_schur = 1;
     ts->chol_fail = 0;
@@ -825,15 +826,17 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
 // grid (1, batch) x 256, dynamic LDS = MARG_LDS
 __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t stride, int flag_bits) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int flag = flag_bits & 255, force_eig = flag_bits >> 8;  // bit 8: debug, see lfvio_debug_force_eig
+  const int flag = flag_bits & 255, force_eig = (flag_bits >> 8) & 1, gated = (flag_bits >> 9) & 1;  // bit 8: debug, see lfvio_debug_force_eig; bit 9: MODE_GATED
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const MargPlan *mp = &S->marg[flag];
   const int tid = threadIdx.x;
   LfvioPrior *out = &S->prior_out;
+  if (gated && !tail_gate(S, tr->done)) return;
   if (!mp->valid) {
     // MARGIN_SECOND_NEW with no prior touching Pose[WINDOW_SIZE-1]: the prior is left as it is
     if (tid == 0) out->valid = -1;  // host copies the input prior through
+    if (gated && tid == 0) S->tail_state = 2;
     return;
   }
   STAMP(S, 10);
@@ -983,5 +986,6 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     out->m = m15 + (S->sharded ? (int)(S->xch[XOFF_C + XS_N0] + 0.5) : mp->N0);
     out->n = n;
     out->num_blocks = mp->nb;
+    if (gated) S->tail_state = 2;
   }
 }

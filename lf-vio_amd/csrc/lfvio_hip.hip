@@ -116,10 +116,11 @@ struct lfvio_ctx {
   hipGraphExec_t graph = nullptr;
   int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0;
   // cached graph of one chunk of passes (synchronous entry points: the loop is launched chunk by chunk)
-  hipGraphExec_t chunk = nullptr, chunk0 = nullptr, tail[3] = {nullptr, nullptr, nullptr};  // chunk0: k_setup + chunk; tail[flag]: gauge + marginalization
+  hipGraphExec_t chunk = nullptr, chunk0 = nullptr, tail[3] = {nullptr, nullptr, nullptr}, fused0[3] = {nullptr, nullptr, nullptr};  // chunk0: k_setup + chunk; tail[flag]: gauge + marginalization
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   bool use_graph = true;
+  int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
   bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
   // landmark-sharded mode (multi-GPU)
   bool shard_active = false;
@@ -140,6 +141,8 @@ void destroy_graph(lfvio_ctx *c) {
   }
   if (c->chunk0) (void)hipGraphExecDestroy(c->chunk0), c->chunk0 = nullptr;
   for (auto &t : c->tail)
+    if (t) (void)hipGraphExecDestroy(t), t = nullptr;
+  for (auto &t : c->fused0)
     if (t) (void)hipGraphExecDestroy(t), t = nullptr;
 }
 
@@ -512,7 +515,7 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   const size_t st = c->L.total;
   launch_lin(c, count, g, mode);
   launch_sum(c, count, g, mode);
-  if (mode == MODE_SOLVE) {
+  if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
     hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
@@ -529,11 +532,24 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   }
 }
 
-__global__ void k_pending(char *base, size_t stride, int count, int *out) {
+// number of slots that still need passes (tail = 0: solve not done; tail = 1: gated marginalization not finished)
+__global__ void k_pending(char *base, size_t stride, int count, int *out, int tail) {
   int n = 0;
-  for (int s = threadIdx.x; s < count; s += 64) n += ((const Slot *)(base + (size_t)s * stride))->tr.done ? 0 : 1;
+  for (int s = threadIdx.x; s < count; s += 64) {
+    const Slot *S = (const Slot *)(base + (size_t)s * stride);
+    n += (tail ? S->tail_state == 2 : S->tr.done != 0) ? 0 : 1;
+  }
   n = __reduce_add_sync(~0ull, n);
   if (threadIdx.x == 0) *out = n;
+}
+
+// a slot that is still not done when the passes are used up ends as it is (NO_CONVERGENCE): the gated tail takes it then
+__global__ void k_force_done(char *base, size_t stride, int count) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < count) {
+    Slot *S = (Slot *)(base + (size_t)s * stride);
+    if (!S->tr.done) S->tr.done = 1;
+  }
 }
 
 // Enqueue the trust-region loop for slots [0, count): max_iter Ceres iterations plus spare
@@ -543,7 +559,11 @@ __global__ void k_pending(char *base, size_t stride, int count, int *out) {
 //     of unfinished slots in between.  A pass costs its ~30 us of launches and first loads whether or not the loop is
 //     already done, and with the speculative candidates of small windows nine iterations are four passes, not twelve.
 constexpr int SOLVE_CHUNK = 4;
-int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive) {
+int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated = false);
+// fused_flag >= 0 (adaptive only): gauge fix + marginalization ride in the graph of the first chunk, gated per slot on
+// `done` — the common case (every window done within the first chunk) is ONE graph launch and one synchronization; *tail_done
+// tells the caller whether anything is left for the (gated) tail graph.
+int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fused_flag = -1, bool *tail_done = nullptr) {
   const Grid g = grid_for(c, count);
   const int passes = std::max(max_iter, 0) + 4;
   if (adaptive && c->use_graph) {
@@ -560,7 +580,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive) {
         if (first)
           hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
         for (int it = 0; it < SOLVE_CHUNK; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate);
-        hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending);
+        hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, 0);
         HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
         HIPCHK(c, hipGraphInstantiate(first ? &c->chunk0 : &c->chunk, graph, nullptr, nullptr, 0));
@@ -568,10 +588,31 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive) {
       }
       c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate;
     }
+    if (tail_done) *tail_done = false;
+    const bool fuse = fused_flag >= 0 && fused_flag < 3;
+    if (fuse && !c->fused0[fused_flag]) {
+      hipGraph_t graph;
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+      for (int it = 0; it < SOLVE_CHUNK; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate);
+      hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
+      const int rc = enqueue_marg(c, count, fused_flag, false, true);
+      hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, 1);
+      HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
+      if (rc) return rc;
+      HIPCHK(c, hipGraphInstantiate(&c->fused0[fused_flag], graph, nullptr, nullptr, 0));
+      HIPCHK(c, hipGraphDestroy(graph));
+    }
+    c->stat_chunks = 0;
     for (int done_passes = 0; done_passes < passes; done_passes += SOLVE_CHUNK) {
-      HIPCHK(c, hipGraphLaunch(done_passes == 0 ? c->chunk0 : c->chunk, c->stream));
+      c->stat_chunks++;
+      HIPCHK(c, hipGraphLaunch(done_passes == 0 ? (fuse ? c->fused0[fused_flag] : c->chunk0) : c->chunk, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (*c->h_pending == 0) break;
+      if (*c->h_pending == 0) {
+        if (tail_done && fuse && done_passes == 0) *tail_done = true;
+        break;
+      }
     }
     HIPCHK(c, hipGetLastError());
     return LFVIO_OK;
@@ -596,13 +637,13 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive) {
   return LFVIO_OK;
 }
 
-int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone) {
+int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated) {
   const Grid g = grid_for(c, count);
-  const int mode = MODE_MARG + flag;
+  const int mode = (MODE_MARG + flag) | (gated ? MODE_GATED : 0);
   if (standalone)
     hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
   launch_iteration(c, count, g, mode);
-  hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag | (c->force_eig ? 256 : 0));
+  hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag | (c->force_eig ? 256 : 0) | (gated ? 512 : 0));
   if (!EIG_TRIDIAG) hipLaunchKernelGGL(k_marg_vecs, dim3(MARG_VEC_WGS, count), dim3(256), 0, c->stream, c->d_base, c->L.total, flag);
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
@@ -773,14 +814,19 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
       c->err = "slot not uploaded";
       return LFVIO_ERR_ARG;
     }
-  int rc = enqueue_solve(c, count, max_iter, adaptive);
+  const bool fuse = adaptive && c->use_graph && marg_flag >= 0 && marg_flag < 3;
+  bool tail_done = false;
+  int rc = enqueue_solve(c, count, max_iter, adaptive, fuse ? marg_flag : -1, &tail_done);
   if (rc) return rc;
-  if (adaptive && c->use_graph && marg_flag >= 0 && marg_flag < 3) {  // gauge fix + marginalization as one graph launch
+  if (fuse) {
+    if (tail_done) return LFVIO_OK;  // the usual case: everything ran in the graph of the first chunk
+    // some window needed more passes: gauge fix + marginalization for the slots that have not had theirs (gated)
     if (!c->tail[marg_flag]) {
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total);
-      rc = enqueue_marg(c, count, marg_flag, false);
+      hipLaunchKernelGGL(k_force_done, dim3((count + 63) / 64), dim3(64), 0, c->stream, c->d_base, c->L.total, count);
+      hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
+      rc = enqueue_marg(c, count, marg_flag, false, true);
       HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
       if (rc) return rc;
       HIPCHK(c, hipGraphInstantiate(&c->tail[marg_flag], graph, nullptr, nullptr, 0));
@@ -789,7 +835,7 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
     HIPCHK(c, hipGraphLaunch(c->tail[marg_flag], c->stream));
     return LFVIO_OK;
   }
-  hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total);
+  hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 0);
   return enqueue_marg(c, count, marg_flag, false);
 }
 
@@ -1071,6 +1117,8 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   (void)hipEventDestroy(e1);
   return LFVIO_OK;
 }
+
+int lfvio_debug_last_chunks(lfvio_ctx *c) { return c ? c->stat_chunks : -1; }
 
 int lfvio_debug_force_eig(lfvio_ctx *c, int on) {
   if (!c) return LFVIO_ERR_ARG;

@@ -19,6 +19,7 @@ class Engine:
         self.lib.lfvio_debug_marg_system.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         self.lib.lfvio_debug_set_graph.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_force_eig.argtypes = [C.c_void_p, C.c_int]
+        self.lib.lfvio_debug_last_chunks.argtypes = [C.c_void_p]
         self.lib.lfvio_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
         self.ctx = self.lib.lfvio_create(device)
         if not self.ctx:
@@ -41,6 +42,9 @@ class Engine:
 
     def set_graph(self, on):
         self.lib.lfvio_debug_set_graph(self.ctx, int(on))
+
+    def last_chunks(self):
+        return int(self.lib.lfvio_debug_last_chunks(self.ctx))
 
     def force_eig(self, on):
         self.lib.lfvio_debug_force_eig(self.ctx, int(on))
