@@ -1101,6 +1101,12 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     switch (which) {
       case 0: launch_lin(c, count, g, MODE_SOLVE); break;
       case 2: launch_sum(c, count, g, MODE_SOLVE); break;  // k_presum + k_sum for large windows
+      case 8: case 9: case 10: {  // k_lin by role: landmark blocks | Gram chunks | IMU factors + prior
+        const int gram_wgs = (g.ch + 3) / 4;
+        const int gx = which == 8 ? g.lm : which == 9 ? gram_wgs : LFVIO_WINDOW_SIZE + 1;
+        hipLaunchKernelGGL(k_lin, dim3(gx, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, which == 8 ? g.lm : 0,
+                           which == 9 ? gram_wgs : 0);
+      } break;
       case 4: case 5: case 6: case 7: {  // k_setup by role: state + table | + IMU sqrt_info | + prior J0^T J0 | + inverse depths
         const int gx = which == 4 ? 1 : which == 5 ? 1 + LFVIO_WINDOW_SIZE : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
         hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);

@@ -73,7 +73,10 @@ def main():
                              f"{sum(idle) / max(len(idle), 1) / 1e3:.2f} |")
             open(os.path.join(OUT, f"bench_{w}_launches.md"), "w").write("\n".join(lines) + "\n")
     # 3. PMC passes (window300 and window100k)
-    md = ["# PMC summary — rocprofv3 --pmc, separate passes, values per launch (mean over launches)", "",
+    md = ["# PMC summary — rocprofv3 --pmc, separate passes, values per WORKING launch", "",
+          "(mean over the launches whose counter is at least a quarter of the largest one of that kernel: the graphs launch every",
+          "kernel in every pass and a launch that has nothing to do returns at once — those would only dilute the mean;",
+          "`launches` = working / all)", "",
           "FETCH_SIZE / WRITE_SIZE are KB as rocprofv3 reports them.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide",
           "(16 B/lane) streaming reads by 2x and is uncalibrated for other widths; the kernels here read 8 B per lane, so the",
           "figures are kept as measured and compared with the algorithmic bytes only as an order of magnitude.", ""]
@@ -91,8 +94,13 @@ def main():
         for k, cs in sorted(agg.items()):
             if k.startswith("__amd"):
                 continue
+            def working(v):
+                top = max(v)
+                return [x for x in v if x >= 0.25 * top] if top > 0 else v
             n = max(len(v) for v in cs.values())
-            md.append(f"| {k} | {n} | " + " | ".join(f"{sum(cs[c]) / len(cs[c]):.1f}" if cs.get(c) else "-" for c in names) + " |")
+            ref = cs.get("SQ_INSTS_VALU") or cs.get("FETCH_SIZE") or next(iter(cs.values()))  # (SQ_WAVES is the same for a launch that returns at once)
+            md.append(f"| {k} | {len(working(ref))} / {n} | " +
+                      " | ".join(f"{sum(working(cs[c])) / len(working(cs[c])):.1f}" if cs.get(c) else "-" for c in names) + " |")
         md.append("")
     open(os.path.join(OUT, "pmc_summary.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md))
