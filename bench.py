@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP64_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz: v_mfma_f64_16x16x4_f64 issues every 64 cycles (tools/micro/mfma64.hip); the FP64 vector rate is the same
 
 
 def algorithmic_bytes(win):
@@ -209,6 +210,17 @@ def main():
                     algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_us=lin_ms * 1e3,
                     note="latency-bound at N=300 (0.12 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep")
     extra = dict(k_sum_us=eng.time_kernel(2, batch, reps) * 1e3, k_solve_us=eng.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
+    # the dense solve (k_solve: one workgroup = one CU per window) is where a small window spends most of its time; its
+    # arithmetic is the Cholesky factorization and two substitutions of the 172 x 172 reduced system
+    KP = 172
+    solve_flops = batch * (KP ** 3 / 3.0 + 2.0 * KP ** 2) * 2.0
+    solve_tf = solve_flops / (extra["k_solve_us"] * 1e-6) / 1e12
+    cus = min(batch, 256)
+    roofline_solve = dict(bound="mfma", kernel="k_solve (Jacobi scaling, blocked Cholesky on v_mfma_f64_16x16x4_f64, substitutions)",
+                          achieved=solve_tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=solve_tf / FP64_PEAK_TFLOPS,
+                          frac_of_the_cus_it_occupies=solve_tf / (FP64_PEAK_TFLOPS * cus / 256.0), cus=cus,
+                          flops_per_launch=solve_flops, avg_launch_us=extra["k_solve_us"],
+                          note="latency/issue-bound on a single CU per window (DESIGN.md section 5); not the kernel section 8(d) prices")
 
     out = dict(metric="sliding-window solves/sec (10 KF x N landmarks)", value=value, unit="solves/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
@@ -217,7 +229,7 @@ def main():
                            observations=int(wins[0].M), windows_per_gpu=batch, max_num_iterations=8,
                            iterations_run=int(sol.c.num_iterations - 1), marginalization="MARGIN_OLD",
                            parallelism=f"{world} independent window stream(s), one per GPU, no data-path collective"),
-               roofline=roofline, kernels_us=extra)
+               roofline=roofline, roofline_k_solve=roofline_solve, kernels_us=extra)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wins[0], flag)
     elif rank == 0:
