@@ -85,10 +85,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
-  {
-    const TRFlags fl = tr_flags(tr);
-    if (fl.done | !fl.do_schur) return;
-  }
+  const TRFlags fl = tr_flags(tr);
+  const int sharded = S->sharded;
+  if (fl.done | !fl.do_schur) return;
   const int tid = threadIdx.x;
   double *Hs = smem;                 // TPACK: H_pp, then S, then L as 16 x 16 tiles (rhs row = row 172)
   double *Ld = Hs + TPACK;           // 16 x 16: the diagonal block just factored, plain, TRANSPOSED (panel solve); later rhs
@@ -137,16 +136,24 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     if (tid < KC) scross = Sg[schur_index(tid, COL_K)];
   }
   // landmark-side scalars: local sums, or the all-reduced totals of the sharded mode
-  const double *ls = S->sharded ? S->xch + XOFF_C : S->lm_sum;
-  if (tr->do_lin && tid == 0) {
-    double cost = ls[0];
-    if (!S->sharded) {
-      cost += S->prior_g[KP];
-      for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += S->imu_out[(size_t)f * IMU_OUT + 930];
+  const double *ls = sharded ? S->xch + XOFF_C : S->lm_sum;
+  // the pieces of the cost at x, one per thread, requested with the rest (summed by thread 0 in the fixed order below)
+  if (tid < 12) {
+    double cp = 0.0;
+    if (tid == 0) cp = ls[0];
+    else if (!sharded) cp = tid == 1 ? S->prior_g[KP] : S->imu_out[(size_t)(tid - 2) * IMU_OUT + 930];
+    scratch[tid] = cp;
+  }
+  __syncthreads();
+  if (fl.do_lin && tid == 0) {
+    double cost = scratch[0];
+    if (!sharded) {
+      cost += scratch[1];
+      for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += scratch[2 + f];
     }
     tr->x_cost = cost;
   }
-  __syncthreads();
+  __syncthreads();  // scratch is reused below
   STAMP(S, 1);
   // ---- Jacobi scaling (iteration 0 only), diagonal_, gradient_  (dogleg_strategy.cc ComputeStep)
   const double mu = tr->mu;
