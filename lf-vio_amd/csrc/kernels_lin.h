@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       t->new_point = 0;
       t->spec_n = 1;
       S->tail_state = 0;
+      S->passes_used = 0;
       if (mode >= MODE_MARG) t->mu = 0.0;
     }
     __shared__ double bt[84 + 256];
@@ -604,7 +605,12 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t strid
   const int do_lin = fl.do_lin, do_schur = fl.do_schur;
   if (mode_bits & MODE_GATED) {
     if (!tail_gate(S, fl.done)) return;
-  } else if (fl.done | (!do_lin & !do_schur)) return;
+  } else {
+    // a pass that starts with the loop still open is a pass this slot needs (the synchronous drivers size the first
+    // graph of the next call from this count)
+    if (mode == MODE_SOLVE && !fl.done && blockIdx.x == 0 && threadIdx.x == 0) S->passes_used++;
+    if (fl.done | (!do_lin & !do_schur)) return;
+  }
   __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLm, gCh); each slot uses its own counts
   int b = blockIdx.x;

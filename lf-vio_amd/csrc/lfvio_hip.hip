@@ -116,7 +116,9 @@ struct lfvio_ctx {
   hipGraphExec_t graph = nullptr;
   int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0;
   // cached graph of one chunk of passes (synchronous entry points: the loop is launched chunk by chunk)
-  hipGraphExec_t chunk = nullptr, chunk0 = nullptr, tail[3] = {nullptr, nullptr, nullptr}, fused0[3] = {nullptr, nullptr, nullptr};  // chunk0: k_setup + chunk; tail[flag]: gauge + marginalization
+  hipGraphExec_t chunk = nullptr, tail[3] = {nullptr, nullptr, nullptr};
+  hipGraphExec_t first[4][13] = {};  // [0: solve only, 1 + flag: with the gated tail][passes in the first graph]
+  int predict_passes = 4;           // passes the previous synchronous call needed; tail[flag]: force-done + gated gauge fix + marginalization
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   bool use_graph = true;
@@ -139,11 +141,11 @@ void destroy_graph(lfvio_ctx *c) {
     (void)hipGraphExecDestroy(c->chunk);
     c->chunk = nullptr;
   }
-  if (c->chunk0) (void)hipGraphExecDestroy(c->chunk0), c->chunk0 = nullptr;
   for (auto &t : c->tail)
     if (t) (void)hipGraphExecDestroy(t), t = nullptr;
-  for (auto &t : c->fused0)
-    if (t) (void)hipGraphExecDestroy(t), t = nullptr;
+  for (auto &row : c->first)
+    for (auto &t : row)
+      if (t) (void)hipGraphExecDestroy(t), t = nullptr;
 }
 
 int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
@@ -533,12 +535,16 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
 }
 
 // number of slots that still need passes (tail = 0: solve not done; tail = 1: gated marginalization not finished)
+// out[1]: the largest number of passes a slot has used so far (k_lin counts them)
 __global__ void k_pending(char *base, size_t stride, int count, int *out, int tail) {
-  int n = 0;
+  int n = 0, used = 0;
   for (int s = threadIdx.x; s < count; s += 64) {
     const Slot *S = (const Slot *)(base + (size_t)s * stride);
     n += (tail ? S->tail_state == 2 : S->tr.done != 0) ? 0 : 1;
+    used = max(used, S->passes_used);
   }
+  used = __reduce_max_sync(~0ull, used);
+  if (threadIdx.x == 0) out[1] = used;
   n = __reduce_add_sync(~0ull, n);
   if (threadIdx.x == 0) *out = n;
 }
@@ -558,7 +564,7 @@ __global__ void k_force_done(char *base, size_t stride, int count) {
 //   adaptive = true (synchronous entry points): the passes go out in chunks of SOLVE_CHUNK and the host reads the number
 //     of unfinished slots in between.  A pass costs its ~30 us of launches and first loads whether or not the loop is
 //     already done, and with the speculative candidates of small windows nine iterations are four passes, not twelve.
-constexpr int SOLVE_CHUNK = 4;
+constexpr int SOLVE_CHUNK = 2, MAX_FIRST_PASSES = 12;  // continuation chunk; longest first graph
 int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated = false);
 // fused_flag >= 0 (adaptive only): gauge fix + marginalization ride in the graph of the first chunk, gated per slot on
 // `done` — the common case (every window done within the first chunk) is ONE graph launch and one synchronization; *tail_done
@@ -572,48 +578,57 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipMalloc((void **)&c->d_pending, 256));
       HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
     }
-    if (!c->chunk || c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate) {
+    if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate) {
       destroy_graph(c);
-      for (int first = 0; first < 2; first++) {
-        hipGraph_t graph;
-        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        if (first)
-          hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
-        for (int it = 0; it < SOLVE_CHUNK; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate);
-        hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, 0);
-        HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
-        HIPCHK(c, hipGraphInstantiate(first ? &c->chunk0 : &c->chunk, graph, nullptr, nullptr, 0));
-        HIPCHK(c, hipGraphDestroy(graph));
-      }
       c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate;
     }
     if (tail_done) *tail_done = false;
     const bool fuse = fused_flag >= 0 && fused_flag < 3;
-    if (fuse && !c->fused0[fused_flag]) {
+    // The first graph carries as many passes as the previous call on this context needed (a stream of windows from one
+    // estimator is steady: the bench window takes 4, windows whose steps are mostly accepted 5 to 8), then — fused —
+    // the gated gauge fix + marginalization; whatever is still pending afterwards continues in chunks of SOLVE_CHUNK.
+    const int first_passes = std::min(std::max(c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
+    hipGraphExec_t &first_graph = c->first[fuse ? 1 + fused_flag : 0][first_passes];
+    auto capture = [&](hipGraphExec_t *out, bool setup, int npass, int tail_flag) -> int {
       hipGraph_t graph;
+      int rc = LFVIO_OK;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
-      for (int it = 0; it < SOLVE_CHUNK; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate);
-      hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
-      const int rc = enqueue_marg(c, count, fused_flag, false, true);
-      hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, 1);
-      HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      if (setup)
+        hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+      for (int it = 0; it < npass; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate);
+      if (tail_flag >= 0) {
+        hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
+        rc = enqueue_marg(c, count, tail_flag, false, true);
+      }
+      hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, tail_flag >= 0 ? 1 : 0);
+      HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
       if (rc) return rc;
-      HIPCHK(c, hipGraphInstantiate(&c->fused0[fused_flag], graph, nullptr, nullptr, 0));
+      HIPCHK(c, hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
+      return LFVIO_OK;
+    };
+    if (!first_graph) {
+      const int rc = capture(&first_graph, true, first_passes, fuse ? fused_flag : -1);
+      if (rc) return rc;
+    }
+    if (!c->chunk) {
+      const int rc = capture(&c->chunk, false, SOLVE_CHUNK, -1);
+      if (rc) return rc;
     }
     c->stat_chunks = 0;
-    for (int done_passes = 0; done_passes < passes; done_passes += SOLVE_CHUNK) {
+    for (int done_passes = 0; done_passes < passes;) {
       c->stat_chunks++;
-      HIPCHK(c, hipGraphLaunch(done_passes == 0 ? (fuse ? c->fused0[fused_flag] : c->chunk0) : c->chunk, c->stream));
+      HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (*c->h_pending == 0) {
-        if (tail_done && fuse && done_passes == 0) *tail_done = true;
+      const bool first = done_passes == 0;
+      done_passes += first ? first_passes : SOLVE_CHUNK;
+      if (c->h_pending[0] == 0) {
+        if (tail_done && fuse && first) *tail_done = true;
         break;
       }
     }
+    c->predict_passes = std::max(c->h_pending[1], 1);  // passes the slowest window has used
     HIPCHK(c, hipGetLastError());
     return LFVIO_OK;
   }

@@ -144,20 +144,28 @@ def test_marginalize_with_prior_and_second_new(eng, oracle):
 
 
 def test_windows_that_need_more_than_one_chunk_of_passes(eng, oracle):
-    """The synchronous call runs gauge fix + marginalization in the graph of the first chunk of passes, per window and
-    only where the solve is done; a window that needs more passes gets them, and its marginalization, afterwards.  Both
-    routes must give what the oracle gives — alone and side by side in one batch."""
-    quick = synth.make_window_with_prior(0, 120, lambda w, f: oracle.optimize(w, f))[0]  # two accepted steps of nine: one chunk
+    """The synchronous call puts as many passes into its first graph as the previous call on the context needed, and gauge
+    fix + marginalization behind them, per window and only where the solve is done; a window that needs more passes gets
+    them, and its marginalization, afterwards.  Every route must give what the oracle gives — alone and side by side in
+    one batch."""
+    quick = synth.make_window_with_prior(0, 120, lambda w, f: oracle.optimize(w, f))[0]  # two accepted steps of nine: four passes
     slow = synth.make_window(1, 120, tr=0.3)  # eight accepted steps: every one is a pass of its own
-    wins, seen = [quick, slow], []
-    for w in wins:
+
+    def check(w):
         sol, prior = eng.optimize(w, abi.MARGIN_OLD)
-        seen.append(eng.last_chunks())
+        k = eng.last_chunks()
         ref_sol, ref_prior = oracle.optimize(w, abi.MARGIN_OLD)
         check_solution(sol, ref_sol, w)
         assert prior.block_list() == ref_prior.block_list()
         assert rel(prior.J().T @ prior.J(), ref_prior.J().T @ ref_prior.J()) < 1e-6
-    assert seen[0] == 1 and seen[1] >= 2, seen  # both routes were taken
+        return k
+
+    check(quick)
+    assert check(quick) == 1  # sized from the call before: one graph, marginalization included
+    assert check(slow) >= 2   # the first graph was too short: continuation chunks, then the gated tail
+    assert check(slow) == 1   # ... and the next call knows
+    assert check(quick) == 1  # a first graph that is too long costs dead passes, not launches
+    wins = [quick, slow]
     # the two windows in one batch: the first chunk finishes one of them, the other goes on
     eng.batch_reserve(2, 120, max(w.M for w in wins))
     for s, w in enumerate(wins):
