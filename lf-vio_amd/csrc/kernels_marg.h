@@ -534,17 +534,38 @@ DEV double wave_sum_dpp(double v) {  // every lane gets the sum over the 64 lane
 // 152 numbers 18 times), the signs are shifted into a mask and counted at the end, and the pair is brought back to unit
 // scale every eight rows (one row grows it by at most ||T||^2).
 typedef const __attribute__((address_space(4))) double sdouble;
+#define STURM_TOUCH8(v) asm volatile("" ::"s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]))
 DEV int sturm_count(sdouble *Tg /* d[96] | e^2[96]; beyond n: d above every shift, e^2 = 0 */, int n, double sigma) {
   // five instructions per row: d - sigma, e^2 p_{i-2}, the fma, and the sign change shifted into a word that is
   // counted once per 16 rows.  Rows beyond n keep the sign (d - sigma > 0, e^2 = 0), so they need no mask; the pair is
   // brought back to unit scale every 16 rows (one row grows it by at most 2 ||T|| + 1).
+  // The scalar loads are software-pipelined in blocks of eight rows: scalar loads return out of order, so a wait for one
+  // block is a wait for everything outstanding — the block in hand is therefore waited for (STURM_TOUCH8) BEFORE the next
+  // one is requested, and the eight rows of arithmetic then run beside that request.
   double pm = 1.0, p = Tg[0] - sigma;
   unsigned cnt = (unsigned)__double2hiint(p) >> 31;
+  double d0[8], e0[8], d1[8], e1[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) d0[u] = Tg[1 + u], e0[u] = Tg[96 + u];
   for (int i0 = 1; i0 < n; i0 += 16) {
     unsigned bits = 0;
+    STURM_TOUCH8(d0);
+    STURM_TOUCH8(e0);
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const double pn = fma(Tg[i0 + u] - sigma, p, -Tg[96 + i0 + u - 1] * pm);
+    for (int u = 0; u < 8; u++) d1[u] = Tg[i0 + 8 + u], e1[u] = Tg[96 + i0 + 8 + u - 1];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const double pn = fma(d0[u] - sigma, p, -e0[u] * pm);
+      bits = __builtin_amdgcn_alignbit(bits, (unsigned)(__double2hiint(pn) ^ __double2hiint(p)), 31);
+      pm = p, p = pn;
+    }
+    STURM_TOUCH8(d1);
+    STURM_TOUCH8(e1);
+#pragma unroll
+    for (int u = 0; u < 8; u++) d0[u] = Tg[i0 + 16 + u], e0[u] = Tg[96 + i0 + 16 + u - 1];  // (up to row 88 < 96)
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const double pn = fma(d1[u] - sigma, p, -e1[u] * pm);
       bits = __builtin_amdgcn_alignbit(bits, (unsigned)(__double2hiint(pn) ^ __double2hiint(p)), 31);
       pm = p, p = pn;
     }
