@@ -600,8 +600,13 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
         hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
         rc = enqueue_marg(c, count, tail_flag, false, true);
       }
-      hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, tail_flag >= 0 ? 1 : 0);
-      HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      if (tail_flag >= 0 && count == 1) {
+        // one window: its {tail_state, passes_used} pair is the answer — copied as it is, no k_pending launch
+        HIPCHK(c, hipMemcpyAsync(c->h_pending + 2, c->d_base + offsetof(Slot, tail_state), 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      } else {
+        hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, tail_flag >= 0 ? 1 : 0);
+        HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      }
       HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
       if (rc) return rc;
       HIPCHK(c, hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
@@ -623,6 +628,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipStreamSynchronize(c->stream));
       const bool first = done_passes == 0;
       done_passes += first ? first_passes : SOLVE_CHUNK;
+      if (first && fuse && count == 1) c->h_pending[0] = c->h_pending[2] == 2 ? 0 : 1, c->h_pending[1] = c->h_pending[3];
       if (c->h_pending[0] == 0) {
         if (tail_done && fuse && first) *tail_done = true;
         break;
