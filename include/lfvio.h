@@ -45,8 +45,10 @@ extern "C" {
 #define LFVIO_OK 0
 #define LFVIO_ERR_ARG (-1)         /* malformed window (bad CSR, NULL, sizes)  */
 #define LFVIO_ERR_DEVICE (-2)      /* HIP runtime error                         */
-#define LFVIO_ERR_NONFINITE (-3)   /* non-finite cost / state                   */
-#define LFVIO_ERR_NOT_PD (-4)      /* reduced system never became PD            */
+#define LFVIO_ERR_NONFINITE (-3)   /* non-finite cost / state / prior           */
+/* A reduced system that never becomes positive definite is NOT an error of the call: as in Ceres, every failed
+ * factorization is an invalid step (mu *= 10), five in a row end the solve with termination = LFVIO_FAILURE and the
+ * state of the last accepted step (trust_region_minimizer.cc: HandleInvalidStep). */
 
 /* marginalization flags: Estimator::MarginalizationFlag, estimator.h:58-62 */
 #define LFVIO_MARGIN_OLD 0
@@ -110,7 +112,8 @@ typedef struct LfvioWindow {
   int estimate_extrinsic;            /* ESTIMATE_EXTRINSIC != 0                */
   int estimate_td;                   /* ESTIMATE_TD: ProjectionTdFactor vs ProjectionFactor */
   int max_num_iterations;            /* NUM_ITERATIONS                          */
-  double max_solver_time_in_seconds; /* <= 0: disabled (parity / bench runs)    */
+  double max_solver_time_in_seconds; /* <= 0: disabled (parity / bench runs); > 0: honoured by the synchronous entry
+                                        points between graph launches (every 2 passes), ignored by *_async    */
 
   /* globals read by the factors (parameters.h:17-41) */
   double g[3];      /* G                                      */

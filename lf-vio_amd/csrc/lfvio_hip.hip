@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -90,6 +91,8 @@ Layout make_layout(int maxN, int maxM) {
 
 struct SlotHostInfo {
   int N = 0, M = 0, gLm = 0, gCh = 0, gSc = 0;
+  int max_iter = 0;          // LfvioWindow::max_num_iterations of the uploaded window
+  double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
   std::vector<int> perm;  // device order -> caller order
   bool uploaded = false;
   LfvioPrior in_prior;    // kept for the "prior passes through" case of MARGIN_SECOND_NEW
@@ -282,6 +285,22 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     c->err = "malformed prior";
     return LFVIO_ERR_ARG;
   }
+  if (pr) {
+    // the blocks index present[kind][frame], prior_cmap and prior_inv below: refuse anything that would leave them
+    for (int i = 0; i < pr->num_blocks; i++) {
+      const int k = pr->blocks[i].kind, f = pr->blocks[i].frame, idx = pr->block_idx[i];
+      const bool framed = k == LFVIO_BLOCK_POSE || k == LFVIO_BLOCK_SPEEDBIAS;
+      if (k < LFVIO_BLOCK_POSE || k > LFVIO_BLOCK_TD || f < 0 || f >= LFVIO_NUM_FRAMES || (!framed && f != 0) || idx < 0 ||
+          idx + local_size(k) > pr->n) {
+        c->err = "malformed prior block (kind / frame / block_idx out of range)";
+        return LFVIO_ERR_ARG;
+      }
+    }
+  }
+  if (w->estimate_td && !(w->row > 0.0)) {  // row_i = uv.y - ROW / 2 and TR / ROW (projection_td_factor.cpp:20-21, 54-55)
+    c->err = "estimate_td needs row > 0";
+    return LFVIO_ERR_ARG;
+  }
   const Layout &L = c->L;
   char *h = c->h_stage;
   char *d = c->d_base + (size_t)slot * L.total;
@@ -292,7 +311,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->max_iter = w->max_num_iterations;
   S->sharded = sharded, S->pose_side = pose_side;
   for (int k = 0; k < 3; k++) S->g[k] = w->g[k];
-  S->tr_over_row = w->tr / w->row;
+  S->tr_over_row = w->row > 0.0 ? w->tr / w->row : 0.0;  // only the td factor reads it (row > 0 checked above)
   S->half_row = w->row / 2;
   S->sqrt_info = w->sqrt_info;
   std::memcpy(S->x0.pose, w->para_pose, sizeof S->x0.pose);
@@ -306,6 +325,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   // ---- landmarks: stable bucket sort by (start_frame, track length)
   SlotHostInfo &info = c->info[slot];
   info.N = N, info.M = M;
+  info.max_iter = w->max_num_iterations, info.max_seconds = w->max_solver_time_in_seconds;
   info.perm.resize(N);
   {
     int count[16 * 16 + 1] = {0};
@@ -483,9 +503,28 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   return LFVIO_OK;
 }
 
+// A HIPCHK that returns in the middle of a stream capture would leave the stream capturing (every later call on it fails):
+// the guard ends the capture and drops the partial graph on any early return.
+struct CaptureGuard {
+  hipStream_t stream;
+  bool active = true;
+  explicit CaptureGuard(hipStream_t s) : stream(s) {}
+  hipError_t end(hipGraph_t *g) {
+    active = false;
+    return hipStreamEndCapture(stream, g);
+  }
+  ~CaptureGuard() {
+    if (!active) return;
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+  }
+};
+
 struct Grid {
   int lm, ch, sc;
 };
+constexpr int CH_BUCKET = 16;
 
 Grid grid_for(lfvio_ctx *c, int count) {
   Grid g{1, 1, 1};
@@ -494,6 +533,11 @@ Grid grid_for(lfvio_ctx *c, int count) {
     g.ch = std::max(g.ch, c->info[s].gCh);
     g.sc = std::max(g.sc, c->info[s].gSc);
   }
+  // The launch dimensions are the key of the captured graphs, and in a stream of windows from one estimator the number of
+  // frame-pair chunks changes with almost every frame: round it up to whole groups of four workgroups (a workgroup of
+  // k_lin takes four chunks) so that neighbouring windows share a graph.  Every kernel tests its block index against
+  // the slot's own counts (the grid of a resident batch is the maximum over its slots anyway), so spare blocks return.
+  g.ch = (g.ch + CH_BUCKET - 1) / CH_BUCKET * CH_BUCKET;
   return g;
 }
 
@@ -569,7 +613,12 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated 
 // fused_flag >= 0 (adaptive only): gauge fix + marginalization ride in the graph of the first chunk, gated per slot on
 // `done` — the common case (every window done within the first chunk) is ONE graph launch and one synchronization; *tail_done
 // tells the caller whether anything is left for the (gated) tail graph.
-int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fused_flag = -1, bool *tail_done = nullptr) {
+// max_seconds > 0 (adaptive only): Ceres' max_solver_time_in_seconds (estimator.cpp:815-822) — TrustRegionMinimizer tests the
+// wall clock at the top of every iteration and stops with NO_CONVERGENCE; here the host tests it between graph launches
+// (the only points where it sees the loop) and ends the open slots the same way (k_force_done).  With a cap the first
+// graph is not sized from the previous call: the loop goes out in chunks of SOLVE_CHUNK passes so that the cap can bite.
+int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fused_flag = -1, bool *tail_done = nullptr,
+                  double max_seconds = -1.0) {
   const Grid g = grid_for(c, count);
   const int passes = std::max(max_iter, 0) + 4;
   if (adaptive && c->use_graph) {
@@ -587,12 +636,15 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     // The first graph carries as many passes as the previous call on this context needed (a stream of windows from one
     // estimator is steady: the bench window takes 4, windows whose steps are mostly accepted 5 to 8), then — fused —
     // the gated gauge fix + marginalization; whatever is still pending afterwards continues in chunks of SOLVE_CHUNK.
-    const int first_passes = std::min(std::max(c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
+    const bool capped = max_seconds > 0.0;
+    const auto t_start = std::chrono::steady_clock::now();
+    const int first_passes = capped ? std::min(SOLVE_CHUNK, passes) : std::min(std::max(c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
     hipGraphExec_t &first_graph = c->first[fuse ? 1 + fused_flag : 0][first_passes];
     auto capture = [&](hipGraphExec_t *out, bool setup, int npass, int tail_flag) -> int {
       hipGraph_t graph;
       int rc = LFVIO_OK;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      CaptureGuard guard(c->stream);
       if (setup)
         hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
       for (int it = 0; it < npass; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate);
@@ -607,8 +659,11 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
         hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, tail_flag >= 0 ? 1 : 0);
         HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       }
-      HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
-      if (rc) return rc;
+      HIPCHK(c, guard.end(&graph));
+      if (rc) {
+        (void)hipGraphDestroy(graph);
+        return rc;
+      }
       HIPCHK(c, hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
       return LFVIO_OK;
@@ -633,8 +688,14 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
         if (tail_done && fuse && first) *tail_done = true;
         break;
       }
+      if (capped && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= max_seconds) {
+        // "Maximum solver time reached": the open slots end where they are, termination stays NO_CONVERGENCE
+        hipLaunchKernelGGL(k_force_done, dim3((count + 63) / 64), dim3(64), 0, c->stream, c->d_base, c->L.total, count);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        break;
+      }
     }
-    c->predict_passes = std::max(c->h_pending[1], 1);  // passes the slowest window has used
+    if (!capped) c->predict_passes = std::max(c->h_pending[1], 1);  // passes the slowest window has used
     HIPCHK(c, hipGetLastError());
     return LFVIO_OK;
   }
@@ -644,8 +705,9 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       if (c->graph) (void)hipGraphExecDestroy(c->graph), c->graph = nullptr;
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      CaptureGuard guard(c->stream);
       for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE);
-      HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
+      HIPCHK(c, guard.end(&graph));
       HIPCHK(c, hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
       c->g_batch = count, c->g_lm = g.lm, c->g_ch = g.ch, c->g_sc = g.sc, c->g_iters = passes;
@@ -690,11 +752,19 @@ int download_solution(lfvio_ctx *c, int slot, LfvioSolution *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   const FrameState &x = xs[cur];
+  const double *lam = (const double *)(hd + hdr);
+  // nothing is written to `out` before the result is known to be finite (the header promises untouched outputs on error)
+  bool finite = std::isfinite(tr->x_cost);
+  for (int k = 0; finite && k < (int)(sizeof(FrameState) / 8); k++) finite = std::isfinite(((const double *)&x)[k]);
+  for (int dl = 0; finite && dl < info.N; dl++) finite = std::isfinite(lam[dl]);
+  if (!finite) {
+    c->err = "non-finite state";
+    return LFVIO_ERR_NONFINITE;
+  }
   std::memcpy(out->para_pose, x.pose, sizeof x.pose);
   std::memcpy(out->para_speed_bias, x.sb, sizeof x.sb);
   std::memcpy(out->para_ex_pose, x.ex, sizeof x.ex);
   out->para_td = x.td;
-  const double *lam = (const double *)(hd + hdr);
   if (out->inv_depth)
     for (int dl = 0; dl < info.N; dl++) out->inv_depth[info.perm[dl]] = lam[dl];
   out->num_iterations = tr->trace_len;
@@ -705,11 +775,6 @@ int download_solution(lfvio_ctx *c, int slot, LfvioSolution *out) {
   out->final_cost = tr->x_cost;
   std::memset(out->trace, 0, sizeof out->trace);
   for (int k = 0; k < tr->trace_len && k < LFVIO_MAX_TRACE; k++) out->trace[k] = tr->trace[k];
-  for (int k = 0; k < (int)(sizeof(FrameState) / 8); k++)
-    if (!std::isfinite(((const double *)&x)[k])) {
-      c->err = "non-finite state";
-      return LFVIO_ERR_NONFINITE;
-    }
   return LFVIO_OK;
 }
 
@@ -737,14 +802,16 @@ int download_prior(lfvio_ctx *c, int slot, LfvioPrior *out) {
   HIPCHK(c, hipMemcpyAsync(hp->linearized_residuals, d + offsetof(Slot, prior_out) + offsetof(LfvioPrior, linearized_residuals),
                            sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  bool finite = true;
+  for (int k = 0; finite && k < n * n; k++) finite = std::isfinite(hp->linearized_jacobians[k]);
+  for (int k = 0; finite && k < n; k++) finite = std::isfinite(hp->linearized_residuals[k]);
+  if (!finite) {
+    c->err = "non-finite prior";
+    return LFVIO_ERR_NONFINITE;
+  }
   std::memcpy(out, hp, head);
   std::memcpy(out->linearized_jacobians, hp->linearized_jacobians, sizeof(double) * n * n);
   std::memcpy(out->linearized_residuals, hp->linearized_residuals, sizeof(double) * n);
-  for (int k = 0; k < n * n; k++)
-    if (!std::isfinite(out->linearized_jacobians[k])) {
-      c->err = "non-finite prior";
-      return LFVIO_ERR_NONFINITE;
-    }
   return LFVIO_OK;
 }
 
@@ -795,7 +862,7 @@ int lfvio_solve(lfvio_ctx *c, const LfvioWindow *in, LfvioSolution *out) {
   int rc = reserve(c, 1, in->num_landmarks, in->num_observations);
   if (rc) return rc;
   if ((rc = upload_window(c, 0, in))) return rc;
-  if ((rc = enqueue_solve(c, 1, in->max_num_iterations, true))) return rc;
+  if ((rc = enqueue_solve(c, 1, in->max_num_iterations, true, -1, nullptr, in->max_solver_time_in_seconds))) return rc;
   return download_solution(c, 0, out);
 }
 
@@ -816,7 +883,7 @@ int lfvio_batch_reserve(lfvio_ctx *c, int batch, int max_landmarks, int max_obse
 }
 
 int lfvio_batch_upload(lfvio_ctx *c, int slot, const LfvioWindow *in) {
-  if (!c || slot < 0 || slot >= c->batch) return LFVIO_ERR_ARG;
+  if (!c || !in || slot < 0 || slot >= c->batch) return LFVIO_ERR_ARG;
   if (in->num_landmarks > c->L.maxN || in->num_observations > c->L.maxM) {
     c->err = "window larger than the reserved capacity";
     return LFVIO_ERR_ARG;
@@ -828,16 +895,22 @@ int lfvio_batch_upload(lfvio_ctx *c, int slot, const LfvioWindow *in) {
 static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adaptive) {
   if (!c || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
-  // every slot carries its own max_iter on the device; the pass count follows the largest
-  const int max_iter = 8;
-  for (int s = 0; s < count; s++)
+  // every slot carries its own max_iter on the device; the pass count follows the largest, the wall-clock cap
+  // (synchronous driver only) the smallest positive one
+  int max_iter = 0;
+  double max_seconds = -1.0;
+  for (int s = 0; s < count; s++) {
     if (!c->info[s].uploaded) {
       c->err = "slot not uploaded";
       return LFVIO_ERR_ARG;
     }
+    max_iter = std::max(max_iter, c->info[s].max_iter);
+    const double t = c->info[s].max_seconds;
+    if (t > 0.0 && (max_seconds <= 0.0 || t < max_seconds)) max_seconds = t;
+  }
   const bool fuse = adaptive && c->use_graph && marg_flag >= 0 && marg_flag < 3;
   bool tail_done = false;
-  int rc = enqueue_solve(c, count, max_iter, adaptive, fuse ? marg_flag : -1, &tail_done);
+  int rc = enqueue_solve(c, count, max_iter, adaptive, fuse ? marg_flag : -1, &tail_done, max_seconds);
   if (rc) return rc;
   if (fuse) {
     if (tail_done) return LFVIO_OK;  // the usual case: everything ran in the graph of the first chunk
@@ -845,11 +918,15 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
     if (!c->tail[marg_flag]) {
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      CaptureGuard guard(c->stream);
       hipLaunchKernelGGL(k_force_done, dim3((count + 63) / 64), dim3(64), 0, c->stream, c->d_base, c->L.total, count);
       hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
       rc = enqueue_marg(c, count, marg_flag, false, true);
-      HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
-      if (rc) return rc;
+      HIPCHK(c, guard.end(&graph));
+      if (rc) {
+        (void)hipGraphDestroy(graph);
+        return rc;
+      }
       HIPCHK(c, hipGraphInstantiate(&c->tail[marg_flag], graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
     }

@@ -182,19 +182,25 @@ def preintegrate(acc0, gyr0, ba, bg, dts, accs, gyrs, noise=(ACC_N, GYR_N, ACC_W
 # trajectory + IMU
 # ----------------------------------------------------------------------------
 class Trajectory:
-    """Smooth random motion, ||v|| ~ 0.5 m/s, ||w|| ~ 0.3 rad/s, sampled at 200 Hz."""
+    """Smooth random motion, ||v|| ~ 0.5 m/s, ||w|| ~ 0.3 rad/s, sampled at 200 Hz.
+    motion: "full"; "rotate" (no translation: every baseline is zero, depth is unobservable); "static" (camera at rest).
+    The random draws are the same for every motion, so a seed names one scene family."""
 
-    def __init__(self, rng, n_keyframes):
+    def __init__(self, rng, n_keyframes, motion="full"):
         self.n_kf = n_keyframes
         n_s = (n_keyframes - 1) * SAMPLES + 1
         self.t = np.arange(n_s) * IMU_DT
         amp = rng.uniform(0.1, 0.3, size=(3, 2))
         frq = rng.uniform(0.1, 0.4, size=(3, 2))
         ph = rng.uniform(0, 2 * np.pi, size=(3, 2))
+        if motion in ("rotate", "static"):
+            amp = amp * 0.0
         self._pa = (amp, frq, ph)
         wamp = rng.uniform(0.05, 0.25, size=(3, 2))
         wfrq = rng.uniform(0.2, 1.0, size=(3, 2))
         wph = rng.uniform(0, 2 * np.pi, size=(3, 2))
+        if motion == "static":
+            wamp = wamp * 0.0
         self._wa = (wamp, wfrq, wph)
         # integrate attitude with 10 sub-steps per IMU sample
         R = exp_so3(rng.normal(0, 0.2, 3))
@@ -249,10 +255,10 @@ def _bearing_f32(v):
 class Scene:
     """Truth trajectory of `n_total` keyframes with IMU measurements."""
 
-    def __init__(self, seed, n_total=12):
+    def __init__(self, seed, n_total=12, motion="full"):
         self.rng = np.random.default_rng(seed)
         rng = self.rng
-        self.traj = Trajectory(rng, n_total)
+        self.traj = Trajectory(rng, n_total, motion)
         self.n_total = n_total
         self.g = np.array([0.0, 0.0, G_NORM])
         self.ba = rng.normal(0, 0.02, 3)
@@ -344,13 +350,13 @@ def _landmarks(rng, scene, kf0, n_landmarks, td_frames, min_track=2):
 
 
 def make_window(seed, n_landmarks=300, kf0=0, scene=None, prior=None, init_state=None, estimate_extrinsic=1,
-                estimate_td=1, tr=0.0, max_num_iterations=8, pose_noise=(0.02, np.deg2rad(0.5)), n_total=12):
+                estimate_td=1, tr=0.0, max_num_iterations=8, pose_noise=(0.02, np.deg2rad(0.5)), n_total=12, motion="full"):
     """One LfvioWindow over keyframes kf0..kf0+10 of Scene(seed).
 
     init_state: optional dict(pose[11,7], speed_bias[11,9], ex_pose, td) to continue a previous solve;
     otherwise truth (+) N(0, 2 cm / 0.5 deg), velocities + N(0, 0.02), biases + noise.
     """
-    scene = scene or Scene(seed, n_total=n_total)
+    scene = scene or Scene(seed, n_total=n_total, motion=motion)
     rng = np.random.default_rng([seed, 7919, kf0, n_landmarks])
     td_frames = TD0 + rng.normal(0, 2e-4, size=abi.NUM_FRAMES)
     lm = _landmarks(rng, scene, kf0, n_landmarks, td_frames)

@@ -100,7 +100,8 @@ def test_shards_sum_to_the_whole_window_gloo(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n", [(2, 300), (3, 300), (2, 20000)])  # 20000: the two-level reductions under sharding
+# 20000: the two-level reductions under sharding; (8, 100000): BASELINE configs[3] at its full size on 8 emulated ranks
+@pytest.mark.parametrize("world,n", [(2, 300), (3, 300), (2, 20000), (8, 100000)])
 def test_two_contexts_emulate_ranks_on_one_gpu(oracle, world, n):
     import torch
     from lfvio.engine import Engine
