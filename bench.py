@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — sliding-window solves/sec of the MI355X Estimator::optimization() hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload ...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one whole optimization() of the resident BASELINE window on every rank: trust-region solve
-(Ceres DENSE_SCHUR + DOGLEG semantics, <= 8 iterations, no wall-clock cap), the gauge fix of
-double2vector(), and MARGIN_OLD marginalization — inputs already resident in HBM, no host round trip
-inside the step.  Workloads (--workload):
-  window300  (default) BASELINE.json configs[1]: one 10-keyframe / 300-landmark window per rank, prior from a
-             warm-up MARGIN_OLD step; latency-bound (sequential solves, one after the other)
-  batch512   configs[4]: 512 independent 300-landmark windows per rank, solved side by side (throughput mode)
-  window100k 10-keyframe / 100 000-landmark window per rank (the large-N sweep that actually loads HBM)
-N > 1: the windows are independent, so ranks simply own different windows (weak scaling, no data-path
-collective); torch.distributed (RCCL) is used for the barriers and the max-over-ranks time only.
+One "step" = one whole optimization(): trust-region solve (Ceres DENSE_SCHUR + DOGLEG semantics, <= 8 iterations, no
+wall-clock cap), the gauge fix of double2vector(), and MARGIN_OLD marginalization — inputs already resident in HBM when the
+timed region starts.  Workloads (--workload; default window300 at N = 1, window100k_sharded at N > 1):
+  window300          BASELINE.json configs[1]: one 10-keyframe / 300-landmark window per rank, prior from a warm-up
+                     MARGIN_OLD step; latency-bound (sequential solves of the resident window, synchronous call)
+  window300_stream   the same shape as a drop-in sees it: 64 CONSECUTIVE, DISTINCT windows of one estimator stream (each
+                     starts from the previous solution and carries the previous prior); every step uploads its window,
+                     optimizes and downloads solution + prior — PCIe inside the timed region, so this is reported with
+                     mean / p50 / p95 and the histogram of passes, never as the headline of the resident config
+  batch512           configs[4]: 512 independent 300-landmark windows per rank (seeds 0..511 of rank 0, 512 DISTINCT
+                     windows), solved side by side (throughput mode); weak scaling, no collective
+  window100k         10-keyframe / 100 000-landmark window on one GPU (per rank at N > 1)
+  window100k_sharded configs[3]: ONE 100 000-landmark window sharded over the N ranks by contiguous landmark ranges
+                     balanced on observations; per pass one sum-all-reduce of [H_pp | g_p | Schur sums | scalars]
+                     (151 KB) and two of 16 scalars over RCCL (torch.distributed, backend nccl) on the library's own
+                     stream, seven enqueues and one decision read per pass; strong scaling
 Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -33,9 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 FP64_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz: v_mfma_f64_16x16x4_f64 issues every 64 cycles (tools/micro/mfma64.hip); the FP64 vector rate is the same
 
 
-def algorithmic_bytes(win):
+def algorithmic_bytes(N, M):
     """bytes one residual/Jacobian sweep must move = 68 (M - N) + 88 N (td variant)."""
-    N, M = win.N, win.M
     return 68 * (M - N) + 88 * N
 
 
@@ -113,18 +117,53 @@ def cpu_baseline(win, flag, target_seconds=12.0):
                        f"mean ms solve/gauge/marg = {parts[0] / n * 1e3:.2f}/{parts[1] / n * 1e3:.3f}/{parts[2] / n * 1e3:.2f}" + mt)
 
 
+# ---- window generation in worker processes (numpy only; the GPU stays in the parent) ------------------------------
+def _gen_warm(seed):
+    from lfvio import abi, synth
+
+    return abi.window_to_dict(synth.make_window(seed, 300, kf0=0, scene=synth.Scene(seed, n_total=12)))
+
+
+def _gen_final(job):
+    from lfvio import abi, synth
+
+    seed, pose, sb, ex, td, prior_d = job
+    scene = synth.Scene(seed, n_total=12)
+    st = synth.continue_state(scene, 1, pose, sb, ex, td, np.random.default_rng([seed, 104729]))
+    return abi.window_to_dict(synth.make_window(seed, 300, kf0=1, scene=scene, prior=abi.prior_from_dict(prior_d), init_state=st))
+
+
+def distinct_windows_with_prior(seeds, optimize):
+    """synth.make_window_with_prior for many seeds: the numpy parts on a process pool, the warm-up MARGIN_OLD step of every
+    seed through the product path (`optimize`) in this process."""
+    import multiprocessing as mp
+
+    from lfvio import abi
+
+    workers = max(1, min(32, (os.cpu_count() or 2) - 1, len(seeds)))
+    with mp.get_context("spawn").Pool(workers) as pool:
+        warm = [abi.window_from_dict(d) for d in pool.map(_gen_warm, seeds, chunksize=4)]
+        jobs = []
+        for seed, w in zip(seeds, warm):
+            sol, prior = optimize(w, abi.MARGIN_OLD)
+            jobs.append((seed, sol.pose, sol.speed_bias, sol.ex_pose, sol.td, abi.prior_to_dict(prior)))
+        return [abi.window_from_dict(d) for d in pool.map(_gen_final, jobs, chunksize=4)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="window300", choices=["window300", "batch512", "window100k"])
+    ap.add_argument("--workload", default=None,
+                    choices=["window300", "window300_stream", "batch512", "window100k", "window100k_sharded"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    workload = args.workload or ("window300" if world == 1 else "window100k_sharded")
     import torch
 
     if not torch.cuda.is_available():
@@ -147,42 +186,96 @@ def main():
     def hip_optimize(w, f):  # warm-up MARGIN_OLD step of the window sequence: the product path itself
         return eng.optimize(w, f)
 
-    # ---- build the resident workload of this rank (seeds differ per rank: independent windows)
-    if args.workload == "window300":
-        n_lm, batch = 300, 1
-        wins = [synth.make_window_with_prior(1000 * rank, n_lm, hip_optimize)[0]]
-        desc = "BASELINE configs[1]: 10-keyframe / 300-landmark window, estimate_extrinsic=1, estimate_td=1, prior from a warm-up MARGIN_OLD step"
-    elif args.workload == "batch512":
-        n_lm, batch = 300, 512
-        base = [synth.make_window_with_prior(1000 * rank + s, n_lm, hip_optimize)[0] for s in range(16)]
-        wins = [base[s % len(base)] for s in range(batch)]
-        desc = "BASELINE configs[4]: 512 independent 10-keyframe / 300-landmark windows (16 distinct seeds cycled), solved side by side"
-    else:
-        n_lm, batch = 100000, 1
-        wins = [synth.make_window(1000 * rank, n_lm)]
-        desc = "10-keyframe / 100 000-landmark window (no prior), whole window on one GPU"
-    eng.batch_reserve(batch, max(w.N for w in wins), max(w.M for w in wins))
-    for s, w in enumerate(wins):
-        eng.batch_upload(s, w)
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up (also instantiates the hipGraph of the trust-region loop)
+    sharded = workload == "window100k_sharded"
+    stream_mode = workload == "window300_stream"
+    extra_cfg = {}
+    lat = None
+    # ---- build the workload of this rank
+    if workload == "window300":
+        n_lm, batch = 300, 1
+        wins = [synth.make_window_with_prior(1000 * rank, n_lm, hip_optimize)[0]]
+        desc = "BASELINE configs[1]: 10-keyframe / 300-landmark window, estimate_extrinsic=1, estimate_td=1, prior from a warm-up MARGIN_OLD step; resident, re-solved every step"
+    elif stream_mode:
+        n_lm, batch, n_stream = 300, 1, 64
+        scene = synth.Scene(1000 * rank, n_total=11 + n_stream)
+        rng = np.random.default_rng([1000 * rank, 104729])
+        wins, prior, st = [], None, None
+        for k in range(n_stream):  # the chain is generated through the product path itself
+            kw = {} if k == 0 else dict(prior=prior, init_state=st)
+            w = synth.make_window(1000 * rank, n_lm, kf0=k, scene=scene, **kw)
+            sol, prior = eng.optimize(w, flag)
+            wins.append(w)
+            st = synth.continue_state(scene, k + 1, sol.pose, sol.speed_bias, sol.ex_pose, sol.td, rng)
+        wins = wins[1:]  # every window of the stream carries a prior
+        desc = (f"{len(wins)} consecutive distinct 10-keyframe / 300-landmark windows of one estimator stream (each from the previous "
+                "solution + prior); per step: upload, optimization(), download of solution and prior")
+    elif workload == "batch512":
+        n_lm, batch = 300, 512
+        wins = distinct_windows_with_prior([100000 * rank + s for s in range(batch)], hip_optimize)
+        desc = "BASELINE configs[4]: 512 independent 10-keyframe / 300-landmark windows, 512 distinct seeds, each with the prior of its own warm-up MARGIN_OLD step, solved side by side"
+    elif workload == "window100k":
+        n_lm, batch = 100000, 1
+        wins = [synth.make_window(1000 * rank, n_lm)]
+        desc = "10-keyframe / 100 000-landmark window (no prior), whole window on one GPU"
+    else:
+        n_lm, batch = 100000, 1
+        wins = [synth.make_window(0, n_lm)]  # the SAME window on every rank: each keeps its landmark range
+        desc = (f"BASELINE configs[3]: ONE 10-keyframe / 100 000-landmark window sharded over {world} GPU(s) by contiguous landmark "
+                "ranges balanced on observation count; RCCL sum-all-reduce of the reduced pose system per pass")
+
+    sw = None
+    if sharded:
+        from lfvio.sharded import ShardedWindow
+
+        sw = ShardedWindow(eng, wins[0], rank, world, (lambda t: dist.all_reduce(t)) if dist is not None else None)
+        b, e = sw.range
+        local_N, local_M = e - b, int(wins[0].obs_offset[e] - wins[0].obs_offset[b])
+    else:
+        eng.batch_reserve(batch, max(w.N for w in wins), max(w.M for w in wins))
+        if not stream_mode:
+            for s, w in enumerate(wins):
+                eng.batch_upload(s, w)
+        local_N, local_M = sum(w.N for w in wins[:batch]), sum(w.M for w in wins[:batch])
+
     # A single window is timed through the synchronous entry point, the call a drop-in Estimator::optimization() makes:
     # the library launches the loop in chunks and stops as soon as the window is done (the host round trips in between
     # are inside the timed region).  A resident batch is enqueued without host synchronisation, steps back to back.
     sync_calls = batch == 1
-    for _ in range(args.warmup):
-        eng.batch_optimize(batch, flag, sync=sync_calls)
+    passes_hist = {}
+
+    def step(k):
+        if sharded:
+            sw.run(flag)
+        elif stream_mode:
+            w = wins[k % len(wins)]
+            eng.batch_upload(0, w)
+            eng.batch_optimize(1, flag, sync=True)
+            eng.batch_download(0, w.N)
+            p = eng.last_passes()
+            passes_hist[p] = passes_hist.get(p, 0) + 1
+        else:
+            eng.batch_optimize(batch, flag, sync=sync_calls)
+
+    for k in range(args.warmup):
+        step(k)
     eng.batch_sync()
+    passes_hist.clear()
     barrier()
+    laps = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.batch_optimize(batch, flag, sync=sync_calls)
+    for k in range(args.steps):
+        if stream_mode:
+            t = time.perf_counter()
+            step(k)
+            laps.append(time.perf_counter() - t)
+        else:
+            step(k)
     eng.batch_sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -190,25 +283,33 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    solves = world * batch * args.steps
+    solves = args.steps * (1 if sharded else world * batch)
     value = solves / elapsed
 
-    # ---- sanity of the timed work: the solve converged to the same cost on every step (deterministic)
-    sol, prior = eng.batch_download(0, wins[0].N)
+    # ---- sanity of the timed work
+    if sharded:
+        sol, _, prior = sw.run(flag)
+        extra_cfg["passes_per_step"] = sw.passes
+    else:
+        sol, prior = eng.batch_download(0, wins[0].N if not stream_mode else wins[(args.steps - 1) % len(wins)].N)
     assert prior.valid == 1 and np.isfinite(sol.c.final_cost) and sol.c.num_iterations >= 2
+    if stream_mode:
+        l = np.array(laps) * 1e3
+        lat = dict(mean_ms=float(l.mean()), p50_ms=float(np.median(l)), p95_ms=float(np.percentile(l, 95)), max_ms=float(l.max()),
+                   passes_histogram={str(k): v for k, v in sorted(passes_hist.items())})
 
     # ---- roofline of the residual/Jacobian sweep kernel (k_lin), measured live with HIP events on the
-    #      library's own stream; algorithmic bytes per launch = (68 (M-N) + 88 N) per resident window
+    #      library's own stream; algorithmic bytes per launch = 68 (M - N) + 88 N over what the launch sweeps
     reps = 200 if n_lm <= 1000 else 20
     lin_ms = eng.time_kernel(0, batch, reps)
-    bytes_per_launch = sum(algorithmic_bytes(w) for w in wins)
+    bytes_per_launch = sum(algorithmic_bytes(w.N, w.M) for w in wins[:batch]) if not sharded else algorithmic_bytes(local_N, local_M)
     achieved = bytes_per_launch / (lin_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(args.workload)
+    traffic, traffic_src = pmc_traffic(workload if not stream_mode else "window300")
     roofline = dict(bound="hbm", kernel="k_lin (visual residual/Jacobian sweep: landmark rows + Schur SYRK, Gram chunks, IMU, prior)",
                     achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                     traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_us=lin_ms * 1e3,
-                    note="latency-bound at N=300 (0.12 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep")
+                    note="latency-bound at N=300 (0.1 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep")
     extra = dict(k_sum_us=eng.time_kernel(2, batch, reps) * 1e3, k_solve_us=eng.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
     # the dense solve (k_solve: one workgroup = one CU per window) is where a small window spends most of its time; its
     # arithmetic is the Cholesky factorization and two substitutions of the 172 x 172 reduced system
@@ -222,14 +323,37 @@ def main():
                           flops_per_launch=solve_flops, avg_launch_us=extra["k_solve_us"],
                           note="latency/issue-bound on a single CU per window (DESIGN.md section 5); not the kernel section 8(d) prices")
 
+    if sharded:
+        par = f"landmark-sharded over {world} GPU(s): ranges balanced on observations, RCCL sum-all-reduce of 151 KB + 2 x 128 B per pass on the library's stream"
+    else:
+        par = f"{world} independent window stream(s), one per GPU, no data-path collective"
+    cfg = dict(workload=workload, description=desc, landmarks=n_lm, observations=int(wins[0].M), windows_per_gpu=batch,
+               max_num_iterations=8, iterations_run=int(sol.c.num_iterations - 1), marginalization="MARGIN_OLD", parallelism=par)
+    cfg.update(extra_cfg)
     out = dict(metric="sliding-window solves/sec (10 KF x N landmarks)", value=value, unit="solves/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload=args.workload, description=desc, landmarks=n_lm,
-                           observations=int(wins[0].M), windows_per_gpu=batch, max_num_iterations=8,
-                           iterations_run=int(sol.c.num_iterations - 1), marginalization="MARGIN_OLD",
-                           parallelism=f"{world} independent window stream(s), one per GPU, no data-path collective"),
+               scaling="strong" if sharded else "weak", vs_baseline=None, dtype="f64", data="synthetic", config=cfg,
                roofline=roofline, roofline_k_solve=roofline_solve, kernels_us=extra)
+    if lat is not None:
+        out["latency"] = lat
+    if sharded and world > 1:
+        # the same window, whole, on ONE GPU (rank 0 while the others wait): the figure the sharded rate is a speed-up over
+        one = None
+        if rank == 0:
+            e1 = Engine(local_rank)
+            e1.batch_reserve(1, wins[0].N, wins[0].M)
+            e1.batch_upload(0, wins[0])
+            for _ in range(3):
+                e1.batch_optimize(1, flag, sync=True)
+            t1 = time.perf_counter()
+            n1 = max(5, min(args.steps, 20))
+            for _ in range(n1):
+                e1.batch_optimize(1, flag, sync=True)
+            one = (time.perf_counter() - t1) / n1
+            e1.close()
+            out["one_gpu_same_window"] = dict(ms_per_step=one * 1e3, value=1.0 / one, unit="solves/s",
+                                              speedup_of_this_run=(1.0 / one) and value / (1.0 / one))
+        barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wins[0], flag)
     elif rank == 0:

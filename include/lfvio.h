@@ -277,6 +277,18 @@ int lfvio_shard_solve(lfvio_ctx *ctx);
 int lfvio_shard_candidate(lfvio_ctx *ctx);
 /* *state: 0 = linearize next, 1 = step rejected (only a new candidate), 2 = terminated */
 int lfvio_shard_decide(lfvio_ctx *ctx, int *state);
+/* Stream-ordered form of the same loop (RCCL is stream-ordered: make lfvio_stream(ctx) the collective's stream).  One
+ * pass is ALWAYS the same seven calls, no host synchronisation in between:
+ *   lfvio_shard_enqueue(ctx, 0); all_reduce(buf[0 : len]);
+ *   lfvio_shard_enqueue(ctx, 1); all_reduce(buf[scalar_offset : len]);
+ *   lfvio_shard_enqueue(ctx, 2); all_reduce(buf[scalar_offset : len]);
+ *   lfvio_shard_enqueue(ctx, 3);                        // decision + a 64-byte flag record to pinned memory
+ * and lfvio_shard_poll() waits for the oldest record not yet read (returns 1 and the state of lfvio_shard_decide, 0 when
+ * nothing is outstanding, < 0 on error), so one pass can be kept in flight behind the decision being read; a pass enqueued
+ * behind a terminated loop does nothing.  lfvio_shard_restart() re-arms the resident shard from its uploaded state. */
+int lfvio_shard_restart(lfvio_ctx *ctx);
+int lfvio_shard_enqueue(lfvio_ctx *ctx, int phase);
+int lfvio_shard_poll(lfvio_ctx *ctx, int *state);
 int lfvio_shard_marg_linearize(lfvio_ctx *ctx, int flag);
 int lfvio_shard_marg_finish(lfvio_ctx *ctx, int flag, LfvioPrior *out);
 int lfvio_shard_finish(lfvio_ctx *ctx, LfvioSolution *out);

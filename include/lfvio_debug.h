@@ -30,6 +30,8 @@ int lfvio_debug_force_eig(lfvio_ctx *ctx, int on);
 /* graph launches the last synchronous solve loop needed (1: every window was done within the first chunk of passes,
    and gauge fix + marginalization ran in the same graph) */
 int lfvio_debug_last_chunks(lfvio_ctx *ctx);
+/* passes of the trust-region loop the slowest window of the last synchronous call used */
+int lfvio_debug_last_passes(lfvio_ctx *ctx);
 #ifdef __cplusplus
 }
 #endif

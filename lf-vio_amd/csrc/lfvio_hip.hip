@@ -126,11 +126,17 @@ struct lfvio_ctx {
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   bool use_graph = true;
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
+  int last_passes = 0;  // passes of the trust-region loop the last synchronous call used (slowest slot)
   bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
   // landmark-sharded mode (multi-GPU)
   bool shard_active = false;
   int shard_begin = 0, shard_end = 0, shard_state = 0;
   std::vector<int> sh_start, sh_off;
+  // stream-ordered sharded driver: ring of pinned flag records, one per enqueued decision (shard.inc)
+  static constexpr int FLAG_RING = 4;
+  int *h_flags = nullptr;
+  hipEvent_t flag_event[FLAG_RING] = {};
+  long long flag_head = 0, flag_tail = 0;
 };
 
 namespace {
@@ -695,7 +701,8 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
         break;
       }
     }
-    if (!capped) c->predict_passes = std::max(c->h_pending[1], 1);  // passes the slowest window has used
+    c->last_passes = std::max(c->h_pending[1], 1);  // passes the slowest window has used
+    if (!capped) c->predict_passes = c->last_passes;
     HIPCHK(c, hipGetLastError());
     return LFVIO_OK;
   }
@@ -849,6 +856,10 @@ void lfvio_destroy(lfvio_ctx *c) {
   if (c->h_down) (void)hipHostFree(c->h_down);
   if (c->d_pending) (void)hipFree(c->d_pending);
   if (c->h_pending) (void)hipHostFree(c->h_pending);
+  if (c->h_flags) {
+    (void)hipHostFree(c->h_flags);
+    for (auto &e : c->flag_event) (void)hipEventDestroy(e);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1223,6 +1234,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
 }
 
 int lfvio_debug_last_chunks(lfvio_ctx *c) { return c ? c->stat_chunks : -1; }
+int lfvio_debug_last_passes(lfvio_ctx *c) { return c ? c->last_passes : -1; }
 
 int lfvio_debug_force_eig(lfvio_ctx *c, int on) {
   if (!c) return LFVIO_ERR_ARG;

@@ -342,7 +342,7 @@ HIP_SYMBOLS = [
     "lfvio_batch_sync", "lfvio_batch_download", "lfvio_stream",
     "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_scalar_offset", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
     "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_marg_linearize", "lfvio_shard_marg_finish",
-    "lfvio_shard_finish", "lfvio_triangulate", "lfvio_shift_depth", "lfvio_preintegrate",
+    "lfvio_shard_finish", "lfvio_shard_restart", "lfvio_shard_enqueue", "lfvio_shard_poll", "lfvio_triangulate", "lfvio_shift_depth", "lfvio_preintegrate",
 ]
 
 
@@ -387,6 +387,9 @@ def load_hip_library(path=None):
     for name in ("lfvio_shard_linearize", "lfvio_shard_solve", "lfvio_shard_candidate"):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.lfvio_shard_decide.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.lfvio_shard_restart.argtypes = [C.c_void_p]
+    lib.lfvio_shard_enqueue.argtypes = [C.c_void_p, C.c_int]
+    lib.lfvio_shard_poll.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.lfvio_shard_finish.argtypes = [C.c_void_p, C.POINTER(SolutionC)]
     _dp = C.POINTER(C.c_double)
     lib.lfvio_triangulate.argtypes = [C.c_void_p, C.POINTER(TriangulateInC), _dp]

@@ -20,6 +20,7 @@ class Engine:
         self.lib.lfvio_debug_set_graph.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_force_eig.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_last_chunks.argtypes = [C.c_void_p]
+        self.lib.lfvio_debug_last_passes.argtypes = [C.c_void_p]
         self.lib.lfvio_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
         self.ctx = self.lib.lfvio_create(device)
         if not self.ctx:
@@ -45,6 +46,9 @@ class Engine:
 
     def last_chunks(self):
         return int(self.lib.lfvio_debug_last_chunks(self.ctx))
+
+    def last_passes(self):
+        return int(self.lib.lfvio_debug_last_passes(self.ctx))
 
     def force_eig(self, on):
         self.lib.lfvio_debug_force_eig(self.ctx, int(on))
@@ -171,6 +175,21 @@ class Engine:
         st = C.c_int(0)
         self._check(self.lib.lfvio_shard_decide(self.ctx, C.byref(st)), "shard_decide")
         return st.value
+
+    def shard_restart(self):
+        self._check(self.lib.lfvio_shard_restart(self.ctx), "shard_restart")
+
+    def shard_enqueue(self, phase):
+        """Enqueue phase 0..3 of one pass on the context's stream; no host synchronisation."""
+        self._check(self.lib.lfvio_shard_enqueue(self.ctx, int(phase)), "shard_enqueue")
+
+    def shard_poll(self):
+        """State of the oldest decision not yet read (0 linearize next, 1 step rejected, 2 terminated), or None."""
+        st = C.c_int(0)
+        rc = self.lib.lfvio_shard_poll(self.ctx, C.byref(st))
+        if rc < 0:
+            self._check(rc, "shard_poll")
+        return st.value if rc == 1 else None
 
     def shard_marginalize_linearize(self, flag):
         rc = self.lib.lfvio_shard_marg_linearize(self.ctx, int(flag))

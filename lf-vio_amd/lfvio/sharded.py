@@ -41,6 +41,69 @@ def exchange_tensor(engine):
     return t, soff
 
 
+class ShardedWindow:
+    """One rank's share of a landmark-sharded window, driven stream-ordered: per pass seven enqueues (four kernel phases,
+    three sum-all-reduces on the context's own stream) and ONE wait — for the decision of the pass before the one just
+    enqueued, so the device never idles behind the host.  Every rank reads identical flags and therefore issues the
+    identical sequence of collectives.
+
+    all_reduce(tensor) must sum `tensor` in place over the ranks, ordered on the current torch stream (for
+    torch.distributed on RCCL that is what dist.all_reduce does); world 1 may pass None.
+    """
+
+    def __init__(self, engine, win, rank, world, all_reduce):
+        import torch
+
+        self.eng, self.win, self.rank, self.world = engine, win, rank, world
+        self.range = partition_landmarks(win.obs_offset, world)[rank]
+        engine.shard_begin(win, self.range[0], self.range[1], add_pose_side=(rank == 0))
+        self.buf, soff = exchange_tensor(engine)
+        self.tail = self.buf[soff:]
+        self.stream = torch.cuda.ExternalStream(engine.stream())
+        self.all_reduce = all_reduce if (all_reduce is not None and world > 1) else (lambda t: None)
+        self.passes = 0
+        self._armed = True
+
+    def _pass(self):
+        e = self.eng
+        e.shard_enqueue(0)
+        self.all_reduce(self.buf)
+        e.shard_enqueue(1)
+        self.all_reduce(self.tail)
+        e.shard_enqueue(2)
+        self.all_reduce(self.tail)
+        e.shard_enqueue(3)
+        self.passes += 1
+
+    def run(self, marg_flag=None):
+        """The trust-region loop (and, with marg_flag, gauge fix + marginalization: one more all-reduce).  Returns
+        (solution, (begin, end)) or (solution after the gauge fix, (begin, end), prior)."""
+        import torch
+
+        if not self._armed:
+            self.eng.shard_restart()
+        self._armed = False
+        self.passes = 0
+        limit = 4 * (self.win.max_num_iterations + 8)
+        with torch.cuda.stream(self.stream):
+            self._pass()
+            while True:
+                self._pass()                  # one pass in flight ...
+                state = self.eng.shard_poll()  # ... behind the decision being read
+                if state == 2:
+                    break
+                if self.passes > limit:
+                    raise RuntimeError("sharded loop did not terminate")
+            while self.eng.shard_poll() is not None:  # the pass in flight was a no-op: drain its record
+                pass
+            if marg_flag is None:
+                return self.eng.shard_finish(self.win.N), self.range
+            if self.eng.shard_marginalize_linearize(marg_flag) == 1:
+                self.all_reduce(self.buf)
+            prior = self.eng.shard_marginalize_finish(marg_flag)
+            return self.eng.shard_finish(self.win.N), self.range, prior
+
+
 def solve_sharded(engine, win, rank, world, all_reduce, marg_flag=None):
     """Run the sharded trust-region loop.  all_reduce(tensor) must sum `tensor` in place over the ranks
     (torch.distributed.all_reduce on the RCCL backend).  Returns (solution, (begin, end)) — inv_depth is filled for

@@ -17,35 +17,87 @@ from lfvio import abi, synth
 pytestmark = pytest.mark.gpu
 
 
-def zero_baseline_window(seed, n, motion, **kw):
-    w = synth.make_window(seed, n, motion=motion, pose_noise=(0.0, np.deg2rad(0.5)), **kw)
+def zero_baseline_window(seed, n, motion, pos_noise=0.0, **kw):
+    w = synth.make_window(seed, n, motion=motion, pose_noise=(pos_noise, np.deg2rad(0.5)), **kw)
     ex = w.ex_pose.copy()
     ex[:3] = 0.0
     return w.copy(ex_pose=ex)
 
 
 @pytest.mark.parametrize("motion", ["rotate", "static"])
-def test_zero_baseline_windows(eng, oracle, motion):
+@pytest.mark.parametrize("baseline", [1e-2, 1e-3, 1e-4, 1e-5])
+def test_shrinking_baseline_tracks_the_oracle(eng, oracle, motion, baseline):
+    """The camera does not translate; the only baseline is the position noise of the initial state (`baseline` metres), so
+    H_ll = a_l falls like baseline^2 (2e-1 ... 2e-7).  The loop must follow the oracle step for step all the way; the
+    inverse-depth bar widens with 1 / min(a_l) — the landmark step is (b_l - w_l . dx) / a_l, and the rounding of the
+    numerator (entries of w_l reach 1e5) does not shrink with a_l.  Measured: poses 1e-10 .. 3e-8, inverse depths
+    6e-8 (a = 2e-1) .. 2e-6 (a = 2e-7)."""
     from test_gpu_parity import check_prior, check_solution, rel
 
+    w = zero_baseline_window(3, 60, motion, baseline)
+    assert int((w.obs_offset[1:] - w.obs_offset[:-1] == 2).sum()) >= 1  # a two-observation, (near) zero-baseline track is in
+    a_min = oracle.linearize(w)["a"].min()
+    lam_tol = max(1e-6, 3e-11 / a_min)
+    ref, sol = oracle.solve(w), eng.solve(w)
+    tag = f"{motion} baseline {baseline:g}: min a_l = {a_min:.2e}, inverse-depth bar {lam_tol:.1e}"
+    tr, rt = sol.trace(), ref.trace()
+    assert (sol.c.num_iterations, sol.c.termination) == (ref.c.num_iterations, ref.c.termination), tag
+    assert [t["successful"] for t in tr] == [t["successful"] for t in rt], tag
+    assert rel([t["radius"] for t in tr], [t["radius"] for t in rt]) < 1e-6, tag
+    assert rel([t["cost"] for t in tr], [t["cost"] for t in rt]) < max(1e-7, 1e-13 / a_min), tag
+    assert np.abs(sol.pose - ref.pose).max() < 1e-6 * max(1.0, np.abs(ref.pose).max()), tag
+    assert np.abs(sol.speed_bias - ref.speed_bias).max() < 1e-6, tag
+    # without translation tic is unobservable (rotation about a point: the estimate itself wanders by decimetres to metres
+    # over the eight iterations, driven by the position noise): its bar is the one digit wider the measurements ask for
+    # (1.9e-6 .. 3.6e-6 on the static windows); the rotation part of the extrinsic stays at 1e-6
+    assert np.abs(sol.ex_pose[:3] - ref.ex_pose[:3]).max() < 1e-5 and np.abs(sol.ex_pose[3:] - ref.ex_pose[3:]).max() < 1e-6, tag
+    assert rel(sol.lam, ref.lam) < lam_tol, tag
+    if baseline >= 1e-3:
+        # the next prior, at the oracle's post-gauge state (identical inputs)
+        ref_opt, _ = oracle.optimize(w, abi.MARGIN_OLD)
+        w2 = abi.apply_solution(w, ref_opt)
+        pref, Aref, bref = oracle.marginalize(w2, abi.MARGIN_OLD, want_Ab=True)
+        p = eng.marginalize(w2, abi.MARGIN_OLD)
+        A, b = eng.marg_system(p.n)
+        check_prior(p, pref, A, b, Aref, bref)
+
+
+@pytest.mark.parametrize("motion", ["rotate", "static"])
+def test_exactly_zero_baseline_is_survived(eng, oracle, motion):
+    """Zero translation, tic = 0: a_l and b_l are pure rounding noise (1e-27), so the landmark steps — and with them the
+    whole trace — are decided by rounding, in the oracle as much as here (the two differ from the first step on; the
+    reference would differ from both).  What can be held: the linearization of everything that is NOT noise agrees, the
+    loop stays finite and descends, and the marginalization (a_l on both sides of eps = 1e-8 at the solution) produces a
+    finite prior of the oracle's structure."""
+    from test_gpu_parity import rel
+
     w = zero_baseline_window(3, 60, motion)
-    assert int((w.obs_offset[1:] - w.obs_offset[:-1] == 2).sum()) >= 1  # a two-observation, zero-baseline track is in
     lin_g, lin_o = eng.linearize(w), oracle.linearize(w)
-    assert lin_o["a"].max() < 1e-20  # the premise: no depth information at the start
-    assert np.abs(lin_g["a"]).max() < 1e-20
+    assert lin_o["a"].max() < 1e-20 and np.abs(lin_g["a"]).max() < 1e-20  # the premise: no depth information
     assert rel(lin_g["H"], lin_o["H"]) < 1e-10 and rel(lin_g["g"], lin_o["g"]) < 1e-10
-    ref = oracle.solve(w)
+    assert abs(lin_g["cost"] - lin_o["cost"]) <= 1e-10 * lin_o["cost"]
     sol = eng.solve(w)
-    check_solution(sol, ref, w)
-    # marginalization at the oracle's post-gauge state (identical inputs): a_l straddles eps there
-    ref_opt, _ = oracle.optimize(w, abi.MARGIN_OLD)
+    ref = oracle.solve(w)
+    assert sol.c.num_iterations == ref.c.num_iterations == 9
+    assert np.isfinite(sol.pose).all() and np.isfinite(sol.lam).all() and np.isfinite(sol.speed_bias).all()
+    acc = [t["cost"] for t in sol.trace() if t["successful"]]
+    assert all(x > y for x, y in zip([sol.c.initial_cost] + acc, acc)) and sol.c.final_cost < 1e-2 * sol.c.initial_cost
+    opt, prior = eng.optimize(w, abi.MARGIN_OLD)
+    ref_opt, ref_prior = oracle.optimize(w, abi.MARGIN_OLD)
+    assert prior.valid == 1 and np.isfinite(prior.J()).all() and np.isfinite(prior.r()).all()
+    assert (prior.m, prior.n, prior.num_blocks) == (ref_prior.m, ref_prior.n, ref_prior.num_blocks)
+    assert prior.block_list() == ref_prior.block_list()
+    # the eps cut on the landmark diagonal, on identical inputs: the oracle's post-gauge state has a_l on both sides of it
     w2 = abi.apply_solution(w, ref_opt)
     a2 = oracle.linearize(w2)["a"][w2.start_frame == 0]
-    assert a2.min() < 1e-8 < a2.max()
+    if motion == "rotate":
+        assert a2.min() < 1e-8 < a2.max()
     pref, Aref, bref = oracle.marginalize(w2, abi.MARGIN_OLD, want_Ab=True)
     p = eng.marginalize(w2, abi.MARGIN_OLD)
     A, b = eng.marg_system(p.n)
-    check_prior(p, pref, A, b, Aref, bref)
+    print(f"{motion}: a_l at the solution in [{a2.min():.1e}, {a2.max():.1e}]; A' rel {rel(A, Aref):.2e}, b' rel {np.abs(b - bref).max() / np.abs(bref).max():.2e}")
+    assert p.block_list() == pref.block_list() and np.isfinite(p.J()).all()
+    assert rel(A, Aref) < 1e-6
 
 
 def _sentinel_solution(n):
@@ -74,9 +126,10 @@ def _sentinel_prior():
 @pytest.mark.parametrize("where", ["obs_point", "para_pose", "inv_depth", "imu"])
 def test_non_finite_input_is_reported_and_outputs_stay_untouched(eng, where):
     w = synth.make_window(5, 40)
+    l0 = int(np.flatnonzero(w.start_frame == 0)[0])  # a landmark the marginalization reads as well
     if where == "obs_point":
         pts = w.obs_point.copy()
-        pts[7, 1] = np.nan
+        pts[int(w.obs_offset[l0]) + 1, 1] = np.nan
         w = w.copy(obs_point=pts)
     elif where == "para_pose":
         pose = w.pose.copy()
@@ -84,13 +137,13 @@ def test_non_finite_input_is_reported_and_outputs_stay_untouched(eng, where):
         w = w.copy(pose=pose)
     elif where == "inv_depth":
         lam = w.inv_depth.copy()
-        lam[2] = np.nan
+        lam[l0] = np.nan
         w = w.copy(inv_depth=lam)
     else:
         imu = list(w.imu)
-        bad = abi.preint_from_array(abi.preint_to_array(imu[2]))
+        bad = abi.preint_from_array(abi.preint_to_array(imu[0]))
         bad.delta_p[1] = np.nan
-        imu[2] = bad
+        imu[0] = bad
         w = w.copy(imu=imu)
     out = _sentinel_solution(w.N)
     assert eng.lib.lfvio_solve(eng.ctx, C.byref(w.c()), C.byref(out.c)) == -3  # LFVIO_ERR_NONFINITE
@@ -103,10 +156,9 @@ def test_non_finite_input_is_reported_and_outputs_stay_untouched(eng, where):
     p = _sentinel_prior()
     assert eng.lib.lfvio_batch_download(eng.ctx, 0, C.byref(out.c), C.byref(p)) == -3
     assert _untouched(out) and (p.valid, p.n, p.m) == (-7, -7, -7)
-    if where != "imu" or True:
-        p = _sentinel_prior()
-        rc = eng.lib.lfvio_marginalize(eng.ctx, C.byref(w.c()), abi.MARGIN_OLD, C.byref(p))
-        assert rc == -3 and (p.valid, p.n, p.m) == (-7, -7, -7) and p.linearized_residuals[0] == -7.0
+    p = _sentinel_prior()
+    rc = eng.lib.lfvio_marginalize(eng.ctx, C.byref(w.c()), abi.MARGIN_OLD, C.byref(p))
+    assert rc == -3 and (p.valid, p.n, p.m) == (-7, -7, -7) and p.linearized_residuals[0] == -7.0
     # the context is still usable
     good = synth.make_window(5, 40)
     assert eng.solve(good).c.num_iterations >= 2

@@ -173,3 +173,164 @@ def test_two_contexts_emulate_ranks_on_one_gpu(oracle, world, n):
     assert abs(sols[0].c.final_cost - want.c.final_cost) <= 1e-7 * want.c.final_cost
     for e in engs:
         e.close()
+
+
+# ---------------------------------------------------------------------------
+# The stream-ordered driver (lfvio.sharded.ShardedWindow): what bench.py --gpus N runs over RCCL
+# ---------------------------------------------------------------------------
+class _ThreadAllReduce:
+    """Sum-all-reduce between `world` threads of one process (one library context and stream each): the stand-in for
+    RCCL when the ranks share a GPU.  Fixed summation order, the same on every rank."""
+
+    def __init__(self, world):
+        import threading
+
+        self.world, self.bar, self.slots = world, threading.Barrier(world), [None] * world
+
+    def rank(self, r):
+        import torch
+
+        def all_reduce(t):
+            torch.cuda.current_stream().synchronize()  # this rank's exchange buffer is complete
+            self.slots[r] = t
+            self.bar.wait()
+            if r == 0:
+                total = torch.stack(self.slots).sum(dim=0)
+                for s in self.slots:
+                    s.copy_(total)
+                torch.cuda.synchronize()
+            self.bar.wait()
+
+        return all_reduce
+
+
+def _check_sharded_result(w, ranges, results, want, want_prior):
+    sols = [r[0] for r in results]
+    priors = [r[2] for r in results]
+    for p in priors:
+        assert (p.valid, p.m, p.n, p.num_blocks) == (1, want_prior.m, want_prior.n, want_prior.num_blocks)
+        assert p.block_list() == want_prior.block_list()
+        assert np.array_equal(p.J(), priors[0].J()) and np.array_equal(p.r(), priors[0].r())  # identical on every rank
+    J, Jw = priors[0].J(), want_prior.J()
+    Aw = Jw.T @ Jw
+    assert np.abs(J.T @ J - Aw).max() < 1e-6 * np.abs(Aw).max()
+    lam = np.zeros(w.N)
+    for r, s in enumerate(sols):
+        b, e = ranges[r]
+        lam[b:e] = s.inv_depth[b:e]
+        assert np.array_equal(s.pose, sols[0].pose) and np.array_equal(s.speed_bias, sols[0].speed_bias)
+        assert (s.c.num_iterations, s.c.termination) == (want.c.num_iterations, want.c.termination)
+    assert np.abs(sols[0].pose - want.pose).max() < 1e-6 * max(1.0, np.abs(want.pose).max())
+    assert np.abs(sols[0].speed_bias - want.speed_bias).max() < 1e-6
+    assert np.abs(lam - want.lam).max() < 1e-6 * np.abs(want.lam).max()
+    assert abs(sols[0].c.final_cost - want.c.final_cost) <= 1e-7 * want.c.final_cost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n", [(2, 300), (4, 3000), (8, 100000)])  # (8, 100000): BASELINE configs[3] at full size
+def test_stream_ordered_driver_on_emulated_ranks(oracle, world, n):
+    """`world` threads, one context each on the same GPU, run ShardedWindow.run() — seven enqueues per pass, one pass in
+    flight behind the decision being read — twice (the second time from the resident shard, as the bench does); the
+    result equals the single-GPU optimization() of the whole window."""
+    import threading
+
+    from lfvio.engine import Engine
+    from lfvio.sharded import ShardedWindow
+
+    ref = Engine(0)
+    warm = (lambda x, f: oracle.optimize(x, f)) if n <= 1000 else (lambda x, f: ref.optimize(x, f))
+    w = synth.make_window_with_prior(4, n, warm)[0]
+    want, want_prior = ref.optimize(w, abi.MARGIN_OLD)
+    ref.close()
+    ar = _ThreadAllReduce(world)
+    engs = [Engine(0) for _ in range(world)]
+    results, errors = [[None, None] for _ in range(world)], []
+
+    def work(r):
+        try:
+            sw = ShardedWindow(engs[r], w, r, world, ar.rank(r))
+            results[r][0] = sw.run(abi.MARGIN_OLD)
+            results[r][1] = sw.run(abi.MARGIN_OLD)  # shard_restart(): no upload
+        except Exception as ex:  # noqa: BLE001
+            errors.append((r, repr(ex)))
+            ar.bar.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    ranges = partition_landmarks(w.obs_offset, world)
+    for k in (0, 1):
+        _check_sharded_result(w, ranges, [results[r][k] for r in range(world)], want, want_prior)
+    for r in range(world):  # the resident re-run is the same computation: bit-identical
+        assert np.array_equal(results[r][0][0].pose, results[r][1][0].pose)
+        assert np.array_equal(results[r][0][2].J(), results[r][1][2].J())
+    for e in engs:
+        e.close()
+
+
+def _two_process_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    for p in (ROOT, os.path.join(ROOT, "lf-vio_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from lfvio.engine import Engine
+    from lfvio.sharded import ShardedWindow
+    from oracle import binding as ob
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    w = synth.make_window_with_prior(3, 300, lambda x, f: ob.optimize(x, f))[0]
+
+    def all_reduce(t):  # gloo over a host staging copy; ordered on the current (= the context's) stream
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+
+    eng = Engine(0)
+    sol, rng, prior = ShardedWindow(eng, w, rank, world, all_reduce).run(abi.MARGIN_OLD)
+    q.put((rank, rng, sol.pose, sol.speed_bias, sol.inv_depth.copy(), sol.c.num_iterations, sol.c.termination, sol.c.final_cost,
+           prior.J(), prior.r(), prior.block_list()))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_processes_drive_the_sharded_solve_over_gloo(eng, oracle):
+    """Two REAL processes (one library context each, both on GPU 0) run the product driver with torch.distributed
+    collectives — gloo on a host staging copy here, RCCL on the device buffer in bench.py; the result must equal the
+    single-process optimization() of the whole window and be bit-identical on both ranks."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_two_process_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    w = synth.make_window_with_prior(3, 300, lambda x, f: oracle.optimize(x, f))[0]
+    want, want_prior = eng.optimize(w, abi.MARGIN_OLD)
+    ref, ref_prior = oracle.optimize(w, abi.MARGIN_OLD)
+    lam = np.zeros(w.N)
+    for rank, (b, e), pose, sb, inv_depth, iters, term, cost, J, r, blocks in got:
+        lam[b:e] = inv_depth[b:e]
+        assert np.array_equal(pose, got[0][2]) and np.array_equal(J, got[0][8]) and np.array_equal(r, got[0][9])
+        assert (iters, term) == (want.c.num_iterations, want.c.termination) == (ref.c.num_iterations, ref.c.termination)
+        assert blocks == want_prior.block_list() == ref_prior.block_list()
+        assert np.abs(pose - want.pose).max() < 1e-6 and np.abs(pose - ref.pose).max() < 1e-6
+        assert abs(cost - ref.c.final_cost) <= 1e-7 * ref.c.final_cost
+    assert np.abs(lam - ref.lam).max() < 1e-6 * np.abs(ref.lam).max()
+    A, Aref = got[0][8].T @ got[0][8], ref_prior.J().T @ ref_prior.J()
+    assert np.abs(A - Aref).max() < 1e-6 * np.abs(Aref).max()
