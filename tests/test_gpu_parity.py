@@ -5,7 +5,8 @@ Tolerances (FP64, sums re-ordered on the device):
   * Gauss-Newton blocks (H_pp, g, a, b, W), cost            1e-10 relative to the block scale
   * trust-region trace: same accept/reject pattern, radii    1e-6, costs 1e-7 relative
   * final state (pose deltas)                                1e-6 relative   (north_star)
-  * marginalization prior: structure exact; A', b'           1e-6 relative (A_mm is ill-conditioned)
+  * marginalization prior: structure exact; A', b', J0^T J0, J0^T r0   1e-6 relative; kept eigen-directions equal up to the
+    eigenvalues within the rounding of A' from eps
 """
 import ctypes as C
 import os
@@ -108,7 +109,12 @@ def check_prior(p, ref, A, b, Aref, bref):
     assert np.abs(b - bref).max() < 1e-6 * np.abs(bref).max()
     J, r = p.J(), p.r()
     assert rel(J.T @ J, Aref) < 1e-6
-    assert np.abs(J.T @ r - bref).max() < 1e-4 * np.abs(bref).max()
+    assert np.abs(J.T @ r - bref).max() < 1e-6 * np.abs(bref).max()  # measured 3e-11 .. 8e-11: b' has nothing in the dropped directions
+    # eigen-directions kept (S > eps, marginalization_factor.cpp:283-291): equal up to the eigenvalues that the rounding of
+    # A' itself can move across eps (Weyl; tests/marg_ref.py)
+    import marg_ref
+
+    assert abs(marg_ref.kept_directions(p) - marg_ref.kept_directions(ref)) <= marg_ref.kept_count_slack(Aref, A)
 
 
 @pytest.mark.parametrize("seed,n", [(0, 300), (7, 60), (8, 1000)])
@@ -216,8 +222,8 @@ def test_full_optimization_chain(eng, oracle):
         assert np.abs(sol.pose[0, :3] - w.pose[0, :3]).max() < 1e-9  # gauge: frame 0 re-pinned
         assert prior.block_list() == ref_prior.block_list() and (prior.m, prior.n) == (ref_prior.m, ref_prior.n)
         J, Jr = prior.J(), ref_prior.J()
-        assert rel(J.T @ J, Jr.T @ Jr) < 1e-5
-        assert np.abs(J.T @ prior.r() - Jr.T @ ref_prior.r()).max() < 1e-4 * np.abs(Jr.T @ ref_prior.r()).max()
+        assert rel(J.T @ J, Jr.T @ Jr) < 1e-6            # measured 5e-11 .. 2e-10
+        assert np.abs(J.T @ prior.r() - Jr.T @ ref_prior.r()).max() < 1e-6 * np.abs(Jr.T @ ref_prior.r()).max()  # measured 6e-9
 
 
 def test_sequence_of_windows_tracks_the_oracle(eng, oracle):
@@ -247,7 +253,7 @@ def test_sequence_of_windows_tracks_the_oracle(eng, oracle):
         assert abs(sg.td - sc.td) < 1e-6 and np.abs(sg.ex_pose - sc.ex_pose).max() < 1e-6, k
         assert (pg.n, pg.num_blocks) == (pc.n, pc.num_blocks) and pg.block_list() == pc.block_list(), k
         Jg, Jc = pg.J(), pc.J()
-        assert rel(Jg.T @ Jg, Jc.T @ Jc) < 1e-5, k
+        assert rel(Jg.T @ Jg, Jc.T @ Jc) < 1e-6, k  # measured 8e-11 .. 1.3e-9
     # the GPU chain on its own priors
     scene = synth.Scene(seed, n_total=11 + steps)
     rng = np.random.default_rng([seed, 104729])
@@ -263,9 +269,9 @@ def test_sequence_of_windows_tracks_the_oracle(eng, oracle):
 
 def test_randomized_sweep_against_the_oracle(eng, oracle):
     """60 random (seed, size, flags, max_iterations, marginalization flag, with / without prior) combinations of the whole
-    optimization() — the cases tests/tools/fuzz_parity.py draws.  Tiny windows sit close to the conditioning limits of the
-    algorithm itself, hence the slightly wider bars on inverse depths and on the prior; a prior whose information is
-    pure cancellation noise (no frame-0 landmark, no input prior: a lone IMU factor marginalized) is not compared."""
+    optimization() — the cases tests/tools/fuzz_parity.py draws — at the north_star's 1e-6 throughout (measured worst of the
+    60: inverse depths 1.3e-7, prior 3.0e-7, both on a one-landmark window); a prior whose information is pure cancellation
+    noise (no frame-0 landmark, no input prior: a lone IMU factor marginalized) is not compared."""
     rng = np.random.default_rng(20260928)
     for case in range(60):
         seed = int(rng.integers(0, 10_000))
@@ -283,13 +289,13 @@ def test_randomized_sweep_against_the_oracle(eng, oracle):
         assert (gs.c.num_iterations, gs.c.termination) == (rs.c.num_iterations, rs.c.termination), tag
         assert np.abs(gs.pose - rs.pose).max() < 1e-6 * max(1.0, np.abs(rs.pose).max()), tag
         assert np.abs(gs.speed_bias - rs.speed_bias).max() < 1e-6, tag
-        assert rel(gs.lam, rs.lam) < 1e-5, tag
+        assert rel(gs.lam, rs.lam) < 1e-6, tag
         assert gp.valid == rp.valid, tag
         if rp.valid == 1:
             assert (gp.m, gp.n, gp.num_blocks) == (rp.m, rp.n, rp.num_blocks) and gp.block_list() == rp.block_list(), tag
             Ar = rp.J().T @ rp.J()
             if np.abs(Ar).max() > 1.0:
-                assert rel(gp.J().T @ gp.J(), Ar) < 1e-4, tag
+                assert rel(gp.J().T @ gp.J(), Ar) < 1e-6, tag
 
 
 def test_batched_windows_match_single(eng, oracle):

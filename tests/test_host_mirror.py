@@ -112,7 +112,7 @@ def test_host_optimization_end_to_end(host, oracle, fused):
         p = host.prior()
         assert p.block_list() == ref_prior.block_list()
         J, Jr = p.J(), ref_prior.J()
-        assert np.abs(J.T @ J - Jr.T @ Jr).max() < 1e-5 * np.abs(Jr.T @ Jr).max()
+        assert np.abs(J.T @ J - Jr.T @ Jr).max() < 1e-6 * np.abs(Jr.T @ Jr).max()
 
 
 @pytest.mark.gpu
