@@ -89,8 +89,11 @@ Layout make_layout(int maxN, int maxM) {
   return L;
 }
 
+size_t down_bytes(int maxN) { return sizeof(FrameState) * 2 + sizeof(TRState) + 2 * ((size_t)maxN * 8 + 128) + sizeof(LfvioPrior) + 4096; }
+
 struct SlotHostInfo {
   int N = 0, M = 0, gLm = 0, gCh = 0, gSc = 0;
+  int marg_n = 0;            // the largest prior (tangent rows) a marginalization of this window can produce
   int max_iter = 0;          // LfvioWindow::max_num_iterations of the uploaded window
   double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
   std::vector<int> perm;  // device order -> caller order
@@ -172,7 +175,7 @@ int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
   HIPCHK(c, hipMalloc((void **)&c->d_base, L.total * (size_t)batch));
   HIPCHK(c, hipMemsetAsync(c->d_base, 0, L.total * (size_t)batch, c->stream));
   HIPCHK(c, hipHostMalloc((void **)&c->h_stage, L.in_end, hipHostMallocDefault));
-  c->h_down_bytes = sizeof(FrameState) * 2 + sizeof(TRState) + (size_t)L.maxN * 8 + sizeof(LfvioPrior) + 4096;
+  c->h_down_bytes = down_bytes(L.maxN);
   HIPCHK(c, hipHostMalloc((void **)&c->h_down, c->h_down_bytes, hipHostMallocDefault));
   c->L = L;
   c->batch = batch;
@@ -456,6 +459,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   }
   plan_marg(w, LFVIO_MARGIN_OLD, N0, kmax0, S->pair_chunk0[11], true, &S->marg[0]);
   plan_marg(w, LFVIO_MARGIN_SECOND_NEW, 0, 0, 0, true, &S->marg[1]);
+  info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   for (int f = 0; f < 2; f++)
     if (S->marg[f].valid && (S->marg[f].n > 76 || S->marg[f].m15 + S->marg[f].n > 92)) {
       // k_marg_solve keeps the dense system in LDS: sized for what the reference's own marginalization produces
@@ -739,28 +743,62 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated)
   return LFVIO_OK;
 }
 
-int download_solution(lfvio_ctx *c, int slot, LfvioSolution *out) {
+// Results come back through one pinned block [x[2] | tr | lam[0] | lam[1] | prior]: every copy a call needs is enqueued and
+// the stream is synchronized ONCE (a round trip costs ~12 us; the drop-in call used to make four).  Which of the two
+// inverse-depth buffers is current is only known from `tr`, so small windows fetch both; windows beyond ONE_TRIP_LM
+// landmarks take a second trip for the one that matters instead of moving megabytes for nothing.
+constexpr int ONE_TRIP_LM = 8192;
+struct Fetched {
+  const FrameState *xs;
+  const TRState *tr;
+  const double *lam[2];
+  LfvioPrior *prior;
+};
+
+int fetch(lfvio_ctx *c, int slot, bool want_sol, bool want_prior, Fetched *f) {
   const Layout &L = c->L;
   char *d = c->d_base + (size_t)slot * L.total;
   const SlotHostInfo &info = c->info[slot];
   char *hd = c->h_down;
-  const size_t hdr = sizeof(FrameState) * 2 + sizeof(TRState);
-  HIPCHK(c, hipMemcpyAsync(hd, d + offsetof(Slot, x), hdr, hipMemcpyDeviceToHost, c->stream));
+  const size_t hdr = sizeof(FrameState) * 2 + sizeof(TRState), lam_bytes = (size_t)info.N * 8;
+  char *h_lam0 = hd + hdr, *h_lam1 = h_lam0 + align_up(lam_bytes + 8, 64), *h_prior = h_lam1 + align_up(lam_bytes + 8, 64);
+  f->xs = (const FrameState *)hd, f->tr = (const TRState *)(hd + sizeof(FrameState) * 2);
+  f->lam[0] = (const double *)h_lam0, f->lam[1] = (const double *)h_lam1, f->prior = (LfvioPrior *)h_prior;
+  const bool both = info.N > 0 && info.N <= ONE_TRIP_LM;
+  if (want_sol) {
+    HIPCHK(c, hipMemcpyAsync(hd, d + offsetof(Slot, x), hdr, hipMemcpyDeviceToHost, c->stream));
+    if (both) {
+      HIPCHK(c, hipMemcpyAsync(h_lam0, d + L.lam[0], lam_bytes, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(h_lam1, d + L.lam[1], lam_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  if (want_prior) {
+    // the dimension of the prior a marginalization of this window can produce is known since the upload (plan_marg)
+    const size_t head = offsetof(LfvioPrior, linearized_jacobians), n = (size_t)info.marg_n;
+    HIPCHK(c, hipMemcpyAsync(h_prior, d + offsetof(Slot, prior_out), head + sizeof(double) * n * n, hipMemcpyDeviceToHost, c->stream));
+    if (n)
+      HIPCHK(c, hipMemcpyAsync(h_prior + offsetof(LfvioPrior, linearized_residuals), d + offsetof(Slot, prior_out) + offsetof(LfvioPrior, linearized_residuals),
+                               sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const FrameState *xs = (const FrameState *)hd;
-  const TRState *tr = (const TRState *)(hd + sizeof(FrameState) * 2);
+  if (want_sol && !both && info.N > 0 && !f->tr->error) {
+    HIPCHK(c, hipMemcpyAsync(f->tr->cur ? h_lam1 : h_lam0, d + L.lam[f->tr->cur], lam_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LFVIO_OK;
+}
+
+// nothing is written to the caller's outputs before the result is known to be usable (the header promises untouched
+// outputs on error): check_* first, then unpack_*
+int check_solution(lfvio_ctx *c, int slot, const Fetched &f) {
+  const SlotHostInfo &info = c->info[slot];
+  const TRState *tr = f.tr;
   if (tr->error) {
     c->err = "non-finite cost";
     return tr->error;
   }
-  const int cur = tr->cur;
-  if (info.N > 0) {
-    HIPCHK(c, hipMemcpyAsync(hd + hdr, d + L.lam[cur], (size_t)info.N * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  const FrameState &x = xs[cur];
-  const double *lam = (const double *)(hd + hdr);
-  // nothing is written to `out` before the result is known to be finite (the header promises untouched outputs on error)
+  const FrameState &x = f.xs[tr->cur];
+  const double *lam = f.lam[tr->cur];
   bool finite = std::isfinite(tr->x_cost);
   for (int k = 0; finite && k < (int)(sizeof(FrameState) / 8); k++) finite = std::isfinite(((const double *)&x)[k]);
   for (int dl = 0; finite && dl < info.N; dl++) finite = std::isfinite(lam[dl]);
@@ -768,6 +806,14 @@ int download_solution(lfvio_ctx *c, int slot, LfvioSolution *out) {
     c->err = "non-finite state";
     return LFVIO_ERR_NONFINITE;
   }
+  return LFVIO_OK;
+}
+
+void unpack_solution(lfvio_ctx *c, int slot, const Fetched &f, LfvioSolution *out) {
+  const SlotHostInfo &info = c->info[slot];
+  const TRState *tr = f.tr;
+  const FrameState &x = f.xs[tr->cur];
+  const double *lam = f.lam[tr->cur];
   std::memcpy(out->para_pose, x.pose, sizeof x.pose);
   std::memcpy(out->para_speed_bias, x.sb, sizeof x.sb);
   std::memcpy(out->para_ex_pose, x.ex, sizeof x.ex);
@@ -782,33 +828,19 @@ int download_solution(lfvio_ctx *c, int slot, LfvioSolution *out) {
   out->final_cost = tr->x_cost;
   std::memset(out->trace, 0, sizeof out->trace);
   for (int k = 0; k < tr->trace_len && k < LFVIO_MAX_TRACE; k++) out->trace[k] = tr->trace[k];
-  return LFVIO_OK;
 }
 
-int download_prior(lfvio_ctx *c, int slot, LfvioPrior *out) {
-  const Layout &L = c->L;
-  char *d = c->d_base + (size_t)slot * L.total;
+// returns LFVIO_OK with *pass = true when nothing was marginalized and the input prior stays
+int check_prior(lfvio_ctx *c, int slot, const Fetched &f, bool *pass) {
   const SlotHostInfo &info = c->info[slot];
-  // header of LfvioPrior up to the Jacobian, then only the n*n / n used entries
-  LfvioPrior *hp = (LfvioPrior *)c->h_down;
-  const size_t head = offsetof(LfvioPrior, linearized_jacobians);
-  HIPCHK(c, hipMemcpyAsync(hp, d + offsetof(Slot, prior_out), head, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (hp->valid == -1) {  // nothing was marginalized: the input prior stays
-    if (info.has_in_prior) *out = info.in_prior;
-    else out->valid = 0;
-    return LFVIO_OK;
-  }
+  const LfvioPrior *hp = f.prior;
+  *pass = hp->valid == -1;
+  if (*pass) return LFVIO_OK;
   const int n = hp->n;
-  if (hp->valid != 1 || n <= 0 || n > LFVIO_MAX_PRIOR_DIM) {
+  if (hp->valid != 1 || n <= 0 || n > LFVIO_MAX_PRIOR_DIM || n > info.marg_n) {
     c->err = "marginalization produced no prior";
     return LFVIO_ERR_DEVICE;
   }
-  HIPCHK(c, hipMemcpyAsync(hp->linearized_jacobians, d + offsetof(Slot, prior_out) + head, sizeof(double) * n * n,
-                           hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(hp->linearized_residuals, d + offsetof(Slot, prior_out) + offsetof(LfvioPrior, linearized_residuals),
-                           sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   bool finite = true;
   for (int k = 0; finite && k < n * n; k++) finite = std::isfinite(hp->linearized_jacobians[k]);
   for (int k = 0; finite && k < n; k++) finite = std::isfinite(hp->linearized_residuals[k]);
@@ -816,11 +848,36 @@ int download_prior(lfvio_ctx *c, int slot, LfvioPrior *out) {
     c->err = "non-finite prior";
     return LFVIO_ERR_NONFINITE;
   }
-  std::memcpy(out, hp, head);
-  std::memcpy(out->linearized_jacobians, hp->linearized_jacobians, sizeof(double) * n * n);
-  std::memcpy(out->linearized_residuals, hp->linearized_residuals, sizeof(double) * n);
   return LFVIO_OK;
 }
+
+void unpack_prior(lfvio_ctx *c, int slot, const Fetched &f, bool pass, LfvioPrior *out) {
+  const SlotHostInfo &info = c->info[slot];
+  if (pass) {
+    if (info.has_in_prior) *out = info.in_prior;
+    else out->valid = 0;
+    return;
+  }
+  const LfvioPrior *hp = f.prior;
+  const int n = hp->n;
+  std::memcpy(out, hp, offsetof(LfvioPrior, linearized_jacobians));
+  std::memcpy(out->linearized_jacobians, hp->linearized_jacobians, sizeof(double) * n * n);
+  std::memcpy(out->linearized_residuals, hp->linearized_residuals, sizeof(double) * n);
+}
+
+int download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior *prior) {
+  Fetched f;
+  int rc = fetch(c, slot, sol != nullptr, prior != nullptr, &f);
+  if (rc) return rc;
+  bool pass = false;
+  if (sol && (rc = check_solution(c, slot, f))) return rc;
+  if (prior && (rc = check_prior(c, slot, f, &pass))) return rc;
+  if (sol) unpack_solution(c, slot, f, sol);
+  if (prior) unpack_prior(c, slot, f, pass, prior);
+  return LFVIO_OK;
+}
+int download_solution(lfvio_ctx *c, int slot, LfvioSolution *out) { return download(c, slot, out, nullptr); }
+int download_prior(lfvio_ctx *c, int slot, LfvioPrior *out) { return download(c, slot, nullptr, out); }
 
 }  // namespace
 
@@ -965,10 +1022,7 @@ int lfvio_batch_optimize(lfvio_ctx *c, int count, int marg_flag) {
 int lfvio_batch_download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior *prior) {
   if (!c || slot < 0 || slot >= c->batch) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
-  int rc = LFVIO_OK;
-  if (sol && (rc = download_solution(c, slot, sol))) return rc;
-  if (prior && (rc = download_prior(c, slot, prior))) return rc;
-  return rc;
+  return download(c, slot, sol, prior);
 }
 
 // ---- the landmark-parallel steps either side of optimization()

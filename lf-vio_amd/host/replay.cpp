@@ -1,8 +1,10 @@
 // replay.cpp — see replay.h.  Reference lines are relative to /root/reference/vins_estimator/src.
 #include "replay.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <numeric>
 
 namespace lfvio {
 
@@ -31,7 +33,7 @@ bool Trace::load(const char *path) {
     }
     const double *d = (const double *)buf.data();
     if (head[0] == 1 && head[1] == 7 * sizeof(double)) {
-      imu.push_back({d[0], Vector3d(d[1], d[2], d[3]), Vector3d(d[4], d[5], d[6])});
+      imu.push_back({d[0], {d[1], d[2], d[3]}, {d[4], d[5], d[6]}});
     } else if (head[0] == 2 && head[1] >= 12) {
       uint32_t n;
       std::memcpy(&n, buf.data() + 8, 4);
@@ -46,21 +48,18 @@ bool Trace::load(const char *path) {
       std::memcpy(m.v.data(), buf.data() + 12, (size_t)n * 36);
       images.push_back(std::move(m));
     } else if (head[0] == 3 && head[1] == (11 * 21 + 3 + 13) * sizeof(double)) {
-      const int W = WINDOW_SIZE + 1;
+      const int W = FRAMES;
       const double *Ps = d, *Rs = Ps + 3 * W, *Vs = Rs + 9 * W, *Bas = Vs + 3 * W, *Bgs = Bas + 3 * W, *gg = Bgs + 3 * W, *t = gg + 3, *r = t + 3;
       for (int i = 0; i < W; i++) {
-        bootstrap.Ps[i] = Vector3d(Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2]);
-        bootstrap.Vs[i] = Vector3d(Vs[3 * i], Vs[3 * i + 1], Vs[3 * i + 2]);
-        bootstrap.Bas[i] = Vector3d(Bas[3 * i], Bas[3 * i + 1], Bas[3 * i + 2]);
-        bootstrap.Bgs[i] = Vector3d(Bgs[3 * i], Bgs[3 * i + 1], Bgs[3 * i + 2]);
+        Keyframe &k = bootstrap.kf[i];
+        k.P = Vector3d(Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2]), k.V = Vector3d(Vs[3 * i], Vs[3 * i + 1], Vs[3 * i + 2]);
+        k.Ba = Vector3d(Bas[3 * i], Bas[3 * i + 1], Bas[3 * i + 2]), k.Bg = Vector3d(Bgs[3 * i], Bgs[3 * i + 1], Bgs[3 * i + 2]);
         for (int a = 0; a < 3; a++)
-          for (int b = 0; b < 3; b++) bootstrap.Rs[i](a, b) = Rs[9 * i + 3 * a + b];
+          for (int b = 0; b < 3; b++) k.R(a, b) = Rs[9 * i + 3 * a + b];
       }
       bootstrap.g = Vector3d(gg[0], gg[1], gg[2]);
       bootstrap.valid = true;
-      tic = Vector3d(t[0], t[1], t[2]);
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) ric(a, b) = r[3 * a + b];
+      std::memcpy(tic, t, sizeof tic), std::memcpy(ric, r, sizeof ric);
       td = r[9];
       has_bootstrap = true;
     }
@@ -69,23 +68,24 @@ bool Trace::load(const char *path) {
   return true;
 }
 
-ImageMap decodeFeatures(const TraceImage &msg) {  // estimator_node.cpp:292-312
-  ImageMap image;
-  for (size_t i = 0; i < msg.size(); i++) {
-    const float *p = &msg.v[9 * i];
-    int v = p[3] + 0.5;
-    int feature_id = v / NUM_OF_CAM;
-    int camera_id = v % NUM_OF_CAM;
-    Vector8d xyz_uv_velocity;
-    xyz_uv_velocity.a[0] = p[0], xyz_uv_velocity.a[1] = p[1], xyz_uv_velocity.a[2] = p[2];  // x y z
-    xyz_uv_velocity.a[3] = p[4], xyz_uv_velocity.a[4] = p[5];                               // p_u p_v
-    xyz_uv_velocity.a[5] = p[6], xyz_uv_velocity.a[6] = p[7], xyz_uv_velocity.a[7] = p[8];  // velocity x y z
-    image[feature_id].emplace_back(camera_id, xyz_uv_velocity);
+void decodeFeatures(const TraceImage &msg, DecodedImage *out) {  // estimator_node.cpp:292-312
+  const size_t n = msg.size();
+  std::vector<int> key(n), idx(n);
+  for (size_t i = 0; i < n; i++) key[i] = (int)(msg.v[9 * i + 3] + 0.5);  // id * NUM_OF_CAM + cam, one camera
+  std::iota(idx.begin(), idx.end(), 0);
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
+  out->ids.clear(), out->pts.clear();
+  for (size_t k = 0; k < n; k++) {
+    const int i = idx[k];
+    if (k > 0 && key[idx[k - 1]] == key[i]) continue;
+    const float *p = &msg.v[9 * (size_t)i];
+    out->ids.push_back(key[i]);
+    const double v[8] = {p[0], p[1], p[2], p[4], p[5], p[6], p[7], p[8]};  // x y z | u v | velocity
+    out->pts.insert(out->pts.end(), v, v + 8);
   }
-  return image;
 }
 
-int replay(Estimator &estimator, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats) {
+int replay(WindowEstimator &est, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats) {
   ReplayStats st;
   std::memset(&st, 0, sizeof st);
   FILE *traj = nullptr;
@@ -93,81 +93,74 @@ int replay(Estimator &estimator, const Trace &trace, const char *traj_path, int 
     traj = std::fopen(traj_path, "w");
     if (!traj) return -1;
   }
+  auto finish = [&](int rc) {
+    if (traj) std::fclose(traj);
+    if (stats) *stats = st;
+    return rc;
+  };
   if (trace.has_bootstrap) {
-    estimator.bootstrap = trace.bootstrap;
-    estimator.tic[0] = trace.tic, estimator.ric[0] = trace.ric;
-    estimator.td = trace.td;
+    // the recording's extrinsic is the CONFIGURED one: a reset after a divergence restores it (setParameter(), estimator.cpp:10-21)
+    std::memcpy(config().tic, trace.tic, sizeof trace.tic), std::memcpy(config().ric, trace.ric, sizeof trace.ric);
+    config().td = trace.td;
+    est.bootstrap = trace.bootstrap;
+    for (int k = 0; k < 3; k++) est.tic(k) = trace.tic[k];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) est.ric(i, j) = trace.ric[3 * i + j];
+    est.td = trace.td;
   }
   const std::vector<TraceImu> &imu = trace.imu;
-  size_t front = 0;  // imu_buf.front()
-  double current_time = -1;
-  double dx = 0, dy = 0, dz = 0, rx = 0, ry = 0, rz = 0;
-  for (const TraceImage &img_msg : trace.images) {
+  size_t front = 0;         // head of the IMU queue
+  double clock = -1;        // time of the last sample handed over
+  double a[3] = {0, 0, 0}, w[3] = {0, 0, 0};
+  DecodedImage img;
+  for (const TraceImage &msg : trace.images) {
     if (max_images > 0 && st.images >= max_images) break;
-    // getMeasurements(), :96-134
-    if (front >= imu.size()) break;
-    if (!(imu.back().t > img_msg.t + estimator.td)) break;  // "wait for imu": nothing more will arrive in a recording
-    if (!(imu[front].t < img_msg.t + estimator.td)) {       // "throw img, only should happen at the beginning"
+    // getMeasurements(), estimator_node.cpp:96-134, against the CURRENT time-offset estimate
+    const double img_t = msg.t + est.td;
+    if (front >= imu.size() || !(imu.back().t > img_t)) break;  // "wait for imu": nothing more arrives in a recording
+    if (!(imu[front].t < img_t)) {                              // "throw img, only should happen at the beginning"
       st.thrown++;
       continue;
     }
-    size_t first = front;
-    while (imu[front].t < img_msg.t + estimator.td) front++;
-    // IMUs = [first, front] — imu_buf.front() is appended without being popped (:127) and comes again with the next image
-    // process(), :218-262
-    for (size_t k = first; k <= front; k++) {
-      const TraceImu &imu_msg = imu[k];
-      double t = imu_msg.t;
-      double img_t = img_msg.t + estimator.td;
-      if (t <= img_t) {
-        if (current_time < 0) current_time = t;
-        double dt = t - current_time;
-        current_time = t;
-        dx = imu_msg.acc.x(), dy = imu_msg.acc.y(), dz = imu_msg.acc.z();
-        rx = imu_msg.gyr.x(), ry = imu_msg.gyr.y(), rz = imu_msg.gyr.z();
-        estimator.processIMU(dt, Vector3d(dx, dy, dz), Vector3d(rx, ry, rz));
-      } else {
-        double dt_1 = img_t - current_time;
-        double dt_2 = t - img_t;
-        current_time = img_t;
-        double w1 = dt_2 / (dt_1 + dt_2);
-        double w2 = dt_1 / (dt_1 + dt_2);
-        dx = w1 * dx + w2 * imu_msg.acc.x();
-        dy = w1 * dy + w2 * imu_msg.acc.y();
-        dz = w1 * dz + w2 * imu_msg.acc.z();
-        rx = w1 * rx + w2 * imu_msg.gyr.x();
-        ry = w1 * ry + w2 * imu_msg.gyr.y();
-        rz = w1 * rz + w2 * imu_msg.gyr.z();
-        estimator.processIMU(dt_1, Vector3d(dx, dy, dz), Vector3d(rx, ry, rz));
+    const size_t first = front;
+    while (imu[front].t < img_t) front++;
+    // samples [first, front]: the first one after the image is used (interpolated) and stays queued for the next image (:127)
+    for (size_t k = first; k <= front; k++) {  // process(), :218-262
+      const TraceImu &m = imu[k];
+      if (m.t <= img_t) {
+        if (clock < 0) clock = m.t;
+        const double dt = m.t - clock;
+        clock = m.t;
+        std::memcpy(a, m.acc, sizeof a), std::memcpy(w, m.gyr, sizeof w);
+        est.pushImu(dt, a, w);
+      } else {  // linear interpolation of the IMU at image time
+        const double dt_1 = img_t - clock, dt_2 = m.t - img_t;
+        clock = img_t;
+        const double w1 = dt_2 / (dt_1 + dt_2), w2 = dt_1 / (dt_1 + dt_2);
+        for (int d = 0; d < 3; d++) a[d] = w1 * a[d] + w2 * m.acc[d], w[d] = w1 * w[d] + w2 * m.gyr[d];
+        est.pushImu(dt_1, a, w);
       }
     }
-    ImageMap image = decodeFeatures(img_msg);
-    const bool was_nonlinear = estimator.solver_flag == Estimator::NON_LINEAR;
-    estimator.last_status = LFVIO_OK;
-    estimator.processImage(image, img_msg.t);
+    decodeFeatures(msg, &img);
+    const bool was_running = est.phase == WindowEstimator::NON_LINEAR;
+    est.status = LFVIO_OK;
+    est.pushImage(msg.t, (int)img.ids.size(), img.ids.data(), img.pts.data());
     st.images++;
-    if (estimator.last_status != LFVIO_OK || estimator.f_manager.last_status != LFVIO_OK) {
-      st.last_status = estimator.last_status != LFVIO_OK ? estimator.last_status : estimator.f_manager.last_status;
-      if (traj) std::fclose(traj);
-      if (stats) *stats = st;
-      return -2;  // the device call failed: no silent continuation
+    if (est.status != LFVIO_OK) {
+      st.last_status = est.status;
+      return finish(-2);  // a device call failed: no silent continuation
     }
-    if (was_nonlinear && estimator.solver_flag == Estimator::INITIAL) st.failures++;  // failureDetection() -> clearState()
-    if (estimator.solver_flag == Estimator::NON_LINEAR) {
-      (estimator.marginalization_flag == Estimator::MARGIN_OLD ? st.keyframes : st.non_keyframes)++;
-      st.iterations += estimator.last_summary.num_iterations;
-      // pubOdometry(), utility/visualization.cpp:114-179: fixed, precision 12, "stamp x y z qx qy qz qw"
-      Quaterniond tmp_Q = Quaterniond(estimator.Rs[WINDOW_SIZE]);
-      const Vector3d &P = estimator.Ps[WINDOW_SIZE];
-      if (traj)
-        std::fprintf(traj, "%.12f %.12f %.12f %.12f %.12f %.12f %.12f %.12f\n", img_msg.t, P.x(), P.y(), P.z(), tmp_Q.x(), tmp_Q.y(), tmp_Q.z(),
-                     tmp_Q.w());
-      st.poses++;
-    }
+    if (was_running && est.phase == WindowEstimator::INITIAL) st.failures++;  // diverged -> reset
+    if (est.phase != WindowEstimator::NON_LINEAR) continue;
+    (est.marg_flag == LFVIO_MARGIN_OLD ? st.keyframes : st.non_keyframes)++;
+    st.iterations += est.summary.num_iterations;
+    // pubOdometry(), utility/visualization.cpp:114-179: fixed, precision 12, "stamp x y z qx qy qz qw"
+    const Keyframe &f = est.kf(WINDOW_SIZE);
+    const Quaterniond q(f.R);
+    if (traj) std::fprintf(traj, "%.12f %.12f %.12f %.12f %.12f %.12f %.12f %.12f\n", msg.t, f.P.x(), f.P.y(), f.P.z(), q.x(), q.y(), q.z(), q.w());
+    st.poses++;
   }
-  if (traj) std::fclose(traj);
-  if (stats) *stats = st;
-  return 0;
+  return finish(0);
 }
 
 }  // namespace lfvio

@@ -1,4 +1,4 @@
-// replay.h — ROS-free recording of what estimator_node.cpp consumes, and the loop that feeds it to the Estimator
+// replay.h — ROS-free recording of what estimator_node.cpp consumes, and the loop that feeds it to the WindowEstimator
 // (SURVEY §8f rank 1).  A trace is the two topics of the node in arrival order plus what stands in for initialStructure():
 //
 //   file   = "LFVT" u32 version(1)  { u32 type, u32 bytes, payload[bytes] }*          (little-endian, packed)
@@ -17,13 +17,13 @@
 #include <string>
 #include <vector>
 
-#include "estimator.h"
+#include "window_estimator.h"
 
 namespace lfvio {
 
 struct TraceImu {
   double t;
-  Vector3d acc, gyr;
+  double acc[3], gyr[3];
 };
 struct TraceImage {
   double t;
@@ -34,9 +34,8 @@ struct Trace {
   std::vector<TraceImu> imu;
   std::vector<TraceImage> images;
   bool has_bootstrap = false;
-  Estimator::Bootstrap bootstrap;
-  Vector3d tic;
-  Matrix3d ric;
+  WindowEstimator::Bootstrap bootstrap;
+  double tic[3] = {0, 0, 0}, ric[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double td = 0;
   std::string error;
   bool load(const char *path);
@@ -46,12 +45,17 @@ struct ReplayStats {
   int images, thrown, keyframes, non_keyframes, poses, failures, last_status, iterations;
 };
 
-// feature message -> the map processImage() takes (estimator_node.cpp:292-312)
-ImageMap decodeFeatures(const TraceImage &msg);
+// feature message -> what WindowEstimator::pushImage() takes (estimator_node.cpp:292-312): feature ids ascending (the
+// reference keys a std::map by id), one 8-vector x y z u v vx vy vz per id (camera 0's, the first entry of an id)
+struct DecodedImage {
+  std::vector<int> ids;
+  std::vector<double> pts;  // n x 8
+};
+void decodeFeatures(const TraceImage &msg, DecodedImage *out);
 
 // getMeasurements() + process() of estimator_node.cpp (:96-134, :206-342) over a loaded trace, single-threaded;
 // after every image in NON_LINEAR state one line of the trajectory file as pubOdometry() writes it
 // (utility/visualization.cpp:173-179).  Returns 0 or a negative error; `stats` may be null.
-int replay(Estimator &estimator, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats);
+int replay(WindowEstimator &estimator, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats);
 
 }  // namespace lfvio

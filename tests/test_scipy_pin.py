@@ -70,7 +70,7 @@ def check_objective(w, linearize, seed):
     st = nr.St(w)
     f0 = robust_residuals(w, st)
     cost = 0.5 * float(f0 @ f0)
-    assert abs(cost - lin["cost"]) <= 1e-12 * cost
+    assert abs(cost - lin["cost"]) <= 1e-11 * cost  # summation order (device: per-block partials)
     free = nr.active_mask(w)
     free[nr.OFF_TD] = False
     D = np.zeros((nr.KP + w.N, 16))
