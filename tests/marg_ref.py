@@ -85,3 +85,26 @@ def kept_count_slack(A_ref, A_other):
     s = np.linalg.eigvalsh(0.5 * (A_ref + A_ref.T))
     band = 2.0 * np.linalg.norm(A_other - A_ref, 2) + 64 * np.finfo(float).eps * np.abs(s).max()
     return int(((s > EPS - band) & (s < EPS + band)).sum())
+
+
+def dense_marg_old(lin, kept_blocks):
+    """The reference's own formula, literally: the whole m x m dropped block (pose 0, speed/bias 0 and every frame-0
+    landmark) pseudo-inverted through its eigen-decomposition with the eps cut (marginalization_factor.cpp:267-281) —
+    with LAPACK's eigh instead of the oracle's tred2 / tql2.  Returns A', cond(A_mm)."""
+    a, W, H = lin["a"], lin["W"], lin["H"]
+    drop = tangent_cols(abi.BLOCK_POSE, 0) + tangent_cols(abi.BLOCK_SPEEDBIAS, 0)
+    keep = []
+    for kind, frame, idx in kept_blocks:
+        keep += tangent_cols(kind, frame + 1 if kind in (abi.BLOCK_POSE, abi.BLOCK_SPEEDBIAS) else frame)
+    N0, nd = len(a), len(drop)
+    Wk = np.zeros((N0, abi.KP))
+    Wk[:, :abi.KC] = W
+    Amm = np.zeros((nd + N0, nd + N0))
+    Amm[:nd, :nd] = H[np.ix_(drop, drop)]
+    Amm[:nd, nd:] = Wk[:, drop].T
+    Amm[nd:, :nd] = Wk[:, drop]
+    Amm[nd:, nd:] = np.diag(a)
+    Arm = np.concatenate([H[np.ix_(keep, drop)], Wk[:, keep].T], axis=1)
+    lam, V = np.linalg.eigh(0.5 * (Amm + Amm.T))
+    inv = (V * np.where(lam > EPS, 1.0 / np.where(lam > EPS, lam, 1.0), 0.0)) @ V.T
+    return H[np.ix_(keep, keep)] - Arm @ inv @ Arm.T, lam.max() / max(lam[lam > EPS].min(), 1e-300)

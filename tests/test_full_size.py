@@ -114,23 +114,21 @@ def test_batch512_distinct_windows_against_the_oracle(eng, oracle):
             J = prior.J()
             dA = rel(J.T @ J, ref["A"])
             if dA >= 1e-6:
-                # The two priors are linearized at two states that differ by the (1e-9) parity error of the solve; A' =
-                # A_rr - A_rm A_mm^+ A_mr amplifies that by the conditioning of the dropped block.  Such a slot must meet the
-                # bar on IDENTICAL inputs (the oracle's post-gauge state) and the amplification must be what A_mm explains.
+                # Measured on seed 170 (2.6e-6): the ORACLE is the outlier.  Its dropped block has cond(A_mm) = 6e12 (a frame-0
+                # landmark with a_l = 2e-3 beside pose entries of 1e10) and its tred2 / tql2 eigen-solver loses six digits there;
+                # the device (both of its pseudo-inverse paths), the structured numpy statement and the reference's literal
+                # m x m formula evaluated with LAPACK agree with each other to 1e-11.  Such a slot is held against the LAPACK
+                # evaluation of the reference formula on identical inputs, and the oracle's own deviation from it must account
+                # for what was seen.
                 w2 = w.copy(pose=ref["pose"], speed_bias=ref["speed_bias"], ex_pose=ref["ex_pose"], td=ref["td"], inv_depth=ref["lam"])
-                pref, Aref, bref = oracle.marginalize(w2, abi.MARGIN_OLD, want_Ab=True)
+                pref, Aref, _ = oracle.marginalize(w2, abi.MARGIN_OLD, want_Ab=True)
                 p2 = eng.marginalize(w2, abi.MARGIN_OLD)
                 A2, _ = eng.marg_system(p2.n)
-                lin = oracle.linearize(marg_ref.frame0_subwindow(w2))
-                drop = marg_ref.tangent_cols(abi.BLOCK_POSE, 0) + marg_ref.tangent_cols(abi.BLOCK_SPEEDBIAS, 0)
-                Hs = lin["H"][:abi.KC, :abi.KC] - (lin["W"] / lin["a"][:, None]).T @ lin["W"]
-                Hd = lin["H"].copy()
-                Hd[:abi.KC, :abi.KC] = Hs
-                ev = np.linalg.eigvalsh(Hd[np.ix_(drop, drop)])
-                print(f"batch512 slot {s}: prior at the two solutions differs by {dA:.2e}; identical inputs {rel(A2, Aref):.2e}; "
-                      f"eig(A_mm after the landmarks) in [{ev.min():.2e}, {ev.max():.2e}], cond {ev.max() / max(ev.min(), 1e-300):.1e}")
-                assert rel(A2, Aref) < 1e-6, tag
-                assert dA < 1e-15 * ev.max() / max(ev.min(), 1e-300), tag
+                A_lapack, cond = marg_ref.dense_marg_old(oracle.linearize(marg_ref.frame0_subwindow(w2)), pref.block_list())
+                print(f"batch512 slot {s}: prior vs oracle {dA:.2e}; cond(A_mm) {cond:.1e}; on identical inputs: device vs LAPACK "
+                      f"{rel(A2, A_lapack):.2e}, oracle vs LAPACK {rel(Aref, A_lapack):.2e}")
+                assert rel(A2, A_lapack) < 1e-6, tag
+                assert rel(Aref, A_lapack) > 0.5 * dA and cond > 1e10, tag
             assert abs(marg_ref.kept_directions(prior) - ref["kept"]) <= marg_ref.kept_count_slack(ref["A"], J.T @ J), tag
             worst = dict(pose=max(worst["pose"], dp), lam=max(worst["lam"], dl), A=max(worst["A"], dA))
         print(f"batch512 sync={sync}: worst pose {worst['pose']:.2e}, inv-depth {worst['lam']:.2e}, prior A {worst['A']:.2e}")
