@@ -122,8 +122,12 @@ def test_batch512_distinct_windows_against_the_oracle(eng, oracle):
                 # for what was seen.
                 w2 = w.copy(pose=ref["pose"], speed_bias=ref["speed_bias"], ex_pose=ref["ex_pose"], td=ref["td"], inv_depth=ref["lam"])
                 pref, Aref, _ = oracle.marginalize(w2, abi.MARGIN_OLD, want_Ab=True)
-                p2 = eng.marginalize(w2, abi.MARGIN_OLD)
-                A2, _ = eng.marg_system(p2.n)
+                from lfvio.engine import Engine
+
+                side = Engine(0)  # its own context: lfvio_marginalize uploads into slot 0, which the batch still needs
+                p2 = side.marginalize(w2, abi.MARGIN_OLD)
+                A2, _ = side.marg_system(p2.n)
+                side.close()
                 A_lapack, cond = marg_ref.dense_marg_old(oracle.linearize(marg_ref.frame0_subwindow(w2)), pref.block_list())
                 print(f"batch512 slot {s}: prior vs oracle {dA:.2e}; cond(A_mm) {cond:.1e}; on identical inputs: device vs LAPACK "
                       f"{rel(A2, A_lapack):.2e}, oracle vs LAPACK {rel(Aref, A_lapack):.2e}")
