@@ -92,7 +92,10 @@ enum {
 // (radius / 2 each time), so one pass can evaluate the step for radius, radius / 2, radius / 4 and k_decide walks through
 // them in Ceres' order.  Candidate 0 lives in x[cur ^ 1] / tab[cur ^ 1] / lam[cur ^ 1] as always, candidates 1, 2 in
 // the *E slots and are copied over when one of them is the accepted step.
-constexpr int SPEC_EXTRA = 2, SPEC_MAX_LM = 320;
+#ifndef LFVIO_SPEC_EXTRA
+#define LFVIO_SPEC_EXTRA 2
+#endif
+constexpr int SPEC_EXTRA = LFVIO_SPEC_EXTRA, SPEC_MAX_LM = 320;
 #define TR_HEAD_FIELDS \
   double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha; \
   double cg, cn; \
