@@ -36,6 +36,32 @@ DEV double readlane_f64(double v, int src) {  // src wave-uniform
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 typedef double solve_d4 __attribute__((ext_vector_type(4)));
+// every lane <- the lane with the same row (lane & 15) in quarter T (lanes 16 T .. 16 T + 15): two gfx950 lane swaps per dword
+template <int T>
+DEV int quarter_bcast32(int v) {
+  auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // [q0 q0 q2 q2] | [q1 q1 q3 q3]
+  const int w = (T & 1) ? r[1] : r[0];
+  auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);  // [lo lo] | [hi hi]
+  return (T & 2) ? q[1] : q[0];
+}
+DEV double quarter_bcast(double x, int t) {  // t: compile-time after unrolling
+  const int hi = __double2hiint(x), lo = __double2loint(x);
+  switch (t) {
+    case 0: return __hiloint2double(quarter_bcast32<0>(hi), quarter_bcast32<0>(lo));
+    case 1: return __hiloint2double(quarter_bcast32<1>(hi), quarter_bcast32<1>(lo));
+    case 2: return __hiloint2double(quarter_bcast32<2>(hi), quarter_bcast32<2>(lo));
+    default: return __hiloint2double(quarter_bcast32<3>(hi), quarter_bcast32<3>(lo));
+  }
+}
+DEV double row_bcast_k(double v, int k) {  // k: compile-time after unrolling
+  switch (k) {
+#define LFVIO_RB(K) case K: return row_bcast<K>(v);
+    LFVIO_RB(0) LFVIO_RB(1) LFVIO_RB(2) LFVIO_RB(3) LFVIO_RB(4) LFVIO_RB(5) LFVIO_RB(6) LFVIO_RB(7) LFVIO_RB(8) LFVIO_RB(9) LFVIO_RB(10)
+    LFVIO_RB(11) LFVIO_RB(12) LFVIO_RB(13) LFVIO_RB(14)
+#undef LFVIO_RB
+    default: return row_bcast<15>(v);
+  }
+}
 
 #define STAMP(S, k) do { if (threadIdx.x == 0) (S)->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -249,36 +275,62 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   // The rhs row rides along as row 12 of block row 10 (never a pivot), which is the forward substitution.
   bool bad = !(mu < 1.0);  // ComputeGaussNewtonStep: `while (mu_ < max_mu_)` — no attempt at mu >= 1
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave in an SGPR: scalar loop control below
-  // F: factor diagonal tile kb in wave 0, one ROW per lane
+  // F: factor diagonal tile kb in wave 0.  Lane (row c, quarter g) owns columns g, g + 4, g + 8, g + 12 of its row of the FULL
+  // symmetric tile (a[i] = A[c][g + 4 i]).  The four pivots of a panel are eliminated on the vector pipe inside the panel only
+  // (pivot by v_readlane, the pivot column for every quarter by v_permlane16/32_swap, the pivot row by DPP row_newbcast — all
+  // requested before the reciprocal they run beside); the columns behind the panel take the rank-4 update
+  // C -= P diag(1/d) P^T in ONE v_mfma_f64_16x16x4_f64 whose A, B and C operands are the registers as they stand: the
+  // accumulator layout D[g + 4 r][c] is the transpose of the ownership, and the tile is symmetric.  30 vector instructions
+  // per pivot instead of 47 (tools/micro/f_mfma.hip: 4 900 -> 3 700 cycles per tile); the raw columns are scaled by
+  // 1/sqrt(d_k) once at the end.
   auto factor = [&](int kb) {
     const int nb = kb < NTL - 1 ? 16 : KP - 16 * (NTL - 1);  // pivots in this block column (12 in the last)
     double *Td = Hs + tile_id(kb, kb) * TSZ;
-    const int row = lane & 15;
-    double a[16];
+    const int c = lane & 15, gq = lane >> 4;
+    solve_d4 a;
 #pragma unroll
-    for (int j = 0; j < 16; j++) a[j] = j <= row ? Td[tsw(row, j)] : 0.0;
-    double mydiag = 1.0;
+    for (int i = 0; i < 4; i++) {
+      const int col = gq + 4 * i;
+      a[i] = col <= c ? Td[tsw(c, col)] : Td[tsw(col, c)];
+    }
+    double dsave[4] = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (k < nb) {
-        const double d = readlane_f64(a[k], k);
-        if (!(d > 0.0)) bad = true;
-        if (row == k) mydiag = d;
-        const double f = row > k ? a[k] * fast_rcp(d) : 0.0;
+    for (int p = 0; p < 4; p++) {
+      double bop = 0.0;  // this lane's B operand: its panel column times 1/d of that column's pivot
 #pragma unroll
-        for (int j = k + 1; j < 16; j++) a[j] = fma(-f, readlane_f64(a[k], j), a[j]);
+      for (int t = 0; t < 4; t++) {
+        const int k = 4 * p + t;
+        if (k < nb) {  // wave-uniform
+          double colk = 0.0, u = 0.0;
+          if (t < 3) {
+            colk = quarter_bcast(a[p], t);
+            u = row_bcast_k(a[p], k);
+          }
+          const double d = readlane_f64(a[p], 16 * t + k);  // pivot: row k in quarter t
+          if (!(d > 0.0)) bad = true;
+          const double rc = fast_rcp(d);
+          if (gq == t) dsave[p] = d, bop = a[p] * rc;
+          if (t < 3) {
+            const double upd = fma(c > k ? -(colk * rc) : 0.0, u, a[p]);
+            if (gq > t) a[p] = upd;
+          }
+        }
+      }
+      if (p < 3 && 4 * p < nb) {
+        solve_d4 cv = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[p], bop, a, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (i > p) a[i] = cv[i];
       }
     }
-    const double myrs = fast_rsqrt(mydiag);
-    if (lane < 16) {
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const double rsj = readlane_f64(myrs, j);
-        double v = 0.0;
-        if (j < nb) v = j < row ? a[j] * rsj : (j == row ? mydiag * myrs : 0.0);
-        Td[tsw(row, j)] = v;
-      }
-      if (lane < nb) invd[16 * kb + lane] = myrs;
+    for (int i = 0; i < 4; i++) {
+      const int col = gq + 4 * i;
+      const double rs = fast_rsqrt(dsave[i]);
+      double v = 0.0;
+      if (col < nb) v = c > col ? a[i] * rs : (c == col ? dsave[i] * rs : 0.0);
+      Td[tsw(c, col)] = v;
+      if (c == col && col < nb) invd[16 * kb + col] = rs;
     }
   };
   // U: tiles [first, first + count) of the enumeration (ti, tj), kb < tj <= ti, every `step`-th; four tiles in flight
@@ -321,9 +373,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
         }
     }
   };
+#ifdef LFVIO_SOLVE_PROFILE
+#define PSTAMP(k, v) do { if (tid == 0) S->dbg[k] = (v); } while (0)
+#define PNOW() ((long long)__builtin_readcyclecounter())
+#else
+#define PSTAMP(k, v) do {} while (0)
+#define PNOW() 0ll
+#endif
   if (wave == 0) factor(0);
   __syncthreads();
+  long long pf = 0, pp = 0, pu = 0, pw = 0;
   for (int kb = 0; kb < NTL - 1; kb++) {
+    const long long c0 = PNOW();
     {  // P: the rows below solve x L_kk^T = a, one thread per row
       const int ta = kb + 1 + (tid >> 4), r = tid & 15;
       if (ta < NTL) {
@@ -342,18 +403,37 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
         for (int j = 0; j < 16; j++) Tp[tsw(r, j)] = x[j];
       }
     }
+    const long long c1 = PNOW();
     __syncthreads();
+    const long long c2 = PNOW();
     {  // U with look-ahead: wave 0 updates the next diagonal tile first and factors it while waves 1..3 update the rest
+      // Wave 0 is on the critical path (next diagonal tile, then its factorization: worth about seven tile updates); in the
+      // first block columns the other three would still be updating long after it is done, so it takes the tail of the
+      // tile list once the factor is out: n0 = (n - 21) / 4 balances 7 + n0 against (n - n0) / 3.
       const int m = NTL - 1 - kb, ntiles = m * (m + 1) / 2;
+      const int n0 = ntiles - 1 > 21 ? (ntiles - 1 - 21) / 4 : 0, split = ntiles - n0;
       if (wave == 0) {
         update(kb, 0, 1, 1);
+        const long long c3 = PNOW();
         factor(kb + 1);
+        const long long c4 = PNOW();
+        pu += c3 - c2, pf += c4 - c3;
+        PSTAMP(8 + kb, c4 - c3);
+        if (n0 > 0) update(kb, split, 1, ntiles);
       } else {
-        update(kb, wave, 3, ntiles);
+        update(kb, wave, 3, split);
       }
     }
+    const long long c5 = PNOW();
     __syncthreads();
+    const long long c6 = PNOW();
+    pp += c1 - c0, pw += (c2 - c1) + (c6 - c5);
+    PSTAMP(19 + kb, c6 - c5);
   }
+  PSTAMP(29, pf);
+  PSTAMP(30, pp);
+  PSTAMP(31, pu);
+  PSTAMP(18, pw);
   STAMP(S, 4);
   {
     double f = bad ? 1.0 : 0.0;
