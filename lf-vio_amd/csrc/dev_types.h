@@ -17,7 +17,9 @@
 
 constexpr int KC = 73;     // camera-side tangent dim: 11 poses * 6 + ex 6 + td 1
 constexpr int KP = 172;    // + 11 speed/bias * 9
-constexpr int WLD = 80;    // leading dimension of W rows (5 MFMA column tiles of 16)
+constexpr int WLD = 80;    // width of a W row in the LDS tile (5 MFMA column tiles of 16); in HBM a row is stored over its
+                           // non-zero span: [6 cnt entries of frames start .. start + cnt - 1 | ex 6 | td | b_l | b_l kappa_l]
+__host__ __device__ inline int w_row_len(int cnt) { return 6 * cnt + 9; }
 constexpr int COL_B = 73;  // W pad column holding b_l
 constexpr int COL_K = 74;  // W pad column holding b_l * kappa_l (Cauchy-point cross term)
 constexpr int NQ = 105;    // 14x14 upper triangle (basis Gram)
@@ -158,6 +160,7 @@ struct Slot {
   int tail_state, passes_used;  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
+  int lbw, lbw_pad_;             // landmark blocks per workgroup of k_lin's landmark role (their Schur SYRK stays in registers)
   double g[3], tr_over_row, half_row, sqrt_info;
   FrameState x0;
   LfvioPreintegration imu[LFVIO_WINDOW_SIZE];
@@ -170,6 +173,7 @@ struct Slot {
   MargPlan marg[2];              // [MARGIN_OLD, MARGIN_SECOND_NEW]
   // ---------------- input arrays (device pointers into the blob)
   GP<int> lm_start, lm_cnt, lm_obs0, lm_perm;
+  GP<int> lm_woff;                 // [N + 1] offset of landmark l's row in W: rows are stored over their non-zero span only
   GP<double> lam0;
   GP<double> obs[8];                // px py pz vx vy vz cur_td uv_y, each [M]
   GP<int> pm_obs, pm_lm;           // [NV] pair-major: observation index, landmark index

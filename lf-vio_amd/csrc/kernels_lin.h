@@ -205,52 +205,59 @@ DEV d3 quad_sum3(d3 v) { return mk3(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z))
 // (cols 73/74 carry b_l and the Cauchy cross-term column) on the FP64 matrix pipe.  Wave w owns tiles w, w+4, w+8,
 // w+12; four landmarks per MFMA: lane (k, c) feeds A[i = c][k] = c_l w_l[16 t + c], B[k][j = c] = w_l[16 u + c]; the
 // accumulator holds D[row = (lane >> 4) + 4 reg][col = lane & 15].
-DEV void schur_block(Slot *S, int blk, int mode, int Nlim, double (*tile)[WLD + 1], const double *lcoef, const double *le) {
+DEV void schur_block(int blk, int mode, int Nlim, double (*tile)[WLD + 1], const double *lcoef, const double *le, double *part) {
   const int tid = threadIdx.x;
-  {
-    const int wv = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
-    double4_t acc[4];
-    int ct[4], cu[4];
+  const int wv = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
+  double4_t acc[4];
+  int ct[4], cu[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    acc[j] = double4_t{0, 0, 0, 0};
+    const int ti = wv + 4 * j;  // upper tile index: (0,0..4) (1,1..4) (2,2..4) (3,3..4) (4,4)
+    const int t = ti < 5 ? 0 : ti < 9 ? 1 : ti < 12 ? 2 : ti < 14 ? 3 : 4;
+    const int u = ti - (t * 5 - (t * (t - 1)) / 2) + t;
+    ct[j] = 16 * t + cc, cu[j] = 16 * u + cc;
+  }
+  int rows = Nlim - blk * LM_BLOCK;
+  rows = rows > LM_BLOCK ? LM_BLOCK : rows;
+  for (int s4 = 0; 4 * s4 < rows; s4++) {
+    const int row = 4 * s4 + kk;
+    const double coef = lcoef[row], eb = le[row];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      acc[j] = double4_t{0, 0, 0, 0};
-      const int ti = wv + 4 * j;  // upper tile index: (0,0..4) (1,1..4) (2,2..4) (3,3..4) (4,4)
-      const int t = ti < 5 ? 0 : ti < 9 ? 1 : ti < 12 ? 2 : ti < 14 ? 3 : 4;
-      const int u = ti - (t * 5 - (t * (t - 1)) / 2) + t;
-      ct[j] = 16 * t + cc, cu[j] = 16 * u + cc;
-    }
-    int rows = Nlim - blk * LM_BLOCK;
-    rows = rows > LM_BLOCK ? LM_BLOCK : rows;
-    for (int s4 = 0; 4 * s4 < rows; s4++) {
-      const int row = 4 * s4 + kk;
-      const double coef = lcoef[row], eb = le[row];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (wv + 4 * j >= NT) continue;  // wave-uniform
-        const double xa = tile[row][ct[j]];
-        double xb = tile[row][cu[j]];
-        if (mode == MODE_SOLVE && cu[j] == COL_K) xb *= eb;  // b/D2 * e  -> z2 column
-        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(coef * xa, xb, acc[j], 0, 0, 0);
-      }
-    }
-    double *out = S->schur_part + (size_t)blk * SCHUR_LEN;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (wv + 4 * j >= NT) continue;
-#pragma unroll
-      for (int r = 0; r < 4; r++) out[(wv + 4 * j) * 256 + r * 64 + lane] = acc[j][r];
+      if (wv + 4 * j >= NT) continue;  // wave-uniform
+      const double xa = tile[row][ct[j]];
+      double xb = tile[row][cu[j]];
+      if (mode == MODE_SOLVE && cu[j] == COL_K) xb *= eb;  // b/D2 * e  -> z2 column
+      acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(coef * xa, xb, acc[j], 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (wv + 4 * j >= NT) continue;
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[(wv + 4 * j) * 256 + r * 64 + lane] = acc[j][r];
+  }
 }
+// tangent column of entry ci of a stored W row (see w_row_len)
+DEV int w_col(int ci, int start, int cnt) { return ci < 6 * cnt ? 6 * start + ci : 66 + (ci - 6 * cnt); }
 
 // A solve repeated with a new mu on an unchanged linearization (do_schur without do_lin): only the Schur weights
 // change.  The block's W rows come back from HBM into the tile and the SYRK is redone.
-DEV void lin_schur_only_role(Slot *S, int blk, double *lds) {
+DEV void lin_schur_only_role(Slot *S, int blk, double *lds, double *part) {
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *lcoef = lds + LM_BLOCK * (WLD + 1) + 64, *le = lcoef + LM_BLOCK;
   const int tid = threadIdx.x;
-  const double *Wb = S->W + (size_t)blk * LM_BLOCK * WLD;
-  for (int e = tid; e < LM_BLOCK * WLD; e += LIN_THREADS) tile[e / WLD][e % WLD] = Wb[e];
+  for (int e = tid; e < LM_BLOCK * (WLD + 1); e += LIN_THREADS) lds[e] = 0.0;
+  __syncthreads();
+  {  // the stored rows back into the 80-wide tile: 4 lanes per landmark
+    const int lml = tid >> 2, q = tid & 3, l = blk * LM_BLOCK + lml;
+    if (l < S->N) {
+      const int st = S->lm_start[l], cnt = S->lm_cnt[l];
+      const double *w = S->W + S->lm_woff[l];
+      for (int ci = q; ci < w_row_len(cnt); ci += 4) tile[lml][w_col(ci, st, cnt)] = w[ci];
+    }
+  }
   if (tid < LM_BLOCK) {
     const int l = blk * LM_BLOCK + tid;
     double cf = 0.0, eb = 0.0;
@@ -265,13 +272,13 @@ DEV void lin_schur_only_role(Slot *S, int blk, double *lds) {
     lcoef[tid] = cf, le[tid] = eb;
   }
   __syncthreads();
-  schur_block(S, blk, MODE_SOLVE, S->N, tile, lcoef, le);
+  schur_block(blk, MODE_SOLVE, S->N, tile, lcoef, le, part);
 }
 
 // Landmark role: 64 landmarks per workgroup, 4 lanes per landmark (lane q takes the observations 1+q, 5+q, 9+q of the
 // track), so the dependent chain per lane is a quarter of the track.  The 80-wide row w_l is built in an LDS tile and
 // leaves as whole 512-byte lines.
-DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
+DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds, double *part) {
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *red = lds + LM_BLOCK * (WLD + 1);
   double *lcoef = red + 64, *le = lcoef + LM_BLOCK;  // Schur weight c_l and e-block of the block's landmarks
@@ -290,10 +297,11 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
   __syncthreads();
   double a = 0, b = 0, cost = 0, lam = 1.0, wtd = 0;
   d3 wPi = mk3(0, 0, 0), wTi = wPi, wTic = wPi, wTx = wPi;
-  int i = 0;
+  int i = 0, cnt_l = 0, woff_l = 0;
   if (valid) {
     i = S->lm_start[l];
     const int k = S->lm_cnt[l], o0 = S->lm_obs0[l];
+    cnt_l = k, woff_l = S->lm_woff[l];
     lam = S->lam[cur][l];
     ObsPair ob;
     load_obs(S, o0, ob.pi, ob.vi, ob.tdi, ob.rowi);
@@ -391,9 +399,12 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds) {
     p[tid] = tid < 4 ? ((red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]))
                      : fmax(fmax(red[4], red[12]), fmax(red[20], red[28]));
   }
-  double *Wb = S->W + (size_t)blk * LM_BLOCK * WLD;
-  for (int e = tid; e < LM_BLOCK * WLD; e += LIN_THREADS) Wb[e] = tile[e / WLD][e % WLD];
-  schur_block(S, blk, mode, Nlim, tile, lcoef, le);
+  // the rows leave over their non-zero span only (the block's rows are one contiguous stretch of W: offsets are prefix sums)
+  if (valid) {
+    double *w = S->W + woff_l;
+    for (int ci = q; ci < w_row_len(cnt_l); ci += 4) w[ci] = tile[lml][w_col(ci, i, cnt_l)];
+  }
+  schur_block(blk, mode, Nlim, tile, lcoef, le, part);
 }
 
 // Gram role: one chunk (<= 64 observations of one frame pair) per WAVE, four chunks per workgroup; the waves never
@@ -597,7 +608,7 @@ DEV void lin_prior_role(Slot *S, int mode, double *lds) {
 
 // mode_bits: the mode, plus MODE_GATED for the marginalization sweep that rides behind the solve passes in the same graph
 // (see tail_gate)
-__global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode_bits, int gLm, int gCh) {
+__global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode_bits, int gLw, int gCh) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   const int mode = mode_bits & (MODE_GATED - 1);
@@ -612,17 +623,21 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t strid
     if (fl.done | (!do_lin & !do_schur)) return;
   }
   __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role
-  // the grid is sized for the largest resident window (gLm, gCh); each slot uses its own counts
+  // the grid is sized for the largest resident window (gLw, gCh); each slot uses its own counts
   int b = blockIdx.x;
-  if (b < gLm) {
-    if (b >= S->nLmBlocks) return;
-    if (is_marg(mode) && b * LM_BLOCK >= marg_plan(S, mode)->N0) return;
-    if (do_lin) lin_landmark_role(S, b, mode, lds);
-    else lin_schur_only_role(S, b, lds);
+  if (b < gLw) {
+    // One landmark block per workgroup, one Schur partial per block.  (Several blocks per workgroup with the partial summed in
+    // LDS was built and measured at 100 000 landmarks: k_presum + k_sum 33.5 -> 25.3 us, but the loop around the sweep — nothing
+    // is carried through it — costs it 50 spilled registers and the landmark role 64 -> 97 us.)
+    const int nblk = is_marg(mode) ? (marg_plan(S, mode)->N0 + LM_BLOCK - 1) / LM_BLOCK : S->nLmBlocks;
+    if (b >= nblk) return;
+    double *part = S->schur_part + (size_t)b * SCHUR_LEN;
+    if (do_lin) lin_landmark_role(S, b, mode, lds, part);
+    else lin_schur_only_role(S, b, lds, part);
     return;
   }
   if (!do_lin) return;
-  b -= gLm;
+  b -= gLw;
   if (b < gCh) {  // gCh workgroups of 4 chunks
     lin_gram_role(S, b, mode, lds);
     return;

@@ -641,17 +641,17 @@ __global__ __launch_bounds__(64) void k_backsub(char *base, size_t stride) {
   const int l = blockIdx.x * LM_BLOCK + lane;
   double gn2 = 0, ggn = 0;
   if (l < S->N) {
-    const double *w = S->W + (size_t)l * WLD;
-    const int lo = 6 * S->lm_start[l], hi = lo + 6 * S->lm_cnt[l];
+    const double *w = S->W + S->lm_woff[l];  // stored over its non-zero span: [frames of the track | ex | td | ..]
+    const int lo = 6 * S->lm_start[l], n6 = 6 * S->lm_cnt[l];
     double d1 = 0, d2 = 0;
-    for (int c = lo; c < hi; c++) {
+    for (int c = 0; c < n6; c++) {
       const double wc = w[c];
-      d1 = fma(wc, ug[c], d1);
-      d2 = fma(wc, un[c], d2);
+      d1 = fma(wc, ug[lo + c], d1);
+      d2 = fma(wc, un[lo + c], d2);
     }
 #pragma unroll
     for (int c = 66; c < KC; c++) {
-      const double wc = w[c];
+      const double wc = w[n6 + c - 66];
       d1 = fma(wc, ug[c], d1);
       d2 = fma(wc, un[c], d2);
     }
@@ -761,17 +761,17 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
     __syncthreads();
     const int l = tid;
     if (l < S->N) {
-      const double *w = S->W + (size_t)l * WLD;
-      const int lo = 6 * S->lm_start[l], hi = lo + 6 * S->lm_cnt[l];
+      const double *w = S->W + S->lm_woff[l];
+      const int lo = 6 * S->lm_start[l], n6 = 6 * S->lm_cnt[l];
       double d1 = 0, d2 = 0;
-      for (int c = lo; c < hi; c++) {
+      for (int c = 0; c < n6; c++) {
         const double wc = w[c];
-        d1 = fma(wc, ug[c], d1);
-        d2 = fma(wc, un[c], d2);
+        d1 = fma(wc, ug[lo + c], d1);
+        d2 = fma(wc, un[lo + c], d2);
       }
 #pragma unroll
       for (int c = 66; c < KC; c++) {
-        const double wc = w[c];
+        const double wc = w[n6 + c - 66];
         d1 = fma(wc, ug[c], d1);
         d2 = fma(wc, un[c], d2);
       }

@@ -36,7 +36,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   int maxN = 0, maxM = 0;
   int capLmBlocks = 0, capChunks = 0, capSchurParts = 0;
   size_t in_begin = 0, in_end = 0, total = 0;
-  size_t lm_start, lm_cnt, lm_obs0, lm_perm, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
+  size_t lm_start, lm_cnt, lm_obs0, lm_perm, lm_woff, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
   size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
       xch, lm_part, cost_part, imu_out, mscr, rotlog, eig_aux;
@@ -58,6 +58,7 @@ Layout make_layout(int maxN, int maxM) {
   const size_t N = std::max(maxN, 1), M = std::max(maxM, 1), LB = (size_t)L.capLmBlocks * LM_BLOCK;
   L.in_begin = o;
   L.lm_start = take(N * 4), L.lm_cnt = take(N * 4), L.lm_obs0 = take(N * 4), L.lm_perm = take(N * 4);
+  L.lm_woff = take((N + 1) * 4);
   L.lam0 = take(N * 8);
   for (int k = 0; k < 8; k++) L.obs[k] = take(M * 8);
   L.pm_obs = take(M * 4), L.pm_lm = take(M * 4);
@@ -92,7 +93,7 @@ Layout make_layout(int maxN, int maxM) {
 size_t down_bytes(int maxN) { return sizeof(FrameState) * 2 + sizeof(TRState) + 2 * ((size_t)maxN * 8 + 128) + sizeof(LfvioPrior) + 4096; }
 
 struct SlotHostInfo {
-  int N = 0, M = 0, gLm = 0, gCh = 0, gSc = 0;
+  int N = 0, M = 0, gLm = 0, gLw = 0, gCh = 0, gSc = 0;  // gLm: landmark blocks of 64; gLw: landmark workgroups of k_lin
   int marg_n = 0;            // the largest prior (tangent rows) a marginalization of this window can produce
   int max_iter = 0;          // LfvioWindow::max_num_iterations of the uploaded window
   double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
@@ -343,7 +344,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     for (int l = 0; l < N; l++) info.perm[count[w->start_frame[l] * 16 + (w->obs_offset[l + 1] - w->obs_offset[l])]++] = l;
   }
   int *lm_start = (int *)(h + L.lm_start), *lm_cnt = (int *)(h + L.lm_cnt), *lm_obs0 = (int *)(h + L.lm_obs0);
-  int *lm_perm = (int *)(h + L.lm_perm);
+  int *lm_perm = (int *)(h + L.lm_perm), *lm_woff = (int *)(h + L.lm_woff);
   double *lam0 = (double *)(h + L.lam0);
   double *obs[8];
   for (int k = 0; k < 8; k++) obs[k] = (double *)(h + L.obs[k]);
@@ -353,6 +354,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     const int l = info.perm[dl];
     const int s = w->start_frame[l], k = w->obs_offset[l + 1] - w->obs_offset[l], o0 = w->obs_offset[l];
     lm_start[dl] = s, lm_cnt[dl] = k, lm_obs0[dl] = o, lm_perm[dl] = l;
+    lm_woff[dl] = dl == 0 ? 0 : lm_woff[dl - 1] + w_row_len(lm_cnt[dl - 1]);
     lam0[dl] = w->inv_depth[l];
     if (s == 0) N0++, kmax0 = std::max(kmax0, k);
     for (int q = 0; q < k; q++, o++) {
@@ -395,10 +397,12 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   }
   S->pair_chunk0[NPAIR] = nChunks;
   S->nChunks = nChunks;
+  lm_woff[N] = N == 0 ? 0 : lm_woff[N - 1] + w_row_len(lm_cnt[N - 1]);
   S->nLmBlocks = (N + LM_BLOCK - 1) / LM_BLOCK;
+  S->lbw = 1;
   S->schur_lm = SCHUR_LM;  // one part per landmark block: k_lin forms it from its LDS tile
   S->nSchurParts = S->nLmBlocks;
-  info.gLm = S->nLmBlocks, info.gCh = nChunks, info.gSc = S->nSchurParts;
+  info.gLm = S->nLmBlocks, info.gLw = S->nSchurParts, info.gCh = nChunks, info.gSc = S->nSchurParts;
   // ---- gather lists of k_sum: which Gram entries (chunk or, for large windows, frame pair; local index of the
   //      20 x 20 block [Pi th_i Pj th_j tic th_ic td | r]) add up to each packed H_pp / g_p entry.  Units ascend, so the
   //      marginalization's subset (pairs (0, j)) is a prefix of every list.
@@ -469,6 +473,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     }
   // ---- device pointers
   S->lm_start.set(S, L.lm_start), S->lm_cnt.set(S, L.lm_cnt), S->lm_obs0.set(S, L.lm_obs0), S->lm_perm.set(S, L.lm_perm);
+  S->lm_woff.set(S, L.lm_woff);
   S->lam0.set(S, L.lam0);
   for (int k = 0; k < 8; k++) S->obs[k].set(S, L.obs[k]);
   S->pm_obs.set(S, L.pm_obs), S->pm_lm.set(S, L.pm_lm);
@@ -532,14 +537,15 @@ struct CaptureGuard {
 };
 
 struct Grid {
-  int lm, ch, sc;
+  int lm, ch, sc, lw;
 };
 constexpr int CH_BUCKET = 16;
 
 Grid grid_for(lfvio_ctx *c, int count) {
-  Grid g{1, 1, 1};
+  Grid g{1, 1, 1, 1};
   for (int s = 0; s < count; s++) {
     g.lm = std::max(g.lm, c->info[s].gLm);
+    g.lw = std::max(g.lw, c->info[s].gLw);
     g.ch = std::max(g.ch, c->info[s].gCh);
     g.sc = std::max(g.sc, c->info[s].gSc);
   }
@@ -553,8 +559,8 @@ Grid grid_for(lfvio_ctx *c, int count) {
 
 void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const int gram_wgs = (g.ch + 3) / 4;  // one chunk per wave
-  hipLaunchKernelGGL(k_lin, dim3(g.lm + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, c->L.total,
-                     mode, g.lm, gram_wgs);
+  hipLaunchKernelGGL(k_lin, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, c->L.total,
+                     mode, g.lw, gram_wgs);
 }
 
 // fixed-order reduction of the partials; two levels once a single k_sum thread would have to walk hundreds of them
@@ -1165,13 +1171,19 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   const Layout &L = c->L;
   char *d = c->d_base;
   const int N = in->num_landmarks;
-  std::vector<double> packed(PACKED), av(N), bv(N), Wv((size_t)N * WLD);
+  std::vector<int> woff(N + 1, 0), lst(N), lcn(N);
+  if (N) {
+    HIPCHK(c, hipMemcpy(woff.data(), d + L.lm_woff, sizeof(int) * (N + 1), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(lst.data(), d + L.lm_start, sizeof(int) * N, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(lcn.data(), d + L.lm_cnt, sizeof(int) * N, hipMemcpyDeviceToHost));
+  }
+  std::vector<double> packed(PACKED), av(N), bv(N), Wv((size_t)woff[N] + 1);
   HIPCHK(c, hipMemcpy(packed.data(), d + L.xch + sizeof(double) * XOFF_H, sizeof(double) * PACKED, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(gp, d + L.xch + sizeof(double) * XOFF_G, sizeof(double) * KP, hipMemcpyDeviceToHost));
   if (N) {
     HIPCHK(c, hipMemcpy(av.data(), d + L.a, sizeof(double) * N, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(bv.data(), d + L.b, sizeof(double) * N, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(Wv.data(), d + L.W, sizeof(double) * N * WLD, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(Wv.data(), d + L.W, sizeof(double) * woff[N], hipMemcpyDeviceToHost));
   }
   TRState tr;
   HIPCHK(c, hipMemcpy(&tr, d + offsetof(Slot, tr), sizeof tr, hipMemcpyDeviceToHost));
@@ -1180,7 +1192,9 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   const std::vector<int> &perm = c->info[0].perm;
   for (int dl = 0; dl < N; dl++) {
     a[perm[dl]] = av[dl], b[perm[dl]] = bv[dl];
-    for (int k = 0; k < KC; k++) W[(size_t)perm[dl] * KC + k] = Wv[(size_t)dl * WLD + k];
+    for (int k = 0; k < KC; k++) W[(size_t)perm[dl] * KC + k] = 0.0;
+    for (int ci = 0; ci < 6 * lcn[dl] + 7; ci++)  // stored span: the track's frames, then ex (6) and td
+      W[(size_t)perm[dl] * KC + (ci < 6 * lcn[dl] ? 6 * lst[dl] + ci : 66 + (ci - 6 * lcn[dl]))] = Wv[(size_t)woff[dl] + ci];
   }
   *cost = tr.x_cost;
   return LFVIO_OK;
@@ -1266,8 +1280,8 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
       case 2: launch_sum(c, count, g, MODE_SOLVE); break;  // k_presum + k_sum for large windows
       case 8: case 9: case 10: {  // k_lin by role: landmark blocks | Gram chunks | IMU factors + prior
         const int gram_wgs = (g.ch + 3) / 4;
-        const int gx = which == 8 ? g.lm : which == 9 ? gram_wgs : LFVIO_WINDOW_SIZE + 1;
-        hipLaunchKernelGGL(k_lin, dim3(gx, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, which == 8 ? g.lm : 0,
+        const int gx = which == 8 ? g.lw : which == 9 ? gram_wgs : LFVIO_WINDOW_SIZE + 1;
+        hipLaunchKernelGGL(k_lin, dim3(gx, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, which == 8 ? g.lw : 0,
                            which == 9 ? gram_wgs : 0);
       } break;
       case 4: case 5: case 6: case 7: {  // k_setup by role: state + table | + IMU sqrt_info | + prior J0^T J0 | + inverse depths
