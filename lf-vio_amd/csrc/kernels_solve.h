@@ -743,7 +743,7 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
     vgr[q] = in ? S->grad_p[i] : 0.0, vgn[q] = in ? S->gn_p[i] : 0.0, vdg[q] = in ? S->diag_p[i] : 1.0, vsc[q] = in ? S->scale_p[i] : 0.0;
   }
   double a = 0, b = 0;
-  if (do_schur && !inline_backsub)
+  if (do_schur && !inline_backsub && !sharded)
     for (int k = tid; k < nLmBlocks; k += nthr) {
       a += S->lm_part[(size_t)k * LMS + 8];
       b += S->lm_part[(size_t)k * LMS + 9];
@@ -1056,32 +1056,51 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
 // k_backsub) or phase C (which = 3: after k_cost) into the exchange scalars, everything else zeroed so that
 // the caller can sum-all-reduce the 16-scalar tail blindly.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_xpack(char *base, size_t stride, int which) {
+__global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int which) {
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   if (!S->sharded) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double *sc = S->xch + XOFF_C;
-  double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-  if (!tr->done && !tr->chol_fail) {
-    for (int k = lane; k < S->nLmBlocks; k += 64) {
-      if (which == 2) {
-        v0 += S->lm_part[(size_t)k * LMS + 8], v1 += S->lm_part[(size_t)k * LMS + 9];
-      } else {
-        const double *p = S->cost_part + (size_t)k * LMS;
-        v0 += p[0], v1 += p[1], v2 += p[2], v3 += p[3], v4 += p[4];
+  __shared__ double red[4][5];
+  double v[5] = {0, 0, 0, 0, 0};
+  const TRFlags fl = tr_flags(tr);
+  if (!fl.done && !fl.chol_fail) {
+    // a rank of a large window has thousands of block partials: 256 threads, the loads of four blocks in flight per thread
+    const int nb = S->nLmBlocks;
+    const double *src = which == 2 ? (const double *)S->lm_part + 8 : (const double *)S->cost_part;
+    const int nv = which == 2 ? 2 : 5;
+    for (int k0 = tid; k0 < nb; k0 += 4 * 256) {
+      double t[4][5];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + 256 * u;
+#pragma unroll
+        for (int q = 0; q < 5; q++) t[u][q] = (k < nb && q < nv) ? src[(size_t)k * LMS + q] : 0.0;
       }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int q = 0; q < 5; q++) v[q] += t[u][q];
     }
-    if (which == 3 && S->pose_side && lane < 11) v0 += S->pose_cost[lane];
+    if (which == 3 && S->pose_side && tid < 11) v[0] += S->pose_cost[tid];
   }
-  v0 = wave_sum(v0), v1 = wave_sum(v1), v2 = wave_sum(v2), v3 = wave_sum(v3), v4 = wave_sum(v4);
-  if (lane < 16) sc[lane] = 0.0;
-  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 5; q++) v[q] = wave_sum(v[q]);
   if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) red[wv][q] = v[q];
+  }
+  if (tid < 16) sc[tid] = 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    double s5[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) s5[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
     if (which == 2) {
-      sc[XS_GN2] = v0, sc[XS_GGN] = v1;
+      sc[XS_GN2] = s5[0], sc[XS_GGN] = s5[1];
     } else {
-      sc[XS_CCOST] = v0, sc[XS_MLIN] = v1, sc[XS_MQUAD] = v2, sc[XS_DN] = v3, sc[XS_XN] = v4;
+      sc[XS_CCOST] = s5[0], sc[XS_MLIN] = s5[1], sc[XS_MQUAD] = s5[2], sc[XS_DN] = s5[3], sc[XS_XN] = s5[4];
     }
   }
 }
@@ -1121,7 +1140,7 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
 #pragma unroll
   for (int z = 0; z < 1 + SPEC_EXTRA; z++) {
     cost[z] = mlin[z] = mquad[z] = dn[z] = xn[z] = 0.0;
-    if (!t.chol_fail && z < K) {
+    if (!t.chol_fail && z < K && !sharded) {
       const double *cp = z == 0 ? (const double *)S->cost_part : (const double *)S->cost_partE + (size_t)(z - 1) * (SPEC_MAX_LM / 64) * LMS;
       const double *pcz = z == 0 ? S->pose_cost : S->pose_costE[z > 0 ? z - 1 : 0];
       double c = 0, l = 0, q = 0, d = 0, x = 0;

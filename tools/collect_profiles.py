@@ -18,8 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
 os.makedirs(OUT, exist_ok=True)
 os.environ["TMPDIR"] = "/tmp"
-WORK = {"window300": ["--steps", "100", "--warmup", "10"], "batch512": ["--workload", "batch512", "--steps", "20", "--warmup", "3"],
-        "window100k": ["--workload", "window100k", "--steps", "40", "--warmup", "5"]}
+WORK = {"window300": ["--steps", "100", "--warmup", "10"],
+        "window300_stream": ["--workload", "window300_stream", "--steps", "126", "--warmup", "10"],
+        "batch512": ["--workload", "batch512", "--steps", "20", "--warmup", "3"],
+        "window100k": ["--workload", "window100k", "--steps", "40", "--warmup", "5"],
+        "window100k_sharded": ["--workload", "window100k_sharded", "--steps", "40", "--warmup", "5"]}
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"],
               ["SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]]
 
