@@ -16,6 +16,7 @@ constexpr int MODE_MARG = 1;        // MODE_MARG + flag: 1 = MARGIN_OLD, 2 = MAR
 // (Slot::tail_state: 0 not run, 2 finished); they leave `done` set, so later solve passes skip the slot.  Nothing a
 // gated kernel tests is written before the last of them (k_marg_solve) ends.
 constexpr int MODE_GATED = 16;
+constexpr int MODE_NOCOUNT = 32;  // k_lin launched role by role: only the first of the launches counts the pass
 DEV bool tail_gate(const Slot *S, int done) { return done && S->tail_state == 0; }
 DEV bool is_marg(int mode) { return mode >= MODE_MARG; }
 DEV const MargPlan *marg_plan(const Slot *S, int mode) { return &S->marg[mode - MODE_MARG]; }
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t strid
   } else {
     // a pass that starts with the loop still open is a pass this slot needs (the synchronous drivers size the first
     // graph of the next call from this count)
-    if (mode == MODE_SOLVE && !fl.done && blockIdx.x == 0 && threadIdx.x == 0) S->passes_used++;
+    if (mode == MODE_SOLVE && !(mode_bits & MODE_NOCOUNT) && !fl.done && blockIdx.x == 0 && threadIdx.x == 0) S->passes_used++;
     if (fl.done | (!do_lin & !do_schur)) return;
   }
   __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role

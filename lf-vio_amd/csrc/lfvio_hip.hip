@@ -540,6 +540,7 @@ struct Grid {
   int lm, ch, sc, lw;
 };
 constexpr int CH_BUCKET = 16;
+constexpr size_t LIN_SPLIT_WGS = 2048;  // launches of k_lin with more workgroups than this are issued role by role
 
 Grid grid_for(lfvio_ctx *c, int count) {
   Grid g{1, 1, 1, 1};
@@ -559,8 +560,18 @@ Grid grid_for(lfvio_ctx *c, int count) {
 
 void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const int gram_wgs = (g.ch + 3) / 4;  // one chunk per wave
-  hipLaunchKernelGGL(k_lin, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, c->L.total,
-                     mode, g.lw, gram_wgs);
+  const size_t st = c->L.total;
+  if ((size_t)count * (g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1) > LIN_SPLIT_WGS) {
+    // A resident batch: the roles go out as three launches of the same kernel.  Measured at 512 windows of 300 landmarks:
+    // landmark role 115 us + Gram role 175 us + IMU / prior roles 104 us on their own, 679 us as ONE grid — workgroups of four
+    // different code paths side by side on every CU (the sweep is ~30 KB of straight-line code per role) do not share an
+    // instruction cache well; two more launches cost 9 us.
+    hipLaunchKernelGGL(k_lin, dim3(g.lw, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, 0);
+    hipLaunchKernelGGL(k_lin, dim3(gram_wgs, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, gram_wgs);
+    hipLaunchKernelGGL(k_lin, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
+    return;
+  }
+  hipLaunchKernelGGL(k_lin, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, gram_wgs);
 }
 
 // fixed-order reduction of the partials; two levels once a single k_sum thread would have to walk hundreds of them
