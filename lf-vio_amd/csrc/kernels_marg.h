@@ -20,6 +20,7 @@ constexpr int MARG_MAXD = 96;  // 15 dropped + 76 kept, padded
 constexpr int LDN = 80;              // LDS row stride of the n x n (n <= 76) eigen-problem, see jacobi_systolic
 constexpr double JACOBI_TOL = 1e-19;  // off-diagonal mass / diagonal mass at which the n x n Jacobi stops, see jacobi_systolic
 constexpr size_t MARG_LDS = (size_t)19072 * sizeof(double);  // >= LPACK + KP + 64 and >= the eigen-phase carve below
+constexpr int BT_GROUP = 4;          // reflectors per step of the back-transformation (bt_apply)
 constexpr bool EIG_TRIDIAG = true;  // n x n eigen-problem: Householder tridiagonalization + multisection + twisted factorization
                                     // (eig_tridiag below); false: the systolic Jacobi + k_marg_vecs
 
@@ -575,124 +576,233 @@ DEV int sturm_count(sdouble *Tg /* d[96] | e^2[96]; beyond n: d above every shif
   }
   return (int)cnt;
 }
+// ---- Householder tridiagonalization steps of eig_tridiag (see there); P = leading live tile of the 5 x 5 register tiles
+struct TriCtx {
+  double *dd, *ee, *tau, *vb0, *vb1, *pp, *RV;
+  int n, r0, c0;
+};
+// d[kk] and the reflector of column kk (or the last e) from row kk, which is final.  Every row group of 16 lanes runs the
+// arithmetic on ITS row of tile P (so that the chain sum -> rsqrt -> reciprocal is straight-line code the scheduler can put
+// beside the rank-2 update of the other tile rows); only the group that owns row kk (own) stores anything.
+template <int P>
+DEV void tri_finish_row(const TriCtx &tc, int kk, const double (&row)[5], bool own) {
+  const int n = tc.n, c0 = tc.c0;
+  double *vb = (kk & 1) ? tc.vb1 : tc.vb0;
+  double a_part = 0.0, ss_part = 0.0, dk = 0.0;
+  bool has_d = false;
+#pragma unroll
+  for (int q = P; q < 5; q++) {
+    const int C = c0 + 16 * q;
+    if (C == kk) dk = row[q], has_d = true;
+    if (C == kk + 1) a_part = row[q];
+    if (C > kk + 1 && C < n) ss_part = fma(row[q], row[q], ss_part);
+  }
+  if (own && has_d) tc.dd[kk] = dk;
+  if (kk + 2 >= n) {
+    if (own && kk == n - 2 && c0 == ((n - 1) & 15)) tc.ee[kk] = a_part;
+    return;
+  }
+  a_part = sum8(a_part), ss_part = sum8(ss_part);
+  const double alpha = a_part + dpp_f64<0x140>(a_part), ss = ss_part + dpp_f64<0x140>(ss_part);
+  const double nn = fma(alpha, alpha, ss);
+  const bool live = ss > 0.0;
+  const double rs = fast_rsqrt(live ? nn : 1.0);
+  const double beta = live ? -copysign(nn * rs, alpha) : alpha;
+  const double t = live ? (beta - alpha) * -copysign(rs, alpha) : 0.0;  // 1 / beta = -sign(alpha) / sqrt(nn)
+  const double scal = live ? fast_rcp(alpha - beta) : 0.0;
+  if (own) {
+#pragma unroll
+    for (int q = P; q < 5; q++) {
+      const int C = c0 + 16 * q;
+      const double v = C == kk + 1 ? 1.0 : ((C > kk + 1 && C < n) ? row[q] * scal : 0.0);
+      vb[C] = v;
+      if (C > kk && C < n) tc.RV[kk * 76 + C - kk - 1] = v;
+    }
+    if (c0 == 0) tc.tau[kk] = t, tc.ee[kk] = beta;
+  }
+}
+// p = tau A v (zero for the rows that are done)
+template <int P>
+DEV void tri_matvec(const TriCtx &tc, int k, const double (&ar)[5][5], double (&vj)[5]) {
+  const double *vb = (k & 1) ? tc.vb1 : tc.vb0;
+  const double t = tc.tau[k];
+#pragma unroll
+  for (int q = P; q < 5; q++) vj[q] = vb[tc.c0 + 16 * q];
+  double sacc[5];
+#pragma unroll
+  for (int i = P; i < 5; i++) {
+    sacc[i] = 0.0;
+#pragma unroll
+    for (int q = P; q < 5; q++) sacc[i] = fma(ar[i][q], vj[q], sacc[i]);
+  }
+#pragma unroll
+  for (int i = P; i < 5; i++) sacc[i] += dpp_f64<0xB1>(sacc[i]);
+#pragma unroll
+  for (int i = P; i < 5; i++) sacc[i] += dpp_f64<0x4E>(sacc[i]);
+#pragma unroll
+  for (int i = P; i < 5; i++) sacc[i] += dpp_f64<0x141>(sacc[i]);
+#pragma unroll
+  for (int i = P; i < 5; i++) sacc[i] += dpp_f64<0x140>(sacc[i]);
+  if (tc.c0 == 0) {
+#pragma unroll
+    for (int i = P; i < 5; i++) tc.pp[tc.r0 + 16 * i] = tc.r0 + 16 * i > k ? t * sacc[i] : 0.0;
+  }
+}
+// A -= v w^T + w v^T with w = p - K v, K = (tau/2)(p.v), written as A -= v p^T + p v^T - 2 K v v^T: the first two terms
+// do not wait for the reduction of p.v; v and p are zero outside k+1 .. n-1.  The tile row that holds row k + 1 goes first
+// and the next reflector is formed from it while the other tile rows take their update.
+template <int P>
+DEV void tri_update(const TriCtx &tc, int k, double (&ar)[5][5], const double (&vj)[5]) {
+  const double *vb = (k & 1) ? tc.vb1 : tc.vb0;
+  const double t = tc.tau[k];
+  double pj[5], vi[5], pi[5], pvs = 0.0;
+#pragma unroll
+  for (int q = P; q < 5; q++) pj[q] = tc.pp[tc.c0 + 16 * q];
+#pragma unroll
+  for (int i = P; i < 5; i++) vi[i] = vb[tc.r0 + 16 * i], pi[i] = tc.pp[tc.r0 + 16 * i];
+#pragma unroll
+  for (int q = P; q < 5; q++) pvs = fma(pj[q], vj[q], pvs);
+  pvs = sum8(pvs);
+  pvs += dpp_f64<0x140>(pvs);
+  const double K2 = t * pvs;
+#pragma unroll
+  for (int i = P; i < 5; i++) {
+#pragma unroll
+    for (int q = P; q < 5; q++) ar[i][q] = fma(-pi[i], vj[q], fma(-vi[i], pj[q], ar[i][q]));
+  }
+#pragma unroll
+  for (int i = P; i < 5; i++) {
+    const double kv = K2 * vi[i];
+#pragma unroll
+    for (int q = P; q < 5; q++) ar[i][q] = fma(kv, vj[q], ar[i][q]);
+    if (i == P) tri_finish_row<P>(tc, k + 1, ar[P], tc.r0 == ((k + 1) & 15));
+  }
+}
+// z <- (I - tau v v^T) z for the eight lanes that share an eigenvector (rows l8 + 8 q), for the NR reflectors k, k - 1, ...
+// of one tile QM = k / 8 (the first tile with live rows): their loads leave together, so the LDS round trip is paid once
+// per group.  Rows beyond n read the zero tail of the reflector's RV row — except for k < 3, where that tail is shorter
+// than the tile, so the first instantiation keeps the upper mask.
+template <int QM, int NR>
+DEV void bt_apply(const double *RV, const double *tau, int k, int n, int l8, double (&zz)[10]) {
+  double vq[NR][10], tk[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int kr = k - r;
+    const double *v = RV + kr * 76 - (kr + 1);  // v[i] for rows i >= kr + 1
+    tk[r] = tau[kr];
+#pragma unroll
+    for (int q = QM; q < 10; q++) {
+      const int i = l8 + 8 * q;
+      if (QM == 0) vq[r][q] = (i > kr && i < n) ? v[i] : 0.0;
+      else vq[r][q] = (q > QM || i > kr) ? v[i] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = QM; q < 10; q++) {
+      if ((q - QM) & 1) s1 = fma(vq[r][q], zz[q], s1);
+      else s0 = fma(vq[r][q], zz[q], s0);
+    }
+    const double s = sum8(s0 + s1) * tk[r];
+#pragma unroll
+    for (int q = QM; q < 10; q++) zz[q] = fma(-s, vq[r][q], zz[q]);
+  }
+}
+template <int NR>
+DEV void bt_dispatch(const double *RV, const double *tau, int k, int n, int l8, double (&zz)[10]) {
+  switch (k >> 3) {
+    case 0: bt_apply<0, NR>(RV, tau, k, n, l8, zz); break;
+    case 1: bt_apply<1, NR>(RV, tau, k, n, l8, zz); break;
+    case 2: bt_apply<2, NR>(RV, tau, k, n, l8, zz); break;
+    case 3: bt_apply<3, NR>(RV, tau, k, n, l8, zz); break;
+    case 4: bt_apply<4, NR>(RV, tau, k, n, l8, zz); break;
+    case 5: bt_apply<5, NR>(RV, tau, k, n, l8, zz); break;
+    case 6: bt_apply<6, NR>(RV, tau, k, n, l8, zz); break;
+    case 7: bt_apply<7, NR>(RV, tau, k, n, l8, zz); break;
+    case 8: bt_apply<8, NR>(RV, tau, k, n, l8, zz); break;
+    default: bt_apply<9, NR>(RV, tau, k, n, l8, zz); break;
+  }
+}
+// |q| < pivmin -> +-pivmin (the sign of q): the quotient-difference recurrences divide by q.  max + sign insertion instead of
+// compare + select: a v_cmp_f64 -> SGPR mask -> v_cndmask round trip costs the chain several times what the arithmetic does.
+DEV double guard_pivot(double q, double pivmin) { return copysign(fmax(fabs(q), pivmin), q); }
 // A: n x n, row stride LDN, full symmetric (destroyed; receives Z, component i of vector m at [i * LDN + m]); b: n;
-// RV: >= n * 76, DM: >= n * LDN, vec: >= 8 * 96 doubles of LDS.  Writes out->linearized_jacobians / _residuals.
-DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, double *DM, double *vec, double *scr, double *Tglob, LfvioPrior *out, double eps, long long *dbg) {
+// RV: >= n * 76, DM: >= n * LDN, vec: >= 7 * 96, nn2: >= 2 * 96 doubles of LDS.  Writes out->linearized_jacobians / _residuals.
+DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, double *DM, double *vec, double *scr, double *nn2, double *Tglob, LfvioPrior *out, double eps, long long *dbg) {
 #define ESTAMP(k) do { if (tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
   ESTAMP(26);
   const int wave = tid >> 6, lane = tid & 63;
   double *dd = vec, *ee = vec + 96, *ee2 = vec + 192, *tau = vec + 288, *lam = vec + 384, *pp = vec + 480, *nrm = vec + 576;
-  // ---- 1. tridiagonalization, the matrix in registers: thread (r0, c0) of a 48 x 16 grid owns A[r0 + 48 i][c0 + 16 q]
-  // (i < 2, q < 5; both triangles).  LDS carries only vectors: the reflector v of the current column (normalized and
-  // zero up to the diagonal, so nothing downstream needs a mask), p = tau A v, the reflectors for the back-transformation.
-  // A row sits in one DPP row of 16 lanes: A v, p.v and the norm of the next reflector are reduced with four DPP steps.
-  // The step is bound by instruction issue (three waves per SIMD, FP64 and DPP at four cycles each), so nothing is
-  // computed twice: the 16 lanes that own row k+1 form the NEXT reflector (dlarfg) right after they have updated that
-  // row, inside the update phase — two barriers per column.  Only the lower triangle of the input is read, like Eigen's
-  // solver (and tred2) do.
-  const int r0 = tid >> 4, c0 = tid & 15;
-  double ar[2][5];
+  // ---- 1. tridiagonalization, the matrix in registers of the first four waves (one per SIMD): thread (r0, c0) of a
+  // 16 x 16 grid owns A[r0 + 16 i][c0 + 16 q] (i, q < 5; both triangles).  LDS carries only vectors: the reflector v of the
+  // current column (normalized and zero up to the diagonal, so nothing downstream needs a mask), p = tau A v, the
+  // reflectors for the back-transformation.  A row sits in one DPP row of 16 lanes: A v, p.v and the norm of the next
+  // reflector are reduced with four DPP steps.  The step is a latency chain (two barriers and four LDS round trips per
+  // column) with the vector pipe underneath it, so the instruction count is what is kept small: four waves instead of
+  // twelve carry the per-thread overhead once per SIMD, and column k only touches the 16 x 16 register tiles that still
+  // hold live rows and columns (tri_matvec / tri_update are instantiated per leading tile P = (k + 1) / 16: 25, 16, 9, 4, 1
+  // tiles).  The 16 lanes that own row k + 1 form the NEXT reflector (dlarfg) right after they have updated that row,
+  // inside the update phase.  Only the lower triangle of the input is read, like Eigen's solver (and tred2) do.
+  const bool tri = tid < 256;
+  const int r0 = (tid >> 4) & 15, c0 = tid & 15;
+  double ar[5][5];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 5; i++)
 #pragma unroll
     for (int q = 0; q < 5; q++) {
-      const int R = r0 + 48 * i, C = c0 + 16 * q;
-      ar[i][q] = (R < n && C < n) ? A[max(R, C) * LDN + min(R, C)] : 0.0;
+      const int R = r0 + 16 * i, C = c0 + 16 * q;
+      ar[i][q] = (tri && R < n && C < n) ? A[max(R, C) * LDN + min(R, C)] : 0.0;
     }
   double *vb0 = lam, *vb1 = nrm;  // free until the eigenvalue search
   if (tid < 96) dd[tid] = 0.0, ee[tid] = 0.0, ee2[tid] = 0.0, tau[tid] = 0.0, vb0[tid] = 0.0, vb1[tid] = 0.0;  // v stays zero beyond n
+  for (int e = tid; e < 76 * 76; e += MARG_THREADS) RV[e] = 0.0;  // the back-transformation reads the tail of a row as rows >= n
   __syncthreads();
-  // called by the 16 lanes that own row kk once that row is final: d[kk], and the reflector of column kk (or the last e)
-  auto finish_row = [&](int kk, const double(&row)[5]) {
-    double *vb = (kk & 1) ? vb1 : vb0;
-    double a_part = 0.0, ss_part = 0.0;
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-      const int C = c0 + 16 * q;
-      if (C == kk) dd[kk] = row[q];
-      if (C == kk + 1) a_part = row[q];
-      if (C > kk + 1 && C < n) ss_part = fma(row[q], row[q], ss_part);
-    }
-    if (kk + 2 >= n) {
-      if (kk == n - 2 && c0 == ((n - 1) & 15)) ee[kk] = a_part;
-      return;
-    }
-    a_part = sum8(a_part), ss_part = sum8(ss_part);
-    const double alpha = a_part + dpp_f64<0x140>(a_part), ss = ss_part + dpp_f64<0x140>(ss_part);
-    double beta = alpha, t = 0.0, scal = 0.0;
-    if (ss > 0.0) {
-      const double nn = alpha * alpha + ss;
-      beta = -copysign(nn * fast_rsqrt(nn), alpha);
-      t = (beta - alpha) * fast_rcp(beta);
-      scal = fast_rcp(alpha - beta);
-    }
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-      const int C = c0 + 16 * q;
-      const double v = C == kk + 1 ? 1.0 : ((C > kk + 1 && C < n) ? row[q] * scal : 0.0);
-      vb[C] = v;
-      if (C > kk && C < n) RV[kk * 76 + C - kk - 1] = v;
-    }
-    if (c0 == 0) tau[kk] = t, ee[kk] = beta;
-  };
-  if (r0 == 0) finish_row(0, ar[0]);
+  TriCtx tc = {dd, ee, tau, vb0, vb1, pp, RV, n, r0, c0};
+  if (tri) tri_finish_row<0>(tc, 0, ar[0], r0 == 0);
   __syncthreads();
   for (int k = 0; k + 2 < n; k++) {
-    const double *vb = (k & 1) ? vb1 : vb0;
-    const double t = tau[k];
+    const int P = (k + 1) >> 4;
     double vj[5];
-#pragma unroll
-    for (int q = 0; q < 5; q++) vj[q] = vb[c0 + 16 * q];
-    {  // p = tau A v (zero for the rows that are done)
-      double sacc[2];
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        sacc[i] = 0.0;
-#pragma unroll
-        for (int q = 0; q < 5; q++) sacc[i] = fma(ar[i][q], vj[q], sacc[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++) sacc[i] += dpp_f64<0xB1>(sacc[i]);
-#pragma unroll
-      for (int i = 0; i < 2; i++) sacc[i] += dpp_f64<0x4E>(sacc[i]);
-#pragma unroll
-      for (int i = 0; i < 2; i++) sacc[i] += dpp_f64<0x141>(sacc[i]);
-#pragma unroll
-      for (int i = 0; i < 2; i++) sacc[i] += dpp_f64<0x140>(sacc[i]);
-      if (c0 == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) pp[r0 + 48 * i] = r0 + 48 * i > k ? t * sacc[i] : 0.0;
+#ifdef LFVIO_TRI_PROFILE
+#define TSTAMP(j) do { if (tid == 0 && k == LFVIO_TRI_PROFILE) dbg[16 + j] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP(j) do { } while (0)
+#endif
+    TSTAMP(0);
+    if (tri) {
+      switch (P) {
+        case 0: tri_matvec<0>(tc, k, ar, vj); break;
+        case 1: tri_matvec<1>(tc, k, ar, vj); break;
+        case 2: tri_matvec<2>(tc, k, ar, vj); break;
+        case 3: tri_matvec<3>(tc, k, ar, vj); break;
+        default: tri_matvec<4>(tc, k, ar, vj); break;
       }
     }
+    TSTAMP(1);
     __syncthreads();
-    {  // w = p - (tau/2)(p.v) v on the fly, A -= v w^T + w v^T; v and p are zero outside k+1 .. n-1
-      double wj[5], vi[2], wi[2], pvs = 0.0;
-#pragma unroll
-      for (int q = 0; q < 5; q++) wj[q] = pp[c0 + 16 * q];
-#pragma unroll
-      for (int i = 0; i < 2; i++) vi[i] = vb[r0 + 48 * i], wi[i] = pp[r0 + 48 * i];
-#pragma unroll
-      for (int q = 0; q < 5; q++) pvs = fma(wj[q], vj[q], pvs);
-      pvs = sum8(pvs);
-      pvs += dpp_f64<0x140>(pvs);
-      const double K = 0.5 * t * pvs;
-#pragma unroll
-      for (int q = 0; q < 5; q++) wj[q] -= K * vj[q];
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        wi[i] -= K * vi[i];
-#pragma unroll
-        for (int q = 0; q < 5; q++) ar[i][q] -= vi[i] * wj[q] + wi[i] * vj[q];
+    TSTAMP(2);
+    if (tri) {
+      switch (P) {
+        case 0: tri_update<0>(tc, k, ar, vj); break;
+        case 1: tri_update<1>(tc, k, ar, vj); break;
+        case 2: tri_update<2>(tc, k, ar, vj); break;
+        case 3: tri_update<3>(tc, k, ar, vj); break;
+        default: tri_update<4>(tc, k, ar, vj); break;
       }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-        if (r0 + 48 * i == k + 1) finish_row(k + 1, ar[i]);
     }
+    TSTAMP(3);
     __syncthreads();
+    TSTAMP(4);
   }
+  if (tri) {
 #pragma unroll
-  for (int i = 0; i < 2; i++)
-    if (r0 + 48 * i == n - 1) finish_row(n - 1, ar[i]);
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+      for (int q = 0; q < 5; q++)
+        if (r0 + 16 * i == n - 1 && c0 + 16 * q == n - 1) dd[n - 1] = ar[i][q];
+  }
   __syncthreads();
   ESTAMP(27);
   // ---- 2. eigenvalues
@@ -743,57 +853,116 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
     if (tid < 256 && m < n && l8 == 0) lam[m] = 0.5 * (lo + hi);
     __syncthreads();
     ESTAMP(28);
-    // ---- 3. eigenvectors of T: thread me runs the stationary recurrence (top down) into A, thread 128 + me the
-    //         progressive one (bottom up) into DM
-    if (tid < n) {
-      const int me = tid;
-      const double l = lam[me];
+    // ---- 3. eigenvectors of T: thread me (set 0) runs the stationary recurrence (top down) into A, thread 128 + me (set 1)
+    //         the progressive one (bottom up) into DM; each set then looks for the twist in its half of the rows and
+    //         multiplies out on its side of it.  Every loop has a uniform trip count (rows on the wrong side of the twist are
+    //         predicated off), so the loads of several rows leave together.
+    const int set = tid >> 7, me = tid & 127;
+    const bool work = set < 2 && me < n;
+    const int mec = work ? me : 0;
+    const double l = lam[mec];
+    // Every loop below runs in blocks of eight rows: the LDS reads of a block leave together, then the chain runs on
+    // registers, then the block is stored — a read issued inside the chain would cost it a round trip per row (LDS
+    // operations complete in order, so it would also wait for the store of the row before).
+    if (work && set == 0) {
       double q = dd[0] - l;
-      A[me] = q;
-      for (int i = 1; i < n; i++) {
-        if (fabs(q) < pivmin) q = -pivmin;
-        q = fma(-ee2[i - 1], fast_rcp(q), dd[i] - l);
-        A[i * LDN + me] = q;
+      A[mec] = q;
+      for (int i0 = 1; i0 < n; i0 += 8) {
+        double dv[8], ev[8], qs[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) dv[u] = dd[i0 + u], ev[u] = ee2[i0 + u - 1];  // (rows up to n + 7 < 96 exist and are zero)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          q = fma(-ev[u], fast_rcp(guard_pivot(q, pivmin)), dv[u] - l);
+          qs[u] = q;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (i0 + u < n) A[(i0 + u) * LDN + mec] = qs[u];
       }
-    } else if (tid >= 128 && tid < 128 + n) {
-      const int me = tid - 128;
-      const double l = lam[me];
+    } else if (work) {
       double q = dd[n - 1] - l;
-      DM[(n - 1) * LDN + me] = q;
-      for (int i = n - 2; i >= 0; i--) {
-        if (fabs(q) < pivmin) q = -pivmin;
-        q = fma(-ee2[i], fast_rcp(q), dd[i] - l);
-        DM[i * LDN + me] = q;
+      DM[(n - 1) * LDN + mec] = q;
+      for (int i0 = n - 2; i0 >= 0; i0 -= 8) {
+        double dv[8], ev[8], qs[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) dv[u] = dd[max(i0 - u, 0)], ev[u] = ee2[max(i0 - u, 0)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          q = fma(-ev[u], fast_rcp(guard_pivot(q, pivmin)), dv[u] - l);
+          qs[u] = q;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (i0 - u >= 0) DM[(i0 - u) * LDN + mec] = qs[u];
       }
     }
     __syncthreads();
-    if (tid < n) {  // twist where |gamma| is smallest and multiply out
-      const int me = tid;
-      const double l = lam[me];
+    ESTAMP(16);
+    {  // |gamma_i| = |s_i + p_i - (d_i - lambda)| is smallest at the twist: each set scans half of the rows
+      const int half = (n + 1) >> 1, i0 = set == 0 ? 0 : half, i1 = set == 0 ? half : n;
       double gmin = 1e300;
-      int kt = 0;
-      for (int i = 0; i < n; i++) {
-        const double g = fabs(A[i * LDN + me] + DM[i * LDN + me] - (dd[i] - l));
-        if (g < gmin) gmin = g, kt = i;
+      int kt = i0;
+      if (work) {
+#pragma unroll 8
+        for (int i = i0; i < i1; i++) {
+          const double g = fabs(A[i * LDN + mec] + DM[i * LDN + mec] - (dd[i] - l));
+          if (g < gmin) gmin = g, kt = i;
+        }
       }
-      double z = 1.0, nn = 1.0;
-      for (int i = kt - 1; i >= 0; i--) {
-        double dp = A[i * LDN + me];
-        if (fabs(dp) < pivmin) dp = -pivmin;
-        z = -ee[i] * fast_rcp(dp) * z;
-        A[i * LDN + me] = z;
-        nn = fma(z, z, nn);
+      __syncthreads();  // (every thread has read e^2 by now)
+      if (work) {
+        pp[set * 96 + mec] = gmin;
+        ((int *)ee2)[set * 96 + mec] = kt;  // (pp | nrm: 192 doubles, free by now)
       }
-      z = 1.0;
-      A[kt * LDN + me] = 1.0;
-      for (int i = kt + 1; i < n; i++) {
-        double dm = DM[i * LDN + me];
-        if (fabs(dm) < pivmin) dm = -pivmin;
-        z = -ee[i - 1] * fast_rcp(dm) * z;
-        A[i * LDN + me] = z;
-        nn = fma(z, z, nn);
+    }
+    __syncthreads();
+    ESTAMP(17);
+    if (work) {
+      const double g0 = pp[mec], g1 = pp[96 + mec];
+      const int kt = g1 < g0 ? ((int *)ee2)[96 + mec] : ((int *)ee2)[mec];  // the first minimum, as one scan would find it
+      double z = 1.0, nn = 0.0;
+      if (set == 0) {
+        A[kt * LDN + mec] = 1.0;
+        for (int i0 = n - 2; i0 >= 0; i0 -= 8) {
+          double c[8], zs[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int i = max(i0 - u, 0);
+            c[u] = -ee[i] * fast_rcp(guard_pivot(A[i * LDN + mec], pivmin));  // (not on the chain of z: one multiplication per row)
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const bool on = i0 - u < kt && i0 - u >= 0;
+            z = on ? c[u] * z : 1.0;
+            zs[u] = z;
+            nn = on ? fma(z, z, nn) : nn;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (i0 - u < kt && i0 - u >= 0) A[(i0 - u) * LDN + mec] = zs[u];
+        }
+      } else {
+        for (int i0 = 1; i0 < n; i0 += 8) {
+          double c[8], zs[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int i = min(i0 + u, n - 1);
+            c[u] = -ee[i - 1] * fast_rcp(guard_pivot(DM[i * LDN + mec], pivmin));
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const bool on = i0 + u > kt && i0 + u < n;
+            z = on ? c[u] * z : 1.0;
+            zs[u] = z;
+            nn = on ? fma(z, z, nn) : nn;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (i0 + u > kt && i0 + u < n) A[(i0 + u) * LDN + mec] = zs[u];
+        }
       }
-      nrm[me] = fast_rsqrt(nn);
+      nn2[set * 96 + mec] = nn;
     }
   }
   __syncthreads();
@@ -804,25 +973,17 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
     const bool live = m < n;
     const int mm = live ? m : 0;
     double zz[10];
-    const double sc = nrm[mm];
+    const double sc = fast_rsqrt(1.0 + nn2[mm] + nn2[96 + mm]);
 #pragma unroll
     for (int q = 0; q < 10; q++) {
       const int i = l8 + 8 * q;
       zz[q] = i < n ? A[i * LDN + mm] * sc : 0.0;
     }
-    for (int k = n - 3; k >= 0; k--) {
-      const double *v = RV + k * 76 - (k + 1);  // v[i] for rows i >= k + 1
-      double vq[10], s = 0.0;
-#pragma unroll
-      for (int q = 0; q < 10; q++) {
-        const int i = l8 + 8 * q;
-        vq[q] = (i > k && i < n) ? v[i] : 0.0;
-        s = fma(vq[q], zz[q], s);
-      }
-      s = sum8(s) * tau[k];
-#pragma unroll
-      for (int q = 0; q < 10; q++) zz[q] = fma(-s, vq[q], zz[q]);
-    }
+    // reflector k only touches rows i > k: the loop runs per leading live tile QM = k / 8 (bt_apply<QM>), the tiles below
+    // it are skipped and only the boundary tile is masked (the tail of every RV row is zero, see the tridiagonalization)
+    int k = n - 3;
+    for (; k >= 0 && (k & (BT_GROUP - 1)) != BT_GROUP - 1; k--) bt_dispatch<1>(RV, tau, k, n, l8, zz);
+    for (; k >= 0; k -= BT_GROUP) bt_dispatch<BT_GROUP>(RV, tau, k, n, l8, zz);
     const double l = lam[mm];
     double rb = 0.0;
 #pragma unroll
@@ -965,7 +1126,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   STAMP(S, 13);
   int sw2 = 0;
   if (EIG_TRIDIAG) {
-    eig_tridiag(Ar, br, n, tid, RV, DMs, vec8, scr, S->eig_aux, out, 1e-8, S->dbg);
+    eig_tridiag(Ar, br, n, tid, RV, DMs, vec8, scr, (double *)cs, S->eig_aux, out, 1e-8, S->dbg);
     if (tid == 0) S->eig_steps = 0;
   } else {
     if (tid < n) {

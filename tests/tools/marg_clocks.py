@@ -15,3 +15,7 @@ for rep in range(2):
     t = np.array(buf[:32], dtype=np.int64)
     print("k_marg_solve", t[15] - t[10], "cycles: gather", t[11] - t[10], "A_mm^+", t[12] - t[11], "Schur + copy", t[13] - t[12], "eigen", t[14] - t[13], "blocks", t[15] - t[14],
           "| eigen: tridiagonalization", t[27] - t[26], "eigenvalues", t[28] - t[27], "eigenvectors of T", t[29] - t[28], "back-transformation + outputs", t[14] - t[29])
+    if t[20] > t[16] > 0:
+        print("   column 15: matvec", t[17] - t[16], "barrier", t[18] - t[17], "update + next reflector", t[19] - t[18], "barrier", t[20] - t[19])
+    print("   eigenvectors of T: recurrences", t[16] - t[28], "twist search", t[17] - t[16], "multiplying out", t[29] - t[17])
+    print("   256 dependent v_fma_f64 inside the kernel:", t[1], "ticks")
