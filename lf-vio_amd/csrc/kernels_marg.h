@@ -109,26 +109,24 @@ DEV bool spd_inverse_wave(const double *Am, double *Xout, int m, int lane, doubl
 #pragma unroll
   for (int j = 0; j < 15; j++) a[j] = (lane < m && j < m) ? Am[lane * m + j] : (lane == j ? 1.0 : 0.0);
   bool ok = true;
+  double dinv = 1.0;
 #pragma unroll
   for (int j = 0; j < 15; j++) {
     const double d = readlane_f64(a[j], j);
     ok = ok && (d > 0.0);
-    const double s = sqrt(d);
-    const double l = lane == j ? s : a[j] / s;
+    const double rs = fast_rsqrt(d);  // (one reciprocal square root per column serves the diagonal, the column and 1 / L_jj)
+    const double l = lane == j ? d * rs : a[j] * rs;
     a[j] = l;
+    dinv = lane == j ? rs : dinv;
 #pragma unroll
-    for (int c = j + 1; c < 15; c++) a[c] -= l * readlane_f64(l, c);
+    for (int c = j + 1; c < 15; c++) a[c] = fma(-l, readlane_f64(l, c), a[c]);
   }
-  double diag = 1.0;
-#pragma unroll
-  for (int j = 0; j < 15; j++) diag = lane == j ? a[j] : diag;
-  const double dinv = 1.0 / diag;
   double y[15];  // y[i] = (L^-1)[i][lane]
 #pragma unroll
   for (int i = 0; i < 15; i++) {
     double t = lane == i ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < i; k++) t -= readlane_f64(a[k], i) * y[k];
+    for (int k = 0; k < i; k++) t = fma(-readlane_f64(a[k], i), y[k], t);
     y[i] = t * readlane_f64(dinv, i);
   }
   double fro = 0;
@@ -497,17 +495,18 @@ DEV int jacobi_small(double *Am, double *Vm, int n, int tid, int nthreads, doubl
 // The n x n (n <= 76) symmetric eigen-problem of marginalization_factor.cpp:283-291 the way Eigen's SelfAdjointEigenSolver
 // and the oracle's tred2 + tql2 pose it — tridiagonalize, solve the tridiagonal problem, transform back — with the serial
 // QL iteration replaced by two steps that are parallel over the eigenvalues:
-//   1. Householder tridiagonalization  A = Q T Q^T  (LAPACK dsytd2 arithmetic), A full-symmetric in LDS: per column one
-//      wave forms the reflector, eight lanes per row take the product A v, every wave forms w = p - (tau/2)(p.v) v on
-//      the fly for its share of the rank-2 update  A -= v w^T + w v^T; three barriers per column.
-//   2. eigenvalues of T by multisection of the Sturm count: eight lanes per eigenvalue index, nine-fold shrink per
-//      round, 18 rounds from the Gershgorin interval down to the rounding level of T.
+//   1. Householder tridiagonalization  A = Q T Q^T  (dsytd2's recurrences), the matrix in the registers of four waves, two
+//      barriers per column (see the step itself in eig_tridiag).
+//   2. eigenvalues of T by multisection of the Sturm count: one shared sweep over an even grid of 256 shifts brackets
+//      every eigenvalue to 1/257 of the Gershgorin interval, then three lanes per eigenvalue quarter their bracket 23 times,
+//      down to the rounding level of T.
 //   3. eigenvectors of T by the twisted factorization (Parlett & Dhillon; LAPACK dlar1v without the relatively robust
-//      representation): one thread per eigenvalue runs the stationary and the progressive quotient-difference recurrence,
-//      twists where |gamma| is smallest and multiplies out from there.  Eigenvalues closer than the rounding level give
-//      parallel vectors; that only happens in the block of noise eigenvalues (|lambda| ~ 1e-6 against ||A'|| ~ 1e6),
-//      whose rows contribute lambda v v^T ~ 1e-6 to J0^T J0 whatever v is.
-//   4. V = Q Z: eight lanes per eigenvector push their column through the reflectors, last to first, and write
+//      representation): one thread per eigenvalue runs the stationary, another the progressive quotient-difference
+//      recurrence; they twist where |gamma| is smallest and each multiplies out on its side of the twist.  Eigenvalues
+//      closer than the rounding level give parallel vectors; that only happens in the block of noise eigenvalues
+//      (|lambda| ~ 1e-6 against ||A'|| ~ 1e6), whose rows contribute lambda v v^T ~ 1e-6 to J0^T J0 whatever v is.
+//   4. V = Q Z: eight lanes per eigenvector push their column through the reflectors, last to first (four reflectors per
+//      step, only the rows they touch), and write
 //      J0 = sqrt(S) V^T,  r0 = sqrt(1/S) V^T b'  for the eigenvalues above eps, zero rows for the others.
 // Rows of J0 come out in ascending eigenvalue order, as Eigen returns them.
 // ---------------------------------------------------------------------------------------------------------------
@@ -545,11 +544,14 @@ DEV int sturm_count(sdouble *Tg /* d[96] | e^2[96]; beyond n: d above every shif
   // one is requested, and the eight rows of arithmetic then run beside that request.
   double pm = 1.0, p = Tg[0] - sigma;
   unsigned cnt = (unsigned)__double2hiint(p) >> 31;
+  // the sign of every p_i is shifted into ONE word that is never cleared (newest at bit 0): after a block of 16 rows its
+  // lower half holds the block's signs and bit 16 the sign before the block, so the sign changes are the set bits of
+  // (bits ^ (bits >> 1)) in the lower half — one integer instruction per row instead of two
+  unsigned bits = (unsigned)__double2hiint(p) >> 31;
   double d0[8], e0[8], d1[8], e1[8];
 #pragma unroll
   for (int u = 0; u < 8; u++) d0[u] = Tg[1 + u], e0[u] = Tg[96 + u];
   for (int i0 = 1; i0 < n; i0 += 16) {
-    unsigned bits = 0;
     STURM_TOUCH8(d0);
     STURM_TOUCH8(e0);
 #pragma unroll
@@ -557,7 +559,7 @@ DEV int sturm_count(sdouble *Tg /* d[96] | e^2[96]; beyond n: d above every shif
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const double pn = fma(d0[u] - sigma, p, -e0[u] * pm);
-      bits = __builtin_amdgcn_alignbit(bits, (unsigned)(__double2hiint(pn) ^ __double2hiint(p)), 31);
+      bits = __builtin_amdgcn_alignbit(bits, (unsigned)__double2hiint(pn), 31);
       pm = p, p = pn;
     }
     STURM_TOUCH8(d1);
@@ -567,10 +569,10 @@ DEV int sturm_count(sdouble *Tg /* d[96] | e^2[96]; beyond n: d above every shif
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const double pn = fma(d1[u] - sigma, p, -e1[u] * pm);
-      bits = __builtin_amdgcn_alignbit(bits, (unsigned)(__double2hiint(pn) ^ __double2hiint(p)), 31);
+      bits = __builtin_amdgcn_alignbit(bits, (unsigned)__double2hiint(pn), 31);
       pm = p, p = pn;
     }
-    cnt += __builtin_popcount(bits);
+    cnt += __builtin_popcount((bits ^ (bits >> 1)) & 0xffffu);
     const int ex = ilogb(fmax(fmax(fabs(p), fabs(pm)), 1e-300));
     p = ldexp(p, -ex), pm = ldexp(pm, -ex);
   }
@@ -838,10 +840,26 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
     // eigenvalue need 18 rounds but ten waves)
     const int g3 = lane == 63 ? 20 : lane / 3, l8 = lane == 63 ? 3 : lane - 3 * g3;  // lane 63 rides along with group 20
     const int m = wave * 21 + g3;
-    double lo = gl, hi = gu;
     const int mm = m < n ? m : n - 1;
+    // round 0 is shared: the 256 threads put an even grid over the Gershgorin interval, and the counts at the grid points
+    // bracket every eigenvalue to 1/257 of it with one sweep (four rounds of the per-eigenvalue quadrisection)
+    {
+      int *cntg = (int *)pp;             // 256 counts (pp | nrm are free until the eigenvectors)
+      double *blo = nn2, *bhi = nn2 + 96;  // bracket of eigenvalue m
+      const double step = (gu - gl) * (1.0 / 257.0);
+      if (tid < 96) blo[tid] = gl, bhi[tid] = gu;  // (whatever the counts say, every eigenvalue has a bracket)
+      if (tid < 256) cntg[tid] = sturm_count(Tg, n, gl + step * (double)(tid + 1));
+      __syncthreads();
+      if (tid <= 256) {  // thread j owns the eigenvalues between grid points j - 1 and j
+        const int c0 = tid > 0 ? cntg[tid - 1] : 0, c1 = tid < 256 ? cntg[tid] : n;
+        const double a = tid > 0 ? gl + step * (double)tid : gl, b = tid < 256 ? gl + step * (double)(tid + 1) : gu;
+        for (int e = max(c0, 0); e < min(c1, n); e++) blo[e] = a, bhi[e] = b;
+      }
+      __syncthreads();
+    }
+    double lo = nn2[mm], hi = nn2[96 + mm];
     if (tid < 256)
-      for (int round = 0; round < 27; round++) {
+      for (int round = 0; round < 23; round++) {
         const double w = hi - lo;
         const double sigma = lo + w * (double)(l8 < 3 ? l8 + 1 : 1) * 0.25;
         const int cnt = sturm_count(Tg, n, sigma);
@@ -1103,11 +1121,30 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     Tm[e] = s;
   }
   __syncthreads();
-  for (int e = tid; e < n * n; e += MARG_THREADS) {
-    const int r = e / n, c = e % n;
-    double s = 0;
-    for (int k = 0; k < m15; k++) s = fma(Tm[r * m15 + k], A[k * D + m15 + c], s);
-    Ar[r * LDN + c] = A[(m15 + r) * D + m15 + c] - s;
+  {  // 4 x 4 outputs per thread (19 x 19 blocks): a quarter of the LDS reads of one output per thread
+    const int nb4 = (n + 3) >> 2;
+    for (int blk = tid; blk < nb4 * nb4; blk += MARG_THREADS) {
+      const int r0 = 4 * (blk / nb4), c0 = 4 * (blk % nb4);
+      double acc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+      for (int k = 0; k < m15; k++) {
+        double tv[4], av[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) tv[i] = Tm[min(r0 + i, n - 1) * m15 + k], av[i] = A[k * D + m15 + min(c0 + i, n - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = fma(tv[i], av[j], acc[i][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (r0 + i < n && c0 + j < n) Ar[(r0 + i) * LDN + c0 + j] = A[(m15 + r0 + i) * D + m15 + c0 + j] - acc[i][j];
+    }
   }
   for (int r = tid; r < n; r += MARG_THREADS) {
     double s = 0;
