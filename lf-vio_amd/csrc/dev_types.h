@@ -120,6 +120,16 @@ struct TRState {
   LfvioIterationSummary trace[LFVIO_MAX_TRACE];
 };
 
+// What the trust-region bookkeeping (k_decide) changes in the header.  In the passes of a graph that follow another pass the
+// bookkeeping rides in the prologue of k_lin (every workgroup repeats it, none of them may write the header the others
+// are reading): workgroup 0 leaves the outcome here with dec_pending set, k_sum / k_presum take their flags from it, and
+// k_solve — one workgroup per slot — moves it into the header (kernels_lin.h MODE_DECIDE, kernels_solve.h commit_decision).
+struct TRDecision {
+  double radius, mu, x_cost, x_norm, cand_cost, model_cost_change;
+  int iteration, cur, do_lin, do_schur, done, termination, chol_fail, num_succ, num_unsucc, consec_invalid, trace_len, skip_step;
+  int acc_z, pad_;  // accepted candidate slot (0: the regular one)
+};
+
 // the eight int flags at the head of the int block of TRHead, fetched with ONE load: the guards at the top of every
 // kernel of the loop test two or three of them, and each separate (dependent, short-circuited) load is a memory round trip
 struct __attribute__((aligned(8))) TRFlags {
@@ -160,7 +170,8 @@ struct Slot {
   int tail_state, passes_used;  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
-  int lbw, lbw_pad_;             // landmark blocks per workgroup of k_lin's landmark role (their Schur SYRK stays in registers)
+  int dec_pending, dec_pad_;     // dec holds a decision k_solve has not moved into the header yet
+  TRDecision dec;
   double g[3], tr_over_row, half_row, sqrt_info;
   FrameState x0;
   LfvioPreintegration imu[LFVIO_WINDOW_SIZE];

@@ -6,6 +6,7 @@
 //   k_sum     : deterministic fixed-order reduction of the per-workgroup partials
 #pragma once
 #include "dev_factors.h"
+#include "tr_decide.h"
 
 #define SLOT(base, stride) ((Slot *)((char *)(base) + (size_t)blockIdx.y * (stride)))
 
@@ -16,6 +17,7 @@ constexpr int MODE_MARG = 1;        // MODE_MARG + flag: 1 = MARGIN_OLD, 2 = MAR
 // (Slot::tail_state: 0 not run, 2 finished); they leave `done` set, so later solve passes skip the slot.  Nothing a
 // gated kernel tests is written before the last of them (k_marg_solve) ends.
 constexpr int MODE_GATED = 16;
+constexpr int MODE_DECIDE = 64;   // the trust-region bookkeeping of the pass before rides in the prologue (see k_lin)
 constexpr int MODE_NOCOUNT = 32;  // k_lin launched role by role: only the first of the launches counts the pass
 DEV bool tail_gate(const Slot *S, int done) { return done && S->tail_state == 0; }
 DEV bool is_marg(int mode) { return mode >= MODE_MARG; }
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       t->spec_n = 1;
       S->tail_state = 0;
       S->passes_used = 0;
+      S->dec_pending = 0;
       if (mode >= MODE_MARG) t->mu = 0.0;
     }
     __shared__ double bt[84 + 256];
@@ -243,9 +246,19 @@ DEV void schur_block(int blk, int mode, int Nlim, double (*tile)[WLD + 1], const
 // tangent column of entry ci of a stored W row (see w_row_len)
 DEV int w_col(int ci, int start, int cnt) { return ci < 6 * cnt ? 6 * start + ci : 66 + (ci - 6 * cnt); }
 
+// The state k_lin linearizes at.  Normally the header's: x / tab / lam [cur] and mu.  In a MODE_DECIDE pass it is what the
+// bookkeeping in the prologue decided, which has not reached the header yet — and when the accepted step is a speculative
+// candidate, its *E slots (one workgroup copies them into the [cur] slots for the kernels that follow, meanwhile).
+struct LinView {
+  const FrameState *x;
+  const Tab *tab;
+  const double *lam;
+  double mu;
+};
+
 // A solve repeated with a new mu on an unchanged linearization (do_schur without do_lin): only the Schur weights
 // change.  The block's W rows come back from HBM into the tile and the SYRK is redone.
-DEV void lin_schur_only_role(Slot *S, int blk, double *lds, double *part) {
+DEV void lin_schur_only_role(Slot *S, const LinView &lv, int blk, double *lds, double *part) {
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *lcoef = lds + LM_BLOCK * (WLD + 1) + 64, *le = lcoef + LM_BLOCK;
   const int tid = threadIdx.x;
@@ -265,7 +278,7 @@ DEV void lin_schur_only_role(Slot *S, int blk, double *lds, double *part) {
     if (l < S->N) {
       const double sc = S->scale_l[l], s2a = sc * sc * S->a[l];
       const double D2 = fmin(fmax(s2a, 1e-6), 1e32);
-      eb = s2a + S->tr.mu * D2;  // e-block + lm_diagonal^2
+      eb = s2a + lv.mu * D2;  // e-block + lm_diagonal^2
       const double einv = 1.0 / eb;
       cf = sc * sc * einv;
       S->einv_l[l] = einv;
@@ -279,20 +292,19 @@ DEV void lin_schur_only_role(Slot *S, int blk, double *lds, double *part) {
 // Landmark role: 64 landmarks per workgroup, 4 lanes per landmark (lane q takes the observations 1+q, 5+q, 9+q of the
 // track), so the dependent chain per lane is a quarter of the track.  The 80-wide row w_l is built in an LDS tile and
 // leaves as whole 512-byte lines.
-DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds, double *part) {
+DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double *lds, double *part) {
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *red = lds + LM_BLOCK * (WLD + 1);
   double *lcoef = red + 64, *le = lcoef + LM_BLOCK;  // Schur weight c_l and e-block of the block's landmarks
   const int tid = threadIdx.x, lml = tid >> 2, q = tid & 3;
   const TRState *tr = &S->tr;
-  const int cur = tr->cur;
-  const Tab *T = &S->tab[cur];
+  const Tab *T = lv.tab;
   const int Nlim = is_marg(mode) ? marg_plan(S, mode)->N0 : S->N;
   const int l = blk * LM_BLOCK + lml;
   const bool valid = l < Nlim;
   const int est_td = S->est_td;
   const int est_ex = is_marg(mode) ? 1 : S->est_ex;  // ResidualBlockInfo::Evaluate asks for every Jacobian
-  const double td = S->x[cur].td;
+  const double td = lv.x->td;
   for (int e = tid; e < LM_BLOCK * (WLD + 1); e += LIN_THREADS) lds[e] = 0.0;
   if (tid < 2 * LM_BLOCK) lcoef[tid] = 0.0;
   __syncthreads();
@@ -303,7 +315,7 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds, double *part
     i = S->lm_start[l];
     const int k = S->lm_cnt[l], o0 = S->lm_obs0[l];
     cnt_l = k, woff_l = S->lm_woff[l];
-    lam = S->lam[cur][l];
+    lam = lv.lam[l];
     ObsPair ob;
     load_obs(S, o0, ob.pi, ob.vi, ob.tdi, ob.rowi);
     const m33 ricT = ldm(T->ricT);
@@ -369,7 +381,7 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds, double *part
       tile[lml][COL_K] = b / D2;
       // Schur weight: e-block + lm_diagonal^2 (k_schur restates this when only mu changes)
       const double s2a = s * s * a;
-      const double eb = s2a + tr->mu * D2, einv = 1.0 / eb;
+      const double eb = s2a + lv.mu * D2, einv = 1.0 / eb;
       le[lml] = eb, lcoef[lml] = s * s * einv;
       S->einv_l[l] = einv;
     } else {
@@ -415,7 +427,7 @@ DEV void lin_landmark_role(Slot *S, int blk, int mode, double *lds, double *part
 // column col to both operands: D += C^T C).  The accumulator is 4 doubles per lane instead of 105 and no cross-lane
 // reduction of the Gram entries is left.  LDS operations of one wave execute in program order, so between the phases
 // only the compiler has to be kept from moving them (wavefront-scope fences).
-DEV void lin_gram_role(Slot *S, int wg, int mode, double *lds) {
+DEV void lin_gram_role(Slot *S, const LinView &lv, int wg, int mode, double *lds) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int chunk = 4 * wg + wv;
   if (chunk >= S->nChunks) return;
@@ -425,14 +437,12 @@ DEV void lin_gram_role(Slot *S, int wg, int mode, double *lds) {
   double(*Qf)[16] = (double(*)[16])(my + 32 * 17);      // 16 x 16
   double(*E)[20] = (double(*)[20])(my + 32 * 17 + 256);  // 14 x 20
   double(*T1)[20] = (double(*)[20]) my;
-  const TRState *tr = &S->tr;
-  const int cur = tr->cur;
-  const Tab *T = &S->tab[cur];
+  const Tab *T = lv.tab;
   const int pair = S->chunk_pair[chunk];
   const int j = pair % 11;
   const int begin = S->chunk_begin[chunk], end = S->chunk_end[chunk];
   const int est_td = S->est_td;
-  const double td = S->x[cur].td;
+  const double td = lv.x->td;
   PairU u;
   load_pair_uniform(T, pair, u);
   // E: basis(14) -> factor columns(20) = [Pi th_i Pj th_j tic th_ic td r]
@@ -445,7 +455,7 @@ DEV void lin_gram_role(Slot *S, int wg, int mode, double *lds) {
   if (idx < end) {
     const int oj = S->pm_obs[idx], l = S->pm_lm[idx];
     const int oi = S->lm_obs0[l];
-    const double lam = S->lam[cur][l];
+    const double lam = lv.lam[l];
     ObsPair ob;
     load_obs(S, oi, ob.pi, ob.vi, ob.tdi, ob.rowi);
     load_obs(S, oj, ob.pj, ob.vj, ob.tdj, ob.rowj);
@@ -517,7 +527,7 @@ DEV void lin_gram_role(Slot *S, int wg, int mode, double *lds) {
   }
 }
 
-DEV void lin_imu_role(Slot *S, int f, int mode, double *lds) {
+DEV void lin_imu_role(Slot *S, const LinView &lv, int f, int mode, double *lds) {
   double(*Jr)[30] = (double(*)[30]) lds;
   double(*Jw)[31] = (double(*)[31])(lds + 450);
   double *rr = lds + 450 + 465, *rw = rr + 16;
@@ -529,7 +539,7 @@ DEV void lin_imu_role(Slot *S, int f, int mode, double *lds) {
     for (int e = tid; e < IMU_OUT; e += LIN_THREADS) out[e] = 0.0;
     return;
   }
-  const FrameState *x = &S->x[S->tr.cur];
+  const FrameState *x = lv.x;
   for (int e = tid; e < 450; e += LIN_THREADS) Jr[e / 30][e % 30] = 0.0;
   __syncthreads();
   // two single-lane jobs on two waves: residual | Jacobian
@@ -569,14 +579,14 @@ DEV void lin_imu_role(Slot *S, int f, int mode, double *lds) {
   }
 }
 
-DEV void lin_prior_role(Slot *S, int mode, double *lds) {
+DEV void lin_prior_role(Slot *S, const LinView &lv, int mode, double *lds) {
   double *dx = lds, *r = lds + KP, *part = r + KP;  // part: [2][KP]
   const int tid = threadIdx.x;
   double *g = S->prior_g;
   for (int c = tid; c < KP + 4; c += LIN_THREADS) g[c] = 0.0;
   if (!S->prior_valid || (S->sharded && !S->pose_side)) return;
   const int n = S->prior_n;
-  const FrameState *x = &S->x[S->tr.cur];
+  const FrameState *x = lv.x;
   if (tid < S->prior_nb) prior_block_dx(S, x, tid, dx);
   __syncthreads();
   const double *J = S->prior_J;
@@ -611,18 +621,49 @@ DEV void lin_prior_role(Slot *S, int mode, double *lds) {
 // (see tail_gate)
 __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode_bits, int gLw, int gCh) {
   Slot *S = SLOT(base, stride);
-  const TRState *tr = &S->tr;
+  TRState *tr = &S->tr;
   const int mode = mode_bits & (MODE_GATED - 1);
   const TRFlags fl = tr_flags(tr);
-  const int do_lin = fl.do_lin, do_schur = fl.do_schur;
+  int do_lin = fl.do_lin, do_schur = fl.do_schur, cur = fl.cur, acc_z = 0;
+  double mu = tr->mu;
   if (mode_bits & MODE_GATED) {
     if (!tail_gate(S, fl.done)) return;
   } else {
+    int done = fl.done;
+    const bool owner = blockIdx.x == 0 && !(mode_bits & MODE_NOCOUNT);
+    if ((mode_bits & MODE_DECIDE) && !done) {
+      // The bookkeeping of the pass before (what k_decide does when it is launched on its own), repeated by every
+      // workgroup: none of them may write the header the others are still reading, so workgroup 0 leaves the outcome in
+      // S->dec for k_sum and k_solve (which moves it into the header) and each workgroup goes on with its own copy.
+      __shared__ TRDecision dsh;
+      if (threadIdx.x < 64) {
+        TRHead t = *reinterpret_cast<const TRHead *>(tr);
+        const int K = decide_candidates(t);
+        DecideSums sm;
+        decide_sums(S, t, K, 0, S->nLmBlocks, threadIdx.x, sm);
+        if (threadIdx.x == 0) {
+          const int az = decide_walk(t, sm, K, 0, S->max_iter, owner ? tr : nullptr);
+          decision_from(dsh, t, az);
+          if (owner) S->dec = dsh, S->dec_pending = 1;
+        }
+      }
+      __syncthreads();
+      // (wave-uniform: kept on the scalar side, the view's pointers included)
+      do_lin = __builtin_amdgcn_readfirstlane(dsh.do_lin), do_schur = __builtin_amdgcn_readfirstlane(dsh.do_schur);
+      cur = __builtin_amdgcn_readfirstlane(dsh.cur), acc_z = __builtin_amdgcn_readfirstlane(dsh.acc_z), done = __builtin_amdgcn_readfirstlane(dsh.done);
+      mu = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dsh.mu)), __builtin_amdgcn_readfirstlane(__double2loint(dsh.mu)));
+      if (acc_z > 0 && blockIdx.x == gridDim.x - 1 && !(mode_bits & MODE_NOCOUNT)) copy_accepted(S, acc_z, cur, S->N, threadIdx.x, LIN_THREADS);
+    }
     // a pass that starts with the loop still open is a pass this slot needs (the synchronous drivers size the first
     // graph of the next call from this count)
-    if (mode == MODE_SOLVE && !(mode_bits & MODE_NOCOUNT) && !fl.done && blockIdx.x == 0 && threadIdx.x == 0) S->passes_used++;
-    if (fl.done | (!do_lin & !do_schur)) return;
+    if (mode == MODE_SOLVE && owner && !done && threadIdx.x == 0) S->passes_used++;
+    if (done | (!do_lin & !do_schur)) return;
   }
+  LinView lv;
+  lv.x = acc_z > 0 ? &S->xE[acc_z > 0 ? acc_z - 1 : 0] : &S->x[cur];
+  lv.tab = acc_z > 0 ? &S->tabE[acc_z > 0 ? acc_z - 1 : 0] : &S->tab[cur];
+  lv.lam = acc_z > 0 ? (const double *)S->lamE[acc_z > 0 ? acc_z - 1 : 0] : (const double *)S->lam[cur];
+  lv.mu = mu;
   __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLw, gCh); each slot uses its own counts
   int b = blockIdx.x;
@@ -633,22 +674,22 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t strid
     const int nblk = is_marg(mode) ? (marg_plan(S, mode)->N0 + LM_BLOCK - 1) / LM_BLOCK : S->nLmBlocks;
     if (b >= nblk) return;
     double *part = S->schur_part + (size_t)b * SCHUR_LEN;
-    if (do_lin) lin_landmark_role(S, b, mode, lds, part);
-    else lin_schur_only_role(S, b, lds, part);
+    if (do_lin) lin_landmark_role(S, lv, b, mode, lds, part);
+    else lin_schur_only_role(S, lv, b, lds, part);
     return;
   }
   if (!do_lin) return;
   b -= gLw;
   if (b < gCh) {  // gCh workgroups of 4 chunks
-    lin_gram_role(S, b, mode, lds);
+    lin_gram_role(S, lv, b, mode, lds);
     return;
   }
   b -= gCh;
   if (b < LFVIO_WINDOW_SIZE) {
-    lin_imu_role(S, b, mode, lds);
+    lin_imu_role(S, lv, b, mode, lds);
     return;
   }
-  lin_prior_role(S, mode, lds);
+  lin_prior_role(S, lv, mode, lds);
 }
 
 // element (R, Cc) of the reduced 80x80 accumulator, R <= Cc
@@ -726,16 +767,14 @@ __global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int m
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   const int mode = mode_bits & (MODE_GATED - 1);
-  {
-    const TRFlags fl = tr_flags(tr);
-    if (mode_bits & MODE_GATED) {
-      if (!tail_gate(S, fl.done)) return;
-    } else if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
-  }
+  const TRFlags fl = tr_flags_decided(S);
+  if (mode_bits & MODE_GATED) {
+    if (!tail_gate(S, fl.done)) return;
+  } else if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
   const int tid = threadIdx.x;
   int b = blockIdx.x;
   if (b < NPAIR) {
-    if (!tr->do_lin) return;
+    if (!fl.do_lin) return;
     const int chunk_limit = is_marg(mode) ? marg_plan(S, mode)->nChunks0 : S->nChunks;
     const int c0 = S->pair_chunk0[b];
     int c1 = S->pair_chunk0[b + 1];
@@ -755,7 +794,7 @@ __global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int m
   }
   b -= NPAIR;
   if (b < PRE_SCHUR_BLOCKS) {
-    if (!tr->do_schur) return;
+    if (!fl.do_schur) return;
     const int grp = b / (SCHUR_LEN / 256), e = (b % (SCHUR_LEN / 256)) * 256 + tid;
     int parts = S->nSchurParts;
     if (is_marg(mode)) parts = (marg_plan(S, mode)->N0 + S->schur_lm - 1) / S->schur_lm;
@@ -773,7 +812,7 @@ __global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int m
     sp[(size_t)p0 * SCHUR_LEN] = (a0 + a1) + (a2 + a3);
     return;
   }
-  if (!tr->do_lin) return;
+  if (!fl.do_lin) return;
   // landmark scalars: 4 sums + 1 max over the blocks; lane-strided partials, then a fixed tree
   __shared__ double red[5][256];
   const int blocks = S->nLmBlocks;
@@ -800,16 +839,14 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   const int mode = mode_bits & (MODE_GATED - 1);
-  {
-    const TRFlags fl = tr_flags(tr);
-    if (mode_bits & MODE_GATED) {
-      if (!tail_gate(S, fl.done)) return;
-    } else if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
-  }
+  const TRFlags fl = tr_flags_decided(S);
+  if (mode_bits & MODE_GATED) {
+    if (!tail_gate(S, fl.done)) return;
+  } else if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
   const int tid = threadIdx.x;
   int b = blockIdx.x;
   if (b < HPP_BLOCKS) {
-    if (!tr->do_lin) return;
+    if (!fl.do_lin) return;
     const int e = b * 256 + tid;
     if (e >= HPP_ITEMS) return;
     double val = 0.0;
@@ -857,7 +894,7 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
   }
   b -= HPP_BLOCKS;
   if (b < SCHUR_LEN / 256) {
-    if (!tr->do_schur) return;
+    if (!fl.do_schur) return;
     const int e = b * 256 + tid;
     int parts = S->nSchurParts;
     if (is_marg(mode)) parts = (marg_plan(S, mode)->N0 + S->schur_lm - 1) / S->schur_lm;
@@ -875,7 +912,7 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
     S->schur_sum[e] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     return;
   }
-  if (!tr->do_lin) return;
+  if (!fl.do_lin) return;
   int blocks = pre ? 0 : S->nLmBlocks;  // pre: lm_sum comes from k_presum
   if (pre) {
   } else if (tid < 4) {

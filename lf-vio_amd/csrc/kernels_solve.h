@@ -7,6 +7,7 @@
 // statement these kernels are checked against.
 #pragma once
 #include "kernels_lin.h"
+#include "tr_decide.h"
 
 constexpr int SOLVE_THREADS = 256;
 constexpr int NROW = KP + 1;                       // + rhs row (forward substitution fused)
@@ -111,7 +112,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
-  const TRFlags fl = tr_flags(tr);
+  // A decision made in the prologue of this pass's k_lin is still parked in S->dec: this kernel is the one workgroup of
+  // the slot, so it moves it into the header (the other threads read the header after the barriers below).
+  const TRFlags fl = tr_flags_decided(S);
+  const int dec_pending = S->dec_pending;
+  const double mu_decided = S->dec.mu;  // (the other threads do not rely on seeing thread 0's header stores)
+  if (threadIdx.x == 0 && dec_pending) {
+    decision_to_header(tr, S->dec);
+    S->dec_pending = 0;
+  }
   const int sharded = S->sharded;
   if (fl.done | !fl.do_schur) return;
   const int tid = threadIdx.x;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   __syncthreads();  // scratch is reused below
   STAMP(S, 1);
   // ---- Jacobi scaling (iteration 0 only), diagonal_, gradient_  (dogleg_strategy.cc ComputeStep)
-  const double mu = tr->mu;
+  const double mu = dec_pending ? mu_decided : tr->mu;
   if (tid < KP) {
     const int i = tid;
     const double hii = hv[i];
@@ -1111,157 +1120,36 @@ __global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int wh
 // meet them — a rejected step halves the radius and the next candidate is the step for that radius; the walk stops at the
 // first accepted, invalid or terminating one.  An accepted candidate beyond the first is copied into the regular slot.
 // ---------------------------------------------------------------------------
+#ifdef LFVIO_DECIDE_PROFILE
+#define DSTAMP(k) STAMP(S, k)
+#else
+#define DSTAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const int lane = threadIdx.x;
   // Everything the kernel needs from the slot header in ONE batch of loads, before the first branch: a load issued
-  // behind a branch waits a full memory round trip (~0.6 us) of its own, and this kernel is nothing but such a chain.
+  // behind a branch waits a full memory round trip of its own, and this kernel is nothing but such a chain.
+  DSTAMP(20);
   TRHead t = *reinterpret_cast<const TRHead *>(tr);
   const int sharded = S->sharded, max_iter = S->max_iter, nLmBlocks = S->nLmBlocks, nlm = S->N;
-  const int cur0 = t.cur;
-  __shared__ int acc_z;
-  if (lane == 0) acc_z = 0;
+  __shared__ int acc_sh;
   if (t.done) return;
-  if (t.chol_fail) {
-    // retry the Gauss-Newton solve with the larger mu; LINEAR_SOLVER_FAILURE once mu >= max_mu
-    if (t.mu < 1.0) {
-      if (lane == 0) {
-        tr->do_lin = sharded ? 1 : 0;
-        tr->do_schur = 1;
-        tr->chol_fail = 0;
-        tr->skip_step = 1;
-      }
-      return;
-    }
-  }
-  const int K = t.chol_fail ? 1 : (t.spec_n < 1 ? 1 : (t.spec_n > 1 + SPEC_EXTRA ? 1 + SPEC_EXTRA : t.spec_n));
-  double cost[1 + SPEC_EXTRA], mlin[1 + SPEC_EXTRA], mquad[1 + SPEC_EXTRA], dn[1 + SPEC_EXTRA], xn[1 + SPEC_EXTRA];
-#pragma unroll
-  for (int z = 0; z < 1 + SPEC_EXTRA; z++) {
-    cost[z] = mlin[z] = mquad[z] = dn[z] = xn[z] = 0.0;
-    if (!t.chol_fail && z < K && !sharded) {
-      const double *cp = z == 0 ? (const double *)S->cost_part : (const double *)S->cost_partE + (size_t)(z - 1) * (SPEC_MAX_LM / 64) * LMS;
-      const double *pcz = z == 0 ? S->pose_cost : S->pose_costE[z > 0 ? z - 1 : 0];
-      double c = 0, l = 0, q = 0, d = 0, x = 0;
-      for (int k = lane; k < nLmBlocks; k += 64) {
-        const double *p = cp + (size_t)k * LMS;
-        c += p[0], l += p[1], q += p[2], d += p[3], x += p[4];
-      }
-      if (lane < 11) c += pcz[lane];
-      cost[z] = wave_sum(c), mlin[z] = wave_sum(l), mquad[z] = wave_sum(q), dn[z] = wave_sum(d), xn[z] = wave_sum(x);
-    }
-  }
-  if (sharded && !t.chol_fail) {  // all-reduced by the caller after k_xpack 3 (one candidate)
-    const double *sc = S->xch + XOFF_C;
-    cost[0] = sc[XS_CCOST], mlin[0] = sc[XS_MLIN], mquad[0] = sc[XS_MQUAD], dn[0] = sc[XS_DN], xn[0] = sc[XS_XN];
-  }
+  const int K = decide_candidates(t);
+  DecideSums sm;
+  decide_sums(S, t, K, sharded, nLmBlocks, lane, sm);
+  DSTAMP(21);
   if (lane == 0) {
-    TRState *trg = tr;
-    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-    const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
-    (void)gradient_tolerance;
-    for (int z = 0; z < K; z++) {
-      const double cgz = z == 0 ? t.cg : t.cgE[z - 1], cnz = z == 0 ? t.cn : t.cnE[z - 1];
-      const double snz = z == 0 ? t.dogleg_step_norm : t.snE[z - 1];
-      const double step_sq = z == 0 ? t.step_sq_pose : t.step_sqE[z - 1], xn2c = z == 0 ? t.xn2_pose_cand : t.xn2E[z - 1];
-      LfvioIterationSummary it;
-      it.cost = t.x_cost, it.cost_change = 0, it.gradient_max_norm = 0, it.step_norm = 0, it.relative_decrease = 0;
-      it.step_is_valid = 0, it.step_is_successful = 0;
-      bool finished = false, go_on = false;
-      bool step_valid = false;
-      double model_cost_change = 0;
-      if (!t.chol_fail) {
-        // model_cost_change = -(J step)^T (r + J step / 2) = -delta.g - 1/2 delta^T H delta
-        // unscaled pose direction delta_p = cg' G + cn' N where gradient_/diagonal_*scale = G, gn/diag*scale = N
-        const double lin = cgz * t.q[Q_gG] + cnz * t.q[Q_gN] + mlin[z];
-        const double quad = cgz * cgz * t.q[Q_GG] + 2.0 * cgz * cnz * t.q[Q_GN] + cnz * cnz * t.q[Q_NN] + mquad[z];
-        model_cost_change = -lin - 0.5 * quad;
-        step_valid = model_cost_change > 0.0;
-      }
-      t.model_cost_change = model_cost_change;
-      it.step_is_valid = step_valid ? 1 : 0;
-      if (!step_valid) {
-        // HandleInvalidStep
-        if (++t.consec_invalid >= 5) {
-          t.termination = LFVIO_FAILURE;
-          t.done = 1;
-          finished = true;
-        } else {
-          t.mu *= 10.0;  // StepIsInvalid
-          t.chol_fail = 0;
-          t.do_lin = sharded ? 1 : 0;  // sharded: the exchange buffers were reduced in place, rebuild them
-          t.do_schur = 1;
-        }
-      } else {
-        t.consec_invalid = 0;
-        const double candidate_cost = isfinite(cost[z]) ? cost[z] : 1.79769313486231570815e+308;
-        t.cand_cost = candidate_cost;
-        it.step_norm = sqrt(step_sq + dn[z]);
-        if (it.step_norm <= parameter_tolerance * (t.x_norm + parameter_tolerance)) {
-          t.termination = LFVIO_CONVERGENCE;
-          t.done = 1;
-          finished = true;
-        } else {
-          it.cost_change = t.x_cost - candidate_cost;
-          if (fabs(it.cost_change) <= function_tolerance * t.x_cost) {
-            t.termination = LFVIO_CONVERGENCE;
-            t.done = 1;
-            finished = true;
-          } else {
-            it.relative_decrease = it.cost_change / model_cost_change;
-            if (it.relative_decrease > min_relative_decrease) {
-              // HandleSuccessfulStep: x <- candidate; the next k_lin re-evaluates cost/gradient there
-              t.cur ^= 1;
-              acc_z = z;
-              t.x_norm = sqrt(xn2c + xn[z]);
-              it.step_is_successful = 1;
-              it.cost = candidate_cost;  // replaced by the re-evaluated x_cost when the trace is read
-              if (it.relative_decrease < 0.25) t.radius *= 0.5;
-              if (it.relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * snz);
-              t.mu = fmax(1e-8, 2.0 * t.mu / 10.0);
-              t.do_lin = 1;
-              t.do_schur = 1;
-              t.x_cost = candidate_cost;
-            } else {
-              // HandleUnsuccessfulStep / StepRejected: the next candidate is the step for the halved radius
-              t.radius *= 0.5;
-              t.do_lin = 0;
-              t.do_schur = 0;
-              it.cost = candidate_cost;
-              go_on = true;
-            }
-          }
-        }
-      }
-      if (finished) break;  // the converged iteration is not pushed (Minimize() returns before Finalize)
-      // FinalizeIterationAndCheckIfMinimizerCanContinue
-      if (it.step_is_successful)
-        t.num_succ++;
-      else
-        t.num_unsucc++;
-      it.trust_region_radius = t.radius;
-      if (t.trace_len < LFVIO_MAX_TRACE) trg->trace[t.trace_len++] = it;
-      if (t.iteration >= max_iter) {
-        t.termination = LFVIO_NO_CONVERGENCE;
-        t.done = 1;
-      } else if (t.radius <= min_trust_region_radius) {
-        t.termination = LFVIO_CONVERGENCE;
-        t.done = 1;
-      }
-      t.iteration++;
-      if (!go_on || t.done) break;
-    }
-    *reinterpret_cast<TRHead *>(trg) = t;
+    const int az = decide_walk(t, sm, K, sharded, max_iter, tr);
+    DSTAMP(22);
+    TRDecision d;
+    decision_from(d, t, az);
+    decision_to_header(tr, d);
+    acc_sh = az | (t.cur << 8);
   }
   __syncthreads();
-  const int az = acc_z;
-  if (az > 0) {  // the accepted step is a speculative candidate: bring it into the slot x[cur ^ 1] stood for
-    const int dst = cur0 ^ 1;
-    const double *xs = (const double *)&S->xE[az - 1], *ts = (const double *)&S->tabE[az - 1], *ls = S->lamE[az - 1];
-    double *xd = (double *)&S->x[dst], *td = (double *)&S->tab[dst], *ld = S->lam[dst];
-    for (int k = lane; k < (int)(sizeof(FrameState) / 8); k += 64) xd[k] = xs[k];
-    for (int k = lane; k < (int)(sizeof(Tab) / 8); k += 64) td[k] = ts[k];
-    for (int k = lane; k < nlm; k += 64) ld[k] = ls[k];
-  }
+  DSTAMP(23);
+  const int az = acc_sh & 255;
+  if (az > 0) copy_accepted(S, az, acc_sh >> 8, nlm, lane, 64);
 }

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -399,7 +400,6 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->nChunks = nChunks;
   lm_woff[N] = N == 0 ? 0 : lm_woff[N - 1] + w_row_len(lm_cnt[N - 1]);
   S->nLmBlocks = (N + LM_BLOCK - 1) / LM_BLOCK;
-  S->lbw = 1;
   S->schur_lm = SCHUR_LM;  // one part per landmark block: k_lin forms it from its LDS tile
   S->nSchurParts = S->nLmBlocks;
   info.gLm = S->nLmBlocks, info.gLw = S->nSchurParts, info.gCh = nChunks, info.gSc = S->nSchurParts;
@@ -584,9 +584,15 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
 }
 
 // speculate: small windows evaluate the steps for radius, radius / 2, radius / 4 in every pass (dev_types.h, SPEC_EXTRA)
-void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool speculate = false) {
+// first / last: position of the pass in the sequence being issued (a graph, or a plain run of passes).  For small windows
+// the trust-region bookkeeping of a pass rides in the prologue of the NEXT pass's k_lin (MODE_DECIDE, one launch less per
+// pass); k_decide itself is only launched behind the last pass, so that the header is final where the sequence ends.
+void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool speculate = false, bool first = true, bool last = true) {
   const size_t st = c->L.total;
-  launch_lin(c, count, g, mode);
+  const bool solve = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & MODE_GATED);
+  static const bool no_merge = std::getenv("LFVIO_NO_MERGE") != nullptr;
+  const bool merge = solve && g.lm <= DOGLEG_INLINE_BLOCKS && !no_merge;
+  launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
   launch_sum(c, count, g, mode);
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
     hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
@@ -601,7 +607,7 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
       hipLaunchKernelGGL(k_cost<4>, dim3(spec * nb, count), dim3(256), 0, c->stream, c->d_base, st, g.lm, spec);
     else
       hipLaunchKernelGGL(k_cost<1>, dim3(spec * nb, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, spec);
-    hipLaunchKernelGGL(k_decide, dim3(1, count), dim3(64), 0, c->stream, c->d_base, st);
+    if (!merge || last) hipLaunchKernelGGL(k_decide, dim3(1, count), dim3(64), 0, c->stream, c->d_base, st);
   }
 }
 
@@ -674,7 +680,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       CaptureGuard guard(c->stream);
       if (setup)
         hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
-      for (int it = 0; it < npass; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate);
+      for (int it = 0; it < npass; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1);
       if (tail_flag >= 0) {
         hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
         rc = enqueue_marg(c, count, tail_flag, false, true);
@@ -734,7 +740,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       CaptureGuard guard(c->stream);
-      for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE);
+      for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1);
       HIPCHK(c, guard.end(&graph));
       HIPCHK(c, hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
@@ -742,7 +748,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     }
     HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
   } else {
-    for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE);
+    for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1);
   }
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
