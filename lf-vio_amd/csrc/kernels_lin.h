@@ -735,25 +735,6 @@ DEV bool col_active(const Slot *S, int c, int mode) {
   return true;
 }
 
-// Gram part of one H_pp / g_p entry: the upload built, per entry, the list of Gram-partial offsets that add up to it
-// (lfvio_hip.hip).  Two dependent loads (list bounds -> offsets -> values) instead of a walk over pair and chunk tables;
-// four accumulators, fixed association => deterministic.
-DEV double gram_gather(const Slot *S, int e, int mode) {
-  const int beg = S->sum_off[e];
-  int end = S->sum_off[e + 1];
-  if (is_marg(mode)) end = marg_plan(S, mode)->nChunks0 > 0 ? S->sum_end_marg[e] : beg;
-  const int *it = S->sum_items;
-  const double *gp = S->pre_gram ? (const double *)S->pairG : (const double *)S->gram_part;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int k = beg;
-  for (; k + 4 <= end; k += 4) {
-    const int o0 = it[k], o1 = it[k + 1], o2 = it[k + 2], o3 = it[k + 3];
-    s0 += gp[o0], s1 += gp[o1], s2 += gp[o2], s3 += gp[o3];
-  }
-  for (; k < end; k++) s0 += gp[it[k]];
-  return (s0 + s1) + (s2 + s3);
-}
-
 // ---------------------------------------------------------------------------
 // k_presum: grid (NPAIR + 15 * groups + 1, batch) x 256, groups = ceil(parts / PRE_GROUP) — only launched for large windows, where one thread of
 // k_sum would otherwise walk thousands of partials.  First level of the fixed-order reductions:
@@ -835,63 +816,130 @@ __global__ __launch_bounds__(256) void k_presum(char *base, size_t stride, int m
   if (tid < 5) S->lm_sum[tid] = red[tid][0];
 }
 
-__global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode_bits, int pre) {
-  Slot *S = SLOT(base, stride);
-  const TRState *tr = &S->tr;
+// Byte offsets, inside a slot blob, of the arrays k_sum's H_pp role reads first (the same for every slot of a context):
+// passed BY VALUE, so that the first round of loads needs nothing from memory but the block and thread index — a GP<>
+// member would have to be fetched first, and every dependent fetch is a memory round trip (~1.5 us) of this short kernel.
+struct SumArgs {
+  long long sum_off, sum_end_marg, sum_items, gram_part, pairG, imu_out, prior_A;
+};
+template <class T>
+DEV T *blob_at(const Slot *S, long long off) { return (T *)((char *)S + off); }
+#define SUM_KEEP(v) asm volatile("" ::"v"(v))
+
+// One entry e of the packed H_pp (e < PACKED) or of g_p: Gram partials of the frame pairs touching it, the (at most two)
+// IMU factors, the prior — added in that fixed order.  Three rounds of loads: (1) flags, list bounds, IMU / prior operands
+// and indices, all addressed from the arguments; (2) the list of partial offsets, the prior's normal-matrix entry;
+// (3) the partials.
+DEV void sum_hpp_entry(Slot *S, const SumArgs &o, int mode_bits, int e) {
   const int mode = mode_bits & (MODE_GATED - 1);
+  const bool in = e < HPP_ITEMS;
+  const int ec = in ? e : 0;  // (the threads past the end go through the loads with entry 0)
+  const bool packed = ec < PACKED;
+  int r, c;
+  if (packed) {
+    r = (int)((sqrt(8.0 * ec + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= ec) r++;
+    while (r * (r + 1) / 2 > ec) r--;
+    c = ec - r * (r + 1) / 2;
+  } else {
+    r = c = ec - PACKED;
+  }
+  // ---- round 1
+  const TRFlags fl = tr_flags_decided(S);
+  const int tail_state = S->tail_state, est_ex = S->est_ex, est_td = S->est_td, prior_valid = S->prior_valid, sharded = S->sharded;
+  const int pose_side = S->pose_side, pre_gram = S->pre_gram, prior_n = S->prior_n;
+  const int marg_chunks = is_marg(mode) ? marg_plan(S, mode)->nChunks0 : 1;
+  const int beg = blob_at<int>(S, o.sum_off)[ec];
+  int end = blob_at<int>(S, o.sum_off)[ec + 1];
+  const int endm = blob_at<int>(S, o.sum_end_marg)[ec];
+  const int pr = S->prior_inv[r], pc = S->prior_inv[c];
+  const double pg = S->prior_g[r];
+  double imu_v[2] = {0.0, 0.0};
+  const int f0 = col_frame(r);
+  const double *imu_out = blob_at<double>(S, o.imu_out);
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int f = f0 - 1 + u;
+    if (f0 >= 0 && f >= 0 && f < LFVIO_WINDOW_SIZE) {
+      const int pl = imu_local(r, f), ql = imu_local(c, f);
+      if (packed) {
+        if (pl >= 0 && ql >= 0) imu_v[u] = imu_out[(size_t)f * IMU_OUT + pl * 30 + ql];
+      } else if (pl >= 0) {
+        imu_v[u] = imu_out[(size_t)f * IMU_OUT + 900 + pl];
+      }
+    }
+  }
+  SUM_KEEP(beg);
+  SUM_KEEP(end);
+  SUM_KEEP(endm);
+  SUM_KEEP(pr);
+  SUM_KEEP(pc);
+  SUM_KEEP(pg);
+  SUM_KEEP(imu_v[0]);
+  SUM_KEEP(imu_v[1]);
+  if (mode_bits & MODE_GATED) {
+    if (!(fl.done && tail_state == 0)) return;
+  } else if (fl.done | !fl.do_lin) return;
+  if (!in) return;
+  const bool act_r = is_marg(mode) || !((!est_ex && r >= off_ex() && r < off_ex() + 6) || (!est_td && r == off_td()));
+  const bool act_c = is_marg(mode) || !((!est_ex && c >= off_ex() && c < off_ex() + 6) || (!est_td && c == off_td()));
+  double val = 0.0;
+  if (act_r && act_c) {
+    // ---- round 2
+    if (is_marg(mode)) end = marg_chunks > 0 ? endm : beg;
+    const bool use_prior = packed && prior_valid && (!sharded || pose_side) && pr >= 0 && pc >= 0;
+    double pa = 0.0;
+    if (use_prior) pa = blob_at<double>(S, o.prior_A)[pr * prior_n + pc];
+    if (r < KC) {
+      // visual: four accumulators, fixed association => deterministic
+      const int *it = blob_at<int>(S, o.sum_items);
+      const double *gp = blob_at<double>(S, pre_gram ? o.pairG : o.gram_part);
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      int k = beg;
+      for (; k + 4 <= end; k += 4) {
+        const int o0 = it[k], o1 = it[k + 1], o2 = it[k + 2], o3 = it[k + 3];
+        s0 += gp[o0], s1 += gp[o1], s2 += gp[o2], s3 += gp[o3];
+      }
+      for (; k < end; k++) s0 += gp[it[k]];
+      val += (s0 + s1) + (s2 + s3);
+    }
+    if (packed) {
+      if (f0 >= 0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int f = f0 - 1 + u;
+          if (f >= 0 && f < LFVIO_WINDOW_SIZE && imu_local(r, f) >= 0 && imu_local(c, f) >= 0) val += imu_v[u];
+        }
+      }
+      if (use_prior) val += pa;  // prior: A' = J0^T J0
+    } else {
+      if (f0 >= 0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int f = f0 - 1 + u;
+          if (f >= 0 && f < LFVIO_WINDOW_SIZE && imu_local(r, f) >= 0) val += imu_v[u];
+        }
+      }
+      val += pg;
+    }
+  }
+  if (packed) S->Hpp[e] = val;
+  else S->gp[r] = val;
+}
+
+__global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode_bits, int pre, const SumArgs o) {
+  Slot *S = SLOT(base, stride);
+  const int mode = mode_bits & (MODE_GATED - 1);
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  if (b < HPP_BLOCKS) {
+    sum_hpp_entry(S, o, mode_bits, b * 256 + tid);
+    return;
+  }
   const TRFlags fl = tr_flags_decided(S);
   if (mode_bits & MODE_GATED) {
     if (!tail_gate(S, fl.done)) return;
   } else if (fl.done | (!fl.do_lin & !fl.do_schur)) return;  // nothing was re-linearized in this pass (rejected step): the sums stand
-  const int tid = threadIdx.x;
-  int b = blockIdx.x;
-  if (b < HPP_BLOCKS) {
-    if (!fl.do_lin) return;
-    const int e = b * 256 + tid;
-    if (e >= HPP_ITEMS) return;
-    double val = 0.0;
-    if (e < PACKED) {
-      int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-      while ((r + 1) * (r + 2) / 2 <= e) r++;
-      while (r * (r + 1) / 2 > e) r--;
-      const int c = e - r * (r + 1) / 2;
-      if (col_active(S, r, mode) && col_active(S, c, mode)) {
-        // ---- visual: Gram entries of the frame pairs that contain both columns
-        if (r < KC) val += gram_gather(S, e, mode);
-        // ---- IMU factors covering both columns (at most two)
-        const int f0 = col_frame(r);
-        if (f0 >= 0) {
-          for (int f = f0 - 1; f <= f0; f++) {
-            if (f < 0 || f >= LFVIO_WINDOW_SIZE) continue;
-            const int p = imu_local(r, f), q = imu_local(c, f);
-            if (p >= 0 && q >= 0) val += S->imu_out[(size_t)f * IMU_OUT + p * 30 + q];
-          }
-        }
-        // ---- prior: A' = J0^T J0
-        if (S->prior_valid && (!S->sharded || S->pose_side)) {
-          const int pr = S->prior_inv[r], pc = S->prior_inv[c];
-          if (pr >= 0 && pc >= 0) val += S->prior_A[pr * S->prior_n + pc];
-        }
-      }
-      S->Hpp[e] = val;
-    } else {
-      const int r = e - PACKED;
-      if (col_active(S, r, mode)) {
-        if (r < KC) val += gram_gather(S, e, mode);
-        const int f0 = col_frame(r);
-        if (f0 >= 0) {
-          for (int f = f0 - 1; f <= f0; f++) {
-            if (f < 0 || f >= LFVIO_WINDOW_SIZE) continue;
-            const int p = imu_local(r, f);
-            if (p >= 0) val += S->imu_out[(size_t)f * IMU_OUT + 900 + p];
-          }
-        }
-        val += S->prior_g[r];
-      }
-      S->gp[r] = val;
-    }
-    return;
-  }
   b -= HPP_BLOCKS;
   if (b < SCHUR_LEN / 256) {
     if (!fl.do_schur) return;

@@ -64,6 +64,7 @@ DEV double row_bcast_k(double v, int k) {  // k: compile-time after unrolling
   }
 }
 
+#define SOLVE_KEEP(v) asm volatile("" ::"v"(v))
 #define STAMP(S, k) do { if (threadIdx.x == 0) (S)->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 
 DEV double block_sum(double v, double *scratch, int tid) {
@@ -108,57 +109,29 @@ DEV double block_max(double v, double *scratch, int tid) {
 // k_solve: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS.
 // Input: H_pp (packed) and g_p assembled by k_sum, Schur sums, landmark scalars.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stride) {
+// xch_off / imu_off: byte offsets of the exchange buffer (H_pp | g_p | Schur sums | scalars) and of the IMU factor outputs
+// inside a slot blob — passed by value so that the whole input of the kernel is requested in ONE round of loads, together
+// with the loop flags and before the first branch (a GP<> member would have to be fetched first: one more round trip).
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stride, long long xch_off, long long imu_off) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
-  // A decision made in the prologue of this pass's k_lin is still parked in S->dec: this kernel is the one workgroup of
-  // the slot, so it moves it into the header (the other threads read the header after the barriers below).
-  const TRFlags fl = tr_flags_decided(S);
-  const int dec_pending = S->dec_pending;
-  const double mu_decided = S->dec.mu;  // (the other threads do not rely on seeing thread 0's header stores)
-  if (threadIdx.x == 0 && dec_pending) {
-    decision_to_header(tr, S->dec);
-    S->dec_pending = 0;
-  }
-  const int sharded = S->sharded;
-  if (fl.done | !fl.do_schur) return;
   const int tid = threadIdx.x;
-  double *Hs = smem;                 // TPACK: H_pp, then S, then L as 16 x 16 tiles (rhs row = row 172)
-  double *Ld = Hs + TPACK;           // 16 x 16: the diagonal block just factored, plain, TRANSPOSED (panel solve); later rhs
-  double *g = Ld + 256;              // KP
-  double *sc = g + KP;               // scale
-  double *dg = sc + KP;              // diagonal_
-  double *gr = dg + KP;              // gradient_
-  double *Gd = gr + KP;              // unscaled Cauchy direction  S gr / dg
-  double *yv = Gd + KP;              // y, then N direction
-  double *hv = yv + KP;              // gauss_newton_step_
-  double *invd = hv + KP;            // 1 / L_ii
-  double *scratch = invd + KP;       // 256 (+64 pad)
-  const bool est_ex = S->est_ex != 0, est_td = S->est_td != 0;
-  auto active = [&](int c) { return (est_ex || c < off_ex() || c >= off_ex() + 6) && (est_td || c != off_td()); };
-  STAMP(S, 0);
   const int er = tid >> 4, ek = tid & 15, esw = tsw(er, ek);  // this thread's entry of every tile
   // This thread's entry (er, ek) of every lower tile: H_pp stays in these registers for the whole kernel — the reduced
   // system is built from them and the quadratic forms G^T H G, G^T H N, N^T H N are taken from them, so H_pp is read once.
   double hreg[NTILES];
+  // the Schur sums this thread will subtract: entry (er, ek) of the 15 pose-side tiles, the rhs column, z2
+  double sreg[15], srhs[5], scross = 0.0, gval = 0.0, cp = 0.0;
+  const double *xch = (const double *)((const char *)S + xch_off);
   {
-    const double *Hg = S->Hpp;
+    const double *Hg = xch + XOFF_H, *Sg = xch + XOFF_S;
 #pragma unroll
     for (int t = 0; t < NTILES; t++) {
       const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
       hreg[t] = (i < KP && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
     }
-#pragma unroll
-    for (int a = 0; a < NTL; a++)
-      if (er == ek && 16 * a + er < KP) hv[16 * a + er] = hreg[tile_id(a, a)];  // the diagonal, for the scaling below
-    if (tid < KP) g[tid] = S->gp[tid];
-  }
-  // the Schur sums this thread will subtract, requested with everything else (a load behind the branches of the build
-  // loop below waits a memory round trip of its own): entry (er, ek) of the 15 pose-side tiles, the rhs column, z2
-  double sreg[15], srhs[5], scross = 0.0;
-  {
-    const double *Sg = S->schur_sum;
+    if (tid < KP) gval = xch[XOFF_G + tid];
     int n15 = 0;
 #pragma unroll
     for (int t = 0; t < NTILES; t++)
@@ -170,15 +143,54 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     for (int b = 0; b < 5; b++) srhs[b] = Sg[schur_index(16 * b + ek, COL_B)];
     if (tid < KC) scross = Sg[schur_index(tid, COL_K)];
   }
+  const int sharded = S->sharded;
   // landmark-side scalars: local sums, or the all-reduced totals of the sharded mode
-  const double *ls = sharded ? S->xch + XOFF_C : S->lm_sum;
-  // the pieces of the cost at x, one per thread, requested with the rest (summed by thread 0 in the fixed order below)
+  const double *ls = sharded ? xch + XOFF_C : S->lm_sum;
+  // the pieces of the cost at x, one per thread (summed by thread 0 in the fixed order below)
   if (tid < 12) {
-    double cp = 0.0;
     if (tid == 0) cp = ls[0];
-    else if (!sharded) cp = tid == 1 ? S->prior_g[KP] : S->imu_out[(size_t)(tid - 2) * IMU_OUT + 930];
-    scratch[tid] = cp;
+    else if (!sharded) cp = tid == 1 ? S->prior_g[KP] : ((const double *)((const char *)S + imu_off))[(size_t)(tid - 2) * IMU_OUT + 930];
   }
+  const bool est_ex = S->est_ex != 0, est_td = S->est_td != 0;
+  // A decision made in the prologue of this pass's k_lin is still parked in S->dec: this kernel is the one workgroup of
+  // the slot, so it moves it into the header (the other threads read the header after the barriers below).
+  const TRFlags fl = tr_flags_decided(S);
+  const int dec_pending = S->dec_pending;
+  const double mu_decided = S->dec.mu;  // (the other threads do not rely on seeing thread 0's header stores)
+  const double mu_header = tr->mu;
+#pragma unroll
+  for (int t = 0; t < NTILES; t++) SOLVE_KEEP(hreg[t]);
+#pragma unroll
+  for (int t = 0; t < 15; t++) SOLVE_KEEP(sreg[t]);
+#pragma unroll
+  for (int t = 0; t < 5; t++) SOLVE_KEEP(srhs[t]);
+  SOLVE_KEEP(scross);
+  SOLVE_KEEP(gval);
+  SOLVE_KEEP(cp);
+  SOLVE_KEEP(mu_header);
+  if (threadIdx.x == 0 && dec_pending) {
+    decision_to_header(tr, S->dec);
+    S->dec_pending = 0;
+  }
+  if (fl.done | !fl.do_schur) return;
+  double *Hs = smem;                 // TPACK: H_pp, then S, then L as 16 x 16 tiles (rhs row = row 172)
+  double *Ld = Hs + TPACK;           // 16 x 16: the diagonal block just factored, plain, TRANSPOSED (panel solve); later rhs
+  double *g = Ld + 256;              // KP
+  double *sc = g + KP;               // scale
+  double *dg = sc + KP;              // diagonal_
+  double *gr = dg + KP;              // gradient_
+  double *Gd = gr + KP;              // unscaled Cauchy direction  S gr / dg
+  double *yv = Gd + KP;              // y, then N direction
+  double *hv = yv + KP;              // gauss_newton_step_
+  double *invd = hv + KP;            // 1 / L_ii
+  double *scratch = invd + KP;       // 256 (+64 pad)
+  auto active = [&](int c) { return (est_ex || c < off_ex() || c >= off_ex() + 6) && (est_td || c != off_td()); };
+  STAMP(S, 0);
+#pragma unroll
+  for (int a = 0; a < NTL; a++)
+    if (er == ek && 16 * a + er < KP) hv[16 * a + er] = hreg[tile_id(a, a)];  // the diagonal, for the scaling below
+  if (tid < KP) g[tid] = gval;
+  if (tid < 12) scratch[tid] = cp;
   __syncthreads();
   if (fl.do_lin && tid == 0) {
     double cost = scratch[0];
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   __syncthreads();  // scratch is reused below
   STAMP(S, 1);
   // ---- Jacobi scaling (iteration 0 only), diagonal_, gradient_  (dogleg_strategy.cc ComputeStep)
-  const double mu = dec_pending ? mu_decided : tr->mu;
+  const double mu = dec_pending ? mu_decided : mu_header;
   if (tid < KP) {
     const int i = tid;
     const double hii = hv[i];

@@ -580,7 +580,10 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const int pre = (g.ch > PRE_CHUNK_LIMIT || g.sc > 4 * PRE_GROUP) ? 1 : 0;
   const int groups = (g.sc + PRE_GROUP - 1) / PRE_GROUP;
   if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + (SCHUR_LEN / 256) * groups + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, groups);
-  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre);
+  const Layout &L = c->L;
+  const SumArgs sa{(long long)L.sum_off, (long long)L.sum_end_marg, (long long)L.sum_items, (long long)L.gram_part, (long long)L.pairG, (long long)L.imu_out,
+                   (long long)L.prior_A};
+  hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre, sa);
 }
 
 // speculate: small windows evaluate the steps for radius, radius / 2, radius / 4 in every pass (dev_types.h, SPEC_EXTRA)
@@ -595,7 +598,7 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
   launch_sum(c, count, g, mode);
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
-    hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st);
+    hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out);
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
     const int spec = speculate && inl ? 1 + SPEC_EXTRA : 1;
@@ -1182,7 +1185,7 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, 1).lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
   launch_lin(c, 1, g, MODE_SOLVE);
   launch_sum(c, 1, g, MODE_SOLVE);
-  hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total);
+  hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total, (long long)c->L.xch, (long long)c->L.imu_out);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const Layout &L = c->L;
@@ -1247,7 +1250,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
   const double mu1 = mu;
   mu = 1e-8;
   if ((rc = run(1, first))) return rc;   // ordinary first pass (fixes the Jacobi scaling: k_solve does that, so run it)
-  hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total);
+  hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total, (long long)c->L.xch, (long long)c->L.imu_out);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   mu = mu1;
   if ((rc = run(0, repeat))) return rc;  // Schur only, new mu
@@ -1305,7 +1308,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
         const int gx = which == 4 ? 1 : which == 5 ? 1 + LFVIO_WINDOW_SIZE : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
         hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
       } break;
-      default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st); break;
+      default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out); break;
     }
   }
   HIPCHK(c, hipEventRecord(e1, c->stream));
