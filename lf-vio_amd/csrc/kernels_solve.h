@@ -411,14 +411,23 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       if (ta < NTL) {
         double *Tp = Hs + tile_id(ta, kb) * TSZ;
         const double *Tk = Hs + tile_id(kb, kb) * TSZ;
-        double x[16];
+        double x[16], dv[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = Tp[tsw(r, j)];
+        for (int j = 0; j < 16; j++) x[j] = Tp[tsw(r, j)], dv[j] = invd[16 * kb + j];
+        // column j of L_kk (uniform addresses) is requested one step ahead: LDS reads complete in order, so a read issued
+        // inside the step that uses it would cost that step a round trip
+        double lc[16], ln[16];
+#pragma unroll
+        for (int t = 1; t < 16; t++) lc[t] = Tk[tsw(t, 0)];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-          x[j] *= invd[16 * kb + j];
 #pragma unroll
-          for (int t = j + 1; t < 16; t++) x[t] = fma(-x[j], Tk[tsw(t, j)], x[t]);  // uniform addresses
+          for (int t = j + 2; t < 16; t++) ln[t] = Tk[tsw(t, j + 1)];
+          x[j] *= dv[j];
+#pragma unroll
+          for (int t = j + 1; t < 16; t++) x[t] = fma(-x[j], lc[t], x[t]);
+#pragma unroll
+          for (int t = j + 2; t < 16; t++) lc[t] = ln[t];
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) Tp[tsw(r, j)] = x[j];
