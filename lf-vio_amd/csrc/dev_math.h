@@ -115,18 +115,33 @@ DEV q4 R2q(const m33 &m) {
     q.y = (m.a[2] - m.a[6]) * t;
     q.z = (m.a[3] - m.a[1]) * t;
   } else {
+    // (Eigen picks the largest diagonal entry i and cycles j, k from it; written out per case, because a run-time index into
+    // the matrix and into the vector part would put both in scratch memory)
     int i = 0;
     if (m.a[4] > m.a[0]) i = 1;
-    if (m.a[8] > m.a[i * 3 + i]) i = 2;
-    int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m.a[i * 3 + i] - m.a[j * 3 + j] - m.a[k * 3 + k] + 1.0);
-    double c[3];
-    c[i] = 0.5 * t;
-    t = 0.5 / t;
-    q.w = (m.a[k * 3 + j] - m.a[j * 3 + k]) * t;
-    c[j] = (m.a[j * 3 + i] + m.a[i * 3 + j]) * t;
-    c[k] = (m.a[k * 3 + i] + m.a[i * 3 + k]) * t;
-    q.x = c[0], q.y = c[1], q.z = c[2];
+    if (m.a[8] > (i == 0 ? m.a[0] : m.a[4])) i = 2;
+    if (i == 0) {  // j = 1, k = 2
+      t = sqrt(m.a[0] - m.a[4] - m.a[8] + 1.0);
+      q.x = 0.5 * t;
+      t = 0.5 / t;
+      q.w = (m.a[7] - m.a[5]) * t;
+      q.y = (m.a[3] + m.a[1]) * t;
+      q.z = (m.a[6] + m.a[2]) * t;
+    } else if (i == 1) {  // j = 2, k = 0
+      t = sqrt(m.a[4] - m.a[8] - m.a[0] + 1.0);
+      q.y = 0.5 * t;
+      t = 0.5 / t;
+      q.w = (m.a[2] - m.a[6]) * t;
+      q.z = (m.a[7] + m.a[5]) * t;
+      q.x = (m.a[1] + m.a[3]) * t;
+    } else {  // j = 0, k = 1
+      t = sqrt(m.a[8] - m.a[0] - m.a[4] + 1.0);
+      q.z = 0.5 * t;
+      t = 0.5 / t;
+      q.w = (m.a[3] - m.a[1]) * t;
+      q.x = (m.a[2] + m.a[6]) * t;
+      q.y = (m.a[5] + m.a[7]) * t;
+    }
   }
   return q;
 }
@@ -159,13 +174,33 @@ DEV double fast_rcp(double x) {
   return y;
 }
 
-DEV double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions over the 64 lanes of a wave, every lane gets the result: three DPP steps inside groups of eight
+// lanes, one across the row of sixteen, then the four row values by v_readlane — DPP moves cost a few cycles each, the
+// ds_bpermute round trips of a __shfl_xor butterfly about a hundred each (six levels, two dwords).
+template <int CTRL>
+DEV double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+DEV double readlane_f64(double v, int src) {  // src wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+DEV double sum8(double v) {  // over aligned groups of eight lanes; every lane of the group gets the sum
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
   return v;
 }
+DEV double wave_sum(double v) {
+  v = sum8(v);
+  v += dpp_f64<0x140>(v);  // row_mirror: the other half of the row of 16
+  return readlane_f64(v, 0) + readlane_f64(v, 16) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
 DEV double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }

@@ -39,27 +39,21 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int ga
   __shared__ double rot[9], P0[3], oP0[3];
   FrameState *x = &S->x[ts->cur];
   if (tid == 0) {
-    // rot_diff from the yaw difference of frame 0 before / after the solve (estimator.cpp:534-560)
-    auto R2ypr = [](const m33 &R, double *ypr) {
-      const double n0 = R.a[0], n1 = R.a[3], n2 = R.a[6];
-      const double o0 = R.a[1], o1 = R.a[4];
-      const double a0 = R.a[2], a1 = R.a[5];
-      const double y = atan2(n1, n0);
-      const double p = atan2(-n2, n0 * cos(y) + n1 * sin(y));
-      const double r = atan2(a0 * sin(y) - a1 * cos(y), -o0 * sin(y) + o1 * cos(y));
-      ypr[0] = y / M_PI * 180.0, ypr[1] = p / M_PI * 180.0, ypr[2] = r / M_PI * 180.0;
-    };
+    // rot_diff from the yaw difference of frame 0 before / after the solve (estimator.cpp:534-560).  The reference goes
+    // through Utility::R2ypr (three atan2 per matrix, degrees) and ypr2R; only the yaw difference and the test "pitch
+    // within one degree of +-90" are used, and both follow from the first column n of the rotation without any
+    // trigonometric function: (cos y, sin y) = (n0, n1) / hypot(n0, n1), cos(pitch) = hypot(n0, n1).
     const m33 Rs0 = q2R(q_from_pose(S->x0.pose[0]));
     const m33 R00 = q2R(q_from_pose(x->pose[0]));
-    double o0[3], o00[3];
-    R2ypr(Rs0, o0);
-    R2ypr(R00, o00);
-    const double yd = (o0[0] - o00[0]) / 180.0 * M_PI;
+    const double h0 = sqrt(Rs0.a[0] * Rs0.a[0] + Rs0.a[3] * Rs0.a[3]), h00 = sqrt(R00.a[0] * R00.a[0] + R00.a[3] * R00.a[3]);
+    const double c0 = Rs0.a[0] / h0, s0 = Rs0.a[3] / h0, c00 = R00.a[0] / h00, s00 = R00.a[3] / h00;
+    const double cyd = c0 * c00 + s0 * s00, syd = s0 * c00 - c0 * s00;  // y_diff = yaw(Rs0) - yaw(R00)
     m33 rd;  // ypr2R(y_diff, 0, 0) = Rz(y) Ry(0) Rx(0)
-    rd.a[0] = cos(yd), rd.a[1] = -sin(yd), rd.a[2] = 0;
-    rd.a[3] = sin(yd), rd.a[4] = cos(yd), rd.a[5] = 0;
+    rd.a[0] = cyd, rd.a[1] = -syd, rd.a[2] = 0;
+    rd.a[3] = syd, rd.a[4] = cyd, rd.a[5] = 0;
     rd.a[6] = 0, rd.a[7] = 0, rd.a[8] = 1;
-    if (fabs(fabs(o0[1]) - 90) < 1.0 || fabs(fabs(o00[1]) - 90) < 1.0) rd = mm(Rs0, tr(R00));
+    const double sin1deg = 0.017452406437283512;  // |pitch| > 89 degrees  <=>  cos(pitch) < sin(1 degree)
+    if (h0 < sin1deg || h00 < sin1deg) rd = mm(Rs0, tr(R00));
     for (int k = 0; k < 9; k++) rot[k] = rd.a[k];
     for (int k = 0; k < 3; k++) P0[k] = x->pose[0][k], oP0[k] = S->x0.pose[0][k];
   }
@@ -510,24 +504,6 @@ DEV int jacobi_small(double *Am, double *Vm, int n, int tid, int nthreads, doubl
 //      J0 = sqrt(S) V^T,  r0 = sqrt(1/S) V^T b'  for the eigenvalues above eps, zero rows for the others.
 // Rows of J0 come out in ascending eigenvalue order, as Eigen returns them.
 // ---------------------------------------------------------------------------------------------------------------
-// cross-lane sums by DPP moves (a few cycles each) instead of ds_bpermute round trips (~100 cycles each)
-template <int CTRL>
-DEV double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-DEV double sum8(double v) {  // over aligned groups of eight lanes; every lane of the group gets the sum
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);  // row_half_mirror
-  return v;
-}
-DEV double wave_sum_dpp(double v) {  // every lane gets the sum over the 64 lanes
-  v = sum8(v);
-  v += dpp_f64<0x140>(v);  // row_mirror: the other half of the row of 16
-  return readlane_f64(v, 0) + readlane_f64(v, 16) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
 // Sturm count of T - sigma I (number of eigenvalues below sigma) by the determinant recurrence
 // p_i = (d_i - sigma) p_{i-1} - e_{i-1}^2 p_{i-2}: two dependent flops per row instead of a division.  T is read through
 // the scalar cache (uniform addresses -> s_load, no LDS or vector-memory traffic: every lane of ten waves walks the same

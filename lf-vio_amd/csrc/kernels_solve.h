@@ -33,9 +33,6 @@ DEV int lidx(int i, int j) { return tile_id(i >> 4, j >> 4) * TSZ + tsw(i & 15, 
 // lane i of every row of 16 lanes <- lane J of its row (one v_mov_b64_dpp row_newbcast)
 template <int J>
 DEV double row_bcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
-DEV double readlane_f64(double v, int src) {  // src wave-uniform
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
-}
 typedef double solve_d4 __attribute__((ext_vector_type(4)));
 // every lane <- the lane with the same row (lane & 15) in quarter T (lanes 16 T .. 16 T + 15): two gfx950 lane swaps per dword
 template <int T>

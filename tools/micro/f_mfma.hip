@@ -58,6 +58,9 @@ template <int NB> DEV bool factor_rows(double *Td, double *invd, int lane) {  //
   return bad;
 }
 
+#ifndef ABL
+#define ABL 0
+#endif
 #ifndef RCP
 #define RCP fast_rcp
 #endif
@@ -82,18 +85,34 @@ template <int NB> DEV bool factor_mfma(double *Td, double *invd, int lane) {  //
       // for every quarter (v_permlane swaps) and row k of this lane's own panel column (DPP)
       double colk = 0.0, u = 0.0;
       if (t < 3) {
+#if ABL & 2
+        colk = a[p];
+#else
         if (t == 0) colk = quarter_bcast<0>(a[p]);
         else if (t == 1) colk = quarter_bcast<1>(a[p]);
         else colk = quarter_bcast<2>(a[p]);
+#endif
+#if ABL & 4
+        u = a[p];
+        if (0)
+#endif
         switch (k) {
 #define RB(K) case K: u = row_bcast<K>(a[p]); break;
           RB(0) RB(1) RB(2) RB(3) RB(4) RB(5) RB(6) RB(7) RB(8) RB(9) RB(10) RB(11) RB(12) RB(13) RB(14) default: u = row_bcast<15>(a[p]);
 #undef RB
         }
       }
+#if ABL & 8
+      const double d = a[p] + 3.0;
+#else
       const double d = readlane_f64(a[p], 16 * t + k);  // pivot: row k in quarter t
+#endif
       if (!(d > 0.0)) bad = true;
+#if ABL & 1
+      const double rc = __builtin_amdgcn_rcp(d);
+#else
       const double rc = RCP(d);
+#endif
       if (g == t) dsave[p] = d, bop = a[p] * rc;  // B operand of the panel's rank-4 update: a[c][k] / d
       if (t < 3) {
         // the rows below the pivot, the panel columns right of it (owned by the quarters above t)
