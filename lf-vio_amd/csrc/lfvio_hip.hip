@@ -594,7 +594,9 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   const size_t st = c->L.total;
   const bool solve = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & MODE_GATED);
   static const bool no_merge = std::getenv("LFVIO_NO_MERGE") != nullptr;
-  const bool merge = solve && g.lm <= DOGLEG_INLINE_BLOCKS && !no_merge;
+  // (latency of few windows only: in a resident batch every workgroup of k_lin repeating the decision costs more of the
+  // GPU than the launch it saves)
+  const bool merge = solve && g.lm <= DOGLEG_INLINE_BLOCKS && !no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
   launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
   launch_sum(c, count, g, mode);
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {

@@ -8,20 +8,23 @@ from lfvio import abi, synth
 from lfvio.engine import Engine
 libs = sys.argv[1:3]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # > 1: a resident batch of that many windows (16 distinct seeds, cycled)
 engs = [Engine(0, p) for p in libs]
-w = synth.make_window_with_prior(0, 300, lambda x, f: engs[0].optimize(x, f))[0]
+wins = [synth.make_window_with_prior(s, 300, lambda x, f: engs[0].optimize(x, f))[0] for s in range(min(batch, 16))]
+reps = 200 if batch == 1 else 10
 for e in engs:
-    e.batch_reserve(1, 300, w.M)
-    e.batch_upload(0, w)
-    for _ in range(30):
-        e.batch_optimize(1, abi.MARGIN_OLD, sync=True)
+    e.batch_reserve(batch, 300, max(w.M for w in wins))
+    for s in range(batch):
+        e.batch_upload(s, wins[s % len(wins)])
+    for _ in range(30 if batch == 1 else 3):
+        e.batch_optimize(batch, abi.MARGIN_OLD, sync=True)
 t = np.zeros((2, rounds))
 for r in range(rounds):
     for k, e in enumerate(engs):
         a = time.perf_counter()
-        for _ in range(200):
-            e.batch_optimize(1, abi.MARGIN_OLD, sync=True)
-        t[k, r] = (time.perf_counter() - a) / 200 * 1e3
+        for _ in range(reps):
+            e.batch_optimize(batch, abi.MARGIN_OLD, sync=True)
+        t[k, r] = (time.perf_counter() - a) / reps * 1e3
 for k, p in enumerate(libs):
     print(f"{os.path.basename(p)}: {t[k].mean():.4f} ms per step (min {t[k].min():.4f})")
 print(f"B - A: {1e3 * (t[1].mean() - t[0].mean()):+.1f} us")
