@@ -619,7 +619,13 @@ DEV void lin_prior_role(Slot *S, const LinView &lv, int mode, double *lds) {
 
 // mode_bits: the mode, plus MODE_GATED for the marginalization sweep that rides behind the solve passes in the same graph
 // (see tail_gate)
-__global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t stride, int mode_bits, int gLw, int gCh) {
+// ROLES: which of the roles the instantiation contains.  The launch of a single window carries all of them; a resident
+// batch goes out role by role (lfvio_hip.hip launch_lin), and each of those kernels is compiled for its role alone: a
+// third of the code in the instruction cache, and the Gram role — 14-wide basis rows and a 4-double accumulator — runs
+// three waves per SIMD where the landmark role needs the registers of two.
+constexpr int LIN_ROLE_LM = 1, LIN_ROLE_GRAM = 2, LIN_ROLE_POSE = 4, LIN_ROLE_ALL = 7;
+template <int ROLES>
+__global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : 2) void k_lin(char *base, size_t stride, int mode_bits, int gLw, int gCh) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const int mode = mode_bits & (MODE_GATED - 1);
@@ -671,25 +677,29 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void k_lin(char *base, size_t strid
     // One landmark block per workgroup, one Schur partial per block.  (Several blocks per workgroup with the partial summed in
     // LDS was built and measured at 100 000 landmarks: k_presum + k_sum 33.5 -> 25.3 us, but the loop around the sweep — nothing
     // is carried through it — costs it 50 spilled registers and the landmark role 64 -> 97 us.)
-    const int nblk = is_marg(mode) ? (marg_plan(S, mode)->N0 + LM_BLOCK - 1) / LM_BLOCK : S->nLmBlocks;
-    if (b >= nblk) return;
-    double *part = S->schur_part + (size_t)b * SCHUR_LEN;
-    if (do_lin) lin_landmark_role(S, lv, b, mode, lds, part);
-    else lin_schur_only_role(S, lv, b, lds, part);
+    if (ROLES & LIN_ROLE_LM) {
+      const int nblk = is_marg(mode) ? (marg_plan(S, mode)->N0 + LM_BLOCK - 1) / LM_BLOCK : S->nLmBlocks;
+      if (b >= nblk) return;
+      double *part = S->schur_part + (size_t)b * SCHUR_LEN;
+      if (do_lin) lin_landmark_role(S, lv, b, mode, lds, part);
+      else lin_schur_only_role(S, lv, b, lds, part);
+    }
     return;
   }
   if (!do_lin) return;
   b -= gLw;
   if (b < gCh) {  // gCh workgroups of 4 chunks
-    lin_gram_role(S, lv, b, mode, lds);
+    if (ROLES & LIN_ROLE_GRAM) lin_gram_role(S, lv, b, mode, lds);
     return;
   }
   b -= gCh;
-  if (b < LFVIO_WINDOW_SIZE) {
-    lin_imu_role(S, lv, b, mode, lds);
-    return;
+  if (ROLES & LIN_ROLE_POSE) {
+    if (b < LFVIO_WINDOW_SIZE) {
+      lin_imu_role(S, lv, b, mode, lds);
+      return;
+    }
+    lin_prior_role(S, lv, mode, lds);
   }
-  lin_prior_role(S, lv, mode, lds);
 }
 
 // element (R, Cc) of the reduced 80x80 accumulator, R <= Cc

@@ -562,16 +562,16 @@ void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const int gram_wgs = (g.ch + 3) / 4;  // one chunk per wave
   const size_t st = c->L.total;
   if ((size_t)count * (g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1) > LIN_SPLIT_WGS) {
-    // A resident batch: the roles go out as three launches of the same kernel.  Measured at 512 windows of 300 landmarks:
+    // A resident batch: the roles go out as separate launches, each of a kernel compiled for that role alone.  Measured at 512 windows of 300 landmarks:
     // landmark role 115 us + Gram role 175 us + IMU / prior roles 104 us on their own, 679 us as ONE grid — workgroups of four
     // different code paths side by side on every CU (the sweep is ~30 KB of straight-line code per role) do not share an
     // instruction cache well; two more launches cost 9 us.
-    hipLaunchKernelGGL(k_lin, dim3(g.lw, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, 0);
-    hipLaunchKernelGGL(k_lin, dim3(gram_wgs, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, gram_wgs);
-    hipLaunchKernelGGL(k_lin, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
+    hipLaunchKernelGGL(k_lin<LIN_ROLE_LM>, dim3(g.lw, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, 0);
+    hipLaunchKernelGGL(k_lin<LIN_ROLE_GRAM>, dim3(gram_wgs, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, gram_wgs);
+    hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
     return;
   }
-  hipLaunchKernelGGL(k_lin, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, gram_wgs);
+  hipLaunchKernelGGL(k_lin<LIN_ROLE_ALL>, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, gram_wgs);
 }
 
 // fixed-order reduction of the partials; two levels once a single k_sum thread would have to walk hundreds of them
@@ -1303,7 +1303,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
       case 8: case 9: case 10: {  // k_lin by role: landmark blocks | Gram chunks | IMU factors + prior
         const int gram_wgs = (g.ch + 3) / 4;
         const int gx = which == 8 ? g.lw : which == 9 ? gram_wgs : LFVIO_WINDOW_SIZE + 1;
-        hipLaunchKernelGGL(k_lin, dim3(gx, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, which == 8 ? g.lw : 0,
+        hipLaunchKernelGGL(k_lin<LIN_ROLE_ALL>, dim3(gx, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, which == 8 ? g.lw : 0,
                            which == 9 ? gram_wgs : 0);
       } break;
       case 4: case 5: case 6: case 7: {  // k_setup by role: state + table | + IMU sqrt_info | + prior J0^T J0 | + inverse depths
