@@ -48,6 +48,7 @@ constexpr int CHUNK_LANES = 64;
 constexpr int CHUNK_MAX = 64;    // observations per Gram chunk: one wave pass; a workgroup of k_lin takes 4 chunks
 constexpr int SCHUR_LM = 64;      // landmarks per Schur SYRK part = one landmark block of k_lin
 constexpr int LMS = 16;          // per-block landmark scalar partials
+constexpr int IMU_RAW = 450 + 16;  // 15 x 30 Jacobian of (pose_i, sb_i, pose_j, sb_j) tangents, 15 residuals (+1 pad)
 constexpr int IMU_OUT = 900 + 30 + 2;
 
 __host__ __device__ inline int off_pose(int f) { return 6 * f; }
@@ -211,6 +212,7 @@ struct Slot {
   double lm_sum[LMS];
   GP<double> cost_part;             // nLmBlocks * LMS (candidate sweep)
   GP<double> imu_out;               // 10 * IMU_OUT
+  GP<double> imu_raw;               // 10 * IMU_RAW: unweighted residual and Jacobian per factor (k_imu_raw, resident batches)
   double prior_g[KP + 4];        // prior gradient (tangent cols) + cost
   double pose_cost[16];          // candidate costs of imu[0..9], prior [10]
   GP<double> Hpp;                   // packed lower KP (assembled by k_sum) = xch + XOFF_H

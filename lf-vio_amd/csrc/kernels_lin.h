@@ -527,6 +527,7 @@ DEV void lin_gram_role(Slot *S, const LinView &lv, int wg, int mode, double *lds
   }
 }
 
+template <bool raw_ready>
 DEV void lin_imu_role(Slot *S, const LinView &lv, int f, int mode, double *lds) {
   double(*Jr)[30] = (double(*)[30]) lds;
   double(*Jw)[31] = (double(*)[31])(lds + 450);
@@ -540,11 +541,19 @@ DEV void lin_imu_role(Slot *S, const LinView &lv, int f, int mode, double *lds) 
     return;
   }
   const FrameState *x = lv.x;
-  for (int e = tid; e < 450; e += LIN_THREADS) Jr[e / 30][e % 30] = 0.0;
-  __syncthreads();
-  // two single-lane jobs on two waves: residual | Jacobian
-  if (tid == 0) imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
-  if (tid == 64) imu_raw_jacobian(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], &Jr[0][0]);
+  if (raw_ready) {
+    // a resident batch: k_imu_raw has evaluated the factor (one lane per factor, 64 factors per wave) — a workgroup per factor
+    // running the two serial jobs below on one lane each spends whole waves of issue slots on them
+    const double *raw = S->imu_raw + (size_t)f * IMU_RAW;
+    for (int e = tid; e < 450; e += LIN_THREADS) Jr[e / 30][e % 30] = raw[e];
+    if (tid < 15) rr[tid] = raw[450 + tid];
+  } else {
+    for (int e = tid; e < 450; e += LIN_THREADS) Jr[e / 30][e % 30] = 0.0;
+    __syncthreads();
+    // two single-lane jobs on two waves: residual | Jacobian
+    if (tid == 0) imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
+    if (tid == 64) imu_raw_jacobian(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], &Jr[0][0]);
+  }
   __syncthreads();
   const double *Sq = S->imu_sqrt[f];
   if (tid < 15) {
@@ -619,13 +628,35 @@ DEV void lin_prior_role(Slot *S, const LinView &lv, int mode, double *lds) {
 
 // mode_bits: the mode, plus MODE_GATED for the marginalization sweep that rides behind the solve passes in the same graph
 // (see tail_gate)
+// k_imu_raw: grid ceil(10 * batch / 64) x 64 — resident batches only.  Unweighted residual and Jacobian of the IMU factors of
+// the pass, ONE LANE PER FACTOR (64 factors per wave, slot = index / 10): the two evaluations are a few thousand serial
+// instructions each, and a workgroup per factor running them on one lane spends a whole wave's issue slots per factor —
+// at 512 windows that was a quarter of the sweep.  Written to S->imu_raw for the IMU role of k_lin<LIN_ROLE_POSE_RAW>, which
+// keeps the part that is parallel inside a factor (sqrt_info weighting, J^T J, J^T r).
+__global__ __launch_bounds__(64) void k_imu_raw(char *base, size_t stride, int count) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= count * LFVIO_WINDOW_SIZE) return;
+  const int slot = g / LFVIO_WINDOW_SIZE, f = g - slot * LFVIO_WINDOW_SIZE;
+  Slot *S = reinterpret_cast<Slot *>(base + stride * (size_t)slot);
+  const TRFlags fl = tr_flags(&S->tr);
+  if (fl.done | !fl.do_lin) return;
+  if (!S->imu_active[f] || (S->sharded && !S->pose_side)) return;
+  const FrameState *x = &S->x[fl.cur];
+  double *raw = S->imu_raw + (size_t)f * IMU_RAW;
+  for (int e = 0; e < 450; e++) raw[e] = 0.0;  // (imu_raw_jacobian fills the non-zero blocks)
+  imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], raw + 450);
+  imu_raw_jacobian(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], raw);
+}
+
 // ROLES: which of the roles the instantiation contains.  The launch of a single window carries all of them; a resident
 // batch goes out role by role (lfvio_hip.hip launch_lin), and each of those kernels is compiled for its role alone: a
 // third of the code in the instruction cache, and the Gram role — 14-wide basis rows and a 4-double accumulator — runs
 // three waves per SIMD where the landmark role needs the registers of two.
 constexpr int LIN_ROLE_LM = 1, LIN_ROLE_GRAM = 2, LIN_ROLE_POSE = 4, LIN_ROLE_ALL = 7;
+constexpr int LIN_ROLE_POSE_RAW = 8;  // the pose-side roles with the IMU factors evaluated beforehand by k_imu_raw
+constexpr int LIN_LDS_POSE = 1024;     // doubles: what the IMU (947) and the prior (688) roles carve out of the workspace
 template <int ROLES>
-__global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : 2) void k_lin(char *base, size_t stride, int mode_bits, int gLw, int gCh) {
+__global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES == LIN_ROLE_POSE_RAW ? 6 : 2)) void k_lin(char *base, size_t stride, int mode_bits, int gLw, int gCh) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const int mode = mode_bits & (MODE_GATED - 1);
@@ -670,7 +701,7 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : 2) void k
   lv.tab = acc_z > 0 ? &S->tabE[acc_z > 0 ? acc_z - 1 : 0] : &S->tab[cur];
   lv.lam = acc_z > 0 ? (const double *)S->lamE[acc_z > 0 ? acc_z - 1 : 0] : (const double *)S->lam[cur];
   lv.mu = mu;
-  __shared__ __attribute__((aligned(16))) double lds[LIN_LDS];  // one workspace, aliased per role
+  __shared__ __attribute__((aligned(16))) double lds[(ROLES & (LIN_ROLE_LM | LIN_ROLE_GRAM)) ? LIN_LDS : LIN_LDS_POSE];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLw, gCh); each slot uses its own counts
   int b = blockIdx.x;
   if (b < gLw) {
@@ -693,9 +724,10 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : 2) void k
     return;
   }
   b -= gCh;
-  if (ROLES & LIN_ROLE_POSE) {
+  if (ROLES & (LIN_ROLE_POSE | LIN_ROLE_POSE_RAW)) {
     if (b < LFVIO_WINDOW_SIZE) {
-      lin_imu_role(S, lv, b, mode, lds);
+      if (ROLES & LIN_ROLE_POSE_RAW) lin_imu_role<true>(S, lv, b, mode, lds);
+      else lin_imu_role<false>(S, lv, b, mode, lds);
       return;
     }
     lin_prior_role(S, lv, mode, lds);

@@ -40,7 +40,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lm_woff, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
   size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
-      xch, lm_part, cost_part, imu_out, mscr, rotlog, eig_aux;
+      xch, lm_part, cost_part, imu_out, imu_raw, mscr, rotlog, eig_aux;
 };
 
 Layout make_layout(int maxN, int maxM) {
@@ -84,6 +84,7 @@ Layout make_layout(int maxN, int maxM) {
   L.lm_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.cost_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.imu_out = take((size_t)LFVIO_WINDOW_SIZE * IMU_OUT * 8);
+  L.imu_raw = take((size_t)LFVIO_WINDOW_SIZE * IMU_RAW * 8);
   L.mscr = take((size_t)HPP_CAP * 8);
   L.rotlog = take((size_t)JLOG_STEPS * JLOG_LD * 16);
   L.eig_aux = take(4096);
@@ -498,7 +499,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     W.schur_part.set(&W, L.schur_part);
     W.xch.set(&W, L.xch);
     W.schur_sum.set(&W, L.xch + (size_t)XOFF_S * 8), W.gp.set(&W, L.xch + (size_t)XOFF_G * 8), W.Hpp.set(&W, L.xch + (size_t)XOFF_H * 8);
-    W.lm_part.set(&W, L.lm_part), W.cost_part.set(&W, L.cost_part), W.imu_out.set(&W, L.imu_out);
+    W.lm_part.set(&W, L.lm_part), W.cost_part.set(&W, L.cost_part), W.imu_out.set(&W, L.imu_out), W.imu_raw.set(&W, L.imu_raw);
     W.mscr.set(&W, L.mscr);
     W.rotlog.set(&W, L.rotlog), W.eig_aux.set(&W, L.eig_aux);
     // field-by-field so that only pointer members are touched
@@ -506,7 +507,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     PUTP(lam); PUTP(lamE); PUTP(cost_partE);
     PUTP(prior_A);
     PUTP(a); PUTP(b); PUTP(W); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
-    PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(xch); PUTP(gp); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out);
+    PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(xch); PUTP(gp); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out); PUTP(imu_raw);
     PUTP(Hpp);
     PUTP(mscr); PUTP(rotlog); PUTP(eig_aux);
 #undef PUTP
@@ -568,7 +569,10 @@ void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
     // instruction cache well; two more launches cost 9 us.
     hipLaunchKernelGGL(k_lin<LIN_ROLE_LM>, dim3(g.lw, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, 0);
     hipLaunchKernelGGL(k_lin<LIN_ROLE_GRAM>, dim3(gram_wgs, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, gram_wgs);
-    hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
+    const bool raw = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & (MODE_GATED | MODE_DECIDE));
+    if (raw) hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
+    if (raw) hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
+    else hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
     return;
   }
   hipLaunchKernelGGL(k_lin<LIN_ROLE_ALL>, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, gram_wgs);
