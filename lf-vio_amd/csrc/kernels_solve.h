@@ -941,7 +941,10 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
 // LPT = lanes per track (and per row of J0 in the prior block).  4: a track of 11 observations is three deep instead of
 // ten — the latency of a single window; 1: a quarter of the waves for the same work — the throughput of a resident batch.
 // ---------------------------------------------------------------------------
-template <int LPT>
+// IMU_ROLE false: the grid has no workgroups for the IMU factors (k_cost_imu evaluates them one lane per factor: resident
+// batches, where a workgroup per factor with its residual on one lane is mostly issue slots spent on idle lanes) and the
+// instantiation carries none of that code.
+template <int LPT, bool IMU_ROLE = true>
 __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, int gLm, int spec) {
   constexpr int COST_THREADS = 64 * LPT, NW = LPT;
   Slot *S = SLOT(base, stride);
@@ -950,7 +953,7 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
   const TRFlags fl = tr_flags(tr);
   const int cur = fl.cur;
   // candidate z of the pass: blocks [z * nb, (z + 1) * nb) of the grid, nb = gLm + 10 + 1 (spec = 1: the one candidate)
-  const int nb = gLm + LFVIO_WINDOW_SIZE + 1;
+  const int nb = gLm + (IMU_ROLE ? LFVIO_WINDOW_SIZE : 0) + 1;
   const int z = spec > 1 ? (int)blockIdx.x / nb : 0;
   const double cg = z == 0 ? tr->cg : tr->cgE[z > 0 ? z - 1 : 0], cn = z == 0 ? tr->cn : tr->cnE[z > 0 ? z - 1 : 0];
   if (fl.done | fl.chol_fail) return;
@@ -1029,7 +1032,7 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
     return;
   }
   b -= gLm;
-  if (b < LFVIO_WINDOW_SIZE) {
+  if (IMU_ROLE && b < LFVIO_WINDOW_SIZE) {
     __shared__ double rr[15];
     double c = 0.0;
     if (S->imu_active[b]) {
@@ -1130,6 +1133,34 @@ __global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int wh
       sc[XS_CCOST] = s5[0], sc[XS_MLIN] = s5[1], sc[XS_MQUAD] = s5[2], sc[XS_DN] = s5[3], sc[XS_XN] = s5[4];
     }
   }
+}
+
+// k_cost_imu: grid ceil(10 * batch / 64) x 64 — the candidate's IMU factor costs of a resident batch, one lane per factor
+// (slot = index / 10): residual, sqrt_info weighting and the squared norm are a thousand serial instructions, which 64
+// factors share per wave here.  Candidate 0 only (resident batches do not speculate).
+__global__ __launch_bounds__(64) void k_cost_imu(char *base, size_t stride, int count) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= count * LFVIO_WINDOW_SIZE) return;
+  const int slot = g / LFVIO_WINDOW_SIZE, f = g - slot * LFVIO_WINDOW_SIZE;
+  Slot *S = reinterpret_cast<Slot *>(base + stride * (size_t)slot);
+  const TRFlags fl = tr_flags(&S->tr);
+  if (fl.done | fl.chol_fail) return;
+  double c = 0.0;
+  if (S->imu_active[f]) {
+    const FrameState *x = &S->x[fl.cur ^ 1];
+    double rr[15];
+    imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
+    const double *Sq = S->imu_sqrt[f];
+#pragma unroll
+    for (int r = 0; r < 15; r++) {
+      double v = 0;
+#pragma unroll
+      for (int k = r; k < 15; k++) v = fma(Sq[r * 15 + k], rr[k], v);
+      c += v * v;
+    }
+    c *= 0.5;
+  }
+  S->pose_cost[f] = c;
 }
 
 // ---------------------------------------------------------------------------

@@ -614,7 +614,10 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
     if ((size_t)count * nb <= 512)
       hipLaunchKernelGGL(k_cost<4>, dim3(spec * nb, count), dim3(256), 0, c->stream, c->d_base, st, g.lm, spec);
-    else
+    else if (spec == 1 && !c->shard_active) {
+      hipLaunchKernelGGL((k_cost<1, false>), dim3(g.lm + 1, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, 1);
+      hipLaunchKernelGGL(k_cost_imu, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
+    } else
       hipLaunchKernelGGL(k_cost<1>, dim3(spec * nb, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, spec);
     if (!merge || last) hipLaunchKernelGGL(k_decide, dim3(1, count), dim3(64), 0, c->stream, c->d_base, st);
   }
