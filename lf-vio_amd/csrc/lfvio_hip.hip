@@ -541,7 +541,8 @@ struct Grid {
   int lm, ch, sc, lw;
 };
 constexpr int CH_BUCKET = 16;
-constexpr size_t LIN_SPLIT_WGS = 2048;  // launches of k_lin with more workgroups than this are issued role by role
+constexpr size_t LIN_SPLIT_WGS = 2048;  // launches of k_lin with more workgroups than this are issued role by role ...
+constexpr int LIN_SPLIT_MIN_BATCH = 8;   // ... when they are a batch: ONE large window (100 000 landmarks: 64 us as one grid, 54 + 35 + 14 role by role) is better off with its roles overlapping
 
 Grid grid_for(lfvio_ctx *c, int count) {
   Grid g{1, 1, 1, 1};
@@ -562,7 +563,7 @@ Grid grid_for(lfvio_ctx *c, int count) {
 void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const int gram_wgs = (g.ch + 3) / 4;  // one chunk per wave
   const size_t st = c->L.total;
-  if ((size_t)count * (g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1) > LIN_SPLIT_WGS) {
+  if (count >= LIN_SPLIT_MIN_BATCH && (size_t)count * (g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1) > LIN_SPLIT_WGS) {
     // A resident batch: the roles go out as separate launches, each of a kernel compiled for that role alone.  Measured at 512 windows of 300 landmarks:
     // landmark role 115 us + Gram role 175 us + IMU / prior roles 104 us on their own, 679 us as ONE grid — workgroups of four
     // different code paths side by side on every CU (the sweep is ~30 KB of straight-line code per role) do not share an
