@@ -613,7 +613,7 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     hipLaunchKernelGGL(k_dogleg, dim3(spec, count), dim3(inl ? DOGLEG_INLINE_THREADS : 128), 0, c->stream, c->d_base, st, inl ? 1 : 0, spec);
     // four lanes per track while the GPU has room for the extra waves (latency of few windows), one when a batch fills it
     const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
-    if ((size_t)count * nb <= 512)
+    if ((size_t)count * nb <= 2048)  // (four waves per workgroup: 8 192 waves = eight per SIMD)
       hipLaunchKernelGGL(k_cost<4>, dim3(spec * nb, count), dim3(256), 0, c->stream, c->d_base, st, g.lm, spec);
     else if (spec == 1 && !c->shard_active) {
       hipLaunchKernelGGL((k_cost<1, false>), dim3(g.lm + 1, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, 1);
