@@ -840,7 +840,10 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
         const double sigma = lo + w * (double)(l8 < 3 ? l8 + 1 : 1) * 0.25;
         const int cnt = sturm_count(Tg, n, sigma);
         const int f1 = cnt <= mm ? 1 : 0;  // eigenvalue mm (0-based, ascending) is >= sigma
-        const int f = __shfl(f1, 3 * g3, 64) + __shfl(f1, 3 * g3 + 1, 64) + __shfl(f1, 3 * g3 + 2, 64);
+        // how many of the group's three shifts lie at or below the eigenvalue: three bits of the wave's ballot (a shuffle
+        // per lane of the group would be three LDS-crossbar round trips per round)
+        const unsigned long long bal = __ballot(f1);
+        const int f = __builtin_popcount((unsigned)(bal >> (3 * g3)) & 7u);
         const double nlo = f == 0 ? lo : lo + w * (double)f * 0.25, nhi = f == 3 ? hi : lo + w * (double)(f + 1) * 0.25;
         lo = nlo, hi = nhi;
       }
