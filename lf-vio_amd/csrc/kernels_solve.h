@@ -481,14 +481,27 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     if (tsel < NTL) {
       const int nb = tsel < NTL - 1 ? 16 : KP - 16 * (NTL - 1);
       double *Tk = Hs + tile_id(tsel, tsel) * TSZ;
-      double x[16];
+      double x[16], dv[16], lr[16], ln[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
+      for (int r = 0; r < 16; r++) dv[r] = invd[16 * tsel + (r < nb ? r : 0)];
+      lr[0] = Tk[tsw(1, 0)];
+      x[0] = (0 >= c && 0 < nb) ? dv[0] : 0.0;
+#pragma unroll
+      for (int r = 1; r < 16; r++) {
+        // row r + 1 of L is requested while row r is in work (an LDS read issued inside the chain costs it a round trip)
+        if (r + 1 < 16) {
+#pragma unroll
+          for (int j = 0; j <= r; j++) ln[j] = Tk[tsw(r + 1, j)];
+        }
         double acc = r == c ? 1.0 : 0.0, acc1 = 0.0;  // two accumulators: half the dependent chain
 #pragma unroll
-        for (int j = 0; j + 1 < r; j += 2) acc = fma(-Tk[tsw(r, j)], x[j], acc), acc1 = fma(-Tk[tsw(r, j + 1)], x[j + 1], acc1);  // x[j] = 0 above the diagonal
-        if (r & 1) acc = fma(-Tk[tsw(r, r - 1)], x[r - 1], acc);
-        x[r] = (r >= c && r < nb) ? (acc + acc1) * invd[16 * tsel + (r < nb ? r : 0)] : 0.0;
+        for (int j = 0; j + 1 < r; j += 2) acc = fma(-lr[j], x[j], acc), acc1 = fma(-lr[j + 1], x[j + 1], acc1);  // x[j] = 0 above the diagonal
+        if (r & 1) acc = fma(-lr[r - 1], x[r - 1], acc);
+        x[r] = (r >= c && r < nb) ? (acc + acc1) * dv[r] : 0.0;
+        if (r + 1 < 16) {
+#pragma unroll
+          for (int j = 0; j <= r; j++) lr[j] = ln[j];
+        }
       }
       // the LDS operations of one wave complete in program order: every read above precedes these writes
 #pragma unroll
