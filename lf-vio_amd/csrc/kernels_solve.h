@@ -744,11 +744,17 @@ DEV void dogleg_coeffs(double grad_sq_total, double gn_sq_total, double grad_gn_
 // spec: number of candidates to prepare (1, or 1 + SPEC_EXTRA for small windows): candidate z is the step for radius / 2^z.
 // Launched with grid.x = spec: workgroup z prepares candidate z (each one repeats the short common part — the kernel is
 // a latency chain, three of them side by side cost what one costs); workgroup 0 alone writes what is shared.
+#ifdef LFVIO_DOGLEG_PROFILE
+#define GSTAMP(k) do { if (blockIdx.x == 0) STAMP(S, k); } while (0)
+#else
+#define GSTAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, size_t stride, int inline_backsub, int spec) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
   const bool first = blockIdx.x == 0;
+  GSTAMP(7);
   const int z_lo = gridDim.x > 1 ? blockIdx.x : 0, z_hi = gridDim.x > 1 ? blockIdx.x + 1 : spec;
   // The kernel is one chain of small dependent steps; a load issued behind a branch or a barrier costs a full memory
   // round trip (~0.6 us) of its own, so everything that is read — the header, this thread's piece of the state, of the
@@ -790,6 +796,7 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
     }
   const int last_ok = t.trace_len > 0 ? tr->trace[t.trace_len - 1].step_is_successful : 0;
   if (t.done || t.chol_fail) return;
+  GSTAMP(8);
   __shared__ double sh[2 * DOGLEG_INLINE_BLOCKS], sh2[2 * (1 + SPEC_EXTRA)];
   __shared__ double delta[KP];
   __shared__ double cand[84 + 256];  // candidate poses (pose[0..10], ex) for build_tab, and its scratch
@@ -801,33 +808,47 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
     __syncthreads();
     const int l = tid;
     if (l < S->N) {
-      const double *w = S->W + S->lm_woff[l];
-      const int lo = 6 * S->lm_start[l], n6 = 6 * S->lm_cnt[l];
+      // two rounds of loads for the whole landmark: (1) where its row starts, its track and its scalars; (2) the row itself —
+      // all eleven frame slots of it at once (a shorter track reads on into the rows behind it, which are dropped), the
+      // dot products then run on registers.  A loop that fetches an entry, uses it and fetches the next is a memory round
+      // trip per entry (13 900 -> 10 500 cycles; what is left is 73 uncoalesced loads per lane).
+      const int woff = S->lm_woff[l], st = S->lm_start[l], cnt = S->lm_cnt[l];
+      const double s = S->scale_l[l], bl = S->b[l], einv = S->einv_l[l], dgl = S->diag_l[l], grl = S->grad_l[l];
+      const double *w = S->W + woff;
+      const int lo = 6 * st, n6 = 6 * cnt;
+      double wv[66], wt[KC - 66];
+#pragma unroll
+      for (int c = 0; c < 66; c++) wv[c] = w[c];
+#pragma unroll
+      for (int c = 66; c < KC; c++) wt[c - 66] = w[n6 + c - 66];
       double d1 = 0, d2 = 0;
-      for (int c = 0; c < n6; c++) {
-        const double wc = w[c];
-        d1 = fma(wc, ug[lo + c], d1);
-        d2 = fma(wc, un[lo + c], d2);
-      }
+#pragma unroll
+      for (int f = 0; f < 11; f++)
+        if (f < cnt) {
+#pragma unroll
+          for (int e = 0; e < 6; e++) {
+            d1 = fma(wv[6 * f + e], ug[lo + 6 * f + e], d1);
+            d2 = fma(wv[6 * f + e], un[lo + 6 * f + e], d2);
+          }
+        }
 #pragma unroll
       for (int c = 66; c < KC; c++) {
-        const double wc = w[n6 + c - 66];
-        d1 = fma(wc, ug[c], d1);
-        d2 = fma(wc, un[c], d2);
+        d1 = fma(wt[c - 66], ug[c], d1);
+        d2 = fma(wt[c - 66], un[c], d2);
       }
-      const double s = S->scale_l[l];
-      const double y = (s * S->b[l] + s * d2) * S->einv_l[l];
-      const double gn = -S->diag_l[l] * y;
+      const double y = (s * bl + s * d2) * einv;
+      const double gn = -dgl * y;
       if (first) {
         S->gn_l[l] = gn;
         S->d1[l] = d1;
         S->d2[l] = d2;
       }
       a = gn * gn;
-      b = S->grad_l[l] * gn;
+      b = grl * gn;
     }
     __syncthreads();  // ug / un alias cand
   }
+  GSTAMP(9);
   // total norms: pose side (k_solve) + landmark partials (k_backsub)
   a = wave_sum(a), b = wave_sum(b);
   if ((tid & 63) == 0) sh[(tid >> 6) * 2] = a, sh[(tid >> 6) * 2 + 1] = b;
@@ -893,6 +914,7 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
   for (int z = z_lo; z < z_hi; z++) {
     const double cg = sh2[2 * z], cn = sh2[2 * z + 1];
     FrameState *xz = z == 0 ? xc : &S->xE[z - 1];
+    GSTAMP(18);
     // delta = (step / diagonal_) * scale, step = cg gradient_ + cn gauss_newton_
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -942,7 +964,9 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
       if (z == 0) tr->step_sq_pose = sdn, tr->xn2_pose_cand = sxn;
       else tr->step_sqE[z - 1] = sdn, tr->xn2E[z - 1] = sxn;
     }
+    GSTAMP(19);
     build_tab(cand, z == 0 ? &S->tab[cur ^ 1] : &S->tabE[z - 1], tid, cand + 84);  // ends on a barrier: delta / sh / cand are free again
+    GSTAMP(3);
   }
 }
 
