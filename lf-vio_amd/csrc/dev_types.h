@@ -34,6 +34,9 @@ constexpr int JLOG_STEPS = 1600;  // >= JMAX_SWEEPS * (n - 1)
 constexpr int JMAX_SWEEPS = 20;
 constexpr int PRE_CHUNK_LIMIT = 2 * 121;  // windows with more Gram chunks reduce them per frame pair first (k_presum)
 constexpr int SUM_ITEMS_CAP = PRE_CHUNK_LIMIT * 209 + 64;
+// Entries of H_pp / g_p that have a visual (Gram) part, i.e. a gather list: rows < KC — the packed prefix and g_p[0, KC).
+// The list bounds are stored by this compact index (0 .. SUM_VIS), not by the packed index: 11 KB per upload, not 60.
+constexpr int SUM_VIS_PACKED = 73 * 74 / 2, SUM_VIS = SUM_VIS_PACKED + 73;
 constexpr int HPP_CAP = 16384;
 // exchange buffer of the landmark-sharded mode (one contiguous sum-all-reduce):
 //   [ H_pp packed | g_p | Schur sums (80x80 upper tiles) | 16 scalars ]

@@ -891,9 +891,11 @@ DEV void sum_hpp_entry(Slot *S, const SumArgs &o, int mode_bits, int e) {
   const int tail_state = S->tail_state, est_ex = S->est_ex, est_td = S->est_td, prior_valid = S->prior_valid, sharded = S->sharded;
   const int pose_side = S->pose_side, pre_gram = S->pre_gram, prior_n = S->prior_n;
   const int marg_chunks = is_marg(mode) ? marg_plan(S, mode)->nChunks0 : 1;
-  const int beg = blob_at<int>(S, o.sum_off)[ec];
-  int end = blob_at<int>(S, o.sum_off)[ec + 1];
-  const int endm = blob_at<int>(S, o.sum_end_marg)[ec];
+  // (list bounds by the compact index of the entries that have a visual part; the others read entry 0 and drop it)
+  const int vis = r < KC ? (packed ? ec : SUM_VIS_PACKED + r) : 0;
+  const int beg = blob_at<int>(S, o.sum_off)[vis];
+  int end = blob_at<int>(S, o.sum_off)[vis + 1];
+  const int endm = blob_at<int>(S, o.sum_end_marg)[vis];
   const int pr = S->prior_inv[r], pc = S->prior_inv[c];
   const double pg = S->prior_g[r];
   double imu_v[2] = {0.0, 0.0};

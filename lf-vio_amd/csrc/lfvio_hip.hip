@@ -65,10 +65,12 @@ Layout make_layout(int maxN, int maxM) {
   L.pm_obs = take(M * 4), L.pm_lm = take(M * 4);
   L.chunk_pair = take((size_t)L.capChunks * 4), L.chunk_begin = take((size_t)L.capChunks * 4),
   L.chunk_end = take((size_t)L.capChunks * 4);
-  L.prior_J = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
+  // (the two arrays whose used part varies most come last, so that an upload copies [in_begin, used end of sum_items)
+  // and the n x n the prior really has — 0.2 MB instead of 0.7 MB at 300 landmarks)
   L.prior_r = take(LFVIO_MAX_PRIOR_DIM * 8);
-  L.sum_off = take((size_t)(PACKED + KP + 1) * 4), L.sum_end_marg = take((size_t)(PACKED + KP) * 4);
+  L.sum_off = take((size_t)(SUM_VIS + 1) * 4), L.sum_end_marg = take((size_t)SUM_VIS * 4);
   L.sum_items = take((size_t)SUM_ITEMS_CAP * 4);
+  L.prior_J = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
   L.in_end = o;
   L.lam[0] = take(LB * 8), L.lam[1] = take(LB * 8);
   for (int k = 0; k < SPEC_EXTRA; k++) L.lamE[k] = take((size_t)SPEC_MAX_LM * 8);
@@ -404,6 +406,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->schur_lm = SCHUR_LM;  // one part per landmark block: k_lin forms it from its LDS tile
   S->nSchurParts = S->nLmBlocks;
   info.gLm = S->nLmBlocks, info.gLw = S->nSchurParts, info.gCh = nChunks, info.gSc = S->nSchurParts;
+  int used_items = 0;
   // ---- gather lists of k_sum: which Gram entries (chunk or, for large windows, frame pair; local index of the
   //      20 x 20 block [Pi th_i Pj th_j tic th_ic td | r]) add up to each packed H_pp / g_p entry.  Units ascend, so the
   //      marginalization's subset (pairs (0, j)) is a prefix of every list.
@@ -413,36 +416,71 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     const int units = S->pre_gram ? NPAIR : nChunks;
     int *sum_off = (int *)(h + L.sum_off), *sum_end_marg = (int *)(h + L.sum_end_marg), *sum_items = (int *)(h + L.sum_items);
     const int marg_units = S->pre_gram ? 11 : S->pair_chunk0[11];  // pairs (0, j) / their chunks
-    // counting sort by destination entry, two passes over (unit, local entry): count, then place in ascending unit order
-    static thread_local std::vector<int> cursor;
-    cursor.assign(PACKED + KP + 1, 0);
-    auto for_each_item = [&](auto &&fn) {
-      for (int u = 0; u < units; u++) {
-        const int p = S->pre_gram ? u : chunk_pair[u];
-        if (S->pre_gram && S->pair_chunk0[p + 1] == S->pair_chunk0[p]) continue;
-        const int i = p / 11, j = p % 11;
+    // Which (frame pair, local entry) pairs feed an H_pp / g_p entry is the same for every window: a table built once.
+    // Only the visual entries have a list (rows < KC: the packed prefix [0, KC (KC + 1) / 2) and g_p[0, KC)); k_sum reads
+    // the bounds of the others but never uses them.  Per upload the lists are ONE pass over those 2 774 entries — the
+    // pairs of the entry in ascending order, each with its chunks in ascending order, so units ascend as before.
+    struct PairLocal {
+      short pair, local;
+    };
+    struct EntryTable {
+      std::vector<int> first;       // [VIS + 1] into items
+      std::vector<PairLocal> items;
+    };
+    constexpr int VIS_PACKED = SUM_VIS_PACKED, VIS = SUM_VIS;  // visual entries: packed prefix, then g_p
+    static_assert(SUM_VIS_PACKED == KC * (KC + 1) / 2 && SUM_VIS == SUM_VIS_PACKED + KC, "compact gather index");
+    static const EntryTable table = [&] {
+      EntryTable t;
+      std::vector<std::vector<PairLocal>> per(VIS);
+      for (int pp = 0; pp < NPAIR; pp++) {
+        const int i = pp / 11, j = pp % 11;
+        if (i >= j) continue;
         for (int lp = 0; lp < 19; lp++) {
           const int cp = col(lp, i, j);
           for (int lq = lp; lq < 20; lq++) {
-            // cp <= cq: the local order follows the tangent order (i < j < ex < td); lq = 19 is the residual column
-            const int e = lq == 19 ? PACKED + cp : col(lq, i, j) * (col(lq, i, j) + 1) / 2 + cp;
-            fn(e, u, u * NGP + lp * 20 - (lp * (lp - 1)) / 2 + (lq - lp));
+            const int e = lq == 19 ? VIS_PACKED + cp : col(lq, i, j) * (col(lq, i, j) + 1) / 2 + cp;
+            per[e].push_back(PairLocal{(short)pp, (short)(lp * 20 - (lp * (lp - 1)) / 2 + (lq - lp))});
           }
         }
       }
-    };
-    for_each_item([&](int e, int, int) { cursor[e + 1]++; });
-    for (int e = 0; e < PACKED + KP; e++) cursor[e + 1] += cursor[e];
-    if (cursor[PACKED + KP] > SUM_ITEMS_CAP) {
+      t.first.assign(VIS + 1, 0);
+      for (int e = 0; e < VIS; e++) {
+        t.first[e + 1] = t.first[e] + (int)per[e].size();
+        t.items.insert(t.items.end(), per[e].begin(), per[e].end());
+      }
+      return t;
+    }();
+    int n_items = 0;
+    bool overflow = false;
+    for (int v = 0; v < VIS && !overflow; v++) {
+      const int e = v;  // the bounds are stored by the compact index
+      sum_off[e] = n_items;
+      int marg_end = n_items;
+      for (int k = table.first[v]; k < table.first[v + 1]; k++) {
+        const int pp = table.items[k].pair, local = table.items[k].local;
+        const int c0 = S->pair_chunk0[pp], c1 = S->pair_chunk0[pp + 1];
+        if (c1 == c0) continue;
+        if (n_items + (c1 - c0) > SUM_ITEMS_CAP) {
+          overflow = true;
+          break;
+        }
+        if (S->pre_gram) {
+          sum_items[n_items++] = pp * NGP + local;
+        } else {
+          for (int ch = c0; ch < c1; ch++) sum_items[n_items++] = ch * NGP + local;
+        }
+        if (pp < 11) marg_end = n_items;  // pairs (0, j): the marginalization's subset, a prefix of the list
+      }
+      sum_end_marg[e] = marg_end;
+    }
+    sum_off[VIS] = n_items;
+    used_items = n_items;
+    if (overflow) {
       c->err = "gather list overflow";
       return LFVIO_ERR_ARG;
     }
-    for (int e = 0; e <= PACKED + KP; e++) sum_off[e] = cursor[e];
-    for (int e = 0; e < PACKED + KP; e++) sum_end_marg[e] = sum_off[e];
-    for_each_item([&](int e, int u, int item) {
-      sum_items[cursor[e]++] = item;
-      if (u < marg_units) sum_end_marg[e]++;
-    });
+    (void)units;
+    (void)marg_units;
   }
   // ---- prior
   info.has_in_prior = pr != nullptr;
@@ -483,7 +521,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->sum_off.set(S, L.sum_off), S->sum_end_marg.set(S, L.sum_end_marg), S->sum_items.set(S, L.sum_items);
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, L.in_end - L.in_begin, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, L.sum_items + (size_t)used_items * 4 - L.in_begin, hipMemcpyHostToDevice, c->stream));
+  if (pr) HIPCHK(c, hipMemcpyAsync(d + L.prior_J, h + L.prior_J, sizeof(double) * pr->n * pr->n, hipMemcpyHostToDevice, c->stream));
   if (!info.uploaded) {
     // work-array pointers: fixed per slot until the next reserve()
     Slot W;
