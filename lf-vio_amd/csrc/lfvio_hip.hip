@@ -271,6 +271,15 @@ void plan_marg(const LfvioWindow *w, int flag, int N0, int kmax0, int nChunks0, 
   mp->n = pos - mp->m15;
 }
 
+// a prior carries n x n of its 172 x 172 Jacobian slots: copy what is there (46 KB instead of 240 KB for n = 76)
+void copy_prior(LfvioPrior *dst, const LfvioPrior *src) {
+  std::memcpy(dst, src, offsetof(LfvioPrior, linearized_jacobians));
+  if (src->valid && src->n > 0 && src->n <= LFVIO_MAX_PRIOR_DIM) {
+    std::memcpy(dst->linearized_jacobians, src->linearized_jacobians, sizeof(double) * src->n * src->n);
+    std::memcpy(dst->linearized_residuals, src->linearized_residuals, sizeof(double) * src->n);
+  }
+}
+
 // Pack one window into the pinned staging blob and upload it to slot `slot`.
 int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0, int pose_side = 1) {
   if (!w || w->num_landmarks < 0 || w->num_observations < 0) {
@@ -486,7 +495,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   info.has_in_prior = pr != nullptr;
   for (int c2 = 0; c2 < KP; c2++) S->prior_inv[c2] = -1;
   if (pr) {
-    info.in_prior = *pr;
+    copy_prior(&info.in_prior, pr);
     S->prior_valid = 1, S->prior_n = pr->n, S->prior_nb = pr->num_blocks;
     for (int i = 0; i < pr->num_blocks; i++) {
       S->prior_kind[i] = pr->blocks[i].kind, S->prior_frame[i] = pr->blocks[i].frame, S->prior_idx[i] = pr->block_idx[i];
@@ -929,7 +938,7 @@ int check_prior(lfvio_ctx *c, int slot, const Fetched &f, bool *pass) {
 void unpack_prior(lfvio_ctx *c, int slot, const Fetched &f, bool pass, LfvioPrior *out) {
   const SlotHostInfo &info = c->info[slot];
   if (pass) {
-    if (info.has_in_prior) *out = info.in_prior;
+    if (info.has_in_prior) copy_prior(out, &info.in_prior);
     else out->valid = 0;
     return;
   }

