@@ -36,3 +36,5 @@ opt = t[1, 1] * 1e6
 for p_ in sorted(set(passes)):
     sel = [i for i, q in enumerate(passes) if q == p_]
     print(f"  {p_} passes: {len(sel)} windows, optimize {opt[sel].mean():.0f} us, launches {np.mean([chunks[i] for i in sel]):.2f}")
+print("passes in stream order:", passes)
+print("graph launches in stream order:", chunks)
