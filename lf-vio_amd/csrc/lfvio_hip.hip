@@ -138,6 +138,7 @@ struct lfvio_ctx {
   bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
   // landmark-sharded mode (multi-GPU)
   bool shard_active = false;
+  bool no_merge = false;  // debug: the trust-region bookkeeping always as its own launch (lfvio_debug_set_decide_merge)
   int shard_begin = 0, shard_end = 0, shard_state = 0;
   std::vector<int> sh_start, sh_off;
   // stream-ordered sharded driver: ring of pinned flag records, one per enqueued decision (shard.inc)
@@ -646,10 +647,9 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
 void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool speculate = false, bool first = true, bool last = true) {
   const size_t st = c->L.total;
   const bool solve = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & MODE_GATED);
-  static const bool no_merge = std::getenv("LFVIO_NO_MERGE") != nullptr;
   // (latency of few windows only: in a resident batch every workgroup of k_lin repeating the decision costs more of the
   // GPU than the launch it saves)
-  const bool merge = solve && g.lm <= DOGLEG_INLINE_BLOCKS && !no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
+  const bool merge = solve && g.lm <= DOGLEG_INLINE_BLOCKS && !c->no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
   launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
   launch_sum(c, count, g, mode);
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
@@ -1392,6 +1392,13 @@ int lfvio_debug_force_eig(lfvio_ctx *c, int on) {
 int lfvio_debug_set_graph(lfvio_ctx *c, int on) {
   if (!c) return LFVIO_ERR_ARG;
   c->use_graph = on != 0;
+  return LFVIO_OK;
+}
+
+int lfvio_debug_set_decide_merge(lfvio_ctx *c, int on) {
+  if (!c) return LFVIO_ERR_ARG;
+  if (c->no_merge != (on == 0)) destroy_graph(c);  // the captured graphs hold the launch sequence
+  c->no_merge = on == 0;
   return LFVIO_OK;
 }
 

@@ -44,6 +44,11 @@ class Engine:
     def set_graph(self, on):
         self.lib.lfvio_debug_set_graph(self.ctx, int(on))
 
+    def set_decide_merge(self, on):
+        """False: k_decide after every pass instead of the bookkeeping in the prologue of the next k_lin (debug)."""
+        self.lib.lfvio_debug_set_decide_merge.argtypes = [C.c_void_p, C.c_int]
+        self.lib.lfvio_debug_set_decide_merge(self.ctx, int(on))
+
     def last_chunks(self):
         return int(self.lib.lfvio_debug_last_chunks(self.ctx))
 

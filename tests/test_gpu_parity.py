@@ -99,6 +99,28 @@ def test_graph_and_direct_launch_agree(eng):
     assert np.array_equal(a.lam, b.lam)
 
 
+@pytest.mark.parametrize("n,kw", [(300, {}), (120, dict(tr=0.3)), (33, dict(estimate_td=0)), (300, dict(max_num_iterations=3))])
+def test_bookkeeping_in_the_prologue_of_k_lin_equals_k_decide(eng, n, kw):
+    """For small windows the trust-region bookkeeping of a pass rides in the prologue of the next pass's k_lin (every
+    workgroup repeats it, workgroup 0 parks the outcome, k_solve commits it); k_decide after every pass is the same
+    arithmetic as its own launch.  Solution, iteration trace and prior must agree bit for bit — with a prior (accepted
+    speculative candidates, rejected steps) and without, through graphs of several chunks (tr = 0.3: a pass per step)."""
+    w = synth.make_window_with_prior(5, n, lambda x, f: eng.optimize(x, f), **kw)[0] if n == 300 else synth.make_window(5, n, **kw)
+    out = []
+    for merge in (False, True, True):
+        eng.set_decide_merge(merge)
+        sol, prior = eng.optimize(w, abi.MARGIN_OLD)
+        out.append((sol, prior))
+    eng.set_decide_merge(True)
+    a, b, c = out
+    for x, y in ((a, b), (b, c)):
+        assert np.array_equal(x[0].pose, y[0].pose) and np.array_equal(x[0].speed_bias, y[0].speed_bias) and np.array_equal(x[0].lam, y[0].lam)
+        assert x[0].c.num_iterations == y[0].c.num_iterations and x[0].c.final_cost == y[0].c.final_cost
+        assert [t["cost"] for t in x[0].trace()] == [t["cost"] for t in y[0].trace()]
+        assert [t["radius"] for t in x[0].trace()] == [t["radius"] for t in y[0].trace()]
+        assert np.array_equal(x[1].J(), y[1].J()) and np.array_equal(x[1].r(), y[1].r())
+
+
 def check_prior(p, ref, A, b, Aref, bref):
     assert p.valid == ref.valid == 1
     assert (p.m, p.n, p.num_blocks) == (ref.m, ref.n, ref.num_blocks)
