@@ -292,6 +292,12 @@ DEV void lin_schur_only_role(Slot *S, const LinView &lv, int blk, double *lds, d
 // Landmark role: 64 landmarks per workgroup, 4 lanes per landmark (lane q takes the observations 1+q, 5+q, 9+q of the
 // track), so the dependent chain per lane is a quarter of the track.  The 80-wide row w_l is built in an LDS tile and
 // leaves as whole 512-byte lines.
+// phase stamps of workgroup 0 (tests/tools/lin_clocks.py)
+#ifdef LFVIO_LIN_PROFILE
+#define LSTAMP(k) do { if (blockIdx.x == 0 && mode == MODE_SOLVE && threadIdx.x == 0) S->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define LSTAMP(k) do { } while (0)
+#endif
 DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double *lds, double *part) {
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *red = lds + LM_BLOCK * (WLD + 1);
@@ -305,9 +311,11 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
   const int est_td = S->est_td;
   const int est_ex = is_marg(mode) ? 1 : S->est_ex;  // ResidualBlockInfo::Evaluate asks for every Jacobian
   const double td = lv.x->td;
+  LSTAMP(22);
   for (int e = tid; e < LM_BLOCK * (WLD + 1); e += LIN_THREADS) lds[e] = 0.0;
   if (tid < 2 * LM_BLOCK) lcoef[tid] = 0.0;
   __syncthreads();
+  LSTAMP(8);
   double a = 0, b = 0, cost = 0, lam = 1.0, wtd = 0;
   d3 wPi = mk3(0, 0, 0), wTi = wPi, wTic = wPi, wTx = wPi;
   int i = 0, cnt_l = 0, woff_l = 0;
@@ -346,6 +354,7 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
       cost += 0.5 * B.rho0;
     }
   }
+  LSTAMP(9);
   // the track's sums over its 4 lanes (fixed order)
   wPi = quad_sum3(wPi), wTi = quad_sum3(wTi), wTic = quad_sum3(wTic), wTx = quad_sum3(wTx);
   wtd = quad_sum(wtd), a = quad_sum(a), b = quad_sum(b), cost = quad_sum(cost);
@@ -397,6 +406,7 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
   } else {
     cost = 0.0;  // counted once per track
   }
+  LSTAMP(18);
   cost = wave_sum(cost);
   g2 = wave_sum(g2);
   asv2 = wave_sum(asv2);
@@ -412,12 +422,15 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
     p[tid] = tid < 4 ? ((red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]))
                      : fmax(fmax(red[4], red[12]), fmax(red[20], red[28]));
   }
+  LSTAMP(19);
   // the rows leave over their non-zero span only (the block's rows are one contiguous stretch of W: offsets are prefix sums)
   if (valid) {
     double *w = S->W + woff_l;
     for (int ci = q; ci < w_row_len(cnt_l); ci += 4) w[ci] = tile[lml][w_col(ci, i, cnt_l)];
   }
+  LSTAMP(23);
   schur_block(blk, mode, Nlim, tile, lcoef, le, part);
+  LSTAMP(20);
 }
 
 // Gram role: one chunk (<= 64 observations of one frame pair) per WAVE, four chunks per workgroup; the waves never
@@ -660,6 +673,7 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const int mode = mode_bits & (MODE_GATED - 1);
+  LSTAMP(21);
   const TRFlags fl = tr_flags(tr);
   int do_lin = fl.do_lin, do_schur = fl.do_schur, cur = fl.cur, acc_z = 0;
   double mu = tr->mu;
