@@ -78,8 +78,6 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     // (pivot row p, its own source row with the swap applied by index), normalizes its pivot-row entry itself and writes
     // the new entry into the other copy — the arithmetic of swap / scale / eliminate, one barrier per pivot instead of six.
     __shared__ double Mb[2][15][31];
-    __shared__ double L[15][16];
-    __shared__ double col[16];
     for (int e = tid; e < 225; e += 256) {
       int r = e / 15, c = e % 15;
       Mb[0][r][c] = S->imu[f].covariance[e];
@@ -114,25 +112,31 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       __syncthreads();
     }
     const double(*M)[31] = Mb[1];  // 15 pivots: the result is in copy 1
+    // Column Cholesky of the inverse in ONE wave, the rows in registers (lane i: row i): the entry of row j a step needs
+    // comes by v_readlane, so the thirty barriers of the LDS version are gone.  Same operations in the same order:
+    // t = m_ij - l_i0 l_j0 - l_i1 l_j1 ..., d = sqrt(t_jj), l_ij = t / d.
     bool ok = true;
+    if (tid < 64) {
+      const int li = tid < 15 ? tid : 0;
+      double lrow[15], mrow[15];
 #pragma unroll
-    for (int j = 0; j < 15; j++) {
-      if (tid >= j && tid < 15) {
-        double t = M[tid][15 + j];
+      for (int j = 0; j < 15; j++) mrow[j] = M[li][15 + j], lrow[j] = 0.0;
 #pragma unroll
-        for (int k = 0; k < j; k++) t -= L[tid][k] * L[j][k];
-        col[tid] = t;
+      for (int j = 0; j < 15; j++) {
+        double t = mrow[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) t -= lrow[k] * readlane_f64(lrow[k], j);
+        const double sj = readlane_f64(t, j);
+        if (!(sj > 0.0)) ok = false;
+        const double d = sqrt(sj);
+        lrow[j] = tid == j ? d : t / d;
       }
-      __syncthreads();
-      const double sj = col[j];
-      if (!(sj > 0.0)) ok = false;
-      const double d = sqrt(sj);
-      if (tid >= j && tid < 15) L[tid][j] = tid == j ? d : col[tid] / d;
-      __syncthreads();
-    }
-    if (tid < 225) {
-      const int i = tid / 15, j = tid % 15;
-      S->imu_sqrt[f][tid] = (j >= i && ok) ? L[j][i] : 0.0;
+      if (tid < 15) {
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+          S->imu_sqrt[f][i * 15 + tid] = (tid >= i && ok) ? lrow[i] : 0.0;  // sqrt_info[i][j] = L[j][i], j >= i
+        }
+      }
     }
     if (!ok && tid == 0) S->imu_active[f] = 0;
   } else if (blockIdx.x >= SETUP_WGS) {
