@@ -126,10 +126,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
 #pragma unroll
     for (int t = 0; t < NTILES; t++) {
       const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
-      // (diagonal tiles are kept as full symmetric tiles: the update of the next diagonal tile hands it to the factorization
-      // in the accumulator layout, which is the transpose of the ownership — see factor)
-      const int hi_ = max(i, j), lo_ = min(i, j);
-      hreg[t] = (hi_ < KP && (j <= i || tile_a(t) == tile_b(t))) ? Hg[hi_ * (hi_ + 1) / 2 + lo_] : 0.0;
+      hreg[t] = (i < KP && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
     }
     if (tid < KP) gval = xch[XOFF_G + tid];
     int n15 = 0;
@@ -242,11 +239,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       const int a = tile_a(t), b = tile_b(t);
       const int i = 16 * a + er, j = 16 * b + ek;
       double v = 0.0;
-      if (i < KP && (j <= i || (a == b && j < KP))) {  // the lower triangle, and the mirror image inside a diagonal tile
+      if (i < KP && j <= i) {
         double h = hreg[t];
-        if (j <= i) qgg_part = fma(h * Gi[a], (i == j) ? Gj[b] : 2.0 * Gj[b], qgg_part);
+        qgg_part = fma(h * Gi[a], (i == j) ? Gj[b] : 2.0 * Gj[b], qgg_part);
         if (ai[a] && aj[b]) {
-          if (a <= 4 && i < KC && j < KC) h -= sreg[a <= 4 ? n15 : 0];
+          if (a <= 4 && i < KC) h -= sreg[a <= 4 ? n15 : 0];  // j <= i < 73
           v = si[a] * sj[b] * h;
           if (i == j) v += mu * dg[i] * dg[i];
         } else {
@@ -258,8 +255,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
           if (j < KC) r -= srhs[b < 5 ? b : 0];  // z1
           v = sj[b] * r;
         }
-      } else if (a == NTL - 1 && b == NTL - 1 && j == KP && i < KP) {
-        if (ai[a]) v = si[a] * g[i];  // the rhs row mirrored into its column of the last diagonal tile (i >= 160 > KC: no Schur part)
       }
       Hs[t * TSZ + esw] = v;
       if (a <= 4) n15++;
@@ -306,19 +301,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
   // accumulator layout D[g + 4 r][c] is the transpose of the ownership, and the tile is symmetric.  30 vector instructions
   // per pivot instead of 47 (tools/micro/f_mfma.hip: 4 900 -> 3 700 cycles per tile); the raw columns are scaled by
   // 1/sqrt(d_k) once at the end.
-  auto factor = [&](int kb, const solve_d4 *init) {
+  auto factor = [&](int kb) {
     const int nb = kb < NTL - 1 ? 16 : KP - 16 * (NTL - 1);  // pivots in this block column (12 in the last)
     double *Td = Hs + tile_id(kb, kb) * TSZ;
     const int c = lane & 15, gq = lane >> 4;
     solve_d4 a;
-    if (init) {
-      a = *init;  // straight from the update: D[g + 4 r][c] of the accumulator IS A[c][g + 4 r] of the symmetric tile
-    } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int col = gq + 4 * i;
-        a[i] = col <= c ? Td[tsw(c, col)] : Td[tsw(col, c)];
-      }
+    for (int i = 0; i < 4; i++) {
+      const int col = gq + 4 * i;
+      a[i] = col <= c ? Td[tsw(c, col)] : Td[tsw(col, c)];
     }
     double dsave[4] = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
@@ -407,7 +398,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
 #define PSTAMP(k, v) do {} while (0)
 #define PNOW() 0ll
 #endif
-  if (wave == 0) factor(0, nullptr);
+  if (wave == 0) factor(0);
   __syncthreads();
   long long pf = 0, pp = 0, pu = 0, pw = 0;
   for (int kb = 0; kb < NTL - 1; kb++) {
@@ -449,20 +440,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
       const int m = NTL - 1 - kb, ntiles = m * (m + 1) / 2;
       const int n0 = ntiles - 1 > 21 ? (ntiles - 1 - 21) / 4 : 0, split = ntiles - n0;
       if (wave == 0) {
-        // the next diagonal tile: updated in registers and factored from there (no LDS round trip in between)
-        solve_d4 dcv;
-        {
-          const int c = lane & 15, gq = lane >> 4, offA = c * TLD + gq, offC = gq * TLD + c;
-          const double *Ta = Hs + tile_id(kb + 1, kb) * TSZ + offA;
-          const double *Tc = Hs + tile_id(kb + 1, kb + 1) * TSZ + offC;
-          double av[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) av[q] = Ta[4 * q], dcv[q] = Tc[4 * TLD * q];
-#pragma unroll
-          for (int q = 0; q < 4; q++) dcv = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[q], av[q], dcv, 0, 0, 0);
-        }
+        update(kb, 0, 1, 1);
         const long long c3 = PNOW();
-        factor(kb + 1, &dcv);
+        factor(kb + 1);
         const long long c4 = PNOW();
         pu += c3 - c2, pf += c4 - c3;
         PSTAMP(8 + kb, c4 - c3);
