@@ -51,17 +51,22 @@ def pmc_traffic(workload):
     import re
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.md")), reverse=True):
-        section = None
+        section, total, found = None, None, None
         for line in open(path):
             m = re.match(r"## (\S+)", line)
             if m:
                 section = m.group(1)
-            elif section == workload and line.startswith("| k_lin |"):
+            elif section == workload and re.match(r"\| (void )?k_lin(<\d+>)? \|", line):
+                # k_lin is a template over its roles: one grid (k_lin<7>) for a single window, one launch per role
+                # (k_lin<1>, <2>, <8>) for a resident batch — a sweep is the sum of the role launches
                 cells = [c.strip() for c in line.strip().strip("|").split("|")]
                 try:
-                    return (float(cells[2]) + float(cells[3])) * 1024.0, os.path.relpath(path, ROOT)
+                    total = (total or 0.0) + (float(cells[2]) + float(cells[3])) * 1024.0
+                    found = os.path.relpath(path, ROOT)
                 except ValueError:
-                    return None, None
+                    pass
+        if total is not None:
+            return total, found
     return None, None
 
 
