@@ -24,8 +24,10 @@ int lfvio_debug_read_clocks(lfvio_ctx *ctx, long long *out32);
 int lfvio_debug_time_kernel(lfvio_ctx *ctx, int which, int count, int reps, double *avg_ms);
 /* 0: launch kernels directly, 1: replay the captured hipGraph (default). */
 int lfvio_debug_set_graph(lfvio_ctx *ctx, int on);
-/* on = 0: the trust-region bookkeeping of a pass always runs as its own launch (k_decide) instead of in the prologue of the
- * next pass's k_lin (small windows).  Both routes must give bit-identical results. */
+/* The launches a pass of few small windows saves by fusion.  on = 1 (default): the trust-region bookkeeping of a pass rides
+ * in the prologue of the next pass's k_lin, and the dogleg step and the cost of its candidates are one launch (k_step).
+ * on = 2: only the first of the two.  on = 0: neither — k_decide, k_dogleg and k_cost each as its own launch.  All three
+ * routes must give bit-identical results. */
 int lfvio_debug_set_decide_merge(lfvio_ctx *ctx, int on);
 /* on != 0: the pseudo-inverse of the dropped block always comes from its eigen-decomposition (marginalization_factor.cpp:267-272);
    default: from a Cholesky factorization when every eigenvalue is provably far above eps, from the eigen-decomposition otherwise. */

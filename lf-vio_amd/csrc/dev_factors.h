@@ -284,10 +284,9 @@ DEV void imu_raw_jacobian(const LfvioPreintegration *pre, const double *G, const
   put33(J, LD, 12, 27, I, 1.0);
 }
 
-// MarginalizationFactor::Evaluate dx part (marginalization_factor.cpp:343-362) for prior block bi.
-DEV void prior_block_dx(const Slot *S, const FrameState *x, int bi, double *dx) {
-  const int kind = S->prior_kind[bi], frame = S->prior_frame[bi], idx = S->prior_idx[bi];
-  const double *x0 = S->prior_x0[bi];
+// MarginalizationFactor::Evaluate dx part (marginalization_factor.cpp:343-362) for one prior block: kind, frame, first
+// column idx and linearization point x0 as uploaded (Slot::prior_kind / prior_frame / prior_idx / prior_x0).
+DEV void prior_block_dx(int kind, int frame, int idx, const double *x0, const FrameState *x, double *dx) {
   const double *xb = kind == LFVIO_BLOCK_POSE ? x->pose[frame]
                      : kind == LFVIO_BLOCK_SPEEDBIAS ? x->sb[frame]
                      : kind == LFVIO_BLOCK_EX_POSE ? x->ex
@@ -298,7 +297,12 @@ DEV void prior_block_dx(const Slot *S, const FrameState *x, int bi, double *dx) 
     double s = (dq.w >= 0) ? 2.0 : -2.0;
     dx[idx + 3] = s * dq.x, dx[idx + 4] = s * dq.y, dx[idx + 5] = s * dq.z;
   } else {
-    int sz = kind == LFVIO_BLOCK_SPEEDBIAS ? 9 : 1;
-    for (int k = 0; k < sz; k++) dx[idx + k] = xb[k] - x0[k];
+    const int sz = kind == LFVIO_BLOCK_SPEEDBIAS ? 9 : 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++)  // (static indices: x0 may live in registers)
+      if (k < sz) dx[idx + k] = xb[k] - x0[k];
   }
+}
+DEV void prior_block_dx(const Slot *S, const FrameState *x, int bi, double *dx) {
+  prior_block_dx(S->prior_kind[bi], S->prior_frame[bi], S->prior_idx[bi], S->prior_x0[bi], x, dx);
 }

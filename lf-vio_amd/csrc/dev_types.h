@@ -102,6 +102,7 @@ enum {
 #define LFVIO_SPEC_EXTRA 2
 #endif
 constexpr int SPEC_EXTRA = LFVIO_SPEC_EXTRA, SPEC_MAX_LM = 320;
+constexpr int WT_PAIRS = (KC + 1) / 2;
 #define TR_HEAD_FIELDS \
   double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha; \
   double cg, cn; \
@@ -209,6 +210,10 @@ struct Slot {
   GP<double> prior_A;               // n*n  (J0^T J0)
   double prior_b0[KP];           // J0^T r0
   GP<double> a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2;
+  GP<double> Wt;  // [WT_PAIRS][SPEC_MAX_LM][2]: windows of at most SPEC_MAX_LM landmarks — the rows of W once more, dense and
+                  // transposed (columns 2p, 2p + 1 of every landmark side by side), for the back-substitution inside
+                  // k_dogleg / k_step: one landmark per lane reads its row as WT_PAIRS coalesced 16-byte loads instead of KC
+                  // lines per lane
   GP<double> gram_part, pairG, schur_part, schur_sum;   // schur_sum = xch + XOFF_S
   GP<double> xch, gp;              // exchange buffer; gp = xch + XOFF_G, Hpp = xch + XOFF_H
   GP<double> lm_part;               // nLmBlocks * LMS

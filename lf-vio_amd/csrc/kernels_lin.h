@@ -432,6 +432,13 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
     double *w = S->W + woff_l;
     for (int ci = q; ci < w_row_len(cnt_l); ci += 4) w[ci] = tile[lml][w_col(ci, i, cnt_l)];
   }
+  if (mode == MODE_SOLVE && S->N <= SPEC_MAX_LM) {
+    // small windows: the block's columns once more, transposed (Slot::Wt) — 512-byte lines, LDS stride 81: no bank conflict
+    // (columns in pairs — [pair][landmark][2] — so that the reader's row is WT_PAIRS 16-byte loads: a wave has 63 loads in flight at most)
+    double2 *wt = (double2 *)(double *)S->Wt + blk * LM_BLOCK + (tid & 63);
+    for (int cp = tid >> 6; cp < WT_PAIRS; cp += LIN_THREADS / 64)
+      wt[(size_t)cp * SPEC_MAX_LM] = make_double2(tile[tid & 63][2 * cp], 2 * cp + 1 < KC ? tile[tid & 63][2 * cp + 1] : 0.0);
+  }
   LSTAMP(23);
   schur_block(blk, mode, Nlim, tile, lcoef, le, part);
   LSTAMP(20);

@@ -749,16 +749,22 @@ DEV void dogleg_coeffs(double grad_sq_total, double gn_sq_total, double grad_gn_
 #else
 #define GSTAMP(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, size_t stride, int inline_backsub, int spec) {
-  Slot *S = SLOT(base, stride);
+// FUSED: the body runs as the prologue of k_step in EVERY workgroup of the candidate's cost evaluation; what the cost body
+// reads afterwards (the landmark part of the step, the candidate state and its pair table) is then written by each of
+// them — the same values from the same inputs — and read back behind a workgroup barrier.  sh2: [cg, cn] per candidate.
+// Returns false when the slot takes no step in this pass.
+// FUSED: the body runs as the prologue of k_step in EVERY workgroup of the candidate's cost evaluation; what the cost body
+// reads afterwards (the landmark part of the step, the candidate state and its pair table) is then written by each of
+// them — the same values from the same inputs — and read back behind a workgroup barrier.  sh2: [cg, cn] per candidate.
+// Returns false when the slot takes no step in this pass.
+template <bool FUSED, bool inline_backsub>
+DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *sh2) {
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
-  const bool first = blockIdx.x == 0;
   GSTAMP(7);
-  const int z_lo = gridDim.x > 1 ? blockIdx.x : 0, z_hi = gridDim.x > 1 ? blockIdx.x + 1 : spec;
   // The kernel is one chain of small dependent steps; a load issued behind a branch or a barrier costs a full memory
-  // round trip (~0.6 us) of its own, so everything that is read — the header, this thread's piece of the state, of the
-  // gradient and of the step vectors, the landmark partials — is requested here in one batch, before the first use.
+  // round trip (1 - 1.5 us) of its own, so everything that is read — the header, this thread's piece of the state, of the
+  // gradient and of the step vectors, the landmark partials, the landmark rows — is requested here in one batch, before the first use.
   const TRHead t = *reinterpret_cast<const TRHead *>(tr);
   const int sharded = S->sharded, nLmBlocks = S->nLmBlocks, est_ex = S->est_ex, est_td = S->est_td;
   const int cur = t.cur, do_schur = t.do_schur;
@@ -795,50 +801,38 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
       b += S->lm_part[(size_t)k * LMS + 9];
     }
   const int last_ok = t.trace_len > 0 ? tr->trace[t.trace_len - 1].step_is_successful : 0;
-  if (t.done || t.chol_fail) return;
+  if (t.done || t.chol_fail) return false;
   GSTAMP(8);
-  __shared__ double sh[2 * DOGLEG_INLINE_BLOCKS], sh2[2 * (1 + SPEC_EXTRA)];
+  __shared__ double sh[2 * DOGLEG_INLINE_BLOCKS];
   __shared__ double delta[KP];
   __shared__ double cand[84 + 256];  // candidate poses (pose[0..10], ex) for build_tab, and its scratch
   if (do_schur && inline_backsub) {
     // k_backsub, one landmark per thread:  y_l = (s_l b_l - s_l w_l . (S_c y_c)) / e_l,  gauss_newton_l = -diagonal_l y_l,
     // and the two dot products w_l . G_c, w_l . N_c every dogleg interpolant needs
+    static_assert(DOGLEG_INLINE_THREADS == SPEC_MAX_LM, "one landmark per thread of k_dogleg / k_step");
     double *ug = cand, *un = cand + WLD;
     for (int c = tid; c < WLD; c += nthr) ug[c] = S->uc_grad[c], un[c] = S->uc_gn[c];
     __syncthreads();
     const int l = tid;
     if (l < S->N) {
-      // two rounds of loads for the whole landmark: (1) where its row starts, its track and its scalars; (2) the row itself —
-      // all eleven frame slots of it at once (a shorter track reads on into the rows behind it, which are dropped), the
-      // dot products then run on registers.  A loop that fetches an entry, uses it and fetches the next is a memory round
-      // trip per entry (13 900 -> 10 500 cycles; what is left is 73 uncoalesced loads per lane).
-      const int woff = S->lm_woff[l], st = S->lm_start[l], cnt = S->lm_cnt[l];
+      // The landmark's row from the transposed copy (Slot::Wt, written by k_lin): WT_PAIRS 16-byte loads that the lanes of a
+      // wave share line by line, all in flight before the first product (a wave holds 63 loads in flight at most; from the
+      // compact rows of W it was KC loads of 64 lines each: 10 500 cycles for this block, now 5 900).  The entries outside
+      // the track's span are zeros, which leave the sums as they are: same products, same order as k_backsub.
       const double s = S->scale_l[l], bl = S->b[l], einv = S->einv_l[l], dgl = S->diag_l[l], grl = S->grad_l[l];
-      const double *w = S->W + woff;
-      const int lo = 6 * st, n6 = 6 * cnt;
-      double wv[66], wt[KC - 66];
+      const double2 *wt = (const double2 *)(const double *)S->Wt + l;
+      double2 wv[WT_PAIRS];
 #pragma unroll
-      for (int c = 0; c < 66; c++) wv[c] = w[c];
-#pragma unroll
-      for (int c = 66; c < KC; c++) wt[c - 66] = w[n6 + c - 66];
+      for (int cp = 0; cp < WT_PAIRS; cp++) wv[cp] = wt[(size_t)cp * SPEC_MAX_LM];
       double d1 = 0, d2 = 0;
 #pragma unroll
-      for (int f = 0; f < 11; f++)
-        if (f < cnt) {
-#pragma unroll
-          for (int e = 0; e < 6; e++) {
-            d1 = fma(wv[6 * f + e], ug[lo + 6 * f + e], d1);
-            d2 = fma(wv[6 * f + e], un[lo + 6 * f + e], d2);
-          }
-        }
-#pragma unroll
-      for (int c = 66; c < KC; c++) {
-        d1 = fma(wt[c - 66], ug[c], d1);
-        d2 = fma(wt[c - 66], un[c], d2);
+      for (int c = 0; c < KC; c++) {
+        const double w = (c & 1) ? wv[c >> 1].y : wv[c >> 1].x;
+        d1 = fma(w, ug[c], d1), d2 = fma(w, un[c], d2);
       }
       const double y = (s * bl + s * d2) * einv;
       const double gn = -dgl * y;
-      if (first) {
+      {  // (every workgroup of the launch, candidate z's or — k_step — cost block's: the same values)
         S->gn_l[l] = gn;
         S->d1[l] = d1;
         S->d2[l] = d2;
@@ -968,6 +962,13 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
     build_tab(cand, z == 0 ? &S->tab[cur ^ 1] : &S->tabE[z - 1], tid, cand + 84);  // ends on a barrier: delta / sh / cand are free again
     GSTAMP(3);
   }
+  return true;
+}
+template <bool INLINE>
+__global__ __launch_bounds__(INLINE ? DOGLEG_INLINE_THREADS : 128) void k_dogleg(char *base, size_t stride, int spec) {
+  __shared__ double sh2[2 * (1 + SPEC_EXTRA)];
+  // (every launch has grid.x = spec: workgroup z prepares candidate z)
+  dogleg_body<false, INLINE>(SLOT(base, stride), (int)blockIdx.x, (int)blockIdx.x + 1, blockIdx.x == 0, spec, sh2);
 }
 
 // ---------------------------------------------------------------------------
@@ -981,20 +982,13 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_dogleg(char *base, si
 // IMU_ROLE false: the grid has no workgroups for the IMU factors (k_cost_imu evaluates them one lane per factor: resident
 // batches, where a workgroup per factor with its residual on one lane is mostly issue slots spent on idle lanes) and the
 // instantiation carries none of that code.
-template <int LPT, bool IMU_ROLE = true>
-__global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, int gLm, int spec) {
-  constexpr int COST_THREADS = 64 * LPT, NW = LPT;
-  Slot *S = SLOT(base, stride);
-  const TRState *tr = &S->tr;
-  // header fields in one batch of loads, before the first branch (a load behind a branch is a round trip of its own)
-  const TRFlags fl = tr_flags(tr);
-  const int cur = fl.cur;
-  // candidate z of the pass: blocks [z * nb, (z + 1) * nb) of the grid, nb = gLm + 10 + 1 (spec = 1: the one candidate)
-  const int nb = gLm + (IMU_ROLE ? LFVIO_WINDOW_SIZE : 0) + 1;
-  const int z = spec > 1 ? (int)blockIdx.x / nb : 0;
-  const double cg = z == 0 ? tr->cg : tr->cgE[z > 0 ? z - 1 : 0], cn = z == 0 ? tr->cn : tr->cnE[z > 0 ? z - 1 : 0];
-  if (fl.done | fl.chol_fail) return;
+// THREADS > 64 LPT (the body behind the dogleg prologue of k_step, whose workgroups are wider): the spare threads go
+// through the barriers with nothing to add.
+template <int LPT, bool IMU_ROLE, int THREADS>
+DEV void cost_body(Slot *S, int cur, int z, int b, int gLm, double cg, double cn) {
+  constexpr int NW = LPT;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool act = THREADS == 64 * LPT || tid < 64 * LPT;
   const int nxt = cur ^ 1;
   const Tab *T = z == 0 ? &S->tab[nxt] : &S->tabE[z - 1];
   const FrameState *x = z == 0 ? &S->x[nxt] : &S->xE[z - 1];
@@ -1002,14 +996,13 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
   double *cost_part = z == 0 ? (double *)S->cost_part : (double *)S->cost_partE + (size_t)(z - 1) * (SPEC_MAX_LM / 64) * LMS;
   double *pose_cost = z == 0 ? S->pose_cost : S->pose_costE[z - 1];
   __shared__ double red[4 * 8];
-  int b = (int)blockIdx.x - z * nb;
   if (b < gLm) {
     if (b >= S->nLmBlocks) return;
     const double td = x->td;
     const int lml = tid / LPT, q = tid % LPT;
     const int l = b * LM_BLOCK + lml;
     double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
-    if (l < S->N) {
+    if (act && l < S->N) {
       const double s = S->scale_l[l];
       const double dl = (cg * S->grad_l[l] + cn * S->gn_l[l]) / S->diag_l[l] * s;
       const double lam = S->lam[cur][l];
@@ -1059,7 +1052,7 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
       }
     }
     cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn);
-    if (lane == 0) red[wv * 8] = cost, red[wv * 8 + 1] = mlin, red[wv * 8 + 2] = mquad, red[wv * 8 + 3] = dn, red[wv * 8 + 4] = xn;
+    if (lane == 0 && act) red[wv * 8] = cost, red[wv * 8 + 1] = mlin, red[wv * 8 + 2] = mquad, red[wv * 8 + 3] = dn, red[wv * 8 + 4] = xn;
     __syncthreads();
     if (tid < 5) {
       double v = red[tid];
@@ -1093,22 +1086,51 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
     double c = 0.0;
     if (S->prior_valid) {
       const int n = S->prior_n;
-      if (tid < S->prior_nb) prior_block_dx(S, x, tid, dx);
-      __syncthreads();
       const double *J = S->prior_J;
-      constexpr int CW = 76 / LPT;  // n <= 76: LPT lanes per row, CW columns each
-      const int q = tid % LPT, c0 = q * CW;
-      for (int row = tid / LPT; row < n; row += 64) {
-        double s = 0.0;
-        for (int cc = c0; cc < c0 + CW && cc < n; cc++) s = fma(J[row * n + cc], dx[cc], s);
-        if (LPT == 4) s = quad_sum(s);
-        if (q == 0) {
+      if (LPT == 4) {
+        // r = r0 + J0 dx, n <= 76 rows: four lanes per row with 19 columns each, rows tid / 4 and that + 64.  The entries of J0
+        // a lane needs are requested in one batch (a loop that loads an entry and uses it is a memory round trip per entry:
+        // 16 000 cycles for this block, the longest of the cost evaluation), before dx is even formed.
+        const int q = tid % LPT, c0 = q * 19, r0 = act ? tid / LPT : n;
+        double jv[2][19], pr0 = 0.0, pr1 = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+          const int row = r0 + 64 * rr;
+          const double prv = (q == 0 && row < n) ? S->prior_r[row] : 0.0;
+          if (rr == 0) pr0 = prv;
+          else pr1 = prv;
+#pragma unroll
+          for (int k = 0; k < 19; k++) jv[rr][k] = (row < n && c0 + k < n) ? J[row * n + c0 + k] : 0.0;
+        }
+        if (tid < S->prior_nb) prior_block_dx(S, x, tid, dx);
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+          const int row = r0 + 64 * rr;
+          if (row < n) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 19; k++)
+              if (c0 + k < n) s = fma(jv[rr][k], dx[c0 + k], s);
+            s = quad_sum(s);
+            if (q == 0) {
+              s += rr == 0 ? pr0 : pr1;
+              c += s * s;
+            }
+          }
+        }
+      } else {
+        if (tid < S->prior_nb) prior_block_dx(S, x, tid, dx);
+        __syncthreads();
+        for (int row = tid; row < n; row += 64) {
+          double s = 0.0;
+          for (int cc = 0; cc < n; cc++) s = fma(J[row * n + cc], dx[cc], s);
           s += S->prior_r[row];
           c += s * s;
         }
       }
       c = wave_sum(c);
-      if (lane == 0) red[wv] = c;
+      if (lane == 0 && act) red[wv] = c;
       __syncthreads();
       c = red[0];
       for (int w = 1; w < NW; w++) c += red[w];
@@ -1116,6 +1138,50 @@ __global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, in
     }
     if (tid == 0) pose_cost[10] = c;
   }
+}
+
+template <int LPT, bool IMU_ROLE = true>
+__global__ __launch_bounds__(64 * LPT) void k_cost(char *base, size_t stride, int gLm, int spec) {
+  Slot *S = SLOT(base, stride);
+  const TRState *tr = &S->tr;
+  // header fields in one batch of loads, before the first branch (a load behind a branch is a round trip of its own)
+  const TRFlags fl = tr_flags(tr);
+  // candidate z of the pass: blocks [z * nb, (z + 1) * nb) of the grid, nb = gLm + 10 + 1 (spec = 1: the one candidate)
+  const int nb = gLm + (IMU_ROLE ? LFVIO_WINDOW_SIZE : 0) + 1;
+  const int z = spec > 1 ? (int)blockIdx.x / nb : 0;
+  const double cg = z == 0 ? tr->cg : tr->cgE[z > 0 ? z - 1 : 0], cn = z == 0 ? tr->cn : tr->cnE[z > 0 ? z - 1 : 0];
+  if (fl.done | fl.chol_fail) return;
+  cost_body<LPT, IMU_ROLE, 64 * LPT>(S, fl.cur, z, (int)blockIdx.x - z * nb, gLm, cg, cn);
+}
+
+// ---------------------------------------------------------------------------
+// k_step: grid (spec (gLm + 10 + 1), batch) x 320 — k_dogleg (with the landmark back-substitution inline) and k_cost<4> as ONE
+// launch, for the few small windows whose passes are latency.  Workgroup (z, b) — candidate z, cost block b — first forms
+// the step like k_dogleg's workgroup z does (every one of them: the dogleg is a chain of a few microseconds that needs the
+// whole window's norms, and sixteen workgroups repeating it side by side take no longer than one), then evaluates its own
+// block of the candidate like k_cost.  No workgroup waits for another; what several write they write identically.
+// One launch and one round of first loads less per pass.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_step(char *base, size_t stride, int gLm, int spec) {
+  Slot *S = SLOT(base, stride);
+  __shared__ double sh2[2 * (1 + SPEC_EXTRA)];
+  const int nb = gLm + LFVIO_WINDOW_SIZE + 1;
+  const int z = spec > 1 ? (int)blockIdx.x / nb : 0;
+  const int cur = tr_flags(&S->tr).cur;
+  // (what one workgroup writes for all — the totals, the gradient norm of a new point — falls to the one with the shortest
+  // cost block: the first IMU factor of candidate 0)
+  const int b = (int)blockIdx.x - z * nb;
+  if (!dogleg_body<true, true>(S, z, z + 1, (int)blockIdx.x == gLm, spec, sh2)) return;
+#ifdef LFVIO_DOGLEG_PROFILE
+  const long long t_role = (long long)__builtin_readcyclecounter();
+#endif
+  // (dogleg_body ends on a workgroup barrier: this workgroup's writes of the candidate are visible to all of its waves)
+  cost_body<4, true, DOGLEG_INLINE_THREADS>(S, cur, z, b, gLm, sh2[2 * z], sh2[2 * z + 1]);
+  GSTAMP(20);
+#ifdef LFVIO_DOGLEG_PROFILE
+  if ((int)blockIdx.x == gLm && threadIdx.x == 0) S->dbg[21] = (long long)__builtin_readcyclecounter() - t_role;     // IMU factor 0 of candidate 0
+  if ((int)blockIdx.x == nb - 1 && threadIdx.x == 0) S->dbg[22] = (long long)__builtin_readcyclecounter() - t_role;  // prior block of candidate 0
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -39,7 +39,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   size_t in_begin = 0, in_end = 0, total = 0;
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lm_woff, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
-  size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
+  size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, Wt, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
       xch, lm_part, cost_part, imu_out, imu_raw, mscr, rotlog, eig_aux;
 };
 
@@ -77,6 +77,7 @@ Layout make_layout(int maxN, int maxM) {
   L.cost_partE = take((size_t)SPEC_EXTRA * (SPEC_MAX_LM / 64) * LMS * 8);
   L.prior_A = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
   L.a = take(LB * 8), L.b = take(LB * 8), L.W = take(LB * WLD * 8);
+  L.Wt = take((size_t)WT_PAIRS * SPEC_MAX_LM * 16);
   L.scale_l = take(LB * 8), L.grad_l = take(LB * 8), L.gn_l = take(LB * 8), L.diag_l = take(LB * 8);
   L.einv_l = take(LB * 8), L.d1 = take(LB * 8), L.d2 = take(LB * 8);
   L.gram_part = take((size_t)L.capChunks * NGP * 8);
@@ -139,6 +140,7 @@ struct lfvio_ctx {
   // landmark-sharded mode (multi-GPU)
   bool shard_active = false;
   bool no_merge = false;  // debug: the trust-region bookkeeping always as its own launch (lfvio_debug_set_decide_merge)
+  bool no_fuse = false;   // debug: k_dogleg and k_cost always as two launches (lfvio_debug_set_decide_merge(ctx, 0 or 2))
   int shard_begin = 0, shard_end = 0, shard_state = 0;
   std::vector<int> sh_start, sh_off;
   // stream-ordered sharded driver: ring of pinned flag records, one per enqueued decision (shard.inc)
@@ -541,7 +543,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     for (int k = 0; k < SPEC_EXTRA; k++) W.lamE[k].set(&W, L.lamE[k]);
     W.cost_partE.set(&W, L.cost_partE);
     W.prior_A.set(&W, L.prior_A);
-    W.a.set(&W, L.a), W.b.set(&W, L.b), W.W.set(&W, L.W);
+    W.a.set(&W, L.a), W.b.set(&W, L.b), W.W.set(&W, L.W), W.Wt.set(&W, L.Wt);
     W.scale_l.set(&W, L.scale_l), W.grad_l.set(&W, L.grad_l), W.gn_l.set(&W, L.gn_l);
     W.diag_l.set(&W, L.diag_l), W.einv_l.set(&W, L.einv_l), W.d1.set(&W, L.d1), W.d2.set(&W, L.d2);
     W.gram_part.set(&W, L.gram_part), W.pairG.set(&W, L.pairG);
@@ -555,7 +557,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
 #define PUTP(field) HIPCHK(c, hipMemcpyAsync(d + offsetof(Slot, field), &W.field, sizeof W.field, hipMemcpyHostToDevice, c->stream))
     PUTP(lam); PUTP(lamE); PUTP(cost_partE);
     PUTP(prior_A);
-    PUTP(a); PUTP(b); PUTP(W); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
+    PUTP(a); PUTP(b); PUTP(W); PUTP(Wt); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
     PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(xch); PUTP(gp); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out); PUTP(imu_raw);
     PUTP(Hpp);
     PUTP(mscr); PUTP(rotlog); PUTP(eig_aux);
@@ -657,11 +659,18 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
     const int spec = speculate && inl ? 1 + SPEC_EXTRA : 1;
-    if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
-    hipLaunchKernelGGL(k_dogleg, dim3(spec, count), dim3(inl ? DOGLEG_INLINE_THREADS : 128), 0, c->stream, c->d_base, st, inl ? 1 : 0, spec);
-    // four lanes per track while the GPU has room for the extra waves (latency of few windows), one when a batch fills it
     const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
-    if ((size_t)count * nb <= 2048)  // (four waves per workgroup: 8 192 waves = eight per SIMD)
+    // few small windows: the step and the cost of its candidates in one launch (k_step)
+    const bool fuse = inl && !c->no_fuse && !c->shard_active && (size_t)count * nb <= 2048;
+    if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
+    if (fuse) hipLaunchKernelGGL(k_step, dim3(spec * nb, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, g.lm, spec);
+    else {
+      if (inl) hipLaunchKernelGGL(k_dogleg<true>, dim3(spec, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, spec);
+      else hipLaunchKernelGGL(k_dogleg<false>, dim3(spec, count), dim3(128), 0, c->stream, c->d_base, st, spec);
+    }
+    // four lanes per track while the GPU has room for the extra waves (latency of few windows), one when a batch fills it
+    if (fuse) {
+    } else if ((size_t)count * nb <= 2048)  // (four waves per workgroup: 8 192 waves = eight per SIMD)
       hipLaunchKernelGGL(k_cost<4>, dim3(spec * nb, count), dim3(256), 0, c->stream, c->d_base, st, g.lm, spec);
     else if (spec == 1 && !c->shard_active) {
       hipLaunchKernelGGL((k_cost<1, false>), dim3(g.lm + 1, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, 1);
@@ -1397,8 +1406,9 @@ int lfvio_debug_set_graph(lfvio_ctx *c, int on) {
 
 int lfvio_debug_set_decide_merge(lfvio_ctx *c, int on) {
   if (!c) return LFVIO_ERR_ARG;
-  if (c->no_merge != (on == 0)) destroy_graph(c);  // the captured graphs hold the launch sequence
+  destroy_graph(c);  // the captured graphs hold the launch sequence
   c->no_merge = on == 0;
+  c->no_fuse = on == 0 || on == 2;
   return LFVIO_OK;
 }
 

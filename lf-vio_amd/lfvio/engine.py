@@ -45,7 +45,8 @@ class Engine:
         self.lib.lfvio_debug_set_graph(self.ctx, int(on))
 
     def set_decide_merge(self, on):
-        """False: k_decide after every pass instead of the bookkeeping in the prologue of the next k_lin (debug)."""
+        """0: k_decide, k_dogleg, k_cost each as a launch of its own; 2: the bookkeeping in the prologue of the next k_lin;
+        1 / True (default): that, and k_dogleg + k_cost as one launch (k_step) — see include/lfvio_debug.h."""
         self.lib.lfvio_debug_set_decide_merge.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_set_decide_merge(self.ctx, int(on))
 

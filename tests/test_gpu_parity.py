@@ -107,13 +107,16 @@ def test_bookkeeping_in_the_prologue_of_k_lin_equals_k_decide(eng, n, kw):
     speculative candidates, rejected steps) and without, through graphs of several chunks (tr = 0.3: a pass per step)."""
     w = synth.make_window_with_prior(5, n, lambda x, f: eng.optimize(x, f), **kw)[0] if n == 300 else synth.make_window(5, n, **kw)
     out = []
-    for merge in (False, True, True):
+    # 0: k_decide, k_dogleg and k_cost as launches of their own; 2: bookkeeping in the prologue of k_lin; 1 (the default): that,
+    # and the dogleg step and the cost of its candidates as one launch (k_step: every workgroup of the cost evaluation forms
+    # the step itself)
+    for merge in (0, 2, 1, 1):
         eng.set_decide_merge(merge)
         sol, prior = eng.optimize(w, abi.MARGIN_OLD)
         out.append((sol, prior))
-    eng.set_decide_merge(True)
-    a, b, c = out
-    for x, y in ((a, b), (b, c)):
+    eng.set_decide_merge(1)
+    a, b, c, d = out
+    for x, y in ((a, b), (b, c), (c, d)):
         assert np.array_equal(x[0].pose, y[0].pose) and np.array_equal(x[0].speed_bias, y[0].speed_bias) and np.array_equal(x[0].lam, y[0].lam)
         assert x[0].c.num_iterations == y[0].c.num_iterations and x[0].c.final_cost == y[0].c.final_cost
         assert [t["cost"] for t in x[0].trace()] == [t["cost"] for t in y[0].trace()]

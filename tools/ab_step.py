@@ -1,5 +1,6 @@
 """A/B of two builds of liblfvio_hip.so on the SAME box: ms per resident window300 optimization(), alternating between the
-libraries (usage: ab_step.py libA.so libB.so [rounds])."""
+libraries (usage: ab_step.py libA.so libB.so [rounds [batch]]; "lib.so@K" calls lfvio_debug_set_decide_merge(K) on that
+engine, so that one build can be compared with itself with a fusion switched off)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd"))
@@ -9,7 +10,10 @@ from lfvio.engine import Engine
 libs = sys.argv[1:3]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # > 1: a resident batch of that many windows (16 distinct seeds, cycled)
-engs = [Engine(0, p) for p in libs]
+engs = [Engine(0, p.split("@")[0]) for p in libs]
+for e, p in zip(engs, libs):
+    if "@" in p:
+        e.set_decide_merge(int(p.split("@")[1]))
 wins = [synth.make_window_with_prior(s, 300, lambda x, f: engs[0].optimize(x, f))[0] for s in range(min(batch, 16))]
 reps = 200 if batch == 1 else 10
 for e in engs:
