@@ -436,8 +436,18 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
     // small windows: the block's columns once more, transposed (Slot::Wt) — 512-byte lines, LDS stride 81: no bank conflict
     // (columns in pairs — [pair][landmark][2] — so that the reader's row is WT_PAIRS 16-byte loads: a wave has 63 loads in flight at most)
     double2 *wt = (double2 *)(double *)S->Wt + blk * LM_BLOCK + (tid & 63);
-    for (int cp = tid >> 6; cp < WT_PAIRS; cp += LIN_THREADS / 64)
-      wt[(size_t)cp * SPEC_MAX_LM] = make_double2(tile[tid & 63][2 * cp], 2 * cp + 1 < KC ? tile[tid & 63][2 * cp + 1] : 0.0);
+    constexpr int WPT = (WT_PAIRS + LIN_THREADS / 64 - 1) / (LIN_THREADS / 64);  // pairs per thread: all read from the tile, then all stored
+    double2 v[WPT];
+#pragma unroll
+    for (int k = 0; k < WPT; k++) {
+      const int cp = (tid >> 6) + (LIN_THREADS / 64) * k, c = cp < WT_PAIRS ? 2 * cp : 0;
+      v[k] = make_double2(tile[tid & 63][c], c + 1 < KC ? tile[tid & 63][c + 1] : 0.0);
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; k++) {
+      const int cp = (tid >> 6) + (LIN_THREADS / 64) * k;
+      if (cp < WT_PAIRS) wt[(size_t)cp * SPEC_MAX_LM] = v[k];
+    }
   }
   LSTAMP(23);
   schur_block(blk, mode, Nlim, tile, lcoef, le, part);
