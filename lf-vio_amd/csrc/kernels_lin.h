@@ -213,31 +213,55 @@ DEV d3 quad_sum3(d3 v) { return mk3(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z))
 // (cols 73/74 carry b_l and the Cauchy cross-term column) on the FP64 matrix pipe.  Wave w owns tiles w, w+4, w+8,
 // w+12; four landmarks per MFMA: lane (k, c) feeds A[i = c][k] = c_l w_l[16 t + c], B[k][j = c] = w_l[16 u + c]; the
 // accumulator holds D[row = (lane >> 4) + 4 reg][col = lane & 15].
+// TIGHT: the form for launches whose landmark role is a latency chain (k_lin with all roles in one grid: single windows);
+// a resident batch (the landmark role as a launch of its own, two waves per SIMD) measured 0.4 % better with the plain loop.
+template <bool TIGHT>
 DEV void schur_block(int blk, int mode, int Nlim, double (*tile)[WLD + 1], const double *lcoef, const double *le, double *part) {
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
   double4_t acc[4];
   int ct[4], cu[4];
+  bool scale_k[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     acc[j] = double4_t{0, 0, 0, 0};
     const int ti = wv + 4 * j;  // upper tile index: (0,0..4) (1,1..4) (2,2..4) (3,3..4) (4,4)
     const int t = ti < 5 ? 0 : ti < 9 ? 1 : ti < 12 ? 2 : ti < 14 ? 3 : 4;
     const int u = ti - (t * 5 - (t * (t - 1)) / 2) + t;
-    ct[j] = 16 * t + cc, cu[j] = 16 * u + cc;
+    ct[j] = ti < NT ? 16 * t + cc : 0, cu[j] = ti < NT ? 16 * u + cc : 0;
+    scale_k[j] = mode == MODE_SOLVE && cu[j] == COL_K;  // b/D2 * e  -> z2 column
   }
   int rows = Nlim - blk * LM_BLOCK;
   rows = rows > LM_BLOCK ? LM_BLOCK : rows;
-  for (int s4 = 0; 4 * s4 < rows; s4++) {
-    const int row = 4 * s4 + kk;
-    const double coef = lcoef[row], eb = le[row];
+  // No branch inside the loop: a tile skipped there (the sixteenth slot, wave 3) was two branches of the wave per tile and
+  // step — 670 cycles per step, now 550 — so wave 3 runs its own loop over three tiles.  (Reading the operands of step s + 1
+  // while the matrix pipe works on step s, kept from being undone with opaque copies, measured no better.)  Rows past the
+  // block's last landmark are zeros in the tile and carry weight zero.
+  auto sweep = [&](auto ntl) {
+    constexpr int NTL = decltype(ntl)::value;
+    for (int s4 = 0; 4 * s4 < rows; s4++) {
+      const int row = 4 * s4 + kk;
+      const double coef = lcoef[row], eb = le[row];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (wv + 4 * j >= NT) continue;  // wave-uniform
-      const double xa = tile[row][ct[j]];
-      double xb = tile[row][cu[j]];
-      if (mode == MODE_SOLVE && cu[j] == COL_K) xb *= eb;  // b/D2 * e  -> z2 column
-      acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(coef * xa, xb, acc[j], 0, 0, 0);
+      for (int j = 0; j < NTL; j++)
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(coef * tile[row][ct[j]], tile[row][cu[j]] * (scale_k[j] ? eb : 1.0), acc[j], 0, 0, 0);
+    }
+  };
+  if (TIGHT) {
+    if (__builtin_amdgcn_readfirstlane(wv) + 12 < NT) sweep(std::integral_constant<int, 4>{});
+    else sweep(std::integral_constant<int, 3>{});
+  } else {
+    for (int s4 = 0; 4 * s4 < rows; s4++) {
+      const int row = 4 * s4 + kk;
+      const double coef = lcoef[row], eb = le[row];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (wv + 4 * j >= NT) continue;  // wave-uniform
+        const double xa = tile[row][ct[j]];
+        double xb = tile[row][cu[j]];
+        if (mode == MODE_SOLVE && cu[j] == COL_K) xb *= eb;  // b/D2 * e  -> z2 column
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(coef * xa, xb, acc[j], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -290,7 +314,7 @@ DEV void lin_schur_only_role(Slot *S, const LinView &lv, int blk, double *lds, d
     lcoef[tid] = cf, le[tid] = eb;
   }
   __syncthreads();
-  schur_block(blk, MODE_SOLVE, S->N, tile, lcoef, le, part);
+  schur_block<false>(blk, MODE_SOLVE, S->N, tile, lcoef, le, part);
 }
 
 // Landmark role: 64 landmarks per workgroup, 4 lanes per landmark (lane q takes the observations 1+q, 5+q, 9+q of the
@@ -302,6 +326,7 @@ DEV void lin_schur_only_role(Slot *S, const LinView &lv, int blk, double *lds, d
 #else
 #define LSTAMP(k) do { } while (0)
 #endif
+template <bool TIGHT>
 DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double *lds, double *part) {
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *red = lds + LM_BLOCK * (WLD + 1);
@@ -450,7 +475,7 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
     }
   }
   LSTAMP(23);
-  schur_block(blk, mode, Nlim, tile, lcoef, le, part);
+  schur_block<TIGHT>(blk, mode, Nlim, tile, lcoef, le, part);
   LSTAMP(20);
 }
 
@@ -747,7 +772,7 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
       const int nblk = is_marg(mode) ? (marg_plan(S, mode)->N0 + LM_BLOCK - 1) / LM_BLOCK : S->nLmBlocks;
       if (b >= nblk) return;
       double *part = S->schur_part + (size_t)b * SCHUR_LEN;
-      if (do_lin) lin_landmark_role(S, lv, b, mode, lds, part);
+      if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL>(S, lv, b, mode, lds, part);
       else lin_schur_only_role(S, lv, b, lds, part);
     }
     return;
