@@ -24,18 +24,35 @@ constexpr int BT_GROUP = 4;          // reflectors per step of the back-transfor
 constexpr bool EIG_TRIDIAG = true;  // n x n eigen-problem: Householder tridiagonalization + multisection + twisted factorization
                                     // (eig_tridiag below); false: the systolic Jacobi + k_marg_vecs
 
+// setDepth / getDepthVector round trip (feature_manager.cpp:148,191), landmarks [l0, l0 + 128)
+DEV void gauge_landmarks(Slot *S, int l0) {
+  const int l = l0 + (int)threadIdx.x;
+  double *lam = S->lam[S->tr.cur];
+  if (l < S->N) lam[l] = 1.0 / (1.0 / lam[l]);
+}
+DEV void gauge_poses(Slot *S, int gated);
 __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int gated) {
   Slot *S = SLOT(base, stride);
-  TRState *ts = &S->tr;
-  const int tid = threadIdx.x;
-  if (gated && !tail_gate(S, ts->done)) return;
+  if (gated && !tail_gate(S, S->tr.done)) return;
   if (blockIdx.x > 0) {
-    // setDepth / getDepthVector round trip (feature_manager.cpp:148,191), 128 landmarks per workgroup
-    const int l = (blockIdx.x - 1) * 128 + tid;
-    double *lam = S->lam[ts->cur];
-    if (l < S->N) lam[l] = 1.0 / (1.0 / lam[l]);
+    gauge_landmarks(S, (blockIdx.x - 1) * 128);
     return;
   }
+  gauge_poses(S, gated);
+}
+// k_decide_gauge: grid (1, batch) x 128 — behind the last pass of a graph of few small windows: k_decide and, for the slots
+// that are done then, the gated k_gauge in ONE launch (one workgroup per slot: nobody else reads the header it rewrites).
+__global__ __launch_bounds__(128) void k_decide_gauge(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  decide_body(S);
+  __syncthreads();  // (the header and the accepted candidate, written by wave 0, are read by all from here on)
+  if (!tail_gate(S, S->tr.done)) return;
+  for (int l0 = 0; l0 < S->N; l0 += 128) gauge_landmarks(S, l0);
+  gauge_poses(S, 1);
+}
+DEV void gauge_poses(Slot *S, int gated) {
+  TRState *ts = &S->tr;
+  const int tid = threadIdx.x;
   __shared__ double rot[9], P0[3], oP0[3];
   FrameState *x = &S->x[ts->cur];
   if (tid == 0) {

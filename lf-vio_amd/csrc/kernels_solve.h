@@ -1277,8 +1277,8 @@ __global__ __launch_bounds__(64) void k_cost_imu(char *base, size_t stride, int 
 #else
 #define DSTAMP(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
-  Slot *S = SLOT(base, stride);
+// (threads past the first wave — k_decide_gauge — only pass the barrier)
+DEV void decide_body(Slot *S) {
   TRState *tr = &S->tr;
   const int lane = threadIdx.x;
   // Everything the kernel needs from the slot header in ONE batch of loads, before the first branch: a load issued
@@ -1288,20 +1288,23 @@ __global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
   const int sharded = S->sharded, max_iter = S->max_iter, nLmBlocks = S->nLmBlocks, nlm = S->N;
   __shared__ int acc_sh;
   if (t.done) return;
-  const int K = decide_candidates(t);
-  DecideSums sm;
-  decide_sums(S, t, K, sharded, nLmBlocks, lane, sm);
-  DSTAMP(21);
-  if (lane == 0) {
-    const int az = decide_walk(t, sm, K, sharded, max_iter, tr);
-    DSTAMP(22);
-    TRDecision d;
-    decision_from(d, t, az);
-    decision_to_header(tr, d);
-    acc_sh = az | (t.cur << 8);
+  if (lane < 64) {
+    const int K = decide_candidates(t);
+    DecideSums sm;
+    decide_sums(S, t, K, sharded, nLmBlocks, lane, sm);
+    DSTAMP(21);
+    if (lane == 0) {
+      const int az = decide_walk(t, sm, K, sharded, max_iter, tr);
+      DSTAMP(22);
+      TRDecision d;
+      decision_from(d, t, az);
+      decision_to_header(tr, d);
+      acc_sh = az | (t.cur << 8);
+    }
   }
   __syncthreads();
   DSTAMP(23);
   const int az = acc_sh & 255;
-  if (az > 0) copy_accepted(S, az, acc_sh >> 8, nlm, lane, 64);
+  if (az > 0 && lane < 64) copy_accepted(S, az, acc_sh >> 8, nlm, lane, 64);
 }
+__global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) { decide_body(SLOT(base, stride)); }

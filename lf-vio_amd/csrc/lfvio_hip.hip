@@ -646,7 +646,8 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
 // first / last: position of the pass in the sequence being issued (a graph, or a plain run of passes).  For small windows
 // the trust-region bookkeeping of a pass rides in the prologue of the NEXT pass's k_lin (MODE_DECIDE, one launch less per
 // pass); k_decide itself is only launched behind the last pass, so that the header is final where the sequence ends.
-void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool speculate = false, bool first = true, bool last = true) {
+// gauge: the gated gauge fix follows this (last) pass — returns true if it went out with the bookkeeping (k_decide_gauge)
+bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool speculate = false, bool first = true, bool last = true, bool gauge = false) {
   const size_t st = c->L.total;
   const bool solve = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & MODE_GATED);
   // (latency of few windows only: in a resident batch every workgroup of k_lin repeating the decision costs more of the
@@ -677,8 +678,13 @@ void launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
       hipLaunchKernelGGL(k_cost_imu, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
     } else
       hipLaunchKernelGGL(k_cost<1>, dim3(spec * nb, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, spec);
+    if (merge && last && gauge && !c->no_fuse) {
+      hipLaunchKernelGGL(k_decide_gauge, dim3(1, count), dim3(128), 0, c->stream, c->d_base, st);
+      return true;
+    }
     if (!merge || last) hipLaunchKernelGGL(k_decide, dim3(1, count), dim3(64), 0, c->stream, c->d_base, st);
   }
+  return false;
 }
 
 // number of slots that still need passes (tail = 0: solve not done; tail = 1: gated marginalization not finished)
@@ -750,9 +756,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       CaptureGuard guard(c->stream);
       if (setup)
         hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
-      for (int it = 0; it < npass; it++) launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1);
+      bool gauged = false;
+      for (int it = 0; it < npass; it++) gauged = launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1, tail_flag >= 0);
       if (tail_flag >= 0) {
-        hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
+        if (!gauged) hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
         rc = enqueue_marg(c, count, tail_flag, false, true);
       }
       if (tail_flag >= 0 && count == 1) {
