@@ -457,7 +457,7 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
     double *w = S->W + woff_l;
     for (int ci = q; ci < w_row_len(cnt_l); ci += 4) w[ci] = tile[lml][w_col(ci, i, cnt_l)];
   }
-  if (mode == MODE_SOLVE && S->N <= SPEC_MAX_LM) {
+  if (TIGHT && mode == MODE_SOLVE && S->N <= SPEC_MAX_LM) {  // (TIGHT: not in the role-by-role launches of a resident batch, whose k_dogleg keeps the compact rows)
     // small windows: the block's columns once more, transposed (Slot::Wt) — 512-byte lines, LDS stride 81: no bank conflict
     // (columns in pairs — [pair][landmark][2] — so that the reader's row is WT_PAIRS 16-byte loads: a wave has 63 loads in flight at most)
     double2 *wt = (double2 *)(double *)S->Wt + blk * LM_BLOCK + (tid & 63);

@@ -757,7 +757,9 @@ DEV void dogleg_coeffs(double grad_sq_total, double gn_sq_total, double grad_gn_
 // reads afterwards (the landmark part of the step, the candidate state and its pair table) is then written by each of
 // them — the same values from the same inputs — and read back behind a workgroup barrier.  sh2: [cg, cn] per candidate.
 // Returns false when the slot takes no step in this pass.
-template <bool FUSED, bool inline_backsub>
+// WT: the inline back-substitution reads Slot::Wt (launches whose k_lin has all roles in one grid and writes it); a resident
+// batch, whose landmark role is a launch of its own and whose sweeps are throughput, keeps the compact rows of W.
+template <bool FUSED, bool inline_backsub, bool WT>
 DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *sh2) {
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
@@ -815,20 +817,47 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
     __syncthreads();
     const int l = tid;
     if (l < S->N) {
-      // The landmark's row from the transposed copy (Slot::Wt, written by k_lin): WT_PAIRS 16-byte loads that the lanes of a
-      // wave share line by line, all in flight before the first product (a wave holds 63 loads in flight at most; from the
-      // compact rows of W it was KC loads of 64 lines each: 10 500 cycles for this block, now 5 900).  The entries outside
-      // the track's span are zeros, which leave the sums as they are: same products, same order as k_backsub.
       const double s = S->scale_l[l], bl = S->b[l], einv = S->einv_l[l], dgl = S->diag_l[l], grl = S->grad_l[l];
-      const double2 *wt = (const double2 *)(const double *)S->Wt + l;
-      double2 wv[WT_PAIRS];
-#pragma unroll
-      for (int cp = 0; cp < WT_PAIRS; cp++) wv[cp] = wt[(size_t)cp * SPEC_MAX_LM];
       double d1 = 0, d2 = 0;
+      if (WT) {
+        // The landmark's row from the transposed copy (Slot::Wt, written by k_lin): WT_PAIRS 16-byte loads that the lanes of
+        // a wave share line by line, all in flight before the first product (a wave holds 63 loads in flight at most; from
+        // the compact rows of W it is KC loads of 64 lines each: 10 500 cycles for this block, 5 900 like this).  The entries
+        // outside the track's span are zeros, which leave the sums as they are: same products, same order.
+        const double2 *wt = (const double2 *)(const double *)S->Wt + l;
+        double2 wv[WT_PAIRS];
 #pragma unroll
-      for (int c = 0; c < KC; c++) {
-        const double w = (c & 1) ? wv[c >> 1].y : wv[c >> 1].x;
-        d1 = fma(w, ug[c], d1), d2 = fma(w, un[c], d2);
+        for (int cp = 0; cp < WT_PAIRS; cp++) wv[cp] = wt[(size_t)cp * SPEC_MAX_LM];
+#pragma unroll
+        for (int c = 0; c < KC; c++) {
+          const double w = (c & 1) ? wv[c >> 1].y : wv[c >> 1].x;
+          d1 = fma(w, ug[c], d1), d2 = fma(w, un[c], d2);
+        }
+      } else {
+        // the compact row: all eleven frame slots of it at once (a shorter track reads on into the rows behind it, which are
+        // dropped), the dot products then run on registers
+        const int woff = S->lm_woff[l], st = S->lm_start[l], cnt = S->lm_cnt[l];
+        const double *w = S->W + woff;
+        const int lo = 6 * st, n6 = 6 * cnt;
+        double wv[66], wt[KC - 66];
+#pragma unroll
+        for (int c = 0; c < 66; c++) wv[c] = w[c];
+#pragma unroll
+        for (int c = 66; c < KC; c++) wt[c - 66] = w[n6 + c - 66];
+#pragma unroll
+        for (int f = 0; f < 11; f++)
+          if (f < cnt) {
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+              d1 = fma(wv[6 * f + e], ug[lo + 6 * f + e], d1);
+              d2 = fma(wv[6 * f + e], un[lo + 6 * f + e], d2);
+            }
+          }
+#pragma unroll
+        for (int c = 66; c < KC; c++) {
+          d1 = fma(wt[c - 66], ug[c], d1);
+          d2 = fma(wt[c - 66], un[c], d2);
+        }
       }
       const double y = (s * bl + s * d2) * einv;
       const double gn = -dgl * y;
@@ -964,11 +993,11 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
   }
   return true;
 }
-template <bool INLINE>
+template <bool INLINE, bool WT = false>
 __global__ __launch_bounds__(INLINE ? DOGLEG_INLINE_THREADS : 128) void k_dogleg(char *base, size_t stride, int spec) {
   __shared__ double sh2[2 * (1 + SPEC_EXTRA)];
   // (every launch has grid.x = spec: workgroup z prepares candidate z)
-  dogleg_body<false, INLINE>(SLOT(base, stride), (int)blockIdx.x, (int)blockIdx.x + 1, blockIdx.x == 0, spec, sh2);
+  dogleg_body<false, INLINE, WT>(SLOT(base, stride), (int)blockIdx.x, (int)blockIdx.x + 1, blockIdx.x == 0, spec, sh2);
 }
 
 // ---------------------------------------------------------------------------
@@ -1171,7 +1200,7 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_step(char *base, size
   // (what one workgroup writes for all — the totals, the gradient norm of a new point — falls to the one with the shortest
   // cost block: the first IMU factor of candidate 0)
   const int b = (int)blockIdx.x - z * nb;
-  if (!dogleg_body<true, true>(S, z, z + 1, (int)blockIdx.x == gLm, spec, sh2)) return;
+  if (!dogleg_body<true, true, true>(S, z, z + 1, (int)blockIdx.x == gLm, spec, sh2)) return;
 #ifdef LFVIO_DOGLEG_PROFILE
   const long long t_role = (long long)__builtin_readcyclecounter();
 #endif

@@ -611,10 +611,15 @@ Grid grid_for(lfvio_ctx *c, int count) {
   return g;
 }
 
+// a resident batch: k_lin role by role (and without the transposed copy of W: its k_dogleg reads the compact rows)
+bool lin_split(int count, const Grid &g) {
+  return count >= LIN_SPLIT_MIN_BATCH && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) > LIN_SPLIT_WGS;
+}
+
 void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const int gram_wgs = (g.ch + 3) / 4;  // one chunk per wave
   const size_t st = c->L.total;
-  if (count >= LIN_SPLIT_MIN_BATCH && (size_t)count * (g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1) > LIN_SPLIT_WGS) {
+  if (lin_split(count, g)) {
     // A resident batch: the roles go out as separate launches, each of a kernel compiled for that role alone.  Measured at 512 windows of 300 landmarks:
     // landmark role 115 us + Gram role 175 us + IMU / prior roles 104 us on their own, 679 us as ONE grid — workgroups of four
     // different code paths side by side on every CU (the sweep is ~30 KB of straight-line code per role) do not share an
@@ -662,11 +667,13 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     const int spec = speculate && inl ? 1 + SPEC_EXTRA : 1;
     const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
     // few small windows: the step and the cost of its candidates in one launch (k_step)
-    const bool fuse = inl && !c->no_fuse && !c->shard_active && (size_t)count * nb <= 2048;
+    const bool split = lin_split(count, g);
+    const bool fuse = inl && !split && !c->no_fuse && !c->shard_active && (size_t)count * nb <= 2048;
     if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
     if (fuse) hipLaunchKernelGGL(k_step, dim3(spec * nb, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, g.lm, spec);
     else {
-      if (inl) hipLaunchKernelGGL(k_dogleg<true>, dim3(spec, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, spec);
+      if (inl && !split) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(spec, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, spec);
+      else if (inl) hipLaunchKernelGGL((k_dogleg<true, false>), dim3(spec, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, spec);
       else hipLaunchKernelGGL(k_dogleg<false>, dim3(spec, count), dim3(128), 0, c->stream, c->d_base, st, spec);
     }
     // four lanes per track while the GPU has room for the extra waves (latency of few windows), one when a batch fills it
