@@ -106,6 +106,10 @@ struct SlotHostInfo {
   bool uploaded = false;
   LfvioPrior in_prior;    // kept for the "prior passes through" case of MARGIN_SECOND_NEW
   bool has_in_prior = false;
+  // k_sum's gather lists on the device are a function of the chunks per frame pair alone: kept from one upload of the slot
+  // to the next while that table stays the same (consecutive windows of one estimator: nearly always)
+  std::vector<int> list_key;  // pair_chunk0[0 .. NPAIR], pre_gram
+  int list_items = -1;
 };
 
 }  // namespace
@@ -419,6 +423,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->nSchurParts = S->nLmBlocks;
   info.gLm = S->nLmBlocks, info.gLw = S->nSchurParts, info.gCh = nChunks, info.gSc = S->nSchurParts;
   int used_items = 0;
+  bool lists_cached = false;
   // ---- gather lists of k_sum: which Gram entries (chunk or, for large windows, frame pair; local index of the
   //      20 x 20 block [Pi th_i Pj th_j tic th_ic td | r]) add up to each packed H_pp / g_p entry.  Units ascend, so the
   //      marginalization's subset (pairs (0, j)) is a prefix of every list.
@@ -464,7 +469,16 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     }();
     int n_items = 0;
     bool overflow = false;
-    for (int v = 0; v < VIS && !overflow; v++) {
+    {
+      // the lists depend on nothing but this table: the ones the device holds from the last upload of the slot still stand
+      // if it has not changed (the pass below over ~11 500 items is the largest single part of an upload)
+      std::vector<int> key(S->pair_chunk0, S->pair_chunk0 + NPAIR + 1);
+      key.push_back(S->pre_gram);
+      lists_cached = info.uploaded && info.list_items >= 0 && key == info.list_key;
+      if (!lists_cached) info.list_key.swap(key), info.list_items = -1;
+    }
+    if (lists_cached) n_items = info.list_items;
+    for (int v = 0; v < VIS && !overflow && !lists_cached; v++) {
       const int e = v;  // the bounds are stored by the compact index
       sum_off[e] = n_items;
       int marg_end = n_items;
@@ -485,7 +499,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
       }
       sum_end_marg[e] = marg_end;
     }
-    sum_off[VIS] = n_items;
+    if (!lists_cached) sum_off[VIS] = n_items;
     used_items = n_items;
     if (overflow) {
       c->err = "gather list overflow";
@@ -533,8 +547,10 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->sum_off.set(S, L.sum_off), S->sum_end_marg.set(S, L.sum_end_marg), S->sum_items.set(S, L.sum_items);
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, L.sum_items + (size_t)used_items * 4 - L.in_begin, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, (lists_cached ? L.sum_off : L.sum_items + (size_t)used_items * 4) - L.in_begin, hipMemcpyHostToDevice,
+                           c->stream));
   if (pr) HIPCHK(c, hipMemcpyAsync(d + L.prior_J, h + L.prior_J, sizeof(double) * pr->n * pr->n, hipMemcpyHostToDevice, c->stream));
+  info.list_items = used_items;  // (only now: an upload refused half-way leaves the key without lists on the device)
   if (!info.uploaded) {
     // work-array pointers: fixed per slot until the next reserve()
     Slot W;
