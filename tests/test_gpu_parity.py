@@ -124,6 +124,24 @@ def test_bookkeeping_in_the_prologue_of_k_lin_equals_k_decide(eng, n, kw):
         assert np.array_equal(x[1].J(), y[1].J()) and np.array_equal(x[1].r(), y[1].r())
 
 
+def test_gather_lists_kept_on_the_device_follow_the_pair_table(eng):
+    """k_sum's gather lists stay on the device from one upload of a slot to the next while the chunks per frame pair do not
+    change (lfvio_hip.hip, SlotHostInfo::list_key).  A sequence that alternates windows with different pair tables, and
+    repeats some, must give what a fresh context gives for each of them, bit for bit."""
+    from lfvio.engine import Engine
+
+    ws = [synth.make_window(0, 300), synth.make_window(3, 7), synth.make_window(1, 300), synth.make_window(9, 1000)]
+    fresh = []
+    for w in ws:
+        e = Engine(0)
+        fresh.append(e.solve(w))
+        e.close()
+    for k in (0, 1, 0, 2, 2, 1, 3, 0, 3, 3, 1):
+        sol = eng.solve(ws[k])
+        assert np.array_equal(sol.pose, fresh[k].pose) and np.array_equal(sol.lam, fresh[k].lam), k
+        assert sol.c.num_iterations == fresh[k].c.num_iterations and sol.c.final_cost == fresh[k].c.final_cost
+
+
 def check_prior(p, ref, A, b, Aref, bref):
     assert p.valid == ref.valid == 1
     assert (p.m, p.n, p.num_blocks) == (ref.m, ref.n, ref.num_blocks)
