@@ -714,12 +714,12 @@ __global__ __launch_bounds__(64) void k_backsub(char *base, size_t stride) {
 }
 
 // ---------------------------------------------------------------------------
-// k_dogleg: grid (1, batch) x 128 — ComputeTraditionalDoglegStep, candidate pose-side state,
-// per-pair table of the candidate.
+// k_dogleg<INLINE, WT>: grid (spec, batch) x 128 (INLINE: x DOGLEG_INLINE_THREADS) — ComputeTraditionalDoglegStep, candidate
+// pose-side state, per-pair table of the candidate.  The body (dogleg_body) is also the prologue of k_step.
 // ---------------------------------------------------------------------------
-// inline_backsub != 0 (windows of at most DOGLEG_INLINE_BLOCKS landmark blocks, launched with DOGLEG_INLINE_THREADS):
-// the landmark part of the Gauss-Newton step (k_backsub) is formed here, one landmark per thread, and that launch is left
-// out of the pass — at this size a kernel is a few microseconds of launch and first-load latency whatever it does.
+// INLINE (windows of at most DOGLEG_INLINE_BLOCKS landmark blocks): the landmark part of the Gauss-Newton step (k_backsub)
+// is formed here, one landmark per thread, and that launch is left out of the pass — at this size a kernel is a few
+// microseconds of launch and first-load latency whatever it does.
 constexpr int DOGLEG_INLINE_BLOCKS = 5, DOGLEG_INLINE_THREADS = 64 * DOGLEG_INLINE_BLOCKS;
 // ComputeTraditionalDoglegStep for one radius: step = cg * gradient_ + cn * gauss_newton_, ||step|| = sn
 DEV void dogleg_coeffs(double grad_sq_total, double gn_sq_total, double grad_gn_total, double alpha, double radius, double &cg, double &cn,
@@ -743,7 +743,8 @@ DEV void dogleg_coeffs(double grad_sq_total, double gn_sq_total, double grad_gn_
 }
 // spec: number of candidates to prepare (1, or 1 + SPEC_EXTRA for small windows): candidate z is the step for radius / 2^z.
 // Launched with grid.x = spec: workgroup z prepares candidate z (each one repeats the short common part — the kernel is
-// a latency chain, three of them side by side cost what one costs); workgroup 0 alone writes what is shared.
+// a latency chain, three of them side by side cost what one costs); workgroup 0 alone writes what is shared — except the
+// landmark part of the step in the INLINE form, which every workgroup writes (the same values).
 #ifdef LFVIO_DOGLEG_PROFILE
 #define GSTAMP(k) do { if (blockIdx.x == 0) STAMP(S, k); } while (0)
 #else
