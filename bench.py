@@ -17,9 +17,9 @@ timed region starts.  Workloads (--workload; default window300 at N = 1, window1
                      windows), solved side by side (throughput mode); weak scaling, no collective
   window100k         10-keyframe / 100 000-landmark window on one GPU (per rank at N > 1)
   window100k_sharded configs[3]: ONE 100 000-landmark window sharded over the N ranks by contiguous landmark ranges
-                     balanced on observations; per pass one sum-all-reduce of [H_pp | g_p | Schur sums | scalars]
-                     (151 KB) and two of 16 scalars over RCCL (torch.distributed, backend nccl) on the library's own
-                     stream, seven enqueues and one decision read per pass; strong scaling
+                     balanced on observations, through lfvio_group (include/lfvio.h): the loop is C++ inside the library
+                     and every collective an ncclAllReduce it issues itself on its own stream (torch.distributed only
+                     launches the ranks and carries the 128-byte RCCL id); strong scaling
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -237,13 +237,23 @@ def main():
         desc = (f"BASELINE configs[3]: ONE 10-keyframe / 100 000-landmark window sharded over {world} GPU(s) by contiguous landmark "
                 "ranges balanced on observation count; RCCL sum-all-reduce of the reduced pose system per pass")
 
-    sw = None
+    grp = None
     if sharded:
-        from lfvio.sharded import ShardedWindow
+        # The C-ABI's own multi-GPU entry point: the loop is C++ inside the library and every collective an ncclAllReduce
+        # it issues itself on its stream (lf-vio_amd/csrc/group.inc).  torch.distributed only launched the processes and
+        # carries the 128-byte RCCL id from rank 0 to the others.
+        from lfvio.engine import Group
 
-        sw = ShardedWindow(eng, wins[0], rank, world, (lambda t: dist.all_reduce(t)) if dist is not None else None)
-        b, e = sw.range
+        if dist is not None:
+            box = [Group.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            grp = Group(rank=rank, world=world, device=local_rank, unique_id=box[0])
+        else:
+            grp = Group(mask=1 << local_rank)
+        grp.upload(wins[0])
+        b, e = grp.range(rank)
         local_N, local_M = e - b, int(wins[0].obs_offset[e] - wins[0].obs_offset[b])
+        extra_cfg["collective"] = grp.backend()
     else:
         eng.batch_reserve(batch, max(w.N for w in wins), max(w.M for w in wins))
         if not stream_mode:
@@ -263,7 +273,7 @@ def main():
 
     def step(k):
         if sharded:
-            sw.run(flag)
+            grp.optimize(flag)
         elif stream_mode:
             w = wins[k % len(wins)]
             eng.batch_upload(0, w, marshalled[k % len(wins)])
@@ -300,8 +310,10 @@ def main():
 
     # ---- sanity of the timed work
     if sharded:
-        sol, _, prior = sw.run(flag)
-        extra_cfg["passes_per_step"] = sw.passes
+        grp.optimize(flag)
+        sol, prior = grp.download()
+        extra_cfg["passes_per_step"] = grp.last_passes()
+        extra_cfg["collectives_per_step"] = grp.last_collectives()
     else:
         sol, prior = eng.batch_download(0, wins[0].N if not stream_mode else wins[(args.steps - 1) % len(wins)].N)
     assert prior.valid == 1 and np.isfinite(sol.c.final_cost) and sol.c.num_iterations >= 2
@@ -313,7 +325,8 @@ def main():
     # ---- roofline of the residual/Jacobian sweep kernel (k_lin), measured live with HIP events on the
     #      library's own stream; algorithmic bytes per launch = 68 (M - N) + 88 N over what the launch sweeps
     reps = 200 if n_lm <= 1000 else 20
-    lin_ms = eng.time_kernel(0, batch, reps)
+    tk = grp if sharded else eng  # (the sharded window lives in the group's context)
+    lin_ms = tk.time_kernel(0, batch, reps)
     bytes_per_launch = sum(algorithmic_bytes(w.N, w.M) for w in wins[:batch]) if not sharded else algorithmic_bytes(local_N, local_M)
     achieved = bytes_per_launch / (lin_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(workload if not stream_mode else "window300")
@@ -322,7 +335,7 @@ def main():
                     traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_us=lin_ms * 1e3,
                     note="latency-bound at N=300 (0.1 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep")
-    extra = dict(k_sum_us=eng.time_kernel(2, batch, reps) * 1e3, k_solve_us=eng.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
+    extra = dict(k_sum_us=tk.time_kernel(2, batch, reps) * 1e3, k_solve_us=tk.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
     # the dense solve (k_solve: one workgroup = one CU per window) is where a small window spends most of its time; its
     # arithmetic is the Cholesky factorization and two substitutions of the 172 x 172 reduced system
     KP = 172
@@ -336,7 +349,8 @@ def main():
                           note="latency/issue-bound on a single CU per window (DESIGN.md section 5); not the kernel section 8(d) prices")
 
     if sharded:
-        par = f"landmark-sharded over {world} GPU(s): ranges balanced on observations, RCCL sum-all-reduce of 151 KB + 2 x 128 B per pass on the library's stream"
+        par = (f"landmark-sharded over {world} GPU(s) by lfvio_group (C++ driver inside the library): ranges balanced on observations, "
+               f"ncclAllReduce on the library's stream, {grp.last_collectives()} collectives per optimization()")
     else:
         par = f"{world} independent window stream(s), one per GPU, no data-path collective"
     cfg = dict(workload=workload, description=desc, landmarks=n_lm, observations=int(wins[0].M), windows_per_gpu=batch,
@@ -409,6 +423,8 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
+    if grp is not None:
+        grp.close()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -293,6 +293,52 @@ int lfvio_shard_marg_linearize(lfvio_ctx *ctx, int flag);
 int lfvio_shard_marg_finish(lfvio_ctx *ctx, int flag, LfvioPrior *out);
 int lfvio_shard_finish(lfvio_ctx *ctx, LfvioSolution *out);
 
+/* ---- multi-GPU groups: the 8-GPU path behind the C-ABI (SURVEY §8b `lfvio_create(int device_mask)`, §8e) -------------
+ * The host side is C++ and the collective is RCCL (ncclAllReduce on each context's own stream), called by the library
+ * itself; librccl is dlopen()ed when the first group is created (LFVIO_RCCL_LIB overrides the search), so a single-GPU
+ * caller has no RCCL dependency.  Three ways to form a group:
+ *   lfvio_group_create(mask)       ONE process (the ROS node: estimator.cpp:484 runs on one thread under m_estimator):
+ *                                  one context + stream per device whose bit is set, ncclCommInitAll
+ *   lfvio_group_create_rank(...)   one process per GPU (torchrun / mpirun): ncclCommInitRank; rank 0 obtains the id from
+ *                                  lfvio_group_unique_id() and the launcher broadcasts its 128 bytes
+ *   lfvio_group_create_local(...)  `shards` ranks on ONE device, the all-reduce a device-side sum in rank order instead
+ *                                  of RCCL — for tests on a one-GPU box
+ * lfvio_group_solve() is what the re-implemented Estimator::optimization() calls in place of lfvio_solve() +
+ * lfvio_marginalize(): every rank is handed the same window, rank r linearizes a contiguous landmark range balanced on
+ * observation count (IMU factors and prior on rank 0), per trust-region pass the ranks sum-all-reduce
+ * [H_pp | g_p | Schur sums | scalars], every rank solves the identical reduced system (no broadcast, identical
+ * decisions), and the marginalization costs one more all-reduce; solution and prior come out identical on every rank,
+ * sol->inv_depth complete.  Same error convention as the single-context calls; lfvio_group_last_error() has the text. */
+#define LFVIO_UNIQUE_ID_BYTES 128
+typedef struct lfvio_group lfvio_group;
+lfvio_group *lfvio_group_create(unsigned device_mask);
+int lfvio_group_unique_id(char id[LFVIO_UNIQUE_ID_BYTES]);
+lfvio_group *lfvio_group_create_rank(int device, int rank, int world, const char id[LFVIO_UNIQUE_ID_BYTES]);
+lfvio_group *lfvio_group_create_local(int device, int shards);
+void lfvio_group_destroy(lfvio_group *g);
+const char *lfvio_group_last_error(const lfvio_group *g);
+int lfvio_group_size(const lfvio_group *g);     /* ranks of the group                       */
+int lfvio_group_local(const lfvio_group *g);    /* contexts (ranks) held by this process    */
+int lfvio_group_rank(const lfvio_group *g);     /* rank of the first local context          */
+lfvio_ctx *lfvio_group_ctx(lfvio_group *g, int i); /* i-th local context (any single-context call may be made on it) */
+const char *lfvio_group_backend(const lfvio_group *g); /* path of the RCCL library in use, or "local" */
+/* optimization() of one window, landmark-sharded: upload + optimize + download, or the three steps on their own (the
+ * window stays resident: lfvio_group_optimize() may be repeated, which is what bench.py times).  marg_flag < 0: the
+ * trust-region solve only. */
+int lfvio_group_solve(lfvio_group *g, const LfvioWindow *in, int marg_flag, LfvioSolution *sol, LfvioPrior *prior);
+int lfvio_group_upload(lfvio_group *g, const LfvioWindow *in);
+int lfvio_group_optimize(lfvio_group *g, int marg_flag);
+int lfvio_group_download(lfvio_group *g, LfvioSolution *sol, LfvioPrior *prior);
+int lfvio_group_range(const lfvio_group *g, int rank, int *lm_begin, int *lm_end); /* landmark range of a rank */
+int lfvio_group_last_passes(const lfvio_group *g);      /* passes / collectives of the last lfvio_group_optimize() */
+int lfvio_group_last_collectives(const lfvio_group *g);
+/* independent resident windows split over the devices of this process (BASELINE "512 independent windows"): slot s
+ * lives on local context s % lfvio_group_local(); no data-path collective */
+int lfvio_group_batch_reserve(lfvio_group *g, int batch, int max_landmarks, int max_observations);
+int lfvio_group_batch_upload(lfvio_group *g, int slot, const LfvioWindow *in);
+int lfvio_group_batch_optimize(lfvio_group *g, int count, int marg_flag);
+int lfvio_group_batch_download(lfvio_group *g, int slot, LfvioSolution *sol, LfvioPrior *prior);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,8 @@
 // layout of dev_types.h, launches the kernel pipeline and unpacks the result.
 // There is NO CPU fallback: without a usable HIP device lfvio_create() fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen()ed by group.inc, not linked
 
 #include <algorithm>
 #include <chrono>
@@ -135,6 +137,7 @@ struct lfvio_ctx {
   hipGraphExec_t chunk = nullptr, tail[3] = {nullptr, nullptr, nullptr};
   hipGraphExec_t first[4][13] = {};  // [0: solve only, 1 + flag: with the gated tail][passes in the first graph]
   int predict_passes = 4;           // passes the previous synchronous call needed; tail[flag]: force-done + gated gauge fix + marginalization
+  double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   bool use_graph = true;
@@ -747,8 +750,8 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated 
 // tells the caller whether anything is left for the (gated) tail graph.
 // max_seconds > 0 (adaptive only): Ceres' max_solver_time_in_seconds (estimator.cpp:815-822) — TrustRegionMinimizer tests the
 // wall clock at the top of every iteration and stops with NO_CONVERGENCE; here the host tests it between graph launches
-// (the only points where it sees the loop) and ends the open slots the same way (k_force_done).  With a cap the first
-// graph is not sized from the previous call: the loop goes out in chunks of SOLVE_CHUNK passes so that the cap can bite.
+// (the only points where it sees the loop) and ends the open slots the same way (k_force_done).  The first graph is sized
+// from the previous call as without a cap, shortened only when the cap is tighter than that many passes would take.
 int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fused_flag = -1, bool *tail_done = nullptr,
                   double max_seconds = -1.0) {
   const Grid g = grid_for(c, count);
@@ -770,7 +773,11 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     // the gated gauge fix + marginalization; whatever is still pending afterwards continues in chunks of SOLVE_CHUNK.
     const bool capped = max_seconds > 0.0;
     const auto t_start = std::chrono::steady_clock::now();
-    const int first_passes = capped ? std::min(SOLVE_CHUNK, passes) : std::min(std::max(c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
+    // With a cap the first graph is still the predicted one — a cap of SOLVER_TIME = 0.04 s (the shipped default) is a few
+    // hundred passes away and must not cost the call its single launch — unless the cap is so tight that the predicted
+    // graph could overrun it: then no more passes than fit (at the measured time per pass), down to a chunk of SOLVE_CHUNK.
+    int first_passes = std::min(std::max(c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
+    if (capped) first_passes = std::max(std::min(SOLVE_CHUNK, passes), std::min(first_passes, (int)std::min(max_seconds / c->pass_seconds, 1e6)));
     hipGraphExec_t &first_graph = c->first[fuse ? 1 + fused_flag : 0][first_passes];
     auto capture = [&](hipGraphExec_t *out, bool setup, int npass, int tail_flag) -> int {
       hipGraph_t graph;
@@ -812,9 +819,14 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     c->stat_chunks = 0;
     for (int done_passes = 0; done_passes < passes;) {
       c->stat_chunks++;
+      const auto t_launch = std::chrono::steady_clock::now();
       HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       const bool first = done_passes == 0;
+      if (!first) {  // time per pass, for sizing a capped call's first graph (continuation chunks carry nothing but passes)
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch).count() / SOLVE_CHUNK;
+        c->pass_seconds = 0.75 * c->pass_seconds + 0.25 * dt;
+      }
       done_passes += first ? first_passes : SOLVE_CHUNK;
       if (first && fuse && count == 1) c->h_pending[0] = c->h_pending[2] == 2 ? 0 : 1, c->h_pending[1] = c->h_pending[3];
       if (c->h_pending[0] == 0) {
@@ -829,7 +841,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       }
     }
     c->last_passes = std::max(c->h_pending[1], 1);  // passes the slowest window has used
-    if (!capped) c->predict_passes = c->last_passes;
+    c->predict_passes = c->last_passes;
     HIPCHK(c, hipGetLastError());
     return LFVIO_OK;
   }
@@ -1444,5 +1456,7 @@ int lfvio_debug_set_decide_merge(lfvio_ctx *c, int on) {
 
 // ---- landmark-sharded API: declared in lfvio.h, implemented in shard.inc
 #include "shard.inc"
+// ---- multi-GPU groups (RCCL): declared in lfvio.h, implemented in group.inc
+#include "group.inc"
 
 }  // extern "C"

@@ -270,6 +270,10 @@ int lfvio_host_get_prior(void *h, LfvioPrior *out) {
 
 // 1 (default): one upload, everything on the device; 0: the literal lfvio_solve / double2vector / lfvio_marginalize flow
 void lfvio_host_set_fused(void *h, int on) { E(h)->fused = on != 0; }
+// HIP devices of the estimator (bit d = device d); before the first call that needs the device.  More than one bit: the
+// optimization() of every frame runs landmark-sharded through an lfvio_group over them.
+void lfvio_host_set_device_mask(unsigned mask) { config().device_mask = mask ? mask : 1u; }
+int lfvio_host_uses_group(void *h) { return E(h)->group != nullptr; }
 
 int lfvio_host_optimization(void *h) {
   WindowEstimator *e = E(h);

@@ -186,15 +186,38 @@ void TrackTable::dropFailed() {
 WindowEstimator::WindowEstimator() {
   std::memset(&summary, 0, sizeof summary);
   std::memset(&prior, 0, sizeof prior);
+  std::memset(&next_, 0, sizeof next_);
   reset();
 }
 
 WindowEstimator::~WindowEstimator() {
-  if (gpu) lfvio_destroy(gpu);
+  if (group) lfvio_group_destroy(group);  // owns its contexts, `gpu` among them
+  else if (gpu) lfvio_destroy(gpu);
 }
 
+namespace {
+// what is there of a prior: header, n x n of the Jacobian slots, n residuals (46 KB instead of 240 KB for n = 76)
+void assign_prior(LfvioPrior *dst, const LfvioPrior *src) {
+  std::memcpy(dst, src, offsetof(LfvioPrior, linearized_jacobians));
+  if (src->valid && src->n > 0 && src->n <= LFVIO_MAX_PRIOR_DIM) {
+    std::memcpy(dst->linearized_jacobians, src->linearized_jacobians, sizeof(double) * src->n * src->n);
+    std::memcpy(dst->linearized_residuals, src->linearized_residuals, sizeof(double) * src->n);
+  }
+}
+}  // namespace
+
 bool WindowEstimator::device() {
-  if (!gpu) gpu = lfvio_create(0);
+  if (!gpu) {
+    const unsigned mask = config().device_mask ? config().device_mask : 1u;
+    if (mask & (mask - 1)) {  // several devices: one group, whose first context also serves the single-device calls
+      group = lfvio_group_create(mask);
+      gpu = group ? lfvio_group_ctx(group, 0) : nullptr;
+    } else {
+      int d = 0;
+      while (!(mask & (1u << d))) d++;
+      gpu = lfvio_create(d);
+    }
+  }
   if (!gpu) status = LFVIO_ERR_DEVICE;  // there is no host fallback: the caller sees the failure
   return gpu != nullptr;
 }
@@ -562,8 +585,18 @@ void WindowEstimator::optimization() {
     std::copy(st.lam_out.begin(), st.lam_out.begin() + w.num_landmarks, para_Feature.begin());
     double2vector();  // :830
   };
-  LfvioPrior next;
+  LfvioPrior &next = next_;
   summary.inv_depth = st.lam_out.data();
+  if (group) {
+    // several devices: the same three steps as below in ONE call — the landmarks sharded over the devices of the group,
+    // every collective an ncclAllReduce the library issues itself (lf-vio_amd/csrc/group.inc)
+    status = lfvio_group_solve(group, &w, marg_flag, &summary, &next);
+    summary.inv_depth = nullptr;
+    if (status != LFVIO_OK) return;
+    take_state();
+    if (marginalize) assign_prior(&prior, &next), has_prior = next.valid != 0;
+    return;
+  }
   if (fused) {
     // one upload; solve (:810-825), the gauge fix of double2vector() (:532-626) and the marginalization (:833-1005) run back
     // to back on the device.  The state that comes back is already re-anchored, so double2vector() below applies a zero
@@ -575,7 +608,7 @@ void WindowEstimator::optimization() {
     summary.inv_depth = nullptr;
     if (status != LFVIO_OK) return;
     take_state();
-    if (marginalize) prior = next, has_prior = next.valid != 0;
+    if (marginalize) assign_prior(&prior, &next), has_prior = next.valid != 0;
     return;
   }
   // the reference's literal sequence: solve, double2vector() on the host, vector2double(), marginalize (two uploads)
@@ -588,7 +621,7 @@ void WindowEstimator::optimization() {
   pack(&w);
   status = lfvio_marginalize(gpu, &w, marg_flag, &next);
   if (status != LFVIO_OK) return;
-  prior = next, has_prior = next.valid != 0;
+  assign_prior(&prior, &next), has_prior = next.valid != 0;
 }
 
 }  // namespace lfvio

@@ -40,6 +40,10 @@ struct Config {
   // configured extrinsic (TIC / RIC, parameters.cpp:88-112): what setParameter() restores after every reset
   double tic[3] = {0, 0, 0};
   double ric[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  // HIP devices the estimator may use: bit d = device d.  One bit (default: device 0): a single context.  Several bits: an
+  // lfvio_group over them — optimization() becomes ONE lfvio_group_solve(), the window's landmarks sharded over the
+  // devices with RCCL all-reduces inside the library (include/lfvio.h; SURVEY §8b lfvio_create(device_mask), §8e).
+  unsigned device_mask = 1u;
 };
 Config &config();
 
@@ -188,9 +192,11 @@ class WindowEstimator {
   LfvioPrior prior;  // last_marginalization_info + its parameter blocks, (kind, frame)-tagged
   LfvioSolution summary;
   int status = LFVIO_OK;
-  lfvio_ctx *gpu = nullptr;
+  lfvio_ctx *gpu = nullptr;      // the context (of the first device of the mask): triangulation, depth shifts, preintegration
+  lfvio_group *group = nullptr;  // more than one device in Config::device_mask: the sharded optimization()
 
  private:
+  LfvioPrior next_;  // the prior being downloaded (240 KB: a member, not a stack object; only header + n x n + n are copied)
   bool device();
   bool applyBootstrap();
   FrameRing ring_;

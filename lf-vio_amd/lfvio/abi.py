@@ -343,6 +343,11 @@ HIP_SYMBOLS = [
     "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_scalar_offset", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
     "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_marg_linearize", "lfvio_shard_marg_finish",
     "lfvio_shard_finish", "lfvio_shard_restart", "lfvio_shard_enqueue", "lfvio_shard_poll", "lfvio_triangulate", "lfvio_shift_depth", "lfvio_preintegrate",
+    "lfvio_group_create", "lfvio_group_unique_id", "lfvio_group_create_rank", "lfvio_group_create_local", "lfvio_group_destroy",
+    "lfvio_group_last_error", "lfvio_group_size", "lfvio_group_local", "lfvio_group_rank", "lfvio_group_ctx", "lfvio_group_backend",
+    "lfvio_group_solve", "lfvio_group_upload", "lfvio_group_optimize", "lfvio_group_download", "lfvio_group_range",
+    "lfvio_group_last_passes", "lfvio_group_last_collectives", "lfvio_group_batch_reserve", "lfvio_group_batch_upload",
+    "lfvio_group_batch_optimize", "lfvio_group_batch_download",
 ]
 
 
@@ -397,6 +402,33 @@ def load_hip_library(path=None):
     lib.lfvio_preintegrate.argtypes = [C.c_void_p, C.c_int, C.POINTER(ImuIntervalC), _dp, C.POINTER(Preintegration)]
     lib.lfvio_shard_marg_linearize.argtypes = [C.c_void_p, C.c_int]
     lib.lfvio_shard_marg_finish.argtypes = [C.c_void_p, C.c_int, C.POINTER(Prior)]
+    # multi-GPU groups (RCCL inside the library)
+    lib.lfvio_group_create.restype = C.c_void_p
+    lib.lfvio_group_create.argtypes = [C.c_uint]
+    lib.lfvio_group_unique_id.argtypes = [C.c_char_p]
+    lib.lfvio_group_create_rank.restype = C.c_void_p
+    lib.lfvio_group_create_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p]
+    lib.lfvio_group_create_local.restype = C.c_void_p
+    lib.lfvio_group_create_local.argtypes = [C.c_int, C.c_int]
+    lib.lfvio_group_destroy.argtypes = [C.c_void_p]
+    lib.lfvio_group_destroy.restype = None
+    lib.lfvio_group_last_error.restype = C.c_char_p
+    lib.lfvio_group_last_error.argtypes = [C.c_void_p]
+    lib.lfvio_group_backend.restype = C.c_char_p
+    lib.lfvio_group_backend.argtypes = [C.c_void_p]
+    for name in ("lfvio_group_size", "lfvio_group_local", "lfvio_group_rank", "lfvio_group_last_passes", "lfvio_group_last_collectives"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.lfvio_group_ctx.restype = C.c_void_p
+    lib.lfvio_group_ctx.argtypes = [C.c_void_p, C.c_int]
+    lib.lfvio_group_solve.argtypes = [C.c_void_p, C.POINTER(WindowC), C.c_int, C.POINTER(SolutionC), C.POINTER(Prior)]
+    lib.lfvio_group_upload.argtypes = [C.c_void_p, C.POINTER(WindowC)]
+    lib.lfvio_group_optimize.argtypes = [C.c_void_p, C.c_int]
+    lib.lfvio_group_download.argtypes = [C.c_void_p, C.POINTER(SolutionC), C.POINTER(Prior)]
+    lib.lfvio_group_range.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.lfvio_group_batch_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.lfvio_group_batch_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(WindowC)]
+    lib.lfvio_group_batch_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.lfvio_group_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(SolutionC), C.POINTER(Prior)]
     return lib
 
 

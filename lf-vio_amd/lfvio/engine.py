@@ -219,3 +219,125 @@ class Engine:
 
     def stream(self):
         return self.lib.lfvio_stream(self.ctx)
+
+
+class Group:
+    """lfvio_group: the multi-GPU entry points of the C-ABI (RCCL called by the library itself; include/lfvio.h).
+
+    Group(mask=0b11)                      one process, the devices of the mask (ncclCommInitAll)
+    Group(rank=r, world=n, device=d, unique_id=b)   one process per GPU (ncclCommInitRank); Group.unique_id() on rank 0,
+                                          its 128 bytes broadcast by the launcher
+    Group(local_shards=k, device=d)       k ranks on one device, device-side sum instead of RCCL (tests)
+    """
+
+    def __init__(self, mask=None, rank=None, world=None, device=0, unique_id=None, local_shards=None, lib_path=None):
+        self.lib = abi.load_hip_library(lib_path)
+        self.g = None
+        if local_shards is not None:
+            self.g = self.lib.lfvio_group_create_local(int(device), int(local_shards))
+        elif rank is not None:
+            assert unique_id is not None and len(unique_id) == 128
+            self.g = self.lib.lfvio_group_create_rank(int(device), int(rank), int(world), bytes(unique_id))
+        else:
+            self.g = self.lib.lfvio_group_create(int(mask if mask is not None else 1))
+        if not self.g:
+            raise RuntimeError("lfvio_group_create failed (no usable HIP device / RCCL): there is no CPU fallback")
+        self._win = None
+
+    @staticmethod
+    def unique_id(lib_path=None):
+        lib = abi.load_hip_library(lib_path)
+        buf = C.create_string_buffer(128)
+        if lib.lfvio_group_unique_id(buf) != 0:
+            raise RuntimeError("lfvio_group_unique_id failed (librccl not loadable)")
+        return buf.raw
+
+    def close(self):
+        if self.g:
+            self.lib.lfvio_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed rc={rc}: {self.lib.lfvio_group_last_error(self.g).decode()}")
+
+    @property
+    def world(self):
+        return int(self.lib.lfvio_group_size(self.g))
+
+    @property
+    def local(self):
+        return int(self.lib.lfvio_group_local(self.g))
+
+    @property
+    def rank(self):
+        return int(self.lib.lfvio_group_rank(self.g))
+
+    def backend(self):
+        return self.lib.lfvio_group_backend(self.g).decode()
+
+    def ctx(self, i=0):
+        return self.lib.lfvio_group_ctx(self.g, i)
+
+    def upload(self, win):
+        self._win = win  # keep the arrays alive
+        self._check(self.lib.lfvio_group_upload(self.g, C.byref(win.c())), "lfvio_group_upload")
+
+    def optimize(self, flag):
+        self._check(self.lib.lfvio_group_optimize(self.g, -1 if flag is None else int(flag)), "lfvio_group_optimize")
+
+    def download(self, want_prior=True):
+        sol = abi.Solution(self._win.N)
+        prior = abi.Prior() if want_prior else None
+        self._check(self.lib.lfvio_group_download(self.g, C.byref(sol.c), C.byref(prior) if want_prior else None), "lfvio_group_download")
+        return sol, prior
+
+    def solve(self, win, flag):
+        """The drop-in call: upload + optimization() + download; returns (solution, prior) — prior None when flag is None."""
+        self._win = win
+        sol = abi.Solution(win.N)
+        prior = abi.Prior() if flag is not None else None
+        self._check(self.lib.lfvio_group_solve(self.g, C.byref(win.c()), -1 if flag is None else int(flag), C.byref(sol.c),
+                                               C.byref(prior) if prior is not None else None), "lfvio_group_solve")
+        return sol, prior
+
+    def range(self, rank):
+        b, e = C.c_int(0), C.c_int(0)
+        self._check(self.lib.lfvio_group_range(self.g, int(rank), C.byref(b), C.byref(e)), "lfvio_group_range")
+        return b.value, e.value
+
+    def last_passes(self):
+        return int(self.lib.lfvio_group_last_passes(self.g))
+
+    def last_collectives(self):
+        return int(self.lib.lfvio_group_last_collectives(self.g))
+
+    def time_kernel(self, which, count, reps, i=0):
+        ms = np.zeros(1)
+        self.lib.lfvio_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
+        rc = self.lib.lfvio_debug_time_kernel(self.ctx(i), which, count, reps, _p(ms))
+        if rc != 0:
+            raise RuntimeError(f"time_kernel failed rc={rc}")
+        return float(ms[0])
+
+    # independent windows split over the local devices
+    def batch_reserve(self, batch, max_landmarks, max_observations):
+        self._check(self.lib.lfvio_group_batch_reserve(self.g, batch, max_landmarks, max_observations), "group_batch_reserve")
+
+    def batch_upload(self, slot, win):
+        self._check(self.lib.lfvio_group_batch_upload(self.g, slot, C.byref(win.c())), "group_batch_upload")
+
+    def batch_optimize(self, count, flag):
+        self._check(self.lib.lfvio_group_batch_optimize(self.g, count, flag), "group_batch_optimize")
+
+    def batch_download(self, slot, n_landmarks, want_prior=True):
+        sol = abi.Solution(n_landmarks)
+        prior = abi.Prior() if want_prior else None
+        self._check(self.lib.lfvio_group_batch_download(self.g, slot, C.byref(sol.c), C.byref(prior) if want_prior else None), "group_batch_download")
+        return sol, prior

@@ -124,4 +124,19 @@ int lfvio_preintegrate(lfvio_ctx *c, int num_intervals, const LfvioImuInterval *
   }
   return LFVIO_OK;
 }
+// lfvio_group over the oracle: the "devices" are one CPU — whatever the mask, ONE oracle context answers (the host mirror
+// references these entry points; the oracle stack of the tests runs with the default single-device mask)
+struct lfvio_group {
+  lfvio_ctx ctx;
+  std::string err;
+};
+lfvio_group *lfvio_group_create(unsigned device_mask) { return device_mask ? new lfvio_group() : nullptr; }
+void lfvio_group_destroy(lfvio_group *g) { delete g; }
+lfvio_ctx *lfvio_group_ctx(lfvio_group *g, int i) { return (g && i == 0) ? &g->ctx : nullptr; }
+const char *lfvio_group_last_error(const lfvio_group *g) { return g ? g->err.c_str() : "null group"; }
+int lfvio_group_solve(lfvio_group *g, const LfvioWindow *in, int marg_flag, LfvioSolution *sol, LfvioPrior *prior) {
+  if (!g || !in || !sol) return LFVIO_ERR_ARG;
+  if (marg_flag < 0) return oracle_solve(in, sol);
+  return oracle_optimize(in, marg_flag, sol, prior, nullptr);
+}
 }

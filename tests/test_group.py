@@ -1,0 +1,163 @@
+"""lfvio_group: the multi-GPU entry points of the C-ABI (include/lfvio.h) — the landmark-sharded optimization() driven by the
+library's own C++ loop with the collective inside the library.
+
+A test box has ONE GPU, so:
+* `lfvio_group_create_local(device, k)` plays k ranks on it (a device-side sum in rank order stands in for RCCL): the
+  whole C++ driver — partition, stream-ordered passes, marginalization, gather of the inverse depths — against the
+  single-context optimization() and the oracle;
+* `lfvio_group_create(1)` (a mask of one device) runs the real thing: librccl loaded by the library, ncclCommInitAll, and
+  every collective of the loop as an ncclAllReduce on the context's stream.
+"""
+import numpy as np
+import pytest
+
+from lfvio import abi, synth
+
+
+def _compare(sol, prior, want, want_prior, tol=1e-6):
+    assert (sol.c.num_iterations, sol.c.termination) == (want.c.num_iterations, want.c.termination)
+    assert np.abs(sol.pose - want.pose).max() < tol * max(1.0, np.abs(want.pose).max())
+    assert np.abs(sol.speed_bias - want.speed_bias).max() < tol * max(1.0, np.abs(want.speed_bias).max())
+    assert np.abs(sol.lam - want.lam).max() < tol * np.abs(want.lam).max()
+    assert abs(sol.c.final_cost - want.c.final_cost) <= 1e-7 * want.c.final_cost
+    assert (prior.valid, prior.m, prior.n, prior.num_blocks) == (1, want_prior.m, want_prior.n, want_prior.num_blocks)
+    assert prior.block_list() == want_prior.block_list()
+    J, Jw = prior.J(), want_prior.J()
+    Aw = Jw.T @ Jw
+    assert np.abs(J.T @ J - Aw).max() < tol * np.abs(Aw).max()
+    bw = Jw.T @ want_prior.r()
+    assert np.abs(J.T @ prior.r() - bw).max() < tol * np.abs(bw).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards,n", [(1, 300), (2, 300), (3, 300), (4, 3000), (8, 100000)])  # (8, 100000): BASELINE configs[3]
+def test_local_group_equals_the_single_gpu_optimization(oracle, shards, n):
+    from lfvio.engine import Engine, Group
+
+    ref = Engine(0)
+    warm = (lambda x, f: oracle.optimize(x, f)) if n <= 1000 else (lambda x, f: ref.optimize(x, f))
+    w = synth.make_window_with_prior(4, n, warm)[0]
+    want, want_prior = ref.optimize(w, abi.MARGIN_OLD)
+    ref.close()
+    g = Group(local_shards=shards)
+    assert (g.world, g.local, g.rank, g.backend()) == (shards, shards, 0, "local")
+    sol, prior = g.solve(w, abi.MARGIN_OLD)  # upload + optimization() + download in one C call
+    _compare(sol, prior, want, want_prior)
+    if n <= 1000:
+        o_sol, o_prior = oracle.optimize(w, abi.MARGIN_OLD)
+        _compare(sol, prior, o_sol, o_prior)
+    # the ranges are contiguous, cover the window and are balanced on observations
+    cuts = [g.range(r) for r in range(shards)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == w.N and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    loads = [int(w.obs_offset[e] - w.obs_offset[b]) for b, e in cuts]
+    assert max(loads) - min(loads) <= 2 * 11
+    # the window stays resident: optimize() again is the same computation, bit for bit
+    passes = g.last_passes()
+    g.optimize(abi.MARGIN_OLD)
+    sol2, prior2 = g.download()
+    assert g.last_passes() == passes
+    assert np.array_equal(sol2.pose, sol.pose) and np.array_equal(sol2.lam, sol.lam) and np.array_equal(prior2.J(), prior.J())
+    # the solve alone (no gauge fix, no marginalization) equals lfvio_solve()
+    e1 = Engine(0)
+    want_s = e1.solve(w)
+    e1.close()
+    g.optimize(None)
+    sol3, _ = g.download(want_prior=False)
+    assert sol3.c.num_iterations == want_s.c.num_iterations
+    assert np.abs(sol3.pose - want_s.pose).max() < 1e-6 * max(1.0, np.abs(want_s.pose).max())
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [300, 20000])
+def test_mask_of_one_device_runs_every_collective_through_rccl(oracle, n):
+    """lfvio_group_create(1): ncclCommInitAll over one device, every all-reduce of the loop an ncclAllReduce on the
+    library's stream.  One rank's sum is its own buffer, so the result is the local group's, bit for bit."""
+    from lfvio.engine import Engine, Group
+
+    ref = Engine(0)
+    warm = (lambda x, f: oracle.optimize(x, f)) if n <= 1000 else (lambda x, f: ref.optimize(x, f))
+    w = synth.make_window_with_prior(5, n, warm)[0]
+    want, want_prior = ref.optimize(w, abi.MARGIN_OLD)
+    ref.close()
+    g = Group(mask=1)
+    assert "rccl" in g.backend() and (g.world, g.local) == (1, 1)
+    sol, prior = g.solve(w, abi.MARGIN_OLD)
+    assert g.last_collectives() >= g.last_passes() + 1 >= 3  # at least one per pass and the marginalization's
+    _compare(sol, prior, want, want_prior)
+    loc = Group(local_shards=1)
+    sol_l, prior_l = loc.solve(w, abi.MARGIN_OLD)
+    assert loc.last_passes() == g.last_passes()
+    assert np.array_equal(sol.pose, sol_l.pose) and np.array_equal(sol.speed_bias, sol_l.speed_bias)
+    assert np.array_equal(sol.lam, sol_l.lam) and np.array_equal(prior.J(), prior_l.J()) and np.array_equal(prior.r(), prior_l.r())
+    # how far the sharded driver is from the unsharded one on the same window (reported, bounded by the bar above)
+    print(f"mask-of-one vs lfvio_batch_optimize: pose {np.abs(sol.pose - want.pose).max():.2e}, "
+          f"bit-identical: {np.array_equal(sol.pose, want.pose) and np.array_equal(prior.J(), want_prior.J())}")
+    loc.close()
+    g.close()
+
+
+@pytest.mark.gpu
+def test_rank_mode_world_one_and_unique_id():
+    """lfvio_group_create_rank with world = 1: ncclGetUniqueId + ncclCommInitRank, the path bench.py takes under torchrun."""
+    from lfvio.engine import Engine, Group
+
+    uid = Group.unique_id()
+    assert len(uid) == 128 and any(uid)
+    g = Group(rank=0, world=1, device=0, unique_id=uid)
+    w = synth.make_window(7, 200)
+    sol, prior = g.solve(w, abi.MARGIN_OLD)
+    e = Engine(0)
+    want, want_prior = e.optimize(w, abi.MARGIN_OLD)
+    e.close()
+    _compare(sol, prior, want, want_prior)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_group_splits_independent_windows_over_its_contexts(oracle):
+    """configs[4] through a group: slot s on local context s % L; every slot equals the single-context result."""
+    from lfvio.engine import Engine, Group
+
+    wins = [synth.make_window(100 + s, 120 + 10 * s) for s in range(5)]
+    e = Engine(0)
+    want = [e.optimize(w, abi.MARGIN_OLD) for w in wins]
+    e.close()
+    g = Group(local_shards=2)
+    g.batch_reserve(len(wins), max(w.N for w in wins), max(w.M for w in wins))
+    for s, w in enumerate(wins):
+        g.batch_upload(s, w)
+    g.batch_optimize(len(wins), abi.MARGIN_OLD)
+    for s, w in enumerate(wins):
+        sol, prior = g.batch_download(s, w.N)
+        assert np.array_equal(sol.pose, want[s][0].pose) and np.array_equal(sol.lam, want[s][0].lam)
+        assert np.array_equal(prior.J(), want[s][1].J())
+    g.close()
+
+
+@pytest.mark.gpu
+def test_group_errors_leave_outputs_untouched():
+    from lfvio.engine import Group
+
+    g = Group(local_shards=2)
+    with pytest.raises(RuntimeError):
+        g.optimize(abi.MARGIN_OLD)  # nothing uploaded
+    w = synth.make_window(3, 100)
+    bad = w.copy(obs_offset=w.obs_offset[::-1].copy())
+    with pytest.raises(RuntimeError):
+        g.solve(bad, abi.MARGIN_OLD)
+    sol, prior = g.solve(w, abi.MARGIN_OLD)  # the group is still usable
+    assert prior.valid == 1 and np.isfinite(sol.c.final_cost)
+    g.close()
+
+
+def test_group_create_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    from lfvio.engine import Group
+
+    for kw in (dict(mask=1), dict(local_shards=2)):
+        with pytest.raises(RuntimeError):
+            Group(**kw)
