@@ -102,14 +102,67 @@ DEV double block_max(double v, double *scratch, int tid) {
   return s;
 }
 
+// What thread 0 of the dense solve leaves in the header once the Gauss-Newton step is there (shared by k_solve_dense and
+// k_solve_sparse): the pose-side sums, and at iteration 0 IterationZero + the first
+// FinalizeIterationAndCheckIfMinimizerCanContinue of trust_region_minimizer.cc.
+DEV void solve_epilogue(Slot *S, TRState *tr, const double *ls, double gn2, double ggn, double gG, double gN, double qgn, double qnn) {
+  tr->q[Q_GN_SQ] = gn2;
+  tr->q[Q_GRAD_GN] = ggn;
+  tr->q[Q_gG] = gG;
+  tr->q[Q_gN] = gN;
+  tr->q[Q_GN] = qgn;
+  tr->q[Q_NN] = qnn;
+  tr->chol_fail = 0;
+  // gradient_max_norm of the pose side is filled in by k_dogleg (off the critical path)
+  if (S->sharded) tr->lm_bmax = ls[XS_BMAX];
+  if (tr->iteration == 0) {
+    {
+      const FrameState *x0 = &S->x[tr->cur];
+      double xn = ls[3];
+      for (int f = 0; f < LFVIO_NUM_FRAMES; f++) {
+        for (int k = 0; k < 7; k++) xn += x0->pose[f][k] * x0->pose[f][k];
+        for (int k = 0; k < 9; k++) xn += x0->sb[f][k] * x0->sb[f][k];
+      }
+      if (S->est_ex)
+        for (int k = 0; k < 7; k++) xn += x0->ex[k] * x0->ex[k];
+      if (S->est_td) xn += x0->td * x0->td;
+      tr->x_norm = sqrt(xn);
+    }
+    LfvioIterationSummary it;
+    it.cost = tr->x_cost;
+    it.cost_change = 0;
+    it.gradient_max_norm = 0;
+    it.step_norm = 0;
+    it.relative_decrease = 0;
+    it.trust_region_radius = tr->radius;
+    it.step_is_valid = 0;
+    it.step_is_successful = 0;
+    tr->trace[0] = it;
+    tr->trace_len = 1;
+    tr->num_unsucc = 1;
+    tr->initial_cost = tr->x_cost;
+    tr->iteration = 1;
+    tr->scaled = 1;
+    tr->new_point = 1;
+    if (S->max_iter <= 0) tr->done = 1;
+    if (!isfinite(tr->x_cost)) {
+      tr->done = 1;
+      tr->error = LFVIO_ERR_NONFINITE;
+    }
+  } else if (tr->do_lin && tr->trace_len > 0) {
+    tr->trace[tr->trace_len - 1].cost = tr->x_cost;  // HandleSuccessfulStep: cost re-evaluated at x
+    tr->new_point = 1;
+  }
+}
+
 // ---------------------------------------------------------------------------
-// k_solve: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS.
+// k_solve_dense: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS.
 // Input: H_pp (packed) and g_p assembled by k_sum, Schur sums, landmark scalars.
 // ---------------------------------------------------------------------------
 // xch_off / imu_off: byte offsets of the exchange buffer (H_pp | g_p | Schur sums | scalars) and of the IMU factor outputs
 // inside a slot blob — passed by value so that the whole input of the kernel is requested in ONE round of loads, together
 // with the loop flags and before the first branch (a GP<> member would have to be fetched first: one more round trip).
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stride, long long xch_off, long long imu_off) {
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_t stride, long long xch_off, long long imu_off) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
@@ -609,56 +662,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(char *base, size_t stri
     block_sum_n(sums, scratch, tid);
     gn2 = sums[0], ggn = sums[1], gG = sums[2], gN = sums[3], qgn = sums[4], qnn = sums[5];
     STAMP(S, 7);
-    if (tid == 0) {
-      tr->q[Q_GN_SQ] = gn2;
-      tr->q[Q_GRAD_GN] = ggn;
-      tr->q[Q_gG] = gG;
-      tr->q[Q_gN] = gN;
-      tr->q[Q_GN] = qgn;
-      tr->q[Q_NN] = qnn;
-      tr->chol_fail = 0;
-      // gradient_max_norm of the pose side is filled in by k_dogleg (off the critical path)
-      if (S->sharded) tr->lm_bmax = ls[XS_BMAX];
-      if (tr->iteration == 0) {
-        // IterationZero + first FinalizeIterationAndCheckIfMinimizerCanContinue
-        {
-          const FrameState *x0 = &S->x[tr->cur];
-          double xn = ls[3];
-          for (int f = 0; f < LFVIO_NUM_FRAMES; f++) {
-            for (int k = 0; k < 7; k++) xn += x0->pose[f][k] * x0->pose[f][k];
-            for (int k = 0; k < 9; k++) xn += x0->sb[f][k] * x0->sb[f][k];
-          }
-          if (S->est_ex)
-            for (int k = 0; k < 7; k++) xn += x0->ex[k] * x0->ex[k];
-          if (S->est_td) xn += x0->td * x0->td;
-          tr->x_norm = sqrt(xn);
-        }
-        LfvioIterationSummary it;
-        it.cost = tr->x_cost;
-        it.cost_change = 0;
-        it.gradient_max_norm = 0;
-        it.step_norm = 0;
-        it.relative_decrease = 0;
-        it.trust_region_radius = tr->radius;
-        it.step_is_valid = 0;
-        it.step_is_successful = 0;
-        tr->trace[0] = it;
-        tr->trace_len = 1;
-        tr->num_unsucc = 1;
-        tr->initial_cost = tr->x_cost;
-        tr->iteration = 1;
-        tr->scaled = 1;
-        tr->new_point = 1;
-        if (S->max_iter <= 0) tr->done = 1;
-        if (!isfinite(tr->x_cost)) {
-          tr->done = 1;
-          tr->error = LFVIO_ERR_NONFINITE;
-        }
-      } else if (tr->do_lin && tr->trace_len > 0) {
-        tr->trace[tr->trace_len - 1].cost = tr->x_cost;  // HandleSuccessfulStep: cost re-evaluated at x
-        tr->new_point = 1;
-      }
-    }
+    if (tid == 0) solve_epilogue(S, tr, ls, gn2, ggn, gG, gN, qgn, qnn);
   }
 }
 

@@ -20,6 +20,7 @@
 #include "../../include/lfvio.h"
 #include "../../include/lfvio_debug.h"
 #include "kernels_marg.h"
+#include "kernels_solve2.h"
 #include "kernels_feat.h"
 
 #define HIPCHK(ctx, call)                                                                      \
@@ -141,6 +142,11 @@ struct lfvio_ctx {
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   bool use_graph = true;
+  // the dense solve of a pass: k_solve_dense; LFVIO_SPARSE_SOLVE=1 selects k_solve_sparse (solve_plan.h: the speed/bias
+  // chain by cyclic reduction, then 91 dense unknowns) — measured 69 us against 62 us, so not the
+  // default — unless a resident window's prior has a speed/bias block of a frame other than 0, which the plan has no slot for
+  S2DevTables *d_s2 = nullptr;
+  bool dense_solve = false, force_dense = true;
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
   int last_passes = 0;  // passes of the trust-region loop the last synchronous call used (slowest slot)
   bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
@@ -517,6 +523,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   if (pr) {
     copy_prior(&info.in_prior, pr);
     S->prior_valid = 1, S->prior_n = pr->n, S->prior_nb = pr->num_blocks;
+    for (int i = 0; i < pr->num_blocks; i++)  // the structure k_solve_sparse assumes: the prior reaches no speed/bias block but sb_0
+      if (pr->blocks[i].kind == LFVIO_BLOCK_SPEEDBIAS && pr->blocks[i].frame != 0) c->dense_solve = true;
     for (int i = 0; i < pr->num_blocks; i++) {
       S->prior_kind[i] = pr->blocks[i].kind, S->prior_frame[i] = pr->blocks[i].frame, S->prior_idx[i] = pr->block_idx[i];
       std::memcpy(S->prior_x0[i], pr->block_x0[i], sizeof(double) * 9);
@@ -666,6 +674,15 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre, sa);
 }
 
+void launch_solve(lfvio_ctx *c, int count) {
+  const size_t st = c->L.total;
+  if (c->dense_solve || c->force_dense)
+    hipLaunchKernelGGL(k_solve_dense, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out);
+  else
+    hipLaunchKernelGGL(k_solve_sparse, dim3(1, count), dim3(S2_THREADS), SOLVE2_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out,
+                       (const S2DevTables *)c->d_s2);
+}
+
 // speculate: small windows evaluate the steps for radius, radius / 2, radius / 4 in every pass (dev_types.h, SPEC_EXTRA)
 // first / last: position of the pass in the sequence being issued (a graph, or a plain run of passes).  For small windows
 // the trust-region bookkeeping of a pass rides in the prologue of the NEXT pass's k_lin (MODE_DECIDE, one launch less per
@@ -680,7 +697,7 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
   launch_sum(c, count, g, mode);
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
-    hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out);
+    launch_solve(c, count);
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
     const int spec = speculate && inl ? 1 + SPEC_EXTRA : 1;
@@ -1031,7 +1048,25 @@ lfvio_ctx *lfvio_create(int device) {
     return nullptr;
   }
   // kernels that need more than the default 64 KiB of LDS
-  (void)hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
+  (void)hipFuncSetAttribute((const void *)k_solve_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
+  (void)hipFuncSetAttribute((const void *)k_solve_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE2_LDS);
+  {  // where the speed/bias entries of H_pp go in the storage of k_solve_sparse (solve_plan.h)
+    std::vector<int> tab(S2_SB_SLOTS * 256, -1);
+    for (int t = 0; t < 256; t++)
+      for (int q = 0; q < 2; q++)
+        for (int k = 0; k < 9; k++) {
+          int i = 0, j = 0, mirror = -1;
+          if (!s2_combo_entry(t + 256 * q, k, &i, &j)) continue;
+          const int dst = s2_store(i, j, &mirror);
+          if (dst >= 0) tab[(9 * q + k) * 256 + t] = dst | ((mirror + 1) << 16);
+        }
+    if (hipMalloc((void **)&c->d_s2, sizeof(S2DevTables)) != hipSuccess ||
+        hipMemcpy(c->d_s2, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      lfvio_destroy(c);
+      return nullptr;
+    }
+  }
+  if (const char *e = getenv("LFVIO_SPARSE_SOLVE")) c->force_dense = e[0] != '1';
   (void)hipFuncSetAttribute((const void *)k_marg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
   const char *env = getenv("LFVIO_NO_GRAPH");
   if (env && env[0] == '1') c->use_graph = false;
@@ -1046,6 +1081,7 @@ void lfvio_destroy(lfvio_ctx *c) {
   if (c->d_feat) (void)hipFree(c->d_feat);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_down) (void)hipHostFree(c->h_down);
+  if (c->d_s2) (void)hipFree(c->d_s2);
   if (c->d_pending) (void)hipFree(c->d_pending);
   if (c->h_pending) (void)hipHostFree(c->h_pending);
   if (c->h_flags) {
@@ -1294,7 +1330,7 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, 1).lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
   launch_lin(c, 1, g, MODE_SOLVE);
   launch_sum(c, 1, g, MODE_SOLVE);
-  hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total, (long long)c->L.xch, (long long)c->L.imu_out);
+  launch_solve(c, 1);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const Layout &L = c->L;
@@ -1359,7 +1395,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
   const double mu1 = mu;
   mu = 1e-8;
   if ((rc = run(1, first))) return rc;   // ordinary first pass (fixes the Jacobi scaling: k_solve does that, so run it)
-  hipLaunchKernelGGL(k_solve, dim3(1, 1), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total, (long long)c->L.xch, (long long)c->L.imu_out);
+  launch_solve(c, 1);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   mu = mu1;
   if ((rc = run(0, repeat))) return rc;  // Schur only, new mu
@@ -1417,7 +1453,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
         const int gx = which == 4 ? 1 : which == 5 ? 1 + LFVIO_WINDOW_SIZE : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
         hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
       } break;
-      default: hipLaunchKernelGGL(k_solve, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out); break;
+      default: launch_solve(c, count); break;
     }
   }
   HIPCHK(c, hipEventRecord(e1, c->stream));

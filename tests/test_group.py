@@ -90,9 +90,10 @@ def test_mask_of_one_device_runs_every_collective_through_rccl(oracle, n):
     assert loc.last_passes() == g.last_passes()
     assert np.array_equal(sol.pose, sol_l.pose) and np.array_equal(sol.speed_bias, sol_l.speed_bias)
     assert np.array_equal(sol.lam, sol_l.lam) and np.array_equal(prior.J(), prior_l.J()) and np.array_equal(prior.r(), prior_l.r())
-    # how far the sharded driver is from the unsharded one on the same window (reported, bounded by the bar above)
-    print(f"mask-of-one vs lfvio_batch_optimize: pose {np.abs(sol.pose - want.pose).max():.2e}, "
-          f"bit-identical: {np.array_equal(sol.pose, want.pose) and np.array_equal(prior.J(), want_prior.J())}")
+    if n <= 320:
+        # a window this small takes the same arithmetic through both drivers (one landmark block, one Schur part):
+        # the group's result is lfvio_batch_optimize()'s, bit for bit
+        assert np.array_equal(sol.pose, want.pose) and np.array_equal(sol.lam, want.lam) and np.array_equal(prior.J(), want_prior.J())
     loc.close()
     g.close()
 
@@ -143,7 +144,7 @@ def test_group_errors_leave_outputs_untouched():
     with pytest.raises(RuntimeError):
         g.optimize(abi.MARGIN_OLD)  # nothing uploaded
     w = synth.make_window(3, 100)
-    bad = w.copy(obs_offset=w.obs_offset[::-1].copy())
+    bad = w.copy(start_frame=np.full_like(w.start_frame, 10))  # every track leaves the window: refused before any upload
     with pytest.raises(RuntimeError):
         g.solve(bad, abi.MARGIN_OLD)
     sol, prior = g.solve(w, abi.MARGIN_OLD)  # the group is still usable

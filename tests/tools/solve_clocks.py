@@ -12,7 +12,14 @@ for rep in range(3):
     eng.linearize(w)  # k_setup, k_lin, k_sum, one k_solve
     buf = (C.c_longlong * 64)()
     eng.lib.lfvio_debug_read_clocks(eng.ctx, buf)
-    t = np.array(buf[:8], dtype=np.int64)
-    names = ["load H/g/Schur", "scaling", "build S + Cauchy", "Cholesky", "bad-flag reduce", "back-substitution", "directions + forms"]
-    print("k_solve total", t[7] - t[0], "cycles:", ", ".join(f"{n} {t[i + 1] - t[i]}" for i, n in enumerate(names)))
+    t = np.array(buf[:32], dtype=np.int64)
+    if os.environ.get("LFVIO_SPARSE_SOLVE") != "1":
+        names = ["load H/g/Schur", "scaling", "build S + Cauchy", "Cholesky", "bad-flag reduce", "back-substitution", "directions + forms"]
+        print("k_solve_dense total", t[7] - t[0], "cycles:", ", ".join(f"{n} {t[i + 1] - t[i]}" for i, n in enumerate(names)))
+    else:  # k_solve_sparse: 15 = entry, 0 = loads done, ..., 8-12 inside the rounds, 14 = remainder solved
+        seq = [(15, "entry"), (0, "loads + zero fill"), (1, "diag, cost"), (2, "scaling"), (3, "build + Cauchy"), (8, "round 1 factor"), (9, "round 1 updates"),
+               (10, "round 2 factor"), (11, "round 2 updates"), (12, "round 3 factor"), (4, "round 3 updates"), (5, "remainder Cholesky"),
+               (14, "remainder back-substitution"), (6, "front back-substitution"), (7, "directions + forms")]
+        print("front 0 (sb_0) update: collect", t[17] - t[16], "commit", t[18] - t[17], "camera tiles (MFMA)", t[19] - t[18])
+        print("k_solve_sparse total", t[7] - t[15], "cycles:", ", ".join(f"{n} {t[k] - t[seq[i - 1][0]]}" for i, (k, n) in enumerate(seq) if i > 0))
 print("k_solve us (events):", eng.time_kernel(3, 1, 50) * 1e3)
