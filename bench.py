@@ -78,6 +78,9 @@ def cpu_baseline(win, flag, target_seconds=12.0):
     sweep the sample is the trust-region solve alone, which makes the CPU figure an upper bound."""
     from oracle import binding as ob
 
+    # the eigen-solver of the timed baseline is the reference's algorithm class (Eigen's SelfAdjointEigenSolver:
+    # tridiagonalization + implicit QL), not the slower Jacobi the parity tests use
+    ob.set_eig_mode(1)
     full = win.N <= 4000
 
     def one():

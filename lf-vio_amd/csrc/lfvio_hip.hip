@@ -524,7 +524,10 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     copy_prior(&info.in_prior, pr);
     S->prior_valid = 1, S->prior_n = pr->n, S->prior_nb = pr->num_blocks;
     for (int i = 0; i < pr->num_blocks; i++)  // the structure k_solve_sparse assumes: the prior reaches no speed/bias block but sb_0
-      if (pr->blocks[i].kind == LFVIO_BLOCK_SPEEDBIAS && pr->blocks[i].frame != 0) c->dense_solve = true;
+      if (pr->blocks[i].kind == LFVIO_BLOCK_SPEEDBIAS && pr->blocks[i].frame != 0 && !c->dense_solve) {
+        c->dense_solve = true;
+        destroy_graph(c);  // the captured passes hold the kernel choice
+      }
     for (int i = 0; i < pr->num_blocks; i++) {
       S->prior_kind[i] = pr->blocks[i].kind, S->prior_frame[i] = pr->blocks[i].frame, S->prior_idx[i] = pr->block_idx[i];
       std::memcpy(S->prior_x0[i], pr->block_x0[i], sizeof(double) * 9);

@@ -171,6 +171,22 @@ def sym_eig(A):
     return d, V
 
 
+def set_td_true_derivative(on):
+    """DIAGNOSTIC (tests/test_td_column.py): the td column of the visual factor as the true derivative instead of the
+    reference's expression (projection_td_factor.cpp:143-146).  Returns the mode now in force; always switch it back."""
+    L = lib()
+    L.oracle_set_td_true_derivative.argtypes = [C.c_int]
+    return L.oracle_set_td_true_derivative(int(bool(on)))
+
+
+def set_eig_mode(mode):
+    """0: cyclic Jacobi (default: what parity is held against), 1: Householder tridiagonalization + implicit QL (the
+    algorithm class of Eigen's SelfAdjointEigenSolver: what bench.py times the CPU baseline with)."""
+    L = lib()
+    L.oracle_set_eig_mode.argtypes = [C.c_int]
+    return L.oracle_set_eig_mode(int(mode))
+
+
 def set_marg_threads(n):
     """4: marginalize() builds A, b on four threads like the reference's ThreadsConstructA (bit-identical sums); 1: serial."""
     L = lib()

@@ -148,6 +148,14 @@ int oracle_optimize(const LfvioWindow *w, int flag, LfvioSolution *sol, LfvioPri
 }
 
 // 4: the Jacobian products of marginalize() run on four threads like the reference's pthreads (timing variant); 1: serial
+int oracle_set_td_true_derivative(int on) {  // diagnostic only: see oracle_factors.cpp
+  g_td_true_derivative = on ? 1 : 0;
+  return g_td_true_derivative;
+}
+int oracle_set_eig_mode(int mode) {  // 0: Jacobi (parity default), 1: tridiagonalization + QL (timing)
+  g_eig_mode = mode == 1 ? 1 : 0;
+  return g_eig_mode;
+}
 int oracle_set_marg_threads(int n) {
   g_marg_threads = n >= 4 ? 4 : 1;
   return g_marg_threads;

@@ -8,6 +8,10 @@
 
 namespace orc {
 
+// DIAGNOSTIC switch (tests/test_td_column.py only): the td column of the visual factor as the true derivative instead of
+// the reference's expression (projection_td_factor.cpp:143-146).  Never set by the parity tests or the CPU baseline.
+int g_td_true_derivative = 0;
+
 // ---------------------------------------------------------------------------
 // ProjectionTdFactor / ProjectionFactor
 // ---------------------------------------------------------------------------
@@ -150,6 +154,14 @@ void visual_evaluate(const VisualFactor &f, bool use_td, double TR, double ROW, 
     }
     if (J_td) {  // :145-146 — NOT the true derivative under UNIT_SPHERE_ERROR; kept literally
       double vj2[2] = {f.velocity_j.x, f.velocity_j.y};
+      if (g_td_true_derivative) {
+        // DIAGNOSTIC ONLY (tests/test_td_column.py): what the second term would be if it were the derivative of
+        // -sqrt_info * tangent_base * normalized(pts_j_td) with respect to td:  + sqrt_info * B * (I/|p| - p p^T/|p|^3) * velocity_j
+        const V3 p = pts_j_td, v = f.velocity_j;
+        const double pn = std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z), pv = (p.x * v.x + p.y * v.y + p.z * v.z) / (pn * pn * pn);
+        const double u[3] = {v.x / pn - p.x * pv, v.y / pn - p.y * pv, v.z / pn - p.z * pv};
+        for (int r = 0; r < 2; r++) vj2[r] = f.tangent_base[r][0] * u[0] + f.tangent_base[r][1] * u[1] + f.tangent_base[r][2] * u[2];
+      }
       for (int r = 0; r < 2; r++) {
         double t = m4[r][0] * f.velocity_i.x + m4[r][1] * f.velocity_i.y + m4[r][2] * f.velocity_i.z;
         J_td[r] = t / inv_dep_i * -1.0 + sqrt_info * vj2[r];

@@ -9,6 +9,8 @@ namespace orc {
 
 // Constant data of one ProjectionTdFactor / ProjectionFactor instance
 // (factor/projection_td_factor.h:20-30, ctor projection_td_factor.cpp:8-34).
+extern int g_td_true_derivative;  // diagnostic: 1 = the td column is the derivative, not the reference's expression
+
 struct VisualFactor {
   V3 pts_i, pts_j;
   V3 velocity_i, velocity_j;

@@ -66,8 +66,77 @@ bool cholesky_lower(const double *A, double *L, int n) {
   return true;
 }
 
+// Which symmetric eigen-solver sym_eig() is.  0 (default, what the parity tests hold the device against): cyclic two-sided
+// Jacobi — slow, but it resolves the small eigenvalues of a graded matrix (cond(A_mm) ~ 1e13: a frame-0 landmark with
+// a_l ~ 1e-3 beside pose entries of 1e10) to working accuracy, where tridiagonalization loses digits in them.  1: Householder
+// tridiagonalization + implicit QL — the algorithm class of Eigen's SelfAdjointEigenSolver, which is what the reference
+// calls (marginalization_factor.cpp:268, 283); bench.py times the CPU baseline with this one.
+int g_eig_mode = 0;
+
+static void sym_eig_tridiagonal(const double *A, int n, double *d, double *Vout);
+
+// Cyclic Jacobi (Rutishauser's formulas): rotations until every off-diagonal entry is negligible RELATIVE to the two
+// diagonal entries it couples (Demmel & Veselic: that criterion is what gives the small eigenvalues their accuracy).
+static void sym_eig_jacobi(const double *A, int n, double *d, double *Vout) {
+  if (n == 0) return;
+  std::vector<double> M(A, A + (size_t)n * n), V((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) V[(size_t)i * n + i] = 1.0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) M[(size_t)i * n + j] = M[(size_t)j * n + i] = 0.5 * (M[(size_t)i * n + j] + M[(size_t)j * n + i]);
+  const double eps = std::pow(2.0, -52.0);
+  double scale = 0.0;
+  for (size_t k = 0; k < (size_t)n * n; k++) scale = std::max(scale, std::fabs(M[k]));
+  const double tiny = scale * 1e-300;
+  for (int sweep = 0; sweep < 100; sweep++) {
+    bool rotated = false;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = M[(size_t)p * n + q];
+        const double app = M[(size_t)p * n + p], aqq = M[(size_t)q * n + q];
+        if (std::fabs(apq) <= eps * std::sqrt(std::fabs(app) * std::fabs(aqq)) || std::fabs(apq) <= tiny) {
+          continue;
+        }
+        rotated = true;
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::hypot(theta, 1.0));
+        const double c = 1.0 / std::hypot(t, 1.0), sn = t * c;
+        M[(size_t)p * n + p] = app - t * apq;
+        M[(size_t)q * n + q] = aqq + t * apq;
+        M[(size_t)p * n + q] = M[(size_t)q * n + p] = 0.0;
+        for (int k = 0; k < n; k++) {
+          if (k != p && k != q) {
+            const double akp = M[(size_t)k * n + p], akq = M[(size_t)k * n + q];
+            M[(size_t)k * n + p] = M[(size_t)p * n + k] = c * akp - sn * akq;
+            M[(size_t)k * n + q] = M[(size_t)q * n + k] = sn * akp + c * akq;
+          }
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - sn * vkq;
+          V[(size_t)k * n + q] = sn * vkp + c * vkq;
+        }
+      }
+    if (!rotated) break;
+  }
+  for (int i = 0; i < n; i++) d[i] = M[(size_t)i * n + i];
+  // ascending sort (Eigen sorts eigenvalues increasingly)
+  for (int i = 0; i < n - 1; i++) {
+    int k = i;
+    for (int j = i + 1; j < n; j++)
+      if (d[j] < d[k]) k = j;
+    if (k != i) {
+      std::swap(d[i], d[k]);
+      for (int r = 0; r < n; r++) std::swap(V[(size_t)r * n + i], V[(size_t)r * n + k]);
+    }
+  }
+  std::copy(V.begin(), V.end(), Vout);
+}
+
+void sym_eig(const double *A, int n, double *d, double *V) {
+  if (g_eig_mode == 1) sym_eig_tridiagonal(A, n, d, V);
+  else sym_eig_jacobi(A, n, d, V);
+}
+
 // Householder tridiagonalization (tred2) + implicit QL (tql2), EISPACK/JAMA form.
-void sym_eig(const double *A, int n, double *d, double *Vout) {
+static void sym_eig_tridiagonal(const double *A, int n, double *d, double *Vout) {
   std::vector<double> Vs(A, A + n * n), e(n);
   double *V = Vs.data();
 #define VV(i, j) V[(i) * n + (j)]

@@ -269,5 +269,6 @@ bool cholesky_lower(const double *A, double *L, int n);
 // V row-major with eigenvectors in columns (Householder tridiagonalization +
 // implicit QL: the algorithm family Eigen's SelfAdjointEigenSolver uses).
 void sym_eig(const double *A, int n, double *d, double *V);
+extern int g_eig_mode;  // 0: cyclic Jacobi (default; parity), 1: tridiagonalization + QL (the reference's algorithm class; CPU-baseline timing)
 
 }  // namespace orc

@@ -100,6 +100,11 @@ def tangent_base(pts_j):
     return np.stack([b1, b2])
 
 
+# DIAGNOSTIC switch (tests/test_td_column.py only): the td column as the true derivative of the residual instead of the
+# reference's expression (projection_td_factor.cpp:143-146)
+TD_TRUE_DERIVATIVE = False
+
+
 def visual(use_td, TR, ROW, s, pts_i, pts_j, vel_i, vel_j, td_i, td_j, uvy_i, uvy_j, pose_i, pose_j, ex, lam, td):
     """r(2), J_pose_i(2x7), J_pose_j(2x7), J_ex(2x7), J_lam(2), J_td(2) — td column AS CODED."""
     B = tangent_base(pts_j)
@@ -132,6 +137,9 @@ def visual(use_td, TR, ROW, s, pts_i, pts_j, vel_i, vel_j, td_i, td_j, uvy_i, uv
     Jex[:, 3:6] = red @ (-T @ skew(Xci) + skew(T @ Xci) + skew(ric.T @ (Rj.T @ (Ri @ tic + Pi - Pj) - tic)))
     Jl = red @ T @ pi * -1.0 / (lam * lam)
     Jtd = red @ T @ vel_i / lam * -1.0 + s * vel_j[:2]
+    if TD_TRUE_DERIVATIVE:
+        pn = np.linalg.norm(pj)
+        Jtd = red @ T @ vel_i / lam * -1.0 + s * (B @ ((np.eye(3) / pn - np.outer(pj, pj) / pn ** 3) @ vel_j))
     return r, Ji, Jj, Jex, Jl, Jtd
 
 

@@ -113,26 +113,11 @@ def test_batch512_distinct_windows_against_the_oracle(eng, oracle):
             assert prior.valid == 1 and (prior.m, prior.n) == (ref["m"], ref["n"]) and prior.block_list() == ref["blocks"], tag
             J = prior.J()
             dA = rel(J.T @ J, ref["A"])
-            if dA >= 1e-6:
-                # Measured on seed 170 (2.6e-6): the ORACLE is the outlier.  Its dropped block has cond(A_mm) = 6e12 (a frame-0
-                # landmark with a_l = 2e-3 beside pose entries of 1e10) and its tred2 / tql2 eigen-solver loses six digits there;
-                # the device (both of its pseudo-inverse paths), the structured numpy statement and the reference's literal
-                # m x m formula evaluated with LAPACK agree with each other to 1e-11.  Such a slot is held against the LAPACK
-                # evaluation of the reference formula on identical inputs, and the oracle's own deviation from it must account
-                # for what was seen.
-                w2 = w.copy(pose=ref["pose"], speed_bias=ref["speed_bias"], ex_pose=ref["ex_pose"], td=ref["td"], inv_depth=ref["lam"])
-                pref, Aref, _ = oracle.marginalize(w2, abi.MARGIN_OLD, want_Ab=True)
-                from lfvio.engine import Engine
-
-                side = Engine(0)  # its own context: lfvio_marginalize uploads into slot 0, which the batch still needs
-                p2 = side.marginalize(w2, abi.MARGIN_OLD)
-                A2, _ = side.marg_system(p2.n)
-                side.close()
-                A_lapack, cond = marg_ref.dense_marg_old(oracle.linearize(marg_ref.frame0_subwindow(w2)), pref.block_list())
-                print(f"batch512 slot {s}: prior vs oracle {dA:.2e}; cond(A_mm) {cond:.1e}; on identical inputs: device vs LAPACK "
-                      f"{rel(A2, A_lapack):.2e}, oracle vs LAPACK {rel(Aref, A_lapack):.2e}")
-                assert rel(A2, A_lapack) < 1e-6, tag
-                assert rel(Aref, A_lapack) > 0.5 * dA and cond > 1e10, tag
+            # (Round 2 needed an arbitration here: on seeds 170 and 440 — cond(A_mm) = 6e12 — the oracle's tridiagonalization +
+            # QL eigen-solver lost six digits in the small eigenvalues the pseudo-inverse divides by and the ORACLE was
+            # 2.6e-6 off.  Its default eigen-solver is now cyclic Jacobi (oracle/oracle_math.cpp), which resolves them: the
+            # plain bar holds for every slot.)
+            assert dA < 1e-6, (tag, dA)
             assert abs(marg_ref.kept_directions(prior) - ref["kept"]) <= marg_ref.kept_count_slack(ref["A"], J.T @ J), tag
             worst = dict(pose=max(worst["pose"], dp), lam=max(worst["lam"], dl), A=max(worst["A"], dA))
         print(f"batch512 sync={sync}: worst pose {worst['pose']:.2e}, inv-depth {worst['lam']:.2e}, prior A {worst['A']:.2e}")
