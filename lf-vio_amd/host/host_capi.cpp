@@ -198,7 +198,7 @@ void lfvio_host_get_buffers(void *h, double *stamps, int *num_samples, int *has_
 }
 
 // Replays an LFVT trace (replay.h) and writes the trajectory file.
-// stats (may be null) = {images, thrown, keyframes, non_keyframes, poses, failures, last_status, iterations}
+// stats (may be null) = {images, thrown, keyframes, non_keyframes, poses, failures, last_status, iterations, restarts, bootstraps}
 int lfvio_host_replay(void *h, const char *trace_path, const char *traj_path, int max_images, int *stats) {
   Trace trace;
   if (!trace.load(trace_path)) return -3;

@@ -47,21 +47,32 @@ bool Trace::load(const char *path) {
       m.v.resize((size_t)n * 9);
       std::memcpy(m.v.data(), buf.data() + 12, (size_t)n * 36);
       images.push_back(std::move(m));
-    } else if (head[0] == 3 && head[1] == (11 * 21 + 3 + 13) * sizeof(double)) {
+    } else if (head[0] == 3 && (head[1] == (11 * 21 + 3 + 13) * sizeof(double) || head[1] == (11 * 21 + 3 + 14) * sizeof(double))) {
       const int W = FRAMES;
       const double *Ps = d, *Rs = Ps + 3 * W, *Vs = Rs + 9 * W, *Bas = Vs + 3 * W, *Bgs = Bas + 3 * W, *gg = Bgs + 3 * W, *t = gg + 3, *r = t + 3;
+      TraceBoot tb;
       for (int i = 0; i < W; i++) {
-        Keyframe &k = bootstrap.kf[i];
+        Keyframe &k = tb.state.kf[i];
         k.P = Vector3d(Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2]), k.V = Vector3d(Vs[3 * i], Vs[3 * i + 1], Vs[3 * i + 2]);
         k.Ba = Vector3d(Bas[3 * i], Bas[3 * i + 1], Bas[3 * i + 2]), k.Bg = Vector3d(Bgs[3 * i], Bgs[3 * i + 1], Bgs[3 * i + 2]);
         for (int a = 0; a < 3; a++)
           for (int b = 0; b < 3; b++) k.R(a, b) = Rs[9 * i + 3 * a + b];
       }
-      bootstrap.g = Vector3d(gg[0], gg[1], gg[2]);
-      bootstrap.valid = true;
-      std::memcpy(tic, t, sizeof tic), std::memcpy(ric, r, sizeof ric);
-      td = r[9];
-      has_bootstrap = true;
+      tb.state.g = Vector3d(gg[0], gg[1], gg[2]);
+      tb.state.valid = true;
+      std::memcpy(tb.tic, t, sizeof tb.tic), std::memcpy(tb.ric, r, sizeof tb.ric);
+      tb.td = r[9];
+      tb.stamp = head[1] == (11 * 21 + 3 + 14) * sizeof(double) ? r[10] : std::nan("");
+      tb.at_image = images.size();
+      if (!has_bootstrap) {
+        bootstrap = tb.state;
+        std::memcpy(tic, tb.tic, sizeof tic), std::memcpy(ric, tb.ric, sizeof ric);
+        td = tb.td;
+        has_bootstrap = true;
+      }
+      boots.push_back(tb);
+    } else if (head[0] == 5) {
+      restarts.push_back(images.size());
     }
   }
   std::fclose(f);
@@ -102,12 +113,12 @@ int replay(WindowEstimator &est, const Trace &trace, const char *traj_path, int 
     // the recording's extrinsic is the CONFIGURED one: a reset after a divergence restores it (setParameter(), estimator.cpp:10-21)
     std::memcpy(config().tic, trace.tic, sizeof trace.tic), std::memcpy(config().ric, trace.ric, sizeof trace.ric);
     config().td = trace.td;
-    est.bootstrap = trace.bootstrap;
     for (int k = 0; k < 3; k++) est.tic(k) = trace.tic[k];
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 3; j++) est.ric(i, j) = trace.ric[3 * i + j];
     est.td = trace.td;
   }
+  size_t next_boot = 0, next_restart = 0, image_index = 0;
   const std::vector<TraceImu> &imu = trace.imu;
   size_t front = 0;         // head of the IMU queue
   double clock = -1;        // time of the last sample handed over
@@ -115,6 +126,28 @@ int replay(WindowEstimator &est, const Trace &trace, const char *traj_path, int 
   DecodedImage img;
   for (const TraceImage &msg : trace.images) {
     if (max_images > 0 && st.images >= max_images) break;
+    // restart messages that arrived before this image: restart_callback (estimator_node.cpp:187-204) empties the queues
+    // and reboots the estimator; integration starts again with the next IMU message
+    for (; next_restart < trace.restarts.size() && trace.restarts[next_restart] <= image_index; next_restart++) {
+      est.reset();
+      clock = -1;
+      st.restarts++;
+    }
+    image_index++;
+    // an estimator that is (again) initializing takes the next bootstrap record of the file: records that describe a time
+    // already passed are skipped, one with a stamp waits for its image (until then the full window slides, as after an
+    // initialStructure() that failed)
+    if (est.phase == WindowEstimator::INITIAL && !est.bootstrap.valid) {
+      while (next_boot < trace.boots.size() && trace.boots[next_boot].stamp < msg.t - 1e-6) next_boot++;
+      if (next_boot < trace.boots.size()) {
+        const TraceBoot &tb = trace.boots[next_boot];
+        if (!(tb.stamp > msg.t + 1e-6)) {  // (NaN: no stamp, take it now)
+          est.bootstrap = tb.state;
+          next_boot++;
+          st.bootstraps++;
+        }
+      }
+    }
     // getMeasurements(), estimator_node.cpp:96-134, against the CURRENT time-offset estimate
     const double img_t = msg.t + est.td;
     if (front >= imu.size() || !(imu.back().t > img_t)) break;  // "wait for imu": nothing more arrives in a recording

@@ -8,8 +8,16 @@
 //                                     published it, feature_tracker_node.cpp:146-151), then channels[0..5].values[i]:
 //                                     id * NUM_OF_CAM + cam, u, v, velocity x, y, z (:152-163; decoded at estimator_node.cpp:292-312)
 //   type 3 = bootstrap                f64 Ps[11][3], Rs[11][9] (row-major), Vs[11][3], Bas[11][3], Bgs[11][3], g[3], tic[3], ric[9], td
-//                                     — the window state initialStructure() + visualInitialAlign() would have produced
+//                                     [, f64 stamp] — the window state initialStructure() + visualInitialAlign() produced
+//                                     (estimator.cpp:160-173), dumped where initialStructure() returns true; the optional
+//                                     stamp is Headers[WINDOW_SIZE] of that moment: the record is then used for the image
+//                                     with that stamp (earlier images of a filling window slide, as after a failed
+//                                     initialStructure(), :177-178), without it at the first full window.  A recording may
+//                                     hold several: after failureDetection() rebooted the estimator (:196-204) or a restart
+//                                     message cleared it, the next one in the file is taken.
 //   type 4 = ground truth (optional)  f64 stamp, p[3], q[4] (x y z w); skipped by the replay, read by tools/ate.py
+//   type 5 = restart                  [f64 stamp] — std_msgs/Bool(true) on the tracker's restart topic: restart_callback
+//                                     (estimator_node.cpp:187-204) clears the buffers, clearState(), setParameter()
 //
 // Unknown record types are skipped, so a recorder can add its own.
 #pragma once
@@ -30,10 +38,18 @@ struct TraceImage {
   std::vector<float> v;  // n x 9
   size_t size() const { return v.size() / 9; }
 };
+struct TraceBoot {
+  WindowEstimator::Bootstrap state;
+  double tic[3], ric[9], td;
+  double stamp;      // NaN: take it at the first full window
+  size_t at_image;   // images recorded before it
+};
 struct Trace {
   std::vector<TraceImu> imu;
   std::vector<TraceImage> images;
-  bool has_bootstrap = false;
+  std::vector<TraceBoot> boots;       // in file order
+  std::vector<size_t> restarts;       // restart messages: number of images recorded before each
+  bool has_bootstrap = false;         // the first bootstrap record (what a recording without reboots has)
   WindowEstimator::Bootstrap bootstrap;
   double tic[3] = {0, 0, 0}, ric[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double td = 0;
@@ -42,7 +58,7 @@ struct Trace {
 };
 
 struct ReplayStats {
-  int images, thrown, keyframes, non_keyframes, poses, failures, last_status, iterations;
+  int images, thrown, keyframes, non_keyframes, poses, failures, last_status, iterations, restarts, bootstraps;
 };
 
 // feature message -> what WindowEstimator::pushImage() takes (estimator_node.cpp:292-312): feature ids ascending (the

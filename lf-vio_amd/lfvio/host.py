@@ -158,11 +158,11 @@ class HostEstimator:
         self.L.lfvio_host_get_buffers(self.h, _p(st), ns.ctypes.data_as(ip), hp.ctypes.data_as(ip), _p(sd))
         return dict(stamps=st, num_samples=ns, has_pre=hp, sum_dt=sd)
 
-    STATS = ("images", "thrown", "keyframes", "non_keyframes", "poses", "failures", "last_status", "iterations")
+    STATS = ("images", "thrown", "keyframes", "non_keyframes", "poses", "failures", "last_status", "iterations", "restarts", "bootstraps")
 
     def replay(self, trace_path, traj_path="", max_images=0):
         """-> (rc, stats dict); rc 0 ok, -2 a device call failed (stats['last_status']), -3 unreadable trace."""
-        o = np.zeros(8, dtype=np.int32)
+        o = np.zeros(10, dtype=np.int32)
         rc = self.L.lfvio_host_replay(self.h, str(trace_path).encode(), str(traj_path).encode(), int(max_images),
                                       o.ctypes.data_as(C.POINTER(C.c_int)))
         return rc, dict(zip(self.STATS, (int(x) for x in o)))

@@ -10,7 +10,7 @@ import numpy as np
 from . import abi, synth
 
 MAGIC = b"LFVT"
-REC_IMU, REC_FEATURES, REC_BOOTSTRAP, REC_TRUTH = 1, 2, 3, 4
+REC_IMU, REC_FEATURES, REC_BOOTSTRAP, REC_TRUTH, REC_RESTART = 1, 2, 3, 4, 5
 
 
 class TraceWriter:
@@ -34,11 +34,23 @@ class TraceWriter:
         a[:, 6:9] = vel
         self._rec(REC_FEATURES, struct.pack("<dI", t, n) + a.tobytes())
 
-    def bootstrap(self, Ps, Rs, Vs, Bas, Bgs, g, tic, ric, td):
+    def bootstrap(self, Ps, Rs, Vs, Bas, Bgs, g, tic, ric, td, stamp=None):
+        """stamp: Headers[WINDOW_SIZE] at the moment initialStructure() returned true — the record then belongs to the image
+        with that stamp (a recording with reboots needs it); without it the record is taken at the first full window."""
         d = np.concatenate([np.ravel(Ps), np.ravel(Rs), np.ravel(Vs), np.ravel(Bas), np.ravel(Bgs), np.ravel(g), np.ravel(tic),
-                            np.ravel(ric), [td]]).astype("<f8")
-        assert d.size == 11 * 21 + 3 + 13
+                            np.ravel(ric), [td]] + ([[stamp]] if stamp is not None else [])).astype("<f8")
+        assert d.size == 11 * 21 + 3 + 13 + (stamp is not None)
         self._rec(REC_BOOTSTRAP, d.tobytes())
+
+    def bootstrap_payload(self, payload):
+        """A type-3 payload as the node's dump hook published it (247 or 248 doubles)."""
+        d = np.asarray(payload, dtype="<f8")
+        assert d.size in (247, 248)
+        self._rec(REC_BOOTSTRAP, d.tobytes())
+
+    def restart(self, t=None):
+        """std_msgs/Bool(true) on the tracker's restart topic (restart_callback, estimator_node.cpp:187-204)."""
+        self._rec(REC_RESTART, struct.pack("<d", t) if t is not None else b"")
 
     def truth(self, t, p, q_xyzw):
         self._rec(REC_TRUTH, struct.pack("<8d", t, *p, *q_xyzw))
@@ -49,7 +61,7 @@ class TraceWriter:
 
 def read_trace(path):
     """-> dict(imu [n,7], images [(t, array[n,9] float32)], bootstrap array or None, truth [n,8])"""
-    out = dict(imu=[], images=[], bootstrap=None, truth=[])
+    out = dict(imu=[], images=[], bootstrap=None, bootstraps=[], restarts=[], truth=[], order=[])
     with open(path, "rb") as f:
         head = f.read(8)
         assert head[:4] == MAGIC and struct.unpack("<I", head[4:])[0] == 1
@@ -59,13 +71,18 @@ def read_trace(path):
                 break
             kind, nbytes = struct.unpack("<II", h)
             p = f.read(nbytes)
+            out["order"].append(kind)
             if kind == REC_IMU:
                 out["imu"].append(struct.unpack("<7d", p))
             elif kind == REC_FEATURES:
                 t, n = struct.unpack("<dI", p[:12])
                 out["images"].append((t, np.frombuffer(p[12:], dtype="<f4").reshape(n, 9).copy()))
             elif kind == REC_BOOTSTRAP:
-                out["bootstrap"] = np.frombuffer(p, dtype="<f8").copy()
+                out["bootstraps"].append(np.frombuffer(p, dtype="<f8").copy())
+                if out["bootstrap"] is None:
+                    out["bootstrap"] = out["bootstraps"][0]
+            elif kind == REC_RESTART:
+                out["restarts"].append(len(out["images"]))
             elif kind == REC_TRUTH:
                 out["truth"].append(struct.unpack("<8d", p))
     out["imu"] = np.array(out["imu"]).reshape(-1, 7)
@@ -73,14 +90,21 @@ def read_trace(path):
     return out
 
 
-def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset=0.0023, pixel_noise=1.0, boot_noise=(0.02, 0.5)):
+def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset=0.0023, pixel_noise=1.0, boot_noise=(0.02, 0.5),
+                restart_at=None, spike_at=None, spike=2.0e4):
     """Write a synthetic recording of `n_frames` images at 10 Hz with 200 Hz IMU and return what was written.
 
     A static cloud of `n_points` points in a 2-12 m shell is seen through the 40-120 deg annulus; a point is tracked over
     a random span of frames and comes back under a new id afterwards, at most `max_cnt` features per image (longest
     tracks first, like the tracker's mask).  Image k is exposed at t = 0.1 k + cam_offset on the IMU clock and stamped
     t - TD0, so the estimator interpolates the IMU at image time (estimator_node.cpp:240-258).  The bootstrap record is
-    the truth of the first 11 frames (+) N(0, boot_noise[0] m / boot_noise[1] deg), zero accelerometer bias."""
+    the truth of the first 11 frames (+) N(0, boot_noise[0] m / boot_noise[1] deg), zero accelerometer bias.
+
+    Reboots mid-recording (estimator.cpp:196-204, estimator_node.cpp:187-204): `restart_at = k` puts a restart message in
+    front of image k; `spike_at = k` adds `spike` m/s^2 to one accelerometer sample just before image k, which throws the
+    window far enough for failureDetection() to reboot the estimator while it processes that image.  Either way the
+    estimator refills its window with the next ten images and a STAMPED bootstrap record — what the node's dump hook
+    writes when initialStructure() succeeds again — follows for the eleventh."""
     scene = synth.Scene(seed, n_total=n_frames + 2)
     rng = np.random.default_rng([seed, 104729])
     traj = scene.traj
@@ -110,14 +134,39 @@ def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset
 
     w = TraceWriter(path)
     truth, images, flags = [], [], []
+    boots_due = {}  # image index -> first frame of the window the bootstrap record describes
+    if restart_at is not None:
+        boots_due[restart_at + abi.WINDOW_SIZE] = restart_at
+    if spike_at is not None:
+        boots_due[spike_at + 1 + abi.WINDOW_SIZE] = spike_at + 1
+
+    def boot_record(first, stamp=None):
+        Ps, Rs, Vs = [], [], []
+        for j in range(first, first + abi.NUM_FRAMES):
+            tj = synth.KF_DT * j + cam_offset
+            Pj, Rj = cam_pose(tj)
+            Ps.append(Pj + rng.normal(0, boot_noise[0], 3))
+            Rs.append(Rj @ synth.exp_so3(rng.normal(0, np.deg2rad(boot_noise[1]), 3)))
+            Vs.append(traj.vel(tj) + rng.normal(0, 0.02, 3))
+        Bgs = np.tile(scene.bg + rng.normal(0, 0.0005, 3), (abi.NUM_FRAMES, 1))
+        b = dict(Ps=np.array(Ps), Rs=np.array(Rs), Vs=np.array(Vs), Bas=np.zeros((abi.NUM_FRAMES, 3)), Bgs=Bgs,
+                 g=np.array([0.0, 0.0, synth.G_NORM]), tic=synth.TIC, ric=synth.RIC, td=synth.TD0)
+        w.bootstrap(stamp=stamp, **b)
+        return b
+
     t_imu = traj.t
     k_imu = 0
     first_seen = {}
     for k in range(n_frames):
         t_img = synth.KF_DT * k + cam_offset
         # IMU messages up to and including the first one after the image (arrival order)
+        if restart_at is not None and k == restart_at:
+            w.restart(synth.KF_DT * k)
         while k_imu < len(t_imu) and t_imu[k_imu] <= t_img + synth.IMU_DT:
-            w.imu(t_imu[k_imu], scene.acc_m[k_imu], scene.gyr_m[k_imu])
+            acc = scene.acc_m[k_imu]
+            if spike_at is not None and k == spike_at and abs(t_imu[k_imu] - (t_img - 4 * synth.IMU_DT)) < 0.5 * synth.IMU_DT:
+                acc = acc + np.array([spike, 0.0, 0.0])
+            w.imu(t_imu[k_imu], acc, scene.gyr_m[k_imu])
             k_imu += 1
         b = bearings(t_img)
         b_prev = bearings(t_img - synth.KF_DT) if t_img - synth.KF_DT >= 0 else b
@@ -149,16 +198,8 @@ def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset
         truth.append((stamp, P, R, traj.vel(t_img)))
         images.append((stamp, ids, xyz.copy(), np.stack([u, v], 1), vel.astype(np.float32).astype(np.float64)))
         if k == abi.WINDOW_SIZE - 1:  # before the 11th image arrives: what initialStructure() would have produced
-            Ps, Rs, Vs = [], [], []
-            for j in range(abi.NUM_FRAMES):
-                tj = synth.KF_DT * j + cam_offset
-                Pj, Rj = cam_pose(tj)
-                Ps.append(Pj + rng.normal(0, boot_noise[0], 3))
-                Rs.append(Rj @ synth.exp_so3(rng.normal(0, np.deg2rad(boot_noise[1]), 3)))
-                Vs.append(traj.vel(tj) + rng.normal(0, 0.02, 3))
-            Bgs = np.tile(scene.bg + rng.normal(0, 0.0005, 3), (abi.NUM_FRAMES, 1))
-            boot = dict(Ps=np.array(Ps), Rs=np.array(Rs), Vs=np.array(Vs), Bas=np.zeros((abi.NUM_FRAMES, 3)), Bgs=Bgs,
-                        g=np.array([0.0, 0.0, synth.G_NORM]), tic=synth.TIC, ric=synth.RIC, td=synth.TD0)
-            w.bootstrap(**boot)
+            boot = boot_record(0)
+        if k in boots_due:  # the estimator has refilled its window after a reboot: the hook's record for THIS image
+            boot_record(boots_due[k], stamp=stamp)
     w.close()
     return dict(scene=scene, truth=truth, images=images, bootstrap=boot, n_ids=next_id)
