@@ -149,8 +149,8 @@ class BagWriter:
     def __init__(self, path, compression="none", chunk_messages=64):
         self.f = open(path, "wb")
         self.f.write(b"#ROSBAG V2.0\n")
-        hdr = _record({"op": b"\x03", "index_pos": struct.pack("<Q", 0), "conn_count": struct.pack("<I", 0), "chunk_count": struct.pack("<I", 0)}, b"")
-        self.f.write(hdr + b" " * (4096 - len(hdr) - 0))  # (real bags pad the header record to 4096 bytes)
+        fields = {"op": b"\x03", "index_pos": struct.pack("<Q", 0), "conn_count": struct.pack("<I", 0), "chunk_count": struct.pack("<I", 0)}
+        self.f.write(_record(fields, b" " * (4096 - 8 - len(_fields(fields)))))  # the bag header record is padded to 4096 bytes
         self.compression, self.per_chunk = compression, chunk_messages
         self.conns, self.buf, self.n = {}, b"", 0
 
@@ -195,9 +195,6 @@ def _parse_fields(h):
 def _records(buf, o=0):
     while o + 4 <= len(buf):
         (hl,) = struct.unpack_from("<I", buf, o)
-        if hl == 0x20202020:  # the padding behind the bag header record
-            o += 4
-            continue
         h = _parse_fields(buf[o + 4:o + 4 + hl])
         (dl,) = struct.unpack_from("<I", buf, o + 4 + hl)
         yield h, buf[o + 8 + hl:o + 8 + hl + dl]
@@ -213,6 +210,8 @@ def read_bag(path):
     def walk(buf, o=0):
         for h, data in _records(buf, o):
             op = h["op"][0]
+            if op == 0x03:  # bag header (its data is padding)
+                continue
             if op == 0x05:
                 comp = h["compression"].decode()
                 if comp == "bz2":
@@ -229,5 +228,6 @@ def read_bag(path):
                 sec, nsec = struct.unpack("<II", h["time"])
                 topic, mtype = conns[cid]
                 yield topic, mtype, sec + nsec * 1e-9, data
+            # 0x04 index data, 0x06 chunk info: not needed to read the messages in order
 
     yield from walk(raw, 13)
