@@ -57,6 +57,13 @@ constexpr int S2_THREADS = 256;
 constexpr int S2_VEC = S2_STORE_LEN;                       // vectors behind the storage
 constexpr size_t SOLVE2_LDS = (size_t)(S2_STORE_LEN + 7 * KP + 96 + 96 + 96 + 256 + 64 + 8) * sizeof(double);
 #define S2_FI(n) std::integral_constant<int, n>{}
+// the fine-grained stamps perturb what they measure (a stamp is a global store of thread 0, and the next barrier waits for
+// it): only in -DLFVIO_SOLVE_PROFILE builds (tests/tools/solve_clocks.py)
+#ifdef LFVIO_SOLVE_PROFILE
+#define XSTAMP(S, k) STAMP(S, k)
+#else
+#define XSTAMP(S, k) do { } while (0)
+#endif
 // tasks of the update segments of a front (+ its rhs x camera row), and rounds of 256 threads they take
 PLAN_HD int s2_seg_tasks(int fi) {
   const S2SegList L = s2_segment_list(fi);
@@ -73,19 +80,23 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
   const int tid = threadIdx.x;
   const int er = tid >> 4, ek = tid & 15, esw = tsw(er, ek);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  STAMP(S, 15);
+  XSTAMP(S, 15);
   // ---- everything this kernel reads, requested in one round before the first branch
   double hc[15], sreg[15], hsb[2][9];
   int sdst[2][9];
   double z1 = 0.0, scross = 0.0, gval = 0.0, cp = 0.0;
   const double *xch = (const double *)((const char *)S + xch_off);
   const double *Hg = xch + XOFF_H, *Sg = xch + XOFF_S;
+  // (explicit tile loops: with tile_a(t) / tile_b(t) in the body the unroller gives up, and a runtime index into the
+  // register arrays is a waterfall of v_readlane — 18 000 cycles for fifteen entries)
 #pragma unroll
-  for (int t = 0; t < 15; t++) {
-    const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
-    hc[t] = (i < KC && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
-    sreg[t] = Sg[schur_index(min(i, j), max(i, j))];
-  }
+  for (int a = 0; a < 5; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      const int t = a * (a + 1) / 2 + b, i = 16 * a + er, j = 16 * b + ek;
+      hc[t] = (i < KC && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
+      sreg[t] = Sg[schur_index(min(i, j), max(i, j))];
+    }
   // the speed/bias entries: two combos per thread (nine consecutive columns of one row each, see S2_NCOMBO)
   int ci[2] = {0, 0}, cj0[2] = {0, 0};
   bool cok[2];
@@ -213,8 +224,10 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
       Gj[a] = j < KC ? Gd[j] : 0.0, sj[a] = j < KC ? sc[j] : 0.0;
     }
 #pragma unroll
-    for (int t = 0; t < 15; t++) {
-      const int a = tile_a(t), b = tile_b(t);
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      const int t = a * (a + 1) / 2 + b;
       const int i = 16 * a + er, j = 16 * b + ek;
       if (i < KC && j <= i) {
         double h = hc[t];
@@ -288,8 +301,13 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
   auto factor_front = [&](int fi) {
     double *X = st + s2_front_base(fi);
     double r0[9], r1[9];
+    const int l1 = lane + 64 < S2_LDX ? lane + 64 : S2_LDX - 1;  // (clamped: the loads stay unconditional)
 #pragma unroll
-    for (int i = 0; i < 9; i++) r0[i] = X[i * S2_LDX + lane], r1[i] = lane + 64 < S2_LDX ? X[i * S2_LDX + 64 + lane] : 0.0;
+    for (int i = 0; i < 9; i++) {
+      r0[i] = X[i * S2_LDX + lane];
+      const double v = X[i * S2_LDX + l1];
+      r1[i] = lane + 64 < S2_LDX ? v : 0.0;
+    }
     double rsv = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -316,38 +334,40 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
     if (lane < 9) finv[9 * fi + lane] = rsv;
   };
   // What a factored front takes out of the rest:  target -= sum_k X[k][p] X[k][q].
-  // (1) everything that touches a speed/bias block or the rhs (solve_plan.h: segments): every thread first forms the sums
-  //     of ALL its tasks (loads only), then subtracts them — a read-modify-write per task inside the loop would put every
-  //     task's loads behind the previous task's store (same array);
+  // Only what the NEXT fronts need is on the critical path of the rounds — the updates of blocks that are fronts
+  // themselves (solve_plan.h: segments of kind 0).  Everything that lands in the dense remainder (rows of sb_6 / sb_8, the
+  // rhs row, camera x camera) waits until all nine fronts are factored and is then taken in ONE pass, every target summed
+  // over the fronts that touch it by the thread (or wave) that owns it.
+  // (1) critical segments: every thread first forms the sums of ALL its tasks (loads only), then subtracts them — a
+  //     read-modify-write per task inside the loop would put every task's loads behind the previous task's store.
   auto seg_collect = [&](auto FI, double *acc, int *addr) {
     constexpr int fi = decltype(FI)::value;
     constexpr S2SegList L = s2_segment_list(fi);
-    constexpr int c0 = s2_c0(fi), nc = s2_c1(fi) - s2_c0(fi), total = s2_seg_tasks(fi), rounds = (total + S2_THREADS - 1) / S2_THREADS;
-    static_assert(rounds <= S2_MAX_SEG_ROUNDS, "segment tasks per thread");
     const double *X = st + s2_front_base(fi);
+    int total = 0;
+#pragma unroll
+    for (int s = 0; s < L.n; s++)
+      if (L.s[s].kind == 0) total += L.s[s].rows * L.s[s].cols;
 #pragma unroll
     for (int it = 0; it < S2_MAX_SEG_ROUNDS; it++) {
       acc[it] = 0.0, addr[it] = -1;
-      if (it < rounds) {
-        const int e = tid + S2_THREADS * it;
+      const int e = tid + S2_THREADS * it;
+      if (e < total) {
         int p = -1, q = -1, a = -1, lo = 0;
 #pragma unroll
         for (int s = 0; s < L.n; s++) {
           const S2Seg gsg = L.s[s];
+          if (gsg.kind != 0) continue;  // compile-time
           const int n = gsg.rows * gsg.cols;
           if (e >= lo && e < lo + n) {
             const int le = e - lo, r = le / gsg.cols, c = le - r * gsg.cols;
-            if (!(gsg.kind == 1 && gsg.tri && c > r)) {
-              p = gsg.src_r + r, q = gsg.src_c + c;
-              if (gsg.kind == 0) a = gsg.base + r * gsg.sr + c * gsg.sc;
-              else a = gsg.swap ? s2_lidx(gsg.i0 + c, gsg.j0 + r) : s2_lidx(gsg.i0 + r, gsg.j0 + c);
-            }
+            p = gsg.src_r + r, q = gsg.src_c + c;
+            a = gsg.base + r * gsg.sr + c * gsg.sc;
           }
           lo += n;
         }
-        if (e >= lo && e < lo + nc) p = S2_COL_RHS, q = S2_COL_CAM + c0 + (e - lo), a = s2_lidx(S2_NR, c0 + (e - lo));  // rhs x camera
-        if (a >= 0) {
-          const double *xp = X + p, *xq = X + q;
+        {
+          const double *xp = X + (a >= 0 ? p : 0), *xq = X + (a >= 0 ? q : 0);  // (unconditional loads)
           double v = 0.0;
 #pragma unroll
           for (int k = 0; k < 9; k++) v = fma(xp[k * S2_LDX], xq[k * S2_LDX], v);
@@ -364,41 +384,6 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
     for (int it = 0; it < S2_MAX_SEG_ROUNDS; it++)
       if (addr[it] >= 0) st[addr[it]] = cur[it] - acc[it];
   };
-  // (2) camera x camera on the matrix pipe:  C(a, b) -= X_a^T X_b  over the 16 x 16 tiles the front's camera range covers,
-  //     three v_mfma_f64_16x16x4_f64 per tile (K = 9 rows of X, padded to 12), tiles dealt round-robin to the waves.  The
-  //     operand of column tile a — lane (c, g) holds X[4 s + g][16 a + c] — serves as A of row tile a and as B of column
-  //     tile a alike.
-  auto cam_update = [&](auto FI) {
-    constexpr int fi = decltype(FI)::value;
-    constexpr int ta0 = s2_c0(fi) / 16, ta1 = (s2_c1(fi) - 1) / 16;
-    const double *X = st + s2_front_base(fi) + S2_COL_CAM;
-    const int c = lane & 15, gq = lane >> 4;
-    double xa[5][3];
-#pragma unroll
-    for (int a = 0; a < 5; a++)
-#pragma unroll
-      for (int s3 = 0; s3 < 3; s3++) {
-        const int k = 4 * s3 + gq, col = 16 * a + c;
-        xa[a][s3] = (a >= ta0 && a <= ta1 && k < 9 && col < KC) ? X[k * S2_LDX + col] : 0.0;
-      }
-    int cnt = 0;
-#pragma unroll
-    for (int a = 0; a < 5; a++)
-#pragma unroll
-      for (int b = 0; b <= a; b++) {
-        if (a < ta0 || a > ta1 || b < ta0) continue;  // compile-time
-        if ((cnt++ & 3) == wave) {
-          double *Tc = st + tile_id(a, b) * TSZ + gq * TLD + c;
-          solve_d4 cv;
-#pragma unroll
-          for (int r = 0; r < 4; r++) cv[r] = Tc[4 * TLD * r];
-#pragma unroll
-          for (int s3 = 0; s3 < 3; s3++) cv = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[a][s3], xa[b][s3], cv, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; r++) Tc[4 * TLD * r] = cv[r];
-        }
-      }
-  };
   auto apply_two = [&](auto FA, auto FB) {  // two fronts with disjoint targets
     double accA[S2_MAX_SEG_ROUNDS], accB[S2_MAX_SEG_ROUNDS];
     int adA[S2_MAX_SEG_ROUNDS], adB[S2_MAX_SEG_ROUNDS];
@@ -406,44 +391,144 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
     seg_collect(FB, accB, adB);
     seg_commit(accA, adA);
     seg_commit(accB, adB);
-    cam_update(FA);
-    cam_update(FB);
   };
   auto apply_one = [&](auto FA) {
     double accA[S2_MAX_SEG_ROUNDS];
     int adA[S2_MAX_SEG_ROUNDS];
-    if (decltype(FA)::value == 5) STAMP(S, 16);
     seg_collect(FA, accA, adA);
-    if (decltype(FA)::value == 5) STAMP(S, 17);
     seg_commit(accA, adA);
-    if (decltype(FA)::value == 5) STAMP(S, 18);
-    cam_update(FA);
-    if (decltype(FA)::value == 5) STAMP(S, 19);
+  };
+  // (2) deferred, rows of a speed/bias block that stays (rem = its remainder index): tasks (r, cc), cc < 9 the block itself
+  //     (lower triangle), cc - 9 < 73 a camera column, cc = 82 the rhs; slot = where the block sits in the front's layout
+  auto defer_rows = [&](int rem, double *acc, int *addr, auto... FS) {
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      const int e = tid + S2_THREADS * it;
+      acc[it] = 0.0, addr[it] = -1;
+      const int r = e / 83, cc = e - 83 * r;
+      const bool live = e < 9 * 83 && !(cc < 9 && cc > r);
+      const int rr = live ? r : 0, cq = live ? cc : 0;  // (clamped: unconditional loads, the sum is dropped)
+      double sum = 0.0;
+      auto contrib = [&](auto FS1) {
+        constexpr int fi = decltype(FS1)::value >> 8, slot = decltype(FS1)::value & 255;
+        constexpr int c0 = s2_c0(fi), c1 = s2_c1(fi);
+        const double *X = st + s2_front_base(fi);
+        const bool in = cq < 9 || cq == 82 || (cq - 9 >= c0 && cq - 9 < c1);
+        const int q = cq < 9 ? slot + cq : cq < 82 ? (in ? S2_COL_CAM + cq - 9 : S2_COL_CAM + c0) : S2_COL_RHS;
+        const double *xp = X + slot + rr, *xq = X + q;
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) v = fma(xp[k * S2_LDX], xq[k * S2_LDX], v);
+        sum += in ? v : 0.0;
+      };
+      (contrib(FS), ...);
+      if (live) acc[it] = sum, addr[it] = cq < 9 ? s2_lidx(rem + rr, rem + cq) : cq < 82 ? s2_lidx(rem + rr, cq - 9) : s2_lidx(S2_NR, rem + rr);
+    }
+  };
+#define S2_FS(fi, slot) std::integral_constant<int, ((fi) << 8) | (slot)>{}
+  // (3) deferred, camera x camera on the matrix pipe:  C(a, b) -= sum over the fronts of X_a^T X_b, the 16 x 16 tiles dealt
+  //     round-robin to the waves, three v_mfma_f64_16x16x4_f64 per front and tile (K = 9 rows of X, padded to 12); lane
+  //     (c, g) holds X[4 s + g][16 a + c] — the operand of column tile a as A and of column tile b as B alike.  Row 91
+  //     (rhs x camera) is the same sum with the rhs column as the left factor, one thread per camera column.
+  auto cam_update_all = [&]() {
+    const int c = lane & 15, gq = lane >> 4;
+    int cnt = 0;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int b = 0; b <= a; b++) {
+        if ((cnt++ & 3) == wave) {
+          double *Tc = st + tile_id(a, b) * TSZ + gq * TLD + c;
+          solve_d4 cv;
+#pragma unroll
+          for (int r = 0; r < 4; r++) cv[r] = Tc[4 * TLD * r];
+#pragma unroll
+          for (int fi = 0; fi < S2_NF; fi++) {
+            const int ta0 = s2_c0(fi) / 16, ta1 = (s2_c1(fi) - 1) / 16;
+            if (a < ta0 || a > ta1 || b < ta0) continue;  // compile-time
+            const double *X = st + s2_front_base(fi) + S2_COL_CAM;
+            double xa[3], xb[3];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; s3++) {
+              // (load first, select afterwards: a load inside a conditional arm is a branch with its own wait, and six of
+              // those per front and tile were most of this pass)
+              const int k = 4 * s3 + gq, kk = k < 9 ? k : 8;
+              const double va = X[kk * S2_LDX + 16 * a + c], vb = X[kk * S2_LDX + 16 * b + c];  // column 16 a + c <= 79: inside the row
+              xa[s3] = (k < 9 && 16 * a + c < KC) ? va : 0.0;
+              xb[s3] = (k < 9 && 16 * b + c < KC) ? vb : 0.0;
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < 3; s3++) cv = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[s3], xb[s3], cv, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) Tc[4 * TLD * r] = cv[r];
+        }
+      }
+    if (tid < KC) {
+      double acc = 0.0;
+#pragma unroll
+      for (int fi = 0; fi < S2_NF; fi++)
+        if (tid >= s2_c0(fi) && tid < s2_c1(fi)) {
+          const double *X = st + s2_front_base(fi);
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < 9; k++) v = fma(X[k * S2_LDX + S2_COL_RHS], X[k * S2_LDX + S2_COL_CAM + tid], v);
+          acc += v;
+        }
+      st[s2_lidx(S2_NR, tid)] -= acc;
+    }
   };
   {
-    // round 1: fronts 0..3 (sb 1 3 5 7), round 2: 4..6 (sb 9 0 4), round 3: 7, 8 (sb 2 10)
+    // round 1: fronts 0..3 (sb 1 3 5 7), round 2: 4..6 (sb 9 0 4), round 3: 7, 8 (sb 2 10); between the rounds only the
+    // updates of later FRONTS: {sb_1 -> sb_0, sb_2; sb_5 -> sb_4} then {sb_3 -> sb_2, sb_4}; {sb_9 -> sb_10; sb_0 -> sb_2} then
+    // {sb_4 -> sb_2}
     factor_front(wave);
     __syncthreads();
-    STAMP(S, 8);
+    XSTAMP(S, 8);
     apply_two(S2_FI(0), S2_FI(2));
     __syncthreads();
-    apply_two(S2_FI(1), S2_FI(3));
+    apply_one(S2_FI(1));
     __syncthreads();
-    STAMP(S, 9);
+    XSTAMP(S, 9);
     if (wave < 3) factor_front(4 + wave);
     __syncthreads();
-    STAMP(S, 10);
-    apply_two(S2_FI(4), S2_FI(6));
+    XSTAMP(S, 10);
+    apply_two(S2_FI(4), S2_FI(5));
     __syncthreads();
-    apply_one(S2_FI(5));
+    apply_one(S2_FI(6));
     __syncthreads();
-    STAMP(S, 11);
+    XSTAMP(S, 11);
     if (wave < 2) factor_front(7 + wave);
     __syncthreads();
-    STAMP(S, 12);
-    apply_one(S2_FI(7));
-    __syncthreads();
-    apply_one(S2_FI(8));
+    XSTAMP(S, 12);
+    // what goes into the remainder: rows of sb_6 (from sb_5, sb_7, sb_4, sb_2), rows of sb_8 (from sb_7, sb_9, sb_10), their
+    // coupling (from sb_7 alone: a segment of kind 1 of front 3), the rhs row and the camera tiles
+    {
+      double acc6[3], acc8[3], acc68 = 0.0;
+      int ad6[3], ad8[3], ad68 = -1;
+      defer_rows(S2_REM_SB6, acc6, ad6, S2_FS(2, S2_COL_B), S2_FS(3, S2_COL_A), S2_FS(6, S2_COL_B), S2_FS(7, S2_COL_A));
+      defer_rows(S2_REM_SB8, acc8, ad8, S2_FS(3, S2_COL_B), S2_FS(4, S2_COL_A), S2_FS(8, S2_COL_A));
+      {  // (sb_8, sb_6) from front 3 (sb_7): rows = sb_6 index (nbA), columns = sb_8 index (nbB)
+        const int e = tid < 81 ? tid : 0, r = e / 9, c = e - 9 * r;
+        const double *X = st + s2_front_base(3);
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) v = fma(X[k * S2_LDX + S2_COL_A + r], X[k * S2_LDX + S2_COL_B + c], v);
+        if (tid < 81) acc68 = v, ad68 = s2_lidx(S2_REM_SB8 + c, S2_REM_SB6 + r);
+      }
+      double cur[7];
+#pragma unroll
+      for (int it = 0; it < 3; it++) cur[it] = st[ad6[it] >= 0 ? ad6[it] : 0], cur[3 + it] = st[ad8[it] >= 0 ? ad8[it] : 0];
+      cur[6] = st[ad68 >= 0 ? ad68 : 0];
+#pragma unroll
+      for (int it = 0; it < 3; it++) {
+        if (ad6[it] >= 0) st[ad6[it]] = cur[it] - acc6[it];
+        if (ad8[it] >= 0) st[ad8[it]] = cur[3 + it] - acc8[it];
+      }
+      if (ad68 >= 0) st[ad68] = cur[6] - acc68;
+    }
+    XSTAMP(S, 13);
+    cam_update_all();
     __syncthreads();
   }
   STAMP(S, 4);
@@ -653,7 +738,7 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
     }
     __syncthreads();
   }
-  STAMP(S, 14);
+  XSTAMP(S, 14);
   // remainder index -> tangent column
   if (tid < NRR) yv[tid < KC ? tid : tid < S2_REM_SB8 ? off_sb(6) + (tid - S2_REM_SB6) : off_sb(8) + (tid - S2_REM_SB8)] = yr[tid];
   __syncthreads();
@@ -672,7 +757,11 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
     double x0[9], x1[9], lt[9][9], zr[9], iv[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-      x0[k] = X[k * S2_LDX + lane], x1[k] = lane + 64 < S2_LDX ? X[k * S2_LDX + 64 + lane] : 0.0;
+      x0[k] = X[k * S2_LDX + lane];
+      {
+        const double v = X[k * S2_LDX + (lane + 64 < S2_LDX ? lane + 64 : S2_LDX - 1)];
+        x1[k] = lane + 64 < S2_LDX ? v : 0.0;
+      }
       zr[k] = X[k * S2_LDX + S2_COL_RHS], iv[k] = finv[9 * fi + k];
 #pragma unroll
       for (int j = k + 1; j < 9; j++) lt[k][j] = X[k * S2_LDX + j];
@@ -714,6 +803,7 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
     }
     return;
   }
+  XSTAMP(S, 20);
   // ---- Gauss-Newton step, directions and pose-side quadratic forms
   if (tid < KP) {
     const double y = yv[tid];
@@ -729,6 +819,7 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
   }
   if (tid >= KC && tid < WLD) S->uc_grad[tid] = S->uc_gn[tid] = 0.0;
   __syncthreads();
+  XSTAMP(S, 21);
   {
     // G^T H N and N^T H N from the entries of H_pp this thread has held in registers since the start
     double qgn = 0, qnn = 0;
@@ -741,8 +832,10 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
         Gj[a] = j < KC ? Gd[j] : 0.0, Nj[a] = j < KC ? yv[j] : 0.0;
       }
 #pragma unroll
-      for (int t = 0; t < 15; t++) {
-        const int a = tile_a(t), b = tile_b(t);
+      for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int b = 0; b <= a; b++) {
+        const int t = a * (a + 1) / 2 + b;
         const int i = 16 * a + er, j = 16 * b + ek;
         if (i < KC && j <= i) {
           const double h = hc[t];
@@ -756,6 +849,7 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
         }
       }
     }
+    XSTAMP(S, 22);
 #pragma unroll
     for (int q = 0; q < 2; q++)
       if (cok[q]) {
@@ -771,6 +865,7 @@ __global__ __launch_bounds__(S2_THREADS) void k_solve_sparse(char *base, size_t 
           qnn = fma(h * w, 2.0 * Ni * Nj[k], qnn);
         }
       }
+    XSTAMP(S, 23);
     double gn2 = 0, ggn = 0, gG = 0, gN = 0;
     if (tid < KP) {
       const double gn = hv[tid];
