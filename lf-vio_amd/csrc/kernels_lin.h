@@ -1036,6 +1036,28 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
   const int mode = mode_bits & (MODE_GATED - 1);
   const int tid = threadIdx.x;
   int b = blockIdx.x;
+  if (S->sharded && mode == MODE_SOLVE && !(mode_bits & MODE_GATED)) {
+    // Landmark-sharded window, stream-ordered driver: the sum-all-reduce behind this kernel goes out in EVERY pass.  In a
+    // pass that re-linearized nothing (rejected step, finished loop) the exchange buffer of the pose-side rank still holds
+    // the reduced sums of the last linearization; every other rank zeroes its copy, so the collective reproduces them, bit
+    // for bit.  (Round 2 had a kernel of its own for this, k_xstage.)
+    const TRFlags f0 = tr_flags(&S->tr);
+    if (f0.done | (!f0.do_lin & !f0.do_schur)) {
+      if (!S->pose_side) {
+        const int e = b * 256 + tid;  // blocks: H_pp | g_p entries, then the Schur sums, then the scalars
+        double *x = S->xch;
+        if (b < HPP_BLOCKS) {
+          if (e < PACKED) x[XOFF_H + e] = 0.0;
+          else if (e < PACKED + KP) x[XOFF_G + (e - PACKED)] = 0.0;
+        } else if (b < HPP_BLOCKS + SCHUR_LEN / 256) {
+          x[XOFF_S + (e - HPP_BLOCKS * 256)] = 0.0;
+        } else if (tid < 16) {
+          x[XOFF_C + tid] = 0.0;
+        }
+      }
+      return;
+    }
+  }
   if (b < HPP_BLOCKS) {
     sum_hpp_entry(S, o, mode_bits, b * 256 + tid);
     return;

@@ -620,14 +620,16 @@ struct CaptureGuard {
 
 struct Grid {
   int lm, ch, sc, lw;
+  int ch_raw;  // largest chunk count of a slot before the rounding of `ch` (what decides the two-level sums: upload_window's pre_gram)
 };
 constexpr int CH_BUCKET = 16;
 constexpr size_t LIN_SPLIT_WGS = 2048;  // launches of k_lin with more workgroups than this are issued role by role ...
 constexpr int LIN_SPLIT_MIN_BATCH = 8;   // ... when they are a batch: ONE large window (100 000 landmarks: 64 us as one grid, 54 + 35 + 14 role by role) is better off with its roles overlapping
 
 Grid grid_for(lfvio_ctx *c, int count) {
-  Grid g{1, 1, 1, 1};
+  Grid g{1, 1, 1, 1, 1};
   for (int s = 0; s < count; s++) {
+    g.ch_raw = std::max(g.ch_raw, c->info[s].gCh);
     g.lm = std::max(g.lm, c->info[s].gLm);
     g.lw = std::max(g.lw, c->info[s].gLw);
     g.ch = std::max(g.ch, c->info[s].gCh);
@@ -668,7 +670,9 @@ void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
 // fixed-order reduction of the partials; two levels once a single k_sum thread would have to walk hundreds of them
 void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   const size_t st = c->L.total;
-  const int pre = (g.ch > PRE_CHUNK_LIMIT || g.sc > 4 * PRE_GROUP) ? 1 : 0;
+  // (from the unrounded chunk count: a slot has pre_gram set iff ITS count exceeds the limit — with the rounded one a window
+  // of 241 or 242 chunks launched k_presum for gather lists that do not use its output)
+  const int pre = (g.ch_raw > PRE_CHUNK_LIMIT || g.sc > 4 * PRE_GROUP) ? 1 : 0;
   const int groups = (g.sc + PRE_GROUP - 1) / PRE_GROUP;
   if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + (SCHUR_LEN / 256) * groups + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, groups);
   const Layout &L = c->L;

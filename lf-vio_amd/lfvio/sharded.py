@@ -1,4 +1,8 @@
-"""Landmark-sharded solve across the GPUs of one node.
+"""Landmark-sharded solve across the GPUs of one node — the PYTHON reference driver.
+
+The product's driver is C++ inside the library (lfvio_group, lf-vio_amd/csrc/group.inc: the loop below with the collective an
+ncclAllReduce the library issues itself); bench.py and the host side use that one.  This module stays as the second,
+independent driver the tests hold it against (torch.distributed / emulated collectives over the exposed exchange buffer).
 
 One process per GPU.  Every rank holds the whole (small) pose-side state and a contiguous CSR range of
 the landmarks balanced on observation count; per trust-region iteration the ranks exchange ONE
@@ -86,16 +90,23 @@ class ShardedWindow:
         self.passes = 0
         limit = 4 * (self.win.max_num_iterations + 8)
         with torch.cuda.stream(self.stream):
-            self._pass()
-            while True:
-                self._pass()                  # one pass in flight ...
-                state = self.eng.shard_poll()  # ... behind the decision being read
-                if state == 2:
-                    break
-                if self.passes > limit:
-                    raise RuntimeError("sharded loop did not terminate")
-            while self.eng.shard_poll() is not None:  # the pass in flight was a no-op: drain its record
-                pass
+            try:
+                self._pass()
+                while True:
+                    self._pass()                  # one pass in flight ...
+                    state = self.eng.shard_poll()  # ... behind the decision being read
+                    if state == 2:
+                        break
+                    if self.passes > limit:
+                        raise RuntimeError("sharded loop did not terminate")
+            finally:
+                # no record may stay outstanding, whatever ended the loop (the pass in flight behind a terminated loop was a
+                # no-op; behind an error its record must still be consumed before the ring is reused)
+                try:
+                    while self.eng.shard_poll() is not None:
+                        pass
+                except RuntimeError:
+                    pass
             if marg_flag is None:
                 return self.eng.shard_finish(self.win.N), self.range
             if self.eng.shard_marginalize_linearize(marg_flag) == 1:

@@ -8,6 +8,8 @@ A test box has ONE GPU, so:
 * `lfvio_group_create(1)` (a mask of one device) runs the real thing: librccl loaded by the library, ncclCommInitAll, and
   every collective of the loop as an ncclAllReduce on the context's stream.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -80,7 +82,11 @@ def test_mask_of_one_device_runs_every_collective_through_rccl(oracle, n):
     w = synth.make_window_with_prior(5, n, warm)[0]
     want, want_prior = ref.optimize(w, abi.MARGIN_OLD)
     ref.close()
-    g = Group(mask=1)
+    os.environ["LFVIO_GROUP_FORCE_COLLECTIVE"] = "1"  # a group of one rank skips its collectives unless told otherwise
+    try:
+        g = Group(mask=1)
+    finally:
+        del os.environ["LFVIO_GROUP_FORCE_COLLECTIVE"]
     assert "rccl" in g.backend() and (g.world, g.local) == (1, 1)
     sol, prior = g.solve(w, abi.MARGIN_OLD)
     assert g.last_collectives() >= g.last_passes() + 1 >= 3  # at least one per pass and the marginalization's

@@ -36,12 +36,15 @@ def short(name):
     return name.split("(")[0]
 
 
+WORKING_US = {}  # workload -> kernel -> mean duration of its working launches (us), from the kernel trace
+
+
 def main():
     py = sys.executable
     bench = os.path.join(ROOT, "bench.py")
     for w, args in WORK.items():
         # 1. the bench line itself (full default length for the headline workload)
-        r = sh([py, bench] + (args if w != "window300" else []))
+        r = sh([py, bench] + (args + ["--no-cpu-baseline"] if w != "window300" else []))
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if line:
             open(os.path.join(OUT, f"bench_{w}.json"), "w").write(line[-1] + "\n")
@@ -49,7 +52,7 @@ def main():
             print(r.stdout[-2000:], r.stderr[-2000:])
         # 2. kernel statistics of the same command (shorter run, no CPU baseline leg)
         d = f"/tmp/prof_{w}"
-        sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", py, bench, "--no-cpu-baseline"] + args)
+        sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", py, bench, "--no-cpu-baseline", "--no-secondary"] + args)
         for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
             rows = list(csv.reader(open(f)))
             with open(os.path.join(OUT, f"bench_{w}_kernel_stats.csv"), "w", newline="") as fo:
@@ -64,6 +67,7 @@ def main():
             dur = defaultdict(list)
             for r_ in csv.DictReader(open(f)):
                 dur[short(r_["Kernel_Name"])].append(int(r_["End_Timestamp"]) - int(r_["Start_Timestamp"]))
+            WORKING_US[w] = {k: (lambda a: sum(a) / max(len(a), 1) / 1e3)([x for x in v if x >= 0.25 * max(v)]) for k, v in dur.items()}
             lines = ["# launches of the same rocprofv3 --kernel-trace run, split at a quarter of the longest launch of each kernel", "",
                      "| kernel | launches | working launches | mean us | early returns | mean us |", "|---|---|---|---|---|---|"]
             for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
@@ -83,17 +87,22 @@ def main():
           "FETCH_SIZE / WRITE_SIZE are KB as rocprofv3 reports them.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide",
           "(16 B/lane) streaming reads by 2x and is uncalibrated for other widths; the kernels here read 8 B per lane, so the",
           "figures are kept as measured and compared with the algorithmic bytes only as an order of magnitude.", ""]
-    for w in ("window300", "window100k"):
+    md += ["`VALU issue` = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration of the launch x 2.4 GHz): the share of the chip's vector",
+           "issue slots the launch used (a wave instruction occupies its SIMD for four cycles; FP64 FMA and v_mfma_f64 run at that",
+           "rate: 78.6 TFLOP/s = every slot an FMA) — the FP64 roofline read off the counters, an upper bound of the useful FLOP",
+           "fraction.  `MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x duration x 2.4 GHz).  Durations: mean of the working launches",
+           "of the kernel trace of the same workload (bench_*_launches.md).", ""]
+    for w in ("window300", "batch512", "window100k"):
         agg = defaultdict(lambda: defaultdict(list))
         for i, ctrs in enumerate(PMC_PASSES):
             d = f"/tmp/pmc_{w}_{i}"
             sh(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--", py, bench, "--no-cpu-baseline",
-                                                 "--steps", "10", "--warmup", "2"] + (WORK[w][:2] if w != "window300" else []))
+                                                 "--no-secondary", "--steps", "10" if w != "batch512" else "4", "--warmup", "2"] + (WORK[w][:2] if w != "window300" else []))
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
                     agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
         names = [c for p in PMC_PASSES for c in p]
-        md += [f"## {w}", "", "| kernel | launches | " + " | ".join(names) + " |", "|---|---|" + "---|" * len(names)]
+        md += [f"## {w}", "", "| kernel | launches | " + " | ".join(names) + " | us | VALU issue | MFMA busy |", "|---|---|" + "---|" * (len(names) + 3)]
         for k, cs in sorted(agg.items()):
             if k.startswith("__amd"):
                 continue
@@ -102,8 +111,14 @@ def main():
                 return [x for x in v if x >= 0.25 * top] if top > 0 else v
             n = max(len(v) for v in cs.values())
             ref = cs.get("SQ_INSTS_VALU") or cs.get("FETCH_SIZE") or next(iter(cs.values()))  # (SQ_WAVES is the same for a launch that returns at once)
+            mean = lambda c: sum(working(cs[c])) / len(working(cs[c])) if cs.get(c) else None
+            us = WORKING_US.get(w, {}).get(k)
+            slots = 1024.0 * us * 2400.0 if us else None
+            occ = f"{mean('SQ_INSTS_VALU') * 4.0 / slots:.4f}" if slots and mean("SQ_INSTS_VALU") is not None else "-"
+            mfma = f"{mean('SQ_VALU_MFMA_BUSY_CYCLES') / slots:.4f}" if slots and mean("SQ_VALU_MFMA_BUSY_CYCLES") is not None else "-"
             md.append(f"| {k} | {len(working(ref))} / {n} | " +
-                      " | ".join(f"{sum(working(cs[c])) / len(working(cs[c])):.1f}" if cs.get(c) else "-" for c in names) + " |")
+                      " | ".join(f"{mean(c):.1f}" if cs.get(c) else "-" for c in names) + f" | {us:.2f} | {occ} | {mfma} |" if us else
+                      f"| {k} | {len(working(ref))} / {n} | " + " | ".join(f"{mean(c):.1f}" if cs.get(c) else "-" for c in names) + " | - | - | - |")
         md.append("")
     open(os.path.join(OUT, "pmc_summary.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md))
