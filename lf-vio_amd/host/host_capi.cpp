@@ -273,6 +273,7 @@ void lfvio_host_set_fused(void *h, int on) { E(h)->fused = on != 0; }
 // HIP devices of the estimator (bit d = device d); before the first call that needs the device.  More than one bit: the
 // optimization() of every frame runs landmark-sharded through an lfvio_group over them.
 void lfvio_host_set_device_mask(unsigned mask) { config().device_mask = mask ? mask : 1u; }
+void lfvio_host_set_local_shards(int n) { config().local_shards = n; }
 int lfvio_host_uses_group(void *h) { return E(h)->group != nullptr; }
 
 int lfvio_host_optimization(void *h) {

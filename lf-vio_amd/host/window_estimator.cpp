@@ -209,7 +209,12 @@ void assign_prior(LfvioPrior *dst, const LfvioPrior *src) {
 bool WindowEstimator::device() {
   if (!gpu) {
     const unsigned mask = config().device_mask ? config().device_mask : 1u;
-    if (mask & (mask - 1)) {  // several devices: one group, whose first context also serves the single-device calls
+    if (config().local_shards > 1) {
+      int d = 0;
+      while (!(mask & (1u << d))) d++;
+      group = lfvio_group_create_local(d, config().local_shards);
+      gpu = group ? lfvio_group_ctx(group, 0) : nullptr;
+    } else if (mask & (mask - 1)) {  // several devices: one group, whose first context also serves the single-device calls
       group = lfvio_group_create(mask);
       gpu = group ? lfvio_group_ctx(group, 0) : nullptr;
     } else {

@@ -44,6 +44,9 @@ struct Config {
   // lfvio_group over them — optimization() becomes ONE lfvio_group_solve(), the window's landmarks sharded over the
   // devices with RCCL all-reduces inside the library (include/lfvio.h; SURVEY §8b lfvio_create(device_mask), §8e).
   unsigned device_mask = 1u;
+  // > 1: the group is `local_shards` ranks on the FIRST device of the mask (lfvio_group_create_local: the collective a
+  // device-side sum) — how a one-GPU box runs the multi-rank path of the estimator end to end (tests)
+  int local_shards = 0;
 };
 Config &config();
 

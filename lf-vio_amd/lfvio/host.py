@@ -63,6 +63,9 @@ class HostEstimator:
         L.lfvio_host_get_prior.argtypes = [C.c_void_p, C.POINTER(abi.Prior)]
         L.lfvio_host_optimization.argtypes = [C.c_void_p]
         L.lfvio_host_set_fused.argtypes = [C.c_void_p, C.c_int]
+        L.lfvio_host_set_device_mask.argtypes = [C.c_uint]
+        L.lfvio_host_set_local_shards.argtypes = [C.c_int]
+        L.lfvio_host_uses_group.argtypes = [C.c_void_p]
         L.lfvio_host_triangulate.argtypes = [C.c_void_p]
         L.lfvio_host_remove_back_shift_depth.argtypes = [C.c_void_p, _dp, _dp]
         L.lfvio_host_num_features.argtypes = [C.c_void_p]

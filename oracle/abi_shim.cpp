@@ -131,6 +131,7 @@ struct lfvio_group {
   std::string err;
 };
 lfvio_group *lfvio_group_create(unsigned device_mask) { return device_mask ? new lfvio_group() : nullptr; }
+lfvio_group *lfvio_group_create_local(int, int shards) { return shards > 0 ? new lfvio_group() : nullptr; }
 void lfvio_group_destroy(lfvio_group *g) { delete g; }
 lfvio_ctx *lfvio_group_ctx(lfvio_group *g, int i) { return (g && i == 0) ? &g->ctx : nullptr; }
 const char *lfvio_group_last_error(const lfvio_group *g) { return g ? g->err.c_str() : "null group"; }

@@ -414,3 +414,39 @@ def test_replay_reboots_mid_recording(host, tmp_path):
     fresh(host)
     rc, st = host.replay(op, jp)
     _check_reboot_run(rc, st, jp, op)
+
+
+@pytest.mark.gpu
+def test_replay_through_a_group_of_ranks(host, tmp_path):
+    """The estimator configured for several ranks (Config::device_mask / local_shards -> lfvio_group): every frame's
+    optimization() is ONE lfvio_group_solve() — landmarks sharded over the ranks, the collective inside the library.  On a
+    one-GPU box the ranks are three shards on that GPU (lfvio_group_create_local); the recording comes out as through the
+    single context: same keyframe decisions and iteration counts, poses equal to the summation-order noise of the shards
+    carried through the chained priors."""
+    import ate
+    from lfvio.engine import Engine  # noqa: F401
+    from lfvio.host import HostEstimator
+
+    tp = str(tmp_path / "rec.lfvt")
+    trace.make_stream(tp, seed=5, n_frames=40)
+    fresh(host)
+    j1 = str(tmp_path / "traj_single.txt")
+    rc, s1 = host.replay(tp, j1)
+    assert rc == 0
+    g = HostEstimator()
+    try:
+        g.L.lfvio_host_set_local_shards(3)
+        g.clear_state()
+        g.set_min_parallax(10.0)
+        j3 = str(tmp_path / "traj_group.txt")
+        rc, s3 = g.replay(tp, j3)
+        assert rc == 0 and g.L.lfvio_host_uses_group(g.h) == 1, s3
+    finally:
+        g.L.lfvio_host_set_local_shards(0)
+        g.close()
+    assert (s1["poses"], s1["keyframes"], s1["non_keyframes"], s1["iterations"], s1["failures"]) == \
+           (s3["poses"], s3["keyframes"], s3["non_keyframes"], s3["iterations"], s3["failures"])
+    a, b = np.loadtxt(j1), np.loadtxt(j3)
+    d = np.abs(a[:, 1:4] - b[:, 1:4]).max(axis=1)
+    assert d[0] < 1e-8 and d.max() < 5e-3, (d[0], d.max())
+    assert abs(ate.ate(j1, tp)["rmse"] - ate.ate(j3, tp)["rmse"]) < 0.005

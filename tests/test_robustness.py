@@ -239,3 +239,29 @@ def test_wall_clock_cap(eng):
     assert roomy.c.num_iterations == free.c.num_iterations and np.array_equal(roomy.pose, free.pose)
     sol, prior = eng.optimize(w.copy(max_solver_time=1e-7), abi.MARGIN_OLD)
     assert sol.c.termination == abi.NO_CONVERGENCE and prior.valid == 1 and np.isfinite(prior.J()).all()
+
+
+@pytest.mark.gpu
+def test_a_window_without_information_ends_as_failure_like_the_oracle(eng, oracle):
+    """trust_region_minimizer.cc HandleInvalidStep: a step whose model_cost_change is not positive is invalid (mu *= 10,
+    StepIsInvalid); five in a row end the solve with FAILURE and the state untouched.  A window with no factor at all — no
+    landmark, no prior, every pre-integration longer than ten seconds (estimator.cpp:720 skips those) — has a zero
+    gradient and a zero Hessian: every step is invalid.  (A never-positive-definite reduced system takes the same exit;
+    with finite inputs J^T J + mu D^2 is always positive definite, so this is the case that reaches it.)"""
+    w = synth.make_window(11, 0)
+    imu = []
+    for p in w.imu:
+        q = abi.preint_from_array(abi.preint_to_array(p))
+        q.sum_dt = 11.0
+        imu.append(q)
+    w = w.copy(imu=imu, prior=None)
+    ref = oracle.solve(w)
+    got = eng.solve(w)
+    assert ref.c.termination == abi.FAILURE and got.c.termination == abi.FAILURE
+    assert (got.c.num_iterations, got.c.num_successful_steps, got.c.num_unsuccessful_steps) == \
+           (ref.c.num_iterations, ref.c.num_successful_steps, ref.c.num_unsuccessful_steps)
+    assert [t["valid"] for t in got.trace()] == [t["valid"] for t in ref.trace()] and not any(t["valid"] for t in got.trace())
+    assert np.array_equal(got.pose, w.pose) and np.array_equal(got.speed_bias, w.speed_bias) and got.c.final_cost == 0.0
+    # the whole optimization() of such a window: nothing to marginalize but the (empty) frame 0 — no error, state as it was
+    sol, prior = eng.optimize(w, abi.MARGIN_SECOND_NEW)
+    assert sol.c.termination == abi.FAILURE and prior.valid == 0
