@@ -206,6 +206,20 @@ int lfvio_batch_sync(lfvio_ctx *ctx);
 /* state returned here is AFTER the gauge fix (what Ps/Rs/Vs... hold after
  * double2vector()), re-expressed through vector2double(). */
 int lfvio_batch_download(lfvio_ctx *ctx, int slot, LfvioSolution *sol, LfvioPrior *prior);
+/* The same call split in two for ONE resident window (slot 0), for callers that use the state before they need the
+ * prior — the reference publishes the pose right after optimization() (estimator_node.cpp:  pubOdometry behind
+ * processImage) and reads last_marginalization_info first in the NEXT optimization() (estimator.cpp:700-706):
+ *   lfvio_batch_optimize_begin   returns with the solution (after the gauge fix, as lfvio_batch_download gives it) as soon as
+ *                                solve + gauge fix are out; the marginalization is still running on the device then
+ *                                (lfvio_batch_optimize_pending() == 1).  The device pushes the state into mapped host memory and
+ *                                the call polls one word of it: no copy, no stream synchronization in front of the caller.
+ *   lfvio_batch_optimize_finish  waits for the rest and delivers the prior (NULL: just wait).  Any other entry point on the
+ *                                context waits for the tail first, so forgetting it costs overlap, not correctness; the prior
+ *                                must be collected before the slot is uploaded again.
+ * lfvio_triangulate / lfvio_shift_depth / lfvio_preintegrate do NOT wait: they run beside the tail on their own stream. */
+int lfvio_batch_optimize_begin(lfvio_ctx *ctx, int marg_flag, LfvioSolution *sol);
+int lfvio_batch_optimize_finish(lfvio_ctx *ctx, LfvioPrior *prior);
+int lfvio_batch_optimize_pending(const lfvio_ctx *ctx);
 /* the context's HIP stream (hipStream_t) for event timing by the caller */
 void *lfvio_stream(lfvio_ctx *ctx);
 

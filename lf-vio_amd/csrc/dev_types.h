@@ -103,6 +103,7 @@ enum {
 #endif
 constexpr int SPEC_EXTRA = LFVIO_SPEC_EXTRA, SPEC_MAX_LM = 320;
 constexpr int WT_PAIRS = (KC + 1) / 2;
+constexpr int MAIL_MAX_LM = 8192;  // landmarks a window may have for its solution to travel through the mailbox (Slot::mail)
 #define TR_HEAD_FIELDS \
   double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha; \
   double cg, cn; \
@@ -124,6 +125,10 @@ struct TRState {
   LfvioIterationSummary it;
   LfvioIterationSummary trace[LFVIO_MAX_TRACE];
 };
+// layout of the mailbox (Slot::mail), the same order as the pinned download block of the host side: the flag word, both
+// state slots (only x[cur] is written), the trust-region header with the trace, both inverse-depth buffers (only [cur])
+constexpr size_t MAIL_X = 64, MAIL_TR = MAIL_X + 2 * sizeof(FrameState), MAIL_LAM = (MAIL_TR + sizeof(TRState) + 63) / 64 * 64,
+                 MAIL_LAM_STRIDE = (size_t)MAIL_MAX_LM * 8, MAIL_BYTES = MAIL_LAM + 2 * MAIL_LAM_STRIDE;
 
 // What the trust-region bookkeeping (k_decide) changes in the header.  In the passes of a graph that follow another pass the
 // bookkeeping rides in the prologue of k_lin (every workgroup repeats it, none of them may write the header the others
@@ -176,6 +181,11 @@ struct Slot {
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
   int dec_pending, dec_pad_;     // dec holds a decision k_solve has not moved into the header yet
+  // Early hand-over of the solution (lfvio_batch_optimize_begin): host memory the device writes directly — 0, or the
+  // mailbox [flag | x[2] | TRState | lam[0] | lam[1]] (MAIL_* below) of the context.  The gated gauge fix ends by copying
+  // the state it has just re-anchored there and raising the flag, so the caller has its poses while the marginalization
+  // of the same graph is still running.
+  long long mail;
   TRDecision dec;
   double g[3], tr_over_row, half_row, sqrt_info;
   FrameState x0;

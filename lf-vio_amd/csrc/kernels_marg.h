@@ -30,7 +30,43 @@ DEV void gauge_landmarks(Slot *S, int l0) {
   double *lam = S->lam[S->tr.cur];
   if (l < S->N) lam[l] = 1.0 / (1.0 / lam[l]);
 }
-DEV void gauge_poses(Slot *S, int gated);
+DEV void gauge_poses(Slot *S, int gated, bool publish);
+// The finished state into the caller's mailbox (Slot::mail, dev_types.h): x[cur], the trust-region header with as much of
+// the trace as there is, lam[cur] — plain stores to host memory, a system-scope fence, then the flag.  Called by every
+// thread of ONE workgroup after the stores of the gauge fix are visible to it.
+DEV void publish_solution(Slot *S) {
+  char *m = (char *)S->mail;
+  if (!m) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const TRState *ts = &S->tr;
+  const int cur = ts->cur, N = S->N;
+  {
+    const double *src = (const double *)&S->x[cur];
+    double *dst = (double *)(m + MAIL_X + (size_t)cur * sizeof(FrameState));
+    for (int k = tid; k < (int)(sizeof(FrameState) / 8); k += nthr) dst[k] = src[k];
+  }
+  {
+    const long long *src = (const long long *)ts;
+    long long *dst = (long long *)(m + MAIL_TR);
+    const int tl = ts->trace_len < LFVIO_MAX_TRACE ? ts->trace_len : LFVIO_MAX_TRACE;
+    const int words = (int)((offsetof(TRState, trace) + (size_t)(tl > 0 ? tl : 0) * sizeof(LfvioIterationSummary)) / 8);
+    for (int k = tid; k < words; k += nthr) dst[k] = src[k];
+  }
+  {
+    const double *src = S->lam[cur];
+    double *dst = (double *)(m + MAIL_LAM + (size_t)cur * MAIL_LAM_STRIDE);
+    for (int k = tid; k < N; k += nthr) dst[k] = src[k];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store((int *)m, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// behind a k_gauge of several workgroups (windows too large for k_decide_gauge): the same gate, then the mailbox
+__global__ __launch_bounds__(256) void k_publish(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  if (!tail_gate(S, S->tr.done)) return;
+  publish_solution(S);
+}
 __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int gated) {
   Slot *S = SLOT(base, stride);
   if (gated && !tail_gate(S, S->tr.done)) return;
@@ -38,7 +74,7 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int ga
     gauge_landmarks(S, (blockIdx.x - 1) * 128);
     return;
   }
-  gauge_poses(S, gated);
+  gauge_poses(S, gated, false);
 }
 // k_decide_gauge: grid (1, batch) x 128 — behind the last pass of a graph of few small windows: k_decide and, for the slots
 // that are done then, the gated k_gauge in ONE launch (one workgroup per slot: nobody else reads the header it rewrites).
@@ -48,9 +84,9 @@ __global__ __launch_bounds__(128) void k_decide_gauge(char *base, size_t stride)
   __syncthreads();  // (the header and the accepted candidate, written by wave 0, are read by all from here on)
   if (!tail_gate(S, S->tr.done)) return;
   for (int l0 = 0; l0 < S->N; l0 += 128) gauge_landmarks(S, l0);
-  gauge_poses(S, 1);
+  gauge_poses(S, 1, true);
 }
-DEV void gauge_poses(Slot *S, int gated) {
+DEV void gauge_poses(Slot *S, int gated, bool publish) {
   TRState *ts = &S->tr;
   const int tid = threadIdx.x;
   __shared__ double rot[9], P0[3], oP0[3];
@@ -100,6 +136,7 @@ DEV void gauge_poses(Slot *S, int gated) {
     bt[80] = qn.x, bt[81] = qn.y, bt[82] = qn.z, bt[83] = qn.w;
   }
   __syncthreads();
+  if (publish) publish_solution(S);  // (ends with a barrier: the header is read before thread 0 changes its flags below)
   if (tid == 0) {
     if (!gated) ts->done = 0;  // gated: `done` stays, the gated sweep that follows tests it like this kernel did
     ts->do_lin = 1;

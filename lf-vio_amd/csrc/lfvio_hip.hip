@@ -122,7 +122,7 @@ struct lfvio_ctx {
   hipStream_t stream = nullptr;
   char *d_feat = nullptr;  // scratch of lfvio_triangulate / lfvio_shift_depth (grow-only)
   size_t feat_bytes = 0;
-  std::vector<char> feat_stage;  // host staging of lfvio_preintegrate (one packed copy)
+  char *h_feat = nullptr;  // pinned mirror of d_feat: the inputs of a feature step go up as ONE copy, its outputs come down as one
   std::string err;
   int batch = 0;
   Layout L;
@@ -141,6 +141,15 @@ struct lfvio_ctx {
   double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
+  // lfvio_batch_optimize_begin / _finish: the solution of slot 0 arrives in host memory the gated gauge fix writes directly
+  // (Slot::mail, dev_types.h MAIL_*) while the marginalization of the same graph is still running; `inflight` from the moment
+  // begin has returned on that flag until the stream has been synchronized again (join_inflight: every entry point that
+  // touches the slots or the stream starts with it).  The landmark-parallel steps either side of optimization()
+  // (triangulate / shift_depth / preintegrate) have their own stream and scratch and do not wait for the tail.
+  char *h_mail = nullptr, *d_mail = nullptr;
+  hipStream_t fstream = nullptr;
+  bool inflight = false;
+  bool inflight_first = false;  // the flag came out of the first graph: {tail_state, passes_used} land in h_pending[2..3] when it ends
   bool use_graph = true;
   // the dense solve of a pass: k_solve_dense; LFVIO_SPARSE_SOLVE=1 selects k_solve_sparse (solve_plan.h: the speed/bias
   // chain by cyclic reduction, then 91 dense unknowns) — measured 69 us against 62 us, so not the
@@ -181,7 +190,35 @@ void destroy_graph(lfvio_ctx *c) {
       if (t) (void)hipGraphExecDestroy(t), t = nullptr;
 }
 
+// The tail of a call whose solution went out early (lfvio_batch_optimize_begin) is still on the stream: wait for it and
+// take the bookkeeping its graph left in the pinned block.  First statement of everything that touches the slots.
+int join_inflight(lfvio_ctx *c) {
+  if (!c->inflight) return LFVIO_OK;
+  c->inflight = false;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->inflight_first) {
+    c->last_passes = std::max(c->h_pending[3], 1);
+    c->predict_passes = c->last_passes;
+    if (c->h_pending[2] != 2) {
+      c->err = "the marginalization behind an early solution did not finish";
+      return LFVIO_ERR_DEVICE;
+    }
+  }
+  return LFVIO_OK;
+}
+
+// After a graph launch: the first of "the solution is in the mailbox" (true) and "everything enqueued has run" (false: the
+// window was not done within these passes and the gated gauge fix did not run, or there is no mailbox for this window).
+bool wait_early(lfvio_ctx *c) {
+  int *flag = (int *)c->h_mail;
+  for (;;) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE)) return true;
+    if (hipStreamQuery(c->stream) != hipErrorNotReady) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
+  }
+}
+
 int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
+  if (int rc = join_inflight(c)) return rc;
   if (c->d_base && batch <= c->batch && maxN <= c->L.maxN && maxM <= c->L.maxM) return LFVIO_OK;
   batch = std::max(batch, c->batch);
   maxN = std::max(maxN, c->L.maxN);
@@ -298,6 +335,7 @@ void copy_prior(LfvioPrior *dst, const LfvioPrior *src) {
 
 // Pack one window into the pinned staging blob and upload it to slot `slot`.
 int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0, int pose_side = 1) {
+  if (int rc = join_inflight(c)) return rc;
   if (!w || w->num_landmarks < 0 || w->num_observations < 0) {
     c->err = "null window / negative sizes";
     return LFVIO_ERR_ARG;
@@ -349,6 +387,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->est_ex = w->estimate_extrinsic != 0, S->est_td = w->estimate_td != 0;
   S->max_iter = w->max_num_iterations;
   S->sharded = sharded, S->pose_side = pose_side;
+  S->mail = (slot == 0 && !sharded && c->d_mail && w->num_landmarks <= MAIL_MAX_LM) ? (long long)(uintptr_t)c->d_mail : 0;
   for (int k = 0; k < 3; k++) S->g[k] = w->g[k];
   S->tr_over_row = w->row > 0.0 ? w->tr / w->row : 0.0;  // only the td factor reads it (row > 0 checked above)
   S->half_row = w->row / 2;
@@ -776,8 +815,11 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated 
 // wall clock at the top of every iteration and stops with NO_CONVERGENCE; here the host tests it between graph launches
 // (the only points where it sees the loop) and ends the open slots the same way (k_force_done).  The first graph is sized
 // from the previous call as without a cap, shortened only when the cap is tighter than that many passes would take.
+// early (adaptive, fused, one window with a mailbox): return as soon as the solution is in the mailbox — the rest of the graph
+// (the marginalization) is still running then and c->inflight says so.
 int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fused_flag = -1, bool *tail_done = nullptr,
-                  double max_seconds = -1.0) {
+                  double max_seconds = -1.0, bool early = false) {
+  if (int rc = join_inflight(c)) return rc;
   const Grid g = grid_for(c, count);
   const int passes = std::max(max_iter, 0) + 4;
   if (adaptive && c->use_graph) {
@@ -813,7 +855,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       bool gauged = false;
       for (int it = 0; it < npass; it++) gauged = launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1, tail_flag >= 0);
       if (tail_flag >= 0) {
-        if (!gauged) hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
+        if (!gauged) {
+          hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
+          if (count == 1) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, c->d_base, c->L.total);  // (k_decide_gauge does it itself)
+        }
         rc = enqueue_marg(c, count, tail_flag, false, true);
       }
       if (tail_flag >= 0 && count == 1) {
@@ -844,7 +889,14 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     for (int done_passes = 0; done_passes < passes;) {
       c->stat_chunks++;
       const auto t_launch = std::chrono::steady_clock::now();
+      const bool watch = early && done_passes == 0 && fuse && count == 1 && c->h_mail && c->info[0].N <= MAIL_MAX_LM;
+      if (watch) __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
       HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk, c->stream));
+      if (watch && wait_early(c)) {  // the window was done inside the first graph: its tail follows in the same graph
+        c->inflight = true, c->inflight_first = true;
+        if (tail_done) *tail_done = true;
+        return LFVIO_OK;
+      }
       HIPCHK(c, hipStreamSynchronize(c->stream));
       const bool first = done_passes == 0;
       if (!first) {  // time per pass, for sizing a capped call's first graph (continuation chunks carry nothing but passes)
@@ -891,6 +943,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
 }
 
 int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated) {
+  if (int rc = join_inflight(c)) return rc;
   const Grid g = grid_for(c, count);
   const int mode = (MODE_MARG + flag) | (gated ? MODE_GATED : 0);
   if (standalone)
@@ -915,6 +968,7 @@ struct Fetched {
 };
 
 int fetch(lfvio_ctx *c, int slot, bool want_sol, bool want_prior, Fetched *f) {
+  if (int rc = join_inflight(c)) return rc;
   const Layout &L = c->L;
   char *d = c->d_base + (size_t)slot * L.total;
   const SlotHostInfo &info = c->info[slot];
@@ -1054,6 +1108,23 @@ lfvio_ctx *lfvio_create(int device) {
     delete c;
     return nullptr;
   }
+  {
+    // The stream of the feature steps must not share a hardware queue with `stream`, or its kernels wait behind the tail they
+    // are meant to run beside: the runtime deals its (four, by default) hardware queues to streams round-robin PER PRIORITY
+    // LEVEL, so with a second context in the process the two streams of one context can land on the same queue (measured:
+    // lfvio_shift_depth 45 us -> 216 us behind a marginalization).  A stream of another priority comes from another pool.
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&c->fstream, hipStreamNonBlocking, greatest) != hipSuccess) c->fstream = nullptr;  // (falls back to `stream`)
+  }
+  // the mailbox: fine-grained host memory mapped into the device's address space.  Without it begin() simply waits for the end.
+  if (hipHostMalloc((void **)&c->h_mail, MAIL_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+    std::memset(c->h_mail, 0, MAIL_BYTES);
+    if (hipHostGetDevicePointer((void **)&c->d_mail, c->h_mail, 0) != hipSuccess) c->d_mail = nullptr;
+  } else {
+    c->h_mail = nullptr;
+    (void)hipGetLastError();
+  }
   // kernels that need more than the default 64 KiB of LDS
   (void)hipFuncSetAttribute((const void *)k_solve_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   (void)hipFuncSetAttribute((const void *)k_solve_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE2_LDS);
@@ -1086,6 +1157,7 @@ void lfvio_destroy(lfvio_ctx *c) {
   destroy_graph(c);
   if (c->d_base) (void)hipFree(c->d_base);
   if (c->d_feat) (void)hipFree(c->d_feat);
+  if (c->h_feat) (void)hipHostFree(c->h_feat);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_down) (void)hipHostFree(c->h_down);
   if (c->d_s2) (void)hipFree(c->d_s2);
@@ -1095,6 +1167,8 @@ void lfvio_destroy(lfvio_ctx *c) {
     (void)hipHostFree(c->h_flags);
     for (auto &e : c->flag_event) (void)hipEventDestroy(e);
   }
+  if (c->h_mail) (void)hipHostFree(c->h_mail);
+  if (c->fstream) (void)hipStreamDestroy(c->fstream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1138,9 +1212,10 @@ int lfvio_batch_upload(lfvio_ctx *c, int slot, const LfvioWindow *in) {
   return upload_window(c, slot, in);
 }
 
-static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adaptive) {
+static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adaptive, bool early = false) {
   if (!c || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
+  if (int rc = join_inflight(c)) return rc;
   // every slot carries its own max_iter on the device; the pass count follows the largest, the wall-clock cap
   // (synchronous driver only) the smallest positive one
   int max_iter = 0;
@@ -1156,7 +1231,7 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
   }
   const bool fuse = adaptive && c->use_graph && marg_flag >= 0 && marg_flag < 3;
   bool tail_done = false;
-  int rc = enqueue_solve(c, count, max_iter, adaptive, fuse ? marg_flag : -1, &tail_done, max_seconds);
+  int rc = enqueue_solve(c, count, max_iter, adaptive, fuse ? marg_flag : -1, &tail_done, max_seconds, early);
   if (rc) return rc;
   if (fuse) {
     if (tail_done) return LFVIO_OK;  // the usual case: everything ran in the graph of the first chunk
@@ -1167,6 +1242,7 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
       CaptureGuard guard(c->stream);
       hipLaunchKernelGGL(k_force_done, dim3((count + 63) / 64), dim3(64), 0, c->stream, c->d_base, c->L.total, count);
       hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
+      if (count == 1) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, c->d_base, c->L.total);
       rc = enqueue_marg(c, count, marg_flag, false, true);
       HIPCHK(c, guard.end(&graph));
       if (rc) {
@@ -1176,7 +1252,10 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
       HIPCHK(c, hipGraphInstantiate(&c->tail[marg_flag], graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
     }
+    const bool watch = early && count == 1 && c->h_mail && c->info[0].N <= MAIL_MAX_LM;
+    if (watch) __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
     HIPCHK(c, hipGraphLaunch(c->tail[marg_flag], c->stream));
+    if (watch && wait_early(c)) c->inflight = true, c->inflight_first = false;
     return LFVIO_OK;
   }
   hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 0);
@@ -1187,6 +1266,7 @@ int lfvio_batch_optimize_async(lfvio_ctx *c, int count, int marg_flag) { return 
 
 int lfvio_batch_sync(lfvio_ctx *c) {
   if (!c) return LFVIO_ERR_ARG;
+  if (int rc = join_inflight(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LFVIO_OK;
 }
@@ -1203,14 +1283,47 @@ int lfvio_batch_download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior 
   return download(c, slot, sol, prior);
 }
 
+// The split form of lfvio_batch_optimize(ctx, 1, marg_flag) + lfvio_batch_download(ctx, 0, sol, prior) for ONE resident window:
+// begin() returns with the solution as soon as solve + gauge fix are out — the gated gauge fix pushes the state into host
+// memory (Slot::mail) and the host polls that word, no copy and no stream synchronization — while the marginalization of the
+// same graph is still running; finish() waits for it and fetches the prior.  (estimator.cpp: the pose is published after
+// optimization(), the prior is first read by the next optimization(): the ~0.19 ms of the marginalization overlap with
+// whatever the caller does in between.)  Windows without a mailbox (more than MAIL_MAX_LM landmarks, no mapped host memory)
+// and windows that were not done within the first graph take the synchronous route inside begin().
+int lfvio_batch_optimize_begin(lfvio_ctx *c, int marg_flag, LfvioSolution *sol) {
+  if (!c || !sol || c->batch < 1) return LFVIO_ERR_ARG;
+  int rc = batch_optimize_impl(c, 1, marg_flag, true, true);
+  if (rc) return rc;
+  if (!c->inflight) return download(c, 0, sol, nullptr);  // (synchronizes)
+  Fetched f;
+  char *m = c->h_mail;
+  f.xs = (const FrameState *)(m + MAIL_X), f.tr = (const TRState *)(m + MAIL_TR);
+  f.lam[0] = (const double *)(m + MAIL_LAM), f.lam[1] = (const double *)(m + MAIL_LAM + MAIL_LAM_STRIDE), f.prior = nullptr;
+  if ((rc = check_solution(c, 0, f))) return rc;
+  unpack_solution(c, 0, f, sol);
+  return LFVIO_OK;
+}
+
+int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
+  if (!c) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  int rc = join_inflight(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return prior ? download(c, 0, nullptr, prior) : LFVIO_OK;
+}
+
+int lfvio_batch_optimize_pending(const lfvio_ctx *c) { return c && c->inflight ? 1 : 0; }
+
 // ---- the landmark-parallel steps either side of optimization()
 static int feat_reserve(lfvio_ctx *c, size_t bytes) {
   if (bytes <= c->feat_bytes) return LFVIO_OK;
   if (c->d_feat) (void)hipFree(c->d_feat);
-  c->d_feat = nullptr, c->feat_bytes = 0;
+  if (c->h_feat) (void)hipHostFree(c->h_feat);
+  c->d_feat = nullptr, c->h_feat = nullptr, c->feat_bytes = 0;
   bytes = align_up(bytes + bytes / 4, 4096);
-  if (hipMalloc(&c->d_feat, bytes) != hipSuccess) {
-    c->err = "out of device memory (feature scratch)";
+  if (hipMalloc(&c->d_feat, bytes) != hipSuccess || hipHostMalloc((void **)&c->h_feat, bytes, hipHostMallocDefault) != hipSuccess) {
+    c->err = "out of memory (feature scratch)";
     return LFVIO_ERR_DEVICE;
   }
   c->feat_bytes = bytes;
@@ -1233,6 +1346,7 @@ int lfvio_triangulate(lfvio_ctx *c, const LfvioTriangulateIn *in, double *estima
     }
   }
   (void)hipSetDevice(c->device);
+  hipStream_t fs = c->fstream ? c->fstream : c->stream;  // not behind the tail of an optimization still in flight
   const size_t oF = 0, oS = align_up(sizeof(FeatFrames), 256), oO = align_up(oS + (size_t)N * 4, 256),
                oP = align_up(oO + (size_t)(N + 1) * 4, 256), oD = align_up(oP + (size_t)M * 24, 256), total = oD + (size_t)N * 8;
   int rc = feat_reserve(c, total);
@@ -1241,17 +1355,19 @@ int lfvio_triangulate(lfvio_ctx *c, const LfvioTriangulateIn *in, double *estima
   std::memcpy(F.Ps, in->Ps, sizeof F.Ps), std::memcpy(F.Rs, in->Rs, sizeof F.Rs);
   std::memcpy(F.tic, in->tic, sizeof F.tic), std::memcpy(F.ric, in->ric, sizeof F.ric);
   F.init_depth = in->init_depth;
-  char *d = c->d_feat;
-  HIPCHK(c, hipMemcpyAsync(d + oF, &F, sizeof F, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + oS, in->start_frame, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + oO, in->obs_offset, (size_t)(N + 1) * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + oP, in->obs_point, (size_t)M * 24, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + oD, estimated_depth, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_triangulate, dim3((N + TRI_THREADS - 1) / TRI_THREADS), dim3(TRI_THREADS), 0, c->stream, (const FeatFrames *)(d + oF), N,
+  char *d = c->d_feat, *h = c->h_feat;  // (a copy from pageable memory costs ~20 us each on this runtime: one packed pinned block instead of five)
+  std::memcpy(h + oF, &F, sizeof F);
+  std::memcpy(h + oS, in->start_frame, (size_t)N * 4);
+  std::memcpy(h + oO, in->obs_offset, (size_t)(N + 1) * 4);
+  std::memcpy(h + oP, in->obs_point, (size_t)M * 24);
+  std::memcpy(h + oD, estimated_depth, (size_t)N * 8);
+  HIPCHK(c, hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, fs));
+  hipLaunchKernelGGL(k_triangulate, dim3((N + TRI_THREADS - 1) / TRI_THREADS), dim3(TRI_THREADS), 0, fs, (const FeatFrames *)(d + oF), N,
                      (const int *)(d + oS), (const int *)(d + oO), (const double *)(d + oP), (double *)(d + oD));
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(estimated_depth, d + oD, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // F and the caller's arrays are pageable: done before returning
+  HIPCHK(c, hipMemcpyAsync(h + oD, d + oD, (size_t)N * 8, hipMemcpyDeviceToHost, fs));
+  HIPCHK(c, hipStreamSynchronize(fs));
+  std::memcpy(estimated_depth, h + oD, (size_t)N * 8);
   return LFVIO_OK;
 }
 
@@ -1261,21 +1377,24 @@ int lfvio_shift_depth(lfvio_ctx *c, int n, const double *uv_i, const double marg
   if (n == 0) return LFVIO_OK;
   if (!uv_i || !marg_R || !marg_P || !new_R || !new_P || !estimated_depth) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
+  hipStream_t fs = c->fstream ? c->fstream : c->stream;  // not behind the tail of an optimization still in flight
   const size_t oT = 0, oU = 256, oD = align_up(oU + (size_t)n * 24, 256), total = oD + (size_t)n * 8;
   int rc = feat_reserve(c, total);
   if (rc) return rc;
   double T[25];
   std::memcpy(T, marg_R, 72), std::memcpy(T + 9, marg_P, 24), std::memcpy(T + 12, new_R, 72), std::memcpy(T + 21, new_P, 24);
   T[24] = init_depth;
-  char *d = c->d_feat;
-  HIPCHK(c, hipMemcpyAsync(d + oT, T, sizeof T, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + oU, uv_i, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + oD, estimated_depth, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_shift_depth, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, (const double *)(d + oU), (const double *)(d + oT),
+  char *d = c->d_feat, *h = c->h_feat;
+  std::memcpy(h + oT, T, sizeof T);
+  std::memcpy(h + oU, uv_i, (size_t)n * 24);
+  std::memcpy(h + oD, estimated_depth, (size_t)n * 8);
+  HIPCHK(c, hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, fs));
+  hipLaunchKernelGGL(k_shift_depth, dim3((n + 255) / 256), dim3(256), 0, fs, n, (const double *)(d + oU), (const double *)(d + oT),
                      (double *)(d + oD));
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(estimated_depth, d + oD, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(h + oD, d + oD, (size_t)n * 8, hipMemcpyDeviceToHost, fs));
+  HIPCHK(c, hipStreamSynchronize(fs));
+  std::memcpy(estimated_depth, h + oD, (size_t)n * 8);
   return LFVIO_OK;
 }
 
@@ -1292,14 +1411,14 @@ int lfvio_preintegrate(lfvio_ctx *c, int num_intervals, const LfvioImuInterval *
     S += (size_t)in[k].num_samples;
   }
   (void)hipSetDevice(c->device);
+  hipStream_t fs = c->fstream ? c->fstream : c->stream;  // not behind the tail of an optimization still in flight
   const size_t K = (size_t)num_intervals;
   const size_t oJ = 0, oN = align_up(K * sizeof(ImuJob), 256), oT = oN + 256, oA = align_up(oT + S * 8, 256), oG = align_up(oA + S * 24, 256),
                oO = align_up(oG + S * 24, 256), total = oO + K * sizeof(LfvioPreintegration);
   int rc = feat_reserve(c, total);
   if (rc) return rc;
-  // one packed staging buffer -> one host-to-device copy
-  c->feat_stage.resize(oO);
-  char *h = c->feat_stage.data();
+  // one packed (pinned) staging block -> one host-to-device copy
+  char *h = c->h_feat;
   size_t off = 0;
   for (int k = 0; k < num_intervals; k++) {
     ImuJob *jb = (ImuJob *)(h + oJ) + k;
@@ -1316,12 +1435,13 @@ int lfvio_preintegrate(lfvio_ctx *c, int num_intervals, const LfvioImuInterval *
   }
   std::memcpy(h + oN, noise, 32);
   char *d = c->d_feat;
-  HIPCHK(c, hipMemcpyAsync(d, h, oO, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_preintegrate, dim3(num_intervals), dim3(PRE_THREADS), 0, c->stream, (const ImuJob *)(d + oJ), (const double *)(d + oT),
+  HIPCHK(c, hipMemcpyAsync(d, h, oO, hipMemcpyHostToDevice, fs));
+  hipLaunchKernelGGL(k_preintegrate, dim3(num_intervals), dim3(PRE_THREADS), 0, fs, (const ImuJob *)(d + oJ), (const double *)(d + oT),
                      (const double *)(d + oA), (const double *)(d + oG), (const double *)(d + oN), (LfvioPreintegration *)(d + oO));
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(out, d + oO, K * sizeof(LfvioPreintegration), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(h + oO, d + oO, K * sizeof(LfvioPreintegration), hipMemcpyDeviceToHost, fs));
+  HIPCHK(c, hipStreamSynchronize(fs));
+  std::memcpy(out, h + oO, K * sizeof(LfvioPreintegration));
   return LFVIO_OK;
 }
 

@@ -255,11 +255,13 @@ int lfvio_host_pack(void *h, LfvioWindow *out) {
 void lfvio_host_set_flag(void *h, int flag) { E(h)->marg_flag = flag; }
 void lfvio_host_set_prior(void *h, const LfvioPrior *p) {
   WindowEstimator *e = E(h);
+  (void)e->collectPrior();
   e->has_prior = p && p->valid;
   if (e->has_prior) e->prior = *p;
 }
 int lfvio_host_get_prior(void *h, LfvioPrior *out) {
   WindowEstimator *e = E(h);
+  (void)e->collectPrior();
   if (!e->has_prior) {
     out->valid = 0;
     return 0;
@@ -274,6 +276,14 @@ void lfvio_host_set_fused(void *h, int on) { E(h)->fused = on != 0; }
 // optimization() of every frame runs landmark-sharded through an lfvio_group over them.
 void lfvio_host_set_device_mask(unsigned mask) { config().device_mask = mask ? mask : 1u; }
 void lfvio_host_set_local_shards(int n) { config().local_shards = n; }
+void lfvio_host_set_split_call(int on) { config().split_call = on != 0; }
+void lfvio_host_get_timers(void *h, double *out6, int reset) {
+  WindowEstimator *e = E(h);
+  for (int k = 0; k < 6; k++) {
+    out6[k] = e->timers[k];
+    if (reset) e->timers[k] = 0.0;
+  }
+}
 int lfvio_host_uses_group(void *h) { return E(h)->group != nullptr; }
 
 int lfvio_host_optimization(void *h) {

@@ -206,6 +206,30 @@ void assign_prior(LfvioPrior *dst, const LfvioPrior *src) {
 }
 }  // namespace
 
+// The marginalization of the last optimization() may still be running on the device (Config::split_call): wait for it and
+// adopt its prior.  Everything that reads `prior` starts here.
+namespace {
+struct Stopwatch {  // adds its lifetime to *acc
+  double *acc;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit Stopwatch(double *a) : acc(a) {}
+  ~Stopwatch() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
+bool WindowEstimator::collectPrior() {
+  if (!prior_pending_) return true;
+  Stopwatch sw(&timers[1]);
+  prior_pending_ = false;
+  const int rc = lfvio_batch_optimize_finish(gpu, &next_);
+  if (rc != LFVIO_OK) {
+    status = rc;
+    return false;
+  }
+  assign_prior(&prior, &next_), has_prior = next_.valid != 0;
+  return true;
+}
+
 bool WindowEstimator::device() {
   if (!gpu) {
     const unsigned mask = config().device_mask ? config().device_mask : 1u;
@@ -231,6 +255,10 @@ void WindowEstimator::reset() {
   // clearState() (estimator.cpp:23-84) followed by setParameter() (:10-21): the CONFIGURED extrinsic and td come back,
   // and a bootstrap record that described the old window is not reused
   const Config &c = config();
+  if (prior_pending_) {  // the prior of a window that is being dropped: wait for the device, keep nothing
+    prior_pending_ = false;
+    (void)lfvio_batch_optimize_finish(gpu, nullptr);
+  }
   ring_.head = 0;
   for (int i = 0; i < FRAMES; i++) {
     frames_[i] = Keyframe();
@@ -384,6 +412,7 @@ void WindowEstimator::slide() {  // estimator.cpp:1011-1131
 }
 
 void WindowEstimator::triangulate() {  // feature_manager.cpp:199-253: the 2k x 4 SVD per landmark runs on the device
+  Stopwatch sw(&timers[2]);
   Staging &st = stage_;
   st.start_frame.clear(), st.obs_offset.assign(1, 0), st.point.clear(), st.lam_out.clear();
   std::vector<int> sel;
@@ -419,6 +448,7 @@ void WindowEstimator::triangulate() {  // feature_manager.cpp:199-253: the 2k x 
 
 void WindowEstimator::reanchorDepths(const Matrix3d &old_R, const Vector3d &old_P, const Matrix3d &new_R, const Vector3d &new_P,
                                      const std::vector<TrackTable::Shifted> &moved) {  // feature_manager.cpp:291-299
+  Stopwatch sw(&timers[3]);
   if (moved.empty() || !device()) return;
   std::vector<double> uv(3 * moved.size()), depth(moved.size());
   for (size_t k = 0; k < moved.size(); k++) {
@@ -436,6 +466,7 @@ void WindowEstimator::reanchorDepths(const Matrix3d &old_R, const Vector3d &old_
 }
 
 bool WindowEstimator::refreshSpans(bool all, const Vector3d *ba, const Vector3d *bg) {
+  Stopwatch sw(&timers[4]);
   // IntegrationBase::{push_back, propagate, repropagate} (integration_base.h:29-158) for every span whose samples or
   // linearization biases changed since its `pre` was made — all of them in ONE device call
   std::vector<LfvioImuInterval> in;
@@ -523,6 +554,7 @@ void WindowEstimator::double2vector() {  // estimator.cpp:532-600 (the relocaliz
 
 void WindowEstimator::pack(LfvioWindow *w) {
   const Config &c = config();
+  (void)collectPrior();
   std::memset(w, 0, sizeof *w);
   std::memcpy(w->para_pose, para_Pose, sizeof para_Pose);
   std::memcpy(w->para_speed_bias, para_SpeedBias, sizeof para_SpeedBias);
@@ -575,6 +607,9 @@ void WindowEstimator::pack(LfvioWindow *w) {
 void WindowEstimator::optimization() {
   status = LFVIO_OK;
   if (!device() || !refreshSpans(false)) return;
+  if (!collectPrior()) return;
+  Stopwatch sw(&timers[0]);
+  timers[5] += 1.0;  // (the marginalization behind the previous call's early state: done long ago, normally)
   vector2double();  // :707
   LfvioWindow w;
   pack(&w);
@@ -608,6 +643,18 @@ void WindowEstimator::optimization() {
     // yaw and a zero shift to it.
     status = lfvio_batch_reserve(gpu, 1, w.num_landmarks, w.num_observations);
     if (status == LFVIO_OK) status = lfvio_batch_upload(gpu, 0, &w);
+    if (status == LFVIO_OK && config().split_call) {
+      // The state comes back as soon as solve + gauge fix are out (the device pushes it into mapped host memory); the
+      // marginalization runs on while the caller publishes the pose, slides the window, takes the next image — its prior is
+      // collected by the first thing that needs it (collectPrior(): the next pack()).
+      status = lfvio_batch_optimize_begin(gpu, marg_flag, &summary);
+      summary.inv_depth = nullptr;
+      if (status != LFVIO_OK) return;
+      take_state();
+      if (marginalize) prior_pending_ = true;
+      else (void)lfvio_batch_optimize_finish(gpu, nullptr);
+      return;
+    }
     if (status == LFVIO_OK) status = lfvio_batch_optimize(gpu, 1, marg_flag);
     if (status == LFVIO_OK) status = lfvio_batch_download(gpu, 0, &summary, marginalize ? &next : nullptr);
     summary.inv_depth = nullptr;

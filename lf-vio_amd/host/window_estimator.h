@@ -17,6 +17,7 @@
 // the host) and optimization() (a1) keep the reference's names and semantics; everything else is named for what it does,
 // and INTEGRATION.md maps the reference's members onto it.
 #pragma once
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -47,6 +48,10 @@ struct Config {
   // > 1: the group is `local_shards` ranks on the FIRST device of the mask (lfvio_group_create_local: the collective a
   // device-side sum) — how a one-GPU box runs the multi-rank path of the estimator end to end (tests)
   int local_shards = 0;
+  // optimization() on one device returns with the state as soon as solve + gauge fix are out and lets the marginalization
+  // finish in the background (lfvio_batch_optimize_begin / _finish): the pose is published ~0.2 ms earlier, the prior is
+  // collected when the next window is packed.  false: the call returns when the prior is on the host as well.
+  bool split_call = true;
 };
 Config &config();
 
@@ -146,6 +151,7 @@ class WindowEstimator {
   void vector2double();  // estimator.cpp:488-530
   void double2vector();  // estimator.cpp:532-600
   void optimization();   // estimator.cpp:676-1009 over include/lfvio.h
+  bool collectPrior();   // waits for a marginalization still in flight (split_call) and adopts its prior; false + status on error
 
   // ---- the loop around it: processIMU / processImage / solveOdometry / slideWindow / failureDetection
   void reset();                                                     // clearState() + setParameter()
@@ -176,6 +182,9 @@ class WindowEstimator {
   Vector3d tic, last_P, last_P0;
   double td = 0, initial_timestamp = 0;
   int slides_old = 0, slides_new = 0, tracked_last = 0;
+  // wall clock spent in the device-backed steps since the last reset of the timers (seconds; tools/replay_stream.py):
+  // [0] optimization() up to the state, [1] collectPrior(), [2] triangulate(), [3] reanchorDepths(), [4] refreshSpans(), [5] calls of [0]
+  double timers[6] = {0, 0, 0, 0, 0, 0};
   TrackTable tracks;
 
   struct Bootstrap {  // what initialStructure() + visualInitialAlign() would leave (estimator.cpp:222-473), from outside
@@ -200,6 +209,7 @@ class WindowEstimator {
 
  private:
   LfvioPrior next_;  // the prior being downloaded (240 KB: a member, not a stack object; only header + n x n + n are copied)
+  bool prior_pending_ = false;  // the marginalization of the last optimization() has not been collected yet (collectPrior)
   bool device();
   bool applyBootstrap();
   FrameRing ring_;

@@ -17,6 +17,7 @@ MAX_TRACE = 64
 
 OK = 0
 MARGIN_OLD = 0
+MAIL_MAX_LM = 8192  # csrc/dev_types.h: largest window whose solution lfvio_batch_optimize_begin hands over early
 MARGIN_SECOND_NEW = 1
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 BLOCK_POSE, BLOCK_SPEEDBIAS, BLOCK_EX_POSE, BLOCK_TD = 0, 1, 2, 3
@@ -340,6 +341,7 @@ HIP_SYMBOLS = [
     "lfvio_create", "lfvio_destroy", "lfvio_last_error", "lfvio_version", "lfvio_solve", "lfvio_marginalize",
     "lfvio_batch_reserve", "lfvio_batch_upload", "lfvio_batch_optimize", "lfvio_batch_optimize_async",
     "lfvio_batch_sync", "lfvio_batch_download", "lfvio_stream",
+    "lfvio_batch_optimize_begin", "lfvio_batch_optimize_finish", "lfvio_batch_optimize_pending",
     "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_scalar_offset", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
     "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_marg_linearize", "lfvio_shard_marg_finish",
     "lfvio_shard_finish", "lfvio_shard_restart", "lfvio_shard_enqueue", "lfvio_shard_poll", "lfvio_triangulate", "lfvio_shift_depth", "lfvio_preintegrate",
@@ -382,6 +384,9 @@ def load_hip_library(path=None):
     lib.lfvio_batch_optimize_async.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.lfvio_batch_sync.argtypes = [C.c_void_p]
     lib.lfvio_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(SolutionC), C.POINTER(Prior)]
+    lib.lfvio_batch_optimize_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(SolutionC)]
+    lib.lfvio_batch_optimize_finish.argtypes = [C.c_void_p, C.POINTER(Prior)]
+    lib.lfvio_batch_optimize_pending.argtypes = [C.c_void_p]
     lib.lfvio_stream.restype = C.c_void_p
     lib.lfvio_stream.argtypes = [C.c_void_p]
     lib.lfvio_shard_begin.argtypes = [C.c_void_p, C.POINTER(WindowC), C.c_int, C.c_int, C.c_int]

@@ -118,6 +118,20 @@ class Engine:
                     "batch_download")
         return sol, prior
 
+    def optimize_begin(self, flag, n_landmarks, out=None):
+        """Slot 0: returns the solution as soon as solve + gauge fix are out; the marginalization may still be running."""
+        sol = out if out is not None else abi.Solution(n_landmarks)
+        self._check(self.lib.lfvio_batch_optimize_begin(self.ctx, flag, C.byref(sol.c)), "batch_optimize_begin")
+        return sol
+
+    def optimize_pending(self):
+        return bool(self.lib.lfvio_batch_optimize_pending(self.ctx))
+
+    def optimize_finish(self, want_prior=True, out=None):
+        prior = (out if out is not None else abi.Prior()) if want_prior else None
+        self._check(self.lib.lfvio_batch_optimize_finish(self.ctx, C.byref(prior) if want_prior else None), "batch_optimize_finish")
+        return prior
+
     def optimize(self, win, flag):
         """Whole optimization() of one window on slot 0: solve -> gauge fix -> marginalization."""
         self.batch_reserve(1, win.N, win.M)

@@ -65,6 +65,8 @@ class HostEstimator:
         L.lfvio_host_set_fused.argtypes = [C.c_void_p, C.c_int]
         L.lfvio_host_set_device_mask.argtypes = [C.c_uint]
         L.lfvio_host_set_local_shards.argtypes = [C.c_int]
+        L.lfvio_host_set_split_call.argtypes = [C.c_int]
+        L.lfvio_host_get_timers.argtypes = [C.c_void_p, _dp, C.c_int]
         L.lfvio_host_uses_group.argtypes = [C.c_void_p]
         L.lfvio_host_triangulate.argtypes = [C.c_void_p]
         L.lfvio_host_remove_back_shift_depth.argtypes = [C.c_void_p, _dp, _dp]
@@ -148,6 +150,13 @@ class HostEstimator:
 
     def failure_detection(self):
         return bool(self.L.lfvio_host_failure_detection(self.h))
+
+    def timers(self, reset=True):
+        """Seconds in the device-backed steps since the last reset: optimization() up to the state, collectPrior(),
+        triangulate(), reanchorDepths(), refreshSpans(); and the number of optimization() calls."""
+        o = np.zeros(6)
+        self.L.lfvio_host_get_timers(self.h, o.ctypes.data_as(_dp), int(reset))
+        return dict(optimization=o[0], collect_prior=o[1], triangulate=o[2], reanchor=o[3], spans=o[4], calls=int(o[5]))
 
     def flow(self):
         o = np.zeros(8, dtype=np.int32)

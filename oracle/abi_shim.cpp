@@ -102,6 +102,18 @@ int lfvio_batch_download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior 
   if (prior && S.has_prior_out) *prior = S.prior_out;
   return LFVIO_OK;
 }
+// the split form: the oracle has nothing to overlap — begin does everything, finish hands the prior over
+int lfvio_batch_optimize_begin(lfvio_ctx *c, int marg_flag, LfvioSolution *sol) {
+  if (!c || !sol || c->slots.empty()) return LFVIO_ERR_ARG;
+  int rc = lfvio_batch_optimize(c, 1, marg_flag);
+  if (rc != LFVIO_OK) return rc;
+  return lfvio_batch_download(c, 0, sol, nullptr);
+}
+int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
+  if (!c) return LFVIO_ERR_ARG;
+  return prior ? lfvio_batch_download(c, 0, nullptr, prior) : LFVIO_OK;
+}
+int lfvio_batch_optimize_pending(const lfvio_ctx *) { return 0; }
 void *lfvio_stream(lfvio_ctx *) { return nullptr; }
 
 int lfvio_triangulate(lfvio_ctx *c, const LfvioTriangulateIn *in, double *estimated_depth) {
