@@ -372,6 +372,54 @@ def main():
                roofline=roofline, roofline_k_solve=roofline_solve, kernels_us=extra)
     if lat is not None:
         out["latency"] = lat
+    if stream_mode and world == 1 and not args.no_secondary:
+        # The same stream through the split call: lfvio_batch_upload_chained (the next window is packed while the marginalization
+        # of the previous one is still running, and collects its prior) + lfvio_batch_optimize_begin (returns with the state).
+        # Same windows, same priors bit for bit (the stream was generated by this library); where the list of windows wraps
+        # around, the window comes with its stored prior.
+        try:
+            bare = [w.copy(prior=None) for w in wins]
+            bare_c = [w.c() for w in bare]
+            carried = abi.Prior()
+            sols = [abi.Solution(w.N) for w in wins]
+            import ctypes as _C
+            _dp = _C.POINTER(_C.c_double)
+            eng.lib.lfvio_debug_upload_times.argtypes = [_C.c_void_p, _dp]
+            up_now, up_seg = np.zeros(4), None
+
+            def chained_step(k):
+                i = k % len(wins)
+                if i == 0:
+                    eng.optimize_finish(False)
+                    eng.batch_upload(0, wins[0], marshalled[0])
+                else:
+                    eng.batch_upload_chained(0, bare[i], carried, bare_c[i])
+                if up_seg is not None and i:
+                    eng.lib.lfvio_debug_upload_times(eng.ctx, up_now.ctypes.data_as(_dp))
+                    up_seg.append(up_now.copy())
+                t_ = time.perf_counter()
+                eng.optimize_begin(flag, wins[i].N, sols[i])
+                return time.perf_counter() - t_
+
+            for k in range(len(wins)):
+                chained_step(k)
+            eng.optimize_finish(False)
+            laps2, state2, up_seg = [], [], []
+            tc = time.perf_counter()
+            for k in range(args.steps):
+                t_ = time.perf_counter()
+                state2.append(chained_step(k))
+                laps2.append(time.perf_counter() - t_)
+            eng.optimize_finish(False)
+            tc = time.perf_counter() - tc
+            l2, s2 = np.array(laps2) * 1e3, np.array(state2) * 1e3
+            out["stream_chained"] = dict(value=args.steps / tc, unit="solves/s", ms_per_window=tc / args.steps * 1e3, mean_ms=float(l2.mean()),
+                                         p95_ms=float(np.percentile(l2, 95)), begin_to_state_mean_ms=float(s2.mean()),
+                                         upload_us=dict(zip(("pack", "collect_prior", "enqueue", "sync"), [float(v) for v in np.array(up_seg).mean(0)])),
+                                         description="per window: lfvio_batch_upload_chained + lfvio_batch_optimize_begin; the marginalization of "
+                                                     "window k overlaps the packing of window k + 1")
+        except Exception as ex:  # noqa: BLE001
+            out["stream_chained"] = dict(error=repr(ex))
     if sharded and world > 1:
         # the same window, whole, on ONE GPU (rank 0 while the others wait): the figure the sharded rate is a speed-up over
         one = None
@@ -442,6 +490,26 @@ def main():
         out["window300_default_cap"] = dict(ms_per_step=(time.perf_counter() - tcap) / ncap * 1e3, max_solver_time_in_seconds=0.032,
                                             graph_launches_per_call=eng.last_chunks())
         eng.batch_upload(0, wins[0])
+        # (a') the same resident call in its split form (lfvio_batch_optimize_begin / _finish): when the caller has the STATE —
+        #      the pose the node publishes — and when the prior is there as well.  The headline stays the whole call.
+        try:
+            sol_ = abi.Solution(wins[0].N)
+            for _ in range(10):
+                eng.optimize_begin(flag, wins[0].N, sol_), eng.optimize_finish(False)
+            t_state, t_all, early = 0.0, 0.0, 0
+            for _ in range(ncap):
+                t0_ = time.perf_counter()
+                eng.optimize_begin(flag, wins[0].N, sol_)
+                t1_ = time.perf_counter()
+                early += int(eng.optimize_pending())
+                eng.optimize_finish(False)
+                t_state += t1_ - t0_
+                t_all += time.perf_counter() - t0_
+            out["window300_split"] = dict(ms_to_state=t_state / ncap * 1e3, ms_per_step=t_all / ncap * 1e3, calls_with_the_state_first=early, calls=ncap,
+                                          description="lfvio_batch_optimize_begin returns when solve + gauge fix are out (state pushed by the device into "
+                                                      "mapped host memory), the marginalization of the same graph still running; _finish waits for it")
+        except Exception as ex:  # noqa: BLE001
+            out["window300_split"] = dict(error=repr(ex))
         # (b) the second headline: BASELINE configs[4] — 512 DISTINCT resident windows solved side by side (throughput mode:
         #     here the chip is full and the roofline fractions mean something)
         try:

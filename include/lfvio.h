@@ -217,6 +217,13 @@ int lfvio_batch_download(lfvio_ctx *ctx, int slot, LfvioSolution *sol, LfvioPrio
  *                                context waits for the tail first, so forgetting it costs overlap, not correctness; the prior
  *                                must be collected before the slot is uploaded again.
  * lfvio_triangulate / lfvio_shift_depth / lfvio_preintegrate do NOT wait: they run beside the tail on their own stream. */
+/* lfvio_batch_upload_chained  the upload of the NEXT window of the same estimator while that marginalization is still
+ *                                running: the window's prior is *prior_io (in->prior is ignored), and if a call is in flight
+ *                                on the context it is THAT call's prior — the landmark tables of the new window are packed
+ *                                on the host while the device finishes, then the prior is collected into *prior_io (as
+ *                                lfvio_batch_optimize_finish would) and goes up with the window.  With nothing in flight it
+ *                                is lfvio_batch_upload with in->prior = prior_io. */
+int lfvio_batch_upload_chained(lfvio_ctx *ctx, int slot, const LfvioWindow *in, LfvioPrior *prior_io);
 int lfvio_batch_optimize_begin(lfvio_ctx *ctx, int marg_flag, LfvioSolution *sol);
 int lfvio_batch_optimize_finish(lfvio_ctx *ctx, LfvioPrior *prior);
 int lfvio_batch_optimize_pending(const lfvio_ctx *ctx);

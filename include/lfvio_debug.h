@@ -34,6 +34,8 @@ int lfvio_debug_set_decide_merge(lfvio_ctx *ctx, int on);
 int lfvio_debug_force_eig(lfvio_ctx *ctx, int on);
 /* graph launches the last synchronous solve loop needed (1: every window was done within the first chunk of passes,
    and gauge fix + marginalization ran in the same graph) */
+/* microseconds of the last upload: host packing | collecting a chained prior | prior + copies enqueued | final synchronization */
+int lfvio_debug_upload_times(lfvio_ctx *ctx, double *out4);
 int lfvio_debug_last_chunks(lfvio_ctx *ctx);
 /* passes of the trust-region loop the slowest window of the last synchronous call used */
 int lfvio_debug_last_passes(lfvio_ctx *ctx);

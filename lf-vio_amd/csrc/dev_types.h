@@ -127,8 +127,10 @@ struct TRState {
 };
 // layout of the mailbox (Slot::mail), the same order as the pinned download block of the host side: the flag word, both
 // state slots (only x[cur] is written), the trust-region header with the trace, both inverse-depth buffers (only [cur])
+// Behind them the prior of the gated marginalization (an LfvioPrior, of which the header, n x n Jacobian entries and n
+// residuals are written), announced by the second flag word; word 2 carries Slot::passes_used of the call.
 constexpr size_t MAIL_X = 64, MAIL_TR = MAIL_X + 2 * sizeof(FrameState), MAIL_LAM = (MAIL_TR + sizeof(TRState) + 63) / 64 * 64,
-                 MAIL_LAM_STRIDE = (size_t)MAIL_MAX_LM * 8, MAIL_BYTES = MAIL_LAM + 2 * MAIL_LAM_STRIDE;
+                 MAIL_LAM_STRIDE = (size_t)MAIL_MAX_LM * 8, MAIL_PRIOR = MAIL_LAM + 2 * MAIL_LAM_STRIDE, MAIL_BYTES = MAIL_PRIOR + sizeof(LfvioPrior);
 
 // What the trust-region bookkeeping (k_decide) changes in the header.  In the passes of a graph that follow another pass the
 // bookkeeping rides in the prologue of k_lin (every workgroup repeats it, none of them may write the header the others

@@ -61,6 +61,27 @@ DEV void publish_solution(Slot *S) {
   __syncthreads();
   if (tid == 0) __hip_atomic_store((int *)m, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// The prior the gated marginalization has just written (Slot::prior_out) into the mailbox, then the second flag.  Called by
+// every thread of k_marg_solve's workgroup at its end, behind a barrier that follows the last store to prior_out.
+DEV void publish_prior(Slot *S) {
+  char *m = (char *)S->mail;
+  if (!m) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const LfvioPrior *src = &S->prior_out;
+  LfvioPrior *dst = (LfvioPrior *)(m + MAIL_PRIOR);
+  const int n = src->valid == 1 ? src->n : 0;
+  {
+    const long long *a = (const long long *)src;
+    long long *b = (long long *)dst;
+    for (int k = tid; k < (int)(offsetof(LfvioPrior, linearized_jacobians) / 8); k += nthr) b[k] = a[k];
+  }
+  for (int k = tid; k < n * n; k += nthr) dst->linearized_jacobians[k] = src->linearized_jacobians[k];
+  for (int k = tid; k < n; k += nthr) dst->linearized_residuals[k] = src->linearized_residuals[k];
+  if (tid == 0) ((int *)m)[2] = S->passes_used;
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store((int *)m + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // behind a k_gauge of several workgroups (windows too large for k_decide_gauge): the same gate, then the mailbox
 __global__ __launch_bounds__(256) void k_publish(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
@@ -78,13 +99,13 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int ga
 }
 // k_decide_gauge: grid (1, batch) x 128 — behind the last pass of a graph of few small windows: k_decide and, for the slots
 // that are done then, the gated k_gauge in ONE launch (one workgroup per slot: nobody else reads the header it rewrites).
-__global__ __launch_bounds__(128) void k_decide_gauge(char *base, size_t stride) {
+__global__ __launch_bounds__(128) void k_decide_gauge(char *base, size_t stride, int publish) {
   Slot *S = SLOT(base, stride);
   decide_body(S);
   __syncthreads();  // (the header and the accepted candidate, written by wave 0, are read by all from here on)
   if (!tail_gate(S, S->tr.done)) return;
   for (int l0 = 0; l0 < S->N; l0 += 128) gauge_landmarks(S, l0);
-  gauge_poses(S, 1, true);
+  gauge_poses(S, 1, publish != 0);  // publish: this call hands its state over early (lfvio_batch_optimize_begin)
 }
 DEV void gauge_poses(Slot *S, int gated, bool publish) {
   TRState *ts = &S->tr;
@@ -1060,6 +1081,7 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
 __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t stride, int flag_bits) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int flag = flag_bits & 255, force_eig = (flag_bits >> 8) & 1, gated = (flag_bits >> 9) & 1;  // bit 8: debug, see lfvio_debug_force_eig; bit 9: MODE_GATED
+  const int publish = (flag_bits >> 10) & 1;  // bit 10: the prior goes into the caller's mailbox as well (lfvio_batch_optimize_begin)
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const MargPlan *mp = &S->marg[flag];
@@ -1070,6 +1092,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     // MARGIN_SECOND_NEW with no prior touching Pose[WINDOW_SIZE-1]: the prior is left as it is
     if (tid == 0) out->valid = -1;  // host copies the input prior through
     if (gated && tid == 0) S->tail_state = 2;
+    if (gated && publish) {
+      __syncthreads();
+      publish_prior(S);
+    }
     return;
   }
   STAMP(S, 10);
@@ -1239,5 +1265,9 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     out->n = n;
     out->num_blocks = mp->nb;
     if (gated) S->tail_state = 2;
+  }
+  if (gated && publish) {
+    __syncthreads();
+    publish_prior(S);
   }
 }

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -135,8 +136,11 @@ struct lfvio_ctx {
   hipGraphExec_t graph = nullptr;
   int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0;
   // cached graph of one chunk of passes (synchronous entry points: the loop is launched chunk by chunk)
-  hipGraphExec_t chunk = nullptr, tail[3] = {nullptr, nullptr, nullptr};
-  hipGraphExec_t first[4][13] = {};  // [0: solve only, 1 + flag: with the gated tail][passes in the first graph]
+  // [publish]: the variants whose gated gauge fix / marginalization also push state and prior into the caller's mailbox
+  // (lfvio_batch_optimize_begin) — a kernel argument, so the plain call pays nothing for the split one
+  bool publish = false;
+  hipGraphExec_t chunk = nullptr, tail[2][3] = {};
+  hipGraphExec_t first[2][4][13] = {};  // [publish][0: solve only, 1 + flag: with the gated tail][passes in the first graph]
   int predict_passes = 4;           // passes the previous synchronous call needed; tail[flag]: force-done + gated gauge fix + marginalization
   double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
@@ -149,6 +153,12 @@ struct lfvio_ctx {
   char *h_mail = nullptr, *d_mail = nullptr;
   hipStream_t fstream = nullptr;
   bool inflight = false;
+  bool unsynced = false;        // finish() took the prior from the mailbox and left the last microseconds of the graph to the next join
+  // a prior collected on the caller's behalf because the slots had to be re-allocated while its call was in flight
+  // (reserve): lfvio_batch_optimize_finish / lfvio_batch_upload_chained hand it over
+  double up_us[4] = {0, 0, 0, 0};  // last upload: host packing | collecting the chained prior | prior + copies enqueued | final synchronization (lfvio_debug_upload_times)
+  std::unique_ptr<LfvioPrior> held;
+  bool has_held = false;
   bool inflight_first = false;  // the flag came out of the first graph: {tail_state, passes_used} land in h_pending[2..3] when it ends
   bool use_graph = true;
   // the dense solve of a pass: k_solve_dense; LFVIO_SPARSE_SOLVE=1 selects k_solve_sparse (solve_plan.h: the speed/bias
@@ -183,16 +193,22 @@ void destroy_graph(lfvio_ctx *c) {
     (void)hipGraphExecDestroy(c->chunk);
     c->chunk = nullptr;
   }
-  for (auto &t : c->tail)
-    if (t) (void)hipGraphExecDestroy(t), t = nullptr;
-  for (auto &row : c->first)
+  for (auto &row : c->tail)
     for (auto &t : row)
       if (t) (void)hipGraphExecDestroy(t), t = nullptr;
+  for (auto &plane : c->first)
+    for (auto &row : plane)
+      for (auto &t : row)
+        if (t) (void)hipGraphExecDestroy(t), t = nullptr;
 }
 
 // The tail of a call whose solution went out early (lfvio_batch_optimize_begin) is still on the stream: wait for it and
 // take the bookkeeping its graph left in the pinned block.  First statement of everything that touches the slots.
 int join_inflight(lfvio_ctx *c) {
+  if (c->unsynced) {
+    c->unsynced = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   if (!c->inflight) return LFVIO_OK;
   c->inflight = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -218,8 +234,13 @@ bool wait_early(lfvio_ctx *c) {
 }
 
 int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
+  if (c->d_base && batch <= c->batch && maxN <= c->L.maxN && maxM <= c->L.maxM) return LFVIO_OK;  // (the usual case: nothing to wait for)
+  if (c->inflight) {  // the slot that holds the prior of the call in flight is about to be freed: collect it first
+    if (!c->held) c->held.reset(new LfvioPrior);
+    if (int rc = lfvio_batch_optimize_finish(c, c->held.get())) return rc;
+    c->has_held = true;
+  }
   if (int rc = join_inflight(c)) return rc;
-  if (c->d_base && batch <= c->batch && maxN <= c->L.maxN && maxM <= c->L.maxM) return LFVIO_OK;
   batch = std::max(batch, c->batch);
   maxN = std::max(maxN, c->L.maxN);
   maxM = std::max(maxM, c->L.maxM);
@@ -255,10 +276,9 @@ inline int tangent_off(int kind, int frame) {
 // Structure of MarginalizationInfo for this window (estimator.cpp:833-1005): which blocks
 // take part, which are dropped, canonical column order (dropped first, then poses / speed-bias
 // by frame, ex pose, td) and the addr_shift of the kept blocks.
-void plan_marg(const LfvioWindow *w, int flag, int N0, int kmax0, int nChunks0, bool imu0_ok, MargPlan *mp) {
+void plan_marg(const LfvioWindow *w, const LfvioPrior *pr, int flag, int N0, int kmax0, int nChunks0, bool imu0_ok, MargPlan *mp) {
   std::memset(mp, 0, sizeof *mp);
   for (int c = 0; c < KP; c++) mp->col[c] = -1;
-  const LfvioPrior *pr = (w->prior && w->prior->valid) ? w->prior : nullptr;
   bool present[4][LFVIO_NUM_FRAMES] = {}, dropped[4][LFVIO_NUM_FRAMES] = {};
   auto touch = [&](int kind, int frame, bool drop) {
     present[kind][frame] = true;
@@ -333,9 +353,45 @@ void copy_prior(LfvioPrior *dst, const LfvioPrior *src) {
   }
 }
 
+}  // namespace
+extern "C" int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior);
+namespace {
+
+int check_input_prior(lfvio_ctx *c, const LfvioPrior *pr) {
+  if (pr && (pr->n <= 0 || pr->n > LFVIO_MAX_PRIOR_DIM || pr->num_blocks <= 0 || pr->num_blocks > LFVIO_MAX_PRIOR_BLOCKS)) {
+    c->err = "malformed prior";
+    return LFVIO_ERR_ARG;
+  }
+  if (pr) {
+    // the blocks index present[kind][frame], prior_cmap and prior_inv below: refuse anything that would leave them
+    for (int i = 0; i < pr->num_blocks; i++) {
+      const int k = pr->blocks[i].kind, f = pr->blocks[i].frame, idx = pr->block_idx[i];
+      const bool framed = k == LFVIO_BLOCK_POSE || k == LFVIO_BLOCK_SPEEDBIAS;
+      if (k < LFVIO_BLOCK_POSE || k > LFVIO_BLOCK_TD || f < 0 || f >= LFVIO_NUM_FRAMES || (!framed && f != 0) || idx < 0 ||
+          idx + local_size(k) > pr->n) {
+        c->err = "malformed prior block (kind / frame / block_idx out of range)";
+        return LFVIO_ERR_ARG;
+      }
+    }
+  }
+  return LFVIO_OK;
+}
+
 // Pack one window into the pinned staging blob and upload it to slot `slot`.
-int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0, int pose_side = 1) {
-  if (int rc = join_inflight(c)) return rc;
+// chain (lfvio_batch_upload_chained): the window's prior is *chain, and if a call is still in flight on the context (the
+// marginalization behind an early state), it is THAT call's prior: the landmark tables and gather lists of the new window —
+// nine tenths of the host work of an upload — are packed while the device finishes it, then the prior is taken from the
+// mailbox into *chain and the upload goes on with it.
+int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0, int pose_side = 1, LfvioPrior *chain = nullptr) {
+  const bool chained = chain && (c->inflight || c->has_held) && slot == 0;
+  const auto t_up0 = std::chrono::steady_clock::now();
+  auto lap = [&](int k, std::chrono::steady_clock::time_point from) {
+    const auto now = std::chrono::steady_clock::now();
+    c->up_us[k] = std::chrono::duration<double>(now - from).count() * 1e6;
+    return now;
+  };
+  if (!chained)
+    if (int rc = join_inflight(c)) return rc;
   if (!w || w->num_landmarks < 0 || w->num_observations < 0) {
     c->err = "null window / negative sizes";
     return LFVIO_ERR_ARG;
@@ -357,23 +413,10 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
       return LFVIO_ERR_ARG;
     }
   }
-  const LfvioPrior *pr = (w->prior && w->prior->valid) ? w->prior : nullptr;
-  if (pr && (pr->n <= 0 || pr->n > LFVIO_MAX_PRIOR_DIM || pr->num_blocks <= 0 || pr->num_blocks > LFVIO_MAX_PRIOR_BLOCKS)) {
-    c->err = "malformed prior";
-    return LFVIO_ERR_ARG;
-  }
-  if (pr) {
-    // the blocks index present[kind][frame], prior_cmap and prior_inv below: refuse anything that would leave them
-    for (int i = 0; i < pr->num_blocks; i++) {
-      const int k = pr->blocks[i].kind, f = pr->blocks[i].frame, idx = pr->block_idx[i];
-      const bool framed = k == LFVIO_BLOCK_POSE || k == LFVIO_BLOCK_SPEEDBIAS;
-      if (k < LFVIO_BLOCK_POSE || k > LFVIO_BLOCK_TD || f < 0 || f >= LFVIO_NUM_FRAMES || (!framed && f != 0) || idx < 0 ||
-          idx + local_size(k) > pr->n) {
-        c->err = "malformed prior block (kind / frame / block_idx out of range)";
-        return LFVIO_ERR_ARG;
-      }
-    }
-  }
+  const LfvioPrior *given = chain ? chain : w->prior;
+  const LfvioPrior *pr = (given && given->valid) ? given : nullptr;  // (chained: not known before the prior section below)
+  if (!chained)
+    if (int rc = check_input_prior(c, pr)) return rc;
   if (w->estimate_td && !(w->row > 0.0)) {  // row_i = uv.y - ROW / 2 and TR / ROW (projection_td_factor.cpp:20-21, 54-55)
     c->err = "estimate_td needs row > 0";
     return LFVIO_ERR_ARG;
@@ -557,6 +600,16 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     (void)marg_units;
   }
   // ---- prior
+  auto t_up1 = lap(0, t_up0);
+  c->up_us[1] = 0.0;
+  if (chained) {
+    // everything above was host work on the staging block; the prior of the call in flight is needed from here on
+    // (c->info[0] still describes THAT window's prior: marg_n, the input prior a pass-through hands back)
+    if (int rc = lfvio_batch_optimize_finish(c, chain)) return rc;
+    pr = chain->valid ? chain : nullptr;
+    if (int rc = check_input_prior(c, pr)) return rc;
+    t_up1 = lap(1, t_up1);
+  }
   info.has_in_prior = pr != nullptr;
   for (int c2 = 0; c2 < KP; c2++) S->prior_inv[c2] = -1;
   if (pr) {
@@ -579,8 +632,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     std::memcpy(h + L.prior_J, pr->linearized_jacobians, sizeof(double) * pr->n * pr->n);
     std::memcpy(h + L.prior_r, pr->linearized_residuals, sizeof(double) * pr->n);
   }
-  plan_marg(w, LFVIO_MARGIN_OLD, N0, kmax0, S->pair_chunk0[11], true, &S->marg[0]);
-  plan_marg(w, LFVIO_MARGIN_SECOND_NEW, 0, 0, 0, true, &S->marg[1]);
+  plan_marg(w, pr, LFVIO_MARGIN_OLD, N0, kmax0, S->pair_chunk0[11], true, &S->marg[0]);
+  plan_marg(w, pr, LFVIO_MARGIN_SECOND_NEW, 0, 0, 0, true, &S->marg[1]);
   info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   for (int f = 0; f < 2; f++)
     if (S->marg[f].valid && (S->marg[f].n > 76 || S->marg[f].m15 + S->marg[f].n > 92)) {
@@ -635,7 +688,9 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     info.uploaded = true;
   }
   // the staging buffer is reused by the next upload
+  const auto t_up2 = lap(2, t_up1);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  lap(3, t_up2);
   return LFVIO_OK;
 }
 
@@ -768,7 +823,7 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     } else
       hipLaunchKernelGGL(k_cost<1>, dim3(spec * nb, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, spec);
     if (merge && last && gauge && !c->no_fuse) {
-      hipLaunchKernelGGL(k_decide_gauge, dim3(1, count), dim3(128), 0, c->stream, c->d_base, st);
+      hipLaunchKernelGGL(k_decide_gauge, dim3(1, count), dim3(128), 0, c->stream, c->d_base, st, c->publish ? 1 : 0);
       return true;
     }
     if (!merge || last) hipLaunchKernelGGL(k_decide, dim3(1, count), dim3(64), 0, c->stream, c->d_base, st);
@@ -844,7 +899,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     // graph could overrun it: then no more passes than fit (at the measured time per pass), down to a chunk of SOLVE_CHUNK.
     int first_passes = std::min(std::max(c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
     if (capped) first_passes = std::max(std::min(SOLVE_CHUNK, passes), std::min(first_passes, (int)std::min(max_seconds / c->pass_seconds, 1e6)));
-    hipGraphExec_t &first_graph = c->first[fuse ? 1 + fused_flag : 0][first_passes];
+    hipGraphExec_t &first_graph = c->first[c->publish ? 1 : 0][fuse ? 1 + fused_flag : 0][first_passes];
     auto capture = [&](hipGraphExec_t *out, bool setup, int npass, int tail_flag) -> int {
       hipGraph_t graph;
       int rc = LFVIO_OK;
@@ -857,7 +912,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       if (tail_flag >= 0) {
         if (!gauged) {
           hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
-          if (count == 1) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, c->d_base, c->L.total);  // (k_decide_gauge does it itself)
+          if (c->publish) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, c->d_base, c->L.total);  // (k_decide_gauge does it itself)
         }
         rc = enqueue_marg(c, count, tail_flag, false, true);
       }
@@ -889,8 +944,8 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     for (int done_passes = 0; done_passes < passes;) {
       c->stat_chunks++;
       const auto t_launch = std::chrono::steady_clock::now();
-      const bool watch = early && done_passes == 0 && fuse && count == 1 && c->h_mail && c->info[0].N <= MAIL_MAX_LM;
-      if (watch) __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
+      const bool watch = early && done_passes == 0 && fuse && c->publish;
+      if (watch) __atomic_store_n((int *)c->h_mail + 1, 0, __ATOMIC_RELAXED), __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
       HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk, c->stream));
       if (watch && wait_early(c)) {  // the window was done inside the first graph: its tail follows in the same graph
         c->inflight = true, c->inflight_first = true;
@@ -949,7 +1004,8 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated)
   if (standalone)
     hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
   launch_iteration(c, count, g, mode);
-  hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total, flag | (c->force_eig ? 256 : 0) | (gated ? 512 : 0));
+  hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total,
+                     flag | (c->force_eig ? 256 : 0) | (gated ? 512 : 0) | (gated && c->publish ? 1024 : 0));
   if (!EIG_TRIDIAG) hipLaunchKernelGGL(k_marg_vecs, dim3(MARG_VEC_WGS, count), dim3(256), 0, c->stream, c->d_base, c->L.total, flag);
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
@@ -1212,10 +1268,26 @@ int lfvio_batch_upload(lfvio_ctx *c, int slot, const LfvioWindow *in) {
   return upload_window(c, slot, in);
 }
 
+int lfvio_batch_upload_chained(lfvio_ctx *c, int slot, const LfvioWindow *in, LfvioPrior *prior_io) {
+  if (!c || !in || !prior_io || slot < 0 || slot >= c->batch) return LFVIO_ERR_ARG;
+  if (in->num_landmarks > c->L.maxN || in->num_observations > c->L.maxM) {
+    c->err = "window larger than the reserved capacity";
+    return LFVIO_ERR_ARG;
+  }
+  (void)hipSetDevice(c->device);
+  return upload_window(c, slot, in, 0, 1, prior_io);
+}
+
 static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adaptive, bool early = false) {
   if (!c || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (int rc = join_inflight(c)) return rc;
+  c->has_held = false;  // (a prior nobody collected before the next optimization is dropped, like one left in the slot)
+  c->publish = early && adaptive && count == 1 && c->h_mail && c->info[0].uploaded && c->info[0].N <= MAIL_MAX_LM;
+  struct PublishOff {
+    lfvio_ctx *c;
+    ~PublishOff() { c->publish = false; }
+  } publish_off{c};
   // every slot carries its own max_iter on the device; the pass count follows the largest, the wall-clock cap
   // (synchronous driver only) the smallest positive one
   int max_iter = 0;
@@ -1236,25 +1308,26 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
   if (fuse) {
     if (tail_done) return LFVIO_OK;  // the usual case: everything ran in the graph of the first chunk
     // some window needed more passes: gauge fix + marginalization for the slots that have not had theirs (gated)
-    if (!c->tail[marg_flag]) {
+    hipGraphExec_t &tail_graph = c->tail[c->publish ? 1 : 0][marg_flag];
+    if (!tail_graph) {
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       CaptureGuard guard(c->stream);
       hipLaunchKernelGGL(k_force_done, dim3((count + 63) / 64), dim3(64), 0, c->stream, c->d_base, c->L.total, count);
       hipLaunchKernelGGL(k_gauge, dim3(1 + (grid_for(c, count).lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
-      if (count == 1) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, c->d_base, c->L.total);
+      if (c->publish) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, c->d_base, c->L.total);
       rc = enqueue_marg(c, count, marg_flag, false, true);
       HIPCHK(c, guard.end(&graph));
       if (rc) {
         (void)hipGraphDestroy(graph);
         return rc;
       }
-      HIPCHK(c, hipGraphInstantiate(&c->tail[marg_flag], graph, nullptr, nullptr, 0));
+      HIPCHK(c, hipGraphInstantiate(&tail_graph, graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
     }
-    const bool watch = early && count == 1 && c->h_mail && c->info[0].N <= MAIL_MAX_LM;
-    if (watch) __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
-    HIPCHK(c, hipGraphLaunch(c->tail[marg_flag], c->stream));
+    const bool watch = c->publish;
+    if (watch) __atomic_store_n((int *)c->h_mail + 1, 0, __ATOMIC_RELAXED), __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
+    HIPCHK(c, hipGraphLaunch(tail_graph, c->stream));
     if (watch && wait_early(c)) c->inflight = true, c->inflight_first = false;
     return LFVIO_OK;
   }
@@ -1307,13 +1380,41 @@ int lfvio_batch_optimize_begin(lfvio_ctx *c, int marg_flag, LfvioSolution *sol) 
 int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
   if (!c) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
+  if (c->has_held) {
+    c->has_held = false;
+    if (prior) copy_prior(prior, c->held.get());
+    return LFVIO_OK;
+  }
+  if (c->inflight && prior) {
+    // the marginalization ends by pushing its prior into the mailbox (publish_prior): wait for that word, not for the stream
+    int *flag = (int *)c->h_mail + 1;
+    bool there = false;
+    for (;;) {
+      if ((there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0)) break;
+      if (hipStreamQuery(c->stream) != hipErrorNotReady) {
+        there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
+        break;
+      }
+    }
+    if (there) {
+      c->inflight = false, c->unsynced = true;  // (what is left of the graph is a copy of two words: the next join waits for it)
+      c->last_passes = std::max(((const int *)c->h_mail)[2], 1);
+      if (c->inflight_first) c->predict_passes = c->last_passes;
+      Fetched f{};
+      f.prior = (LfvioPrior *)(c->h_mail + MAIL_PRIOR);
+      bool pass = false;
+      if (int rc = check_prior(c, 0, f, &pass)) return rc;
+      unpack_prior(c, 0, f, pass, prior);
+      return LFVIO_OK;
+    }
+  }
   int rc = join_inflight(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return prior ? download(c, 0, nullptr, prior) : LFVIO_OK;
 }
 
-int lfvio_batch_optimize_pending(const lfvio_ctx *c) { return c && c->inflight ? 1 : 0; }
+int lfvio_batch_optimize_pending(const lfvio_ctx *c) { return c && (c->inflight || c->has_held) ? 1 : 0; }
 
 // ---- the landmark-parallel steps either side of optimization()
 static int feat_reserve(lfvio_ctx *c, size_t bytes) {
@@ -1593,6 +1694,11 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   return LFVIO_OK;
 }
 
+int lfvio_debug_upload_times(lfvio_ctx *c, double *out4) {
+  if (!c || !out4) return LFVIO_ERR_ARG;
+  for (int k = 0; k < 4; k++) out4[k] = c->up_us[k];
+  return LFVIO_OK;
+}
 int lfvio_debug_last_chunks(lfvio_ctx *c) { return c ? c->stat_chunks : -1; }
 int lfvio_debug_last_passes(lfvio_ctx *c) { return c ? c->last_passes : -1; }
 

@@ -554,7 +554,7 @@ void WindowEstimator::double2vector() {  // estimator.cpp:532-600 (the relocaliz
 
 void WindowEstimator::pack(LfvioWindow *w) {
   const Config &c = config();
-  (void)collectPrior();
+  if (!chain_upload_) (void)collectPrior();  // (optimization() on one device lets the upload collect it: lfvio_batch_upload_chained)
   std::memset(w, 0, sizeof *w);
   std::memcpy(w->para_pose, para_Pose, sizeof para_Pose);
   std::memcpy(w->para_speed_bias, para_SpeedBias, sizeof para_SpeedBias);
@@ -607,16 +607,22 @@ void WindowEstimator::pack(LfvioWindow *w) {
 void WindowEstimator::optimization() {
   status = LFVIO_OK;
   if (!device() || !refreshSpans(false)) return;
-  if (!collectPrior()) return;
+  // The marginalization behind the previous call's early state may still be running.  On one device with one upload the
+  // window is packed and its tables are built while it finishes: the upload collects the prior itself (chained); every other
+  // route waits for it here.
+  const bool chain = prior_pending_ && fused && !group && config().split_call;
+  if (!chain && !collectPrior()) return;
   Stopwatch sw(&timers[0]);
-  timers[5] += 1.0;  // (the marginalization behind the previous call's early state: done long ago, normally)
+  timers[5] += 1.0;
   vector2double();  // :707
   LfvioWindow w;
+  chain_upload_ = chain;
   pack(&w);
+  chain_upload_ = false;
   Staging &st = stage_;
   st.lam_out.assign(w.num_landmarks > 0 ? w.num_landmarks : 1, 0.0);
-  const bool second_new = marg_flag == LFVIO_MARGIN_SECOND_NEW && has_prior && prior.valid;
-  const bool marginalize = marg_flag == LFVIO_MARGIN_OLD || second_new;
+  bool second_new = marg_flag == LFVIO_MARGIN_SECOND_NEW && has_prior && prior.valid;  // (chained upload: decided again once the prior is there)
+  bool marginalize = marg_flag == LFVIO_MARGIN_OLD || second_new;
   auto take_state = [&] {
     std::memcpy(para_Pose, summary.para_pose, sizeof para_Pose);
     std::memcpy(para_SpeedBias, summary.para_speed_bias, sizeof para_SpeedBias);
@@ -642,7 +648,18 @@ void WindowEstimator::optimization() {
     // to back on the device.  The state that comes back is already re-anchored, so double2vector() below applies a zero
     // yaw and a zero shift to it.
     status = lfvio_batch_reserve(gpu, 1, w.num_landmarks, w.num_observations);
-    if (status == LFVIO_OK) status = lfvio_batch_upload(gpu, 0, &w);
+    if (status == LFVIO_OK && chain) {
+      // `prior` is an output here first (the prior of the call in flight), then the window's input
+      w.prior = nullptr;
+      status = lfvio_batch_upload_chained(gpu, 0, &w, &prior);
+      prior_pending_ = lfvio_batch_optimize_pending(gpu) != 0;  // (an upload refused before it got to the prior leaves it where it was)
+      if (!prior_pending_) has_prior = prior.valid != 0;
+      if (status == LFVIO_OK) {
+        second_new = marg_flag == LFVIO_MARGIN_SECOND_NEW && has_prior;
+        marginalize = marg_flag == LFVIO_MARGIN_OLD || second_new;
+      }
+    } else if (status == LFVIO_OK)
+      status = lfvio_batch_upload(gpu, 0, &w);
     if (status == LFVIO_OK && config().split_call) {
       // The state comes back as soon as solve + gauge fix are out (the device pushes it into mapped host memory); the
       // marginalization runs on while the caller publishes the pose, slides the window, takes the next image — its prior is

@@ -209,6 +209,7 @@ class WindowEstimator {
 
  private:
   LfvioPrior next_;  // the prior being downloaded (240 KB: a member, not a stack object; only header + n x n + n are copied)
+  bool chain_upload_ = false;   // pack() on behalf of an optimization() whose upload collects the pending prior itself
   bool prior_pending_ = false;  // the marginalization of the last optimization() has not been collected yet (collectPrior)
   bool device();
   bool applyBootstrap();

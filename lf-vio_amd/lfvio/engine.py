@@ -102,6 +102,12 @@ class Engine:
         statements — ctypes plumbing of this wrapper, not part of the call a C++ host makes."""
         self._check(self.lib.lfvio_batch_upload(self.ctx, slot, C.byref(marshalled if marshalled is not None else win.c())), "batch_upload")
 
+    def batch_upload_chained(self, slot, win, prior, marshalled=None):
+        """The next window of the same estimator: its prior is `prior` (an abi.Prior, in/out) — the one of the call still in
+        flight on this context if there is one (collected into `prior` while the window is being packed)."""
+        self._check(self.lib.lfvio_batch_upload_chained(self.ctx, slot, C.byref(marshalled if marshalled is not None else win.c()), C.byref(prior)),
+                    "batch_upload_chained")
+
     def batch_optimize(self, count, flag, sync=True):
         fn = self.lib.lfvio_batch_optimize if sync else self.lib.lfvio_batch_optimize_async
         self._check(fn(self.ctx, count, flag), "batch_optimize")

@@ -50,6 +50,7 @@ struct SlotCopy {  // a window with its arrays owned
 struct lfvio_ctx {
   std::string err;
   std::vector<SlotCopy> slots;
+  bool pending = false;  // lfvio_batch_optimize_begin without its _finish yet
 };
 
 extern "C" {
@@ -102,18 +103,31 @@ int lfvio_batch_download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior 
   if (prior && S.has_prior_out) *prior = S.prior_out;
   return LFVIO_OK;
 }
+// chained upload: the prior a begin() left uncollected (the shim's "in flight") or the one given
+int lfvio_batch_upload_chained(lfvio_ctx *c, int slot, const LfvioWindow *in, LfvioPrior *prior_io) {
+  if (!c || !in || !prior_io || slot < 0 || slot >= (int)c->slots.size()) return LFVIO_ERR_ARG;
+  if (c->pending && slot == 0) {
+    int rc = lfvio_batch_optimize_finish(c, prior_io);
+    if (rc != LFVIO_OK) return rc;
+  }
+  LfvioWindow w = *in;
+  w.prior = prior_io->valid ? prior_io : nullptr;
+  return lfvio_batch_upload(c, slot, &w);
+}
 // the split form: the oracle has nothing to overlap — begin does everything, finish hands the prior over
 int lfvio_batch_optimize_begin(lfvio_ctx *c, int marg_flag, LfvioSolution *sol) {
   if (!c || !sol || c->slots.empty()) return LFVIO_ERR_ARG;
   int rc = lfvio_batch_optimize(c, 1, marg_flag);
   if (rc != LFVIO_OK) return rc;
+  c->pending = true;
   return lfvio_batch_download(c, 0, sol, nullptr);
 }
 int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
   if (!c) return LFVIO_ERR_ARG;
+  c->pending = false;
   return prior ? lfvio_batch_download(c, 0, nullptr, prior) : LFVIO_OK;
 }
-int lfvio_batch_optimize_pending(const lfvio_ctx *) { return 0; }
+int lfvio_batch_optimize_pending(const lfvio_ctx *c) { return c && c->pending ? 1 : 0; }
 void *lfvio_stream(lfvio_ctx *) { return nullptr; }
 
 int lfvio_triangulate(lfvio_ctx *c, const LfvioTriangulateIn *in, double *estimated_depth) {

@@ -152,3 +152,84 @@ def test_any_other_entry_point_joins_the_tail():
     r2s, r2p = whole(Engine(0), w2, abi.MARGIN_OLD)
     same_solution(sol2, r2s)
     same_prior(prior2, r2p)
+
+
+def stream_windows(eng, n_windows, n_lm=200, seed=21):
+    """A chain of consecutive windows of one estimator, generated through the product path (as bench.py's stream)."""
+    scene = synth.Scene(seed, n_total=11 + n_windows + 1)
+    rng = np.random.default_rng([seed, 104729])
+    wins, prior, st = [], None, None
+    for k in range(n_windows + 1):
+        kw = {} if k == 0 else dict(prior=prior, init_state=st)
+        w = synth.make_window(seed, n_lm, kf0=k, scene=scene, **kw)
+        sol, prior = whole(eng, w, abi.MARGIN_OLD)
+        wins.append((w, sol, prior))
+        st = synth.continue_state(scene, k + 1, sol.pose, sol.speed_bias, sol.ex_pose, sol.td, rng)
+    return wins
+
+
+def test_chained_upload_follows_the_stream():
+    """upload_chained(k + 1) while the marginalization of window k is in flight: every window of the chain gets, bit for
+    bit, the solution and the prior of the plain upload / optimize / download sequence that generated the chain."""
+    ref = stream_windows(Engine(0), 8)
+    eng = Engine(0)
+    eng.batch_reserve(1, 400, 3000)
+    carried = abi.Prior()  # the caller's one prior buffer, in and out
+    for k, (w, rsol, rprior) in enumerate(ref):
+        bare = w.copy(prior=None)  # the window WITHOUT its prior: it has to come out of the call in flight
+        if k == 0:
+            eng.batch_upload(0, w)
+        else:
+            eng.batch_upload_chained(0, bare, carried)
+            assert not eng.optimize_pending()
+            same_prior(carried, ref[k - 1][2])  # collected on the way
+        sol = eng.optimize_begin(abi.MARGIN_OLD, w.N)
+        same_solution(sol, rsol)
+    same_prior(eng.optimize_finish(), ref[-1][2])
+
+
+def test_chained_upload_with_nothing_in_flight_is_a_plain_upload():
+    ref = stream_windows(Engine(0), 2)
+    eng = Engine(0)
+    eng.batch_reserve(1, 400, 3000)
+    w, rsol, rprior = ref[1]
+    given = ref[0][2]
+    eng.batch_upload_chained(0, w.copy(prior=None), given)
+    sol = eng.optimize_begin(abi.MARGIN_OLD, w.N)
+    same_solution(sol, rsol)
+    same_prior(eng.optimize_finish(), rprior)
+    none = abi.Prior()  # valid = 0: a window without a prior
+    eng.batch_upload_chained(0, ref[0][0], none)
+    same_solution(eng.optimize_begin(abi.MARGIN_OLD, ref[0][0].N), ref[0][1])
+    eng.optimize_finish(False)
+
+
+def test_chained_upload_across_a_reallocation():
+    """The next window does not fit the reservation: reserve() re-allocates the slots while the marginalization is in flight —
+    the prior is collected first and still reaches the chained upload."""
+    ref = stream_windows(Engine(0), 2)
+    eng = Engine(0)
+    w0, w1 = ref[0][0], ref[1][0]
+    eng.batch_reserve(1, w0.N, w0.M)
+    eng.batch_upload(0, w0)
+    eng.optimize_begin(abi.MARGIN_OLD, w0.N)
+    eng.batch_reserve(1, 5000, 40000)  # grows: the old slot (with the prior in it) is freed
+    carried = abi.Prior()
+    eng.batch_upload_chained(0, w1.copy(prior=None), carried)
+    same_prior(carried, ref[0][2])
+    same_solution(eng.optimize_begin(abi.MARGIN_OLD, w1.N), ref[1][1])
+    same_prior(eng.optimize_finish(), ref[1][2])
+
+
+def test_chained_upload_refused_leaves_the_prior_collectable():
+    ref = stream_windows(Engine(0), 1)
+    eng = Engine(0)
+    w0 = ref[0][0]
+    eng.batch_reserve(1, 400, 3000)
+    eng.batch_upload(0, w0)
+    eng.optimize_begin(abi.MARGIN_OLD, w0.N)
+    bad = ref[1][0].copy(prior=None, start_frame=np.full(ref[1][0].N, 10, dtype=np.int32))  # every track leaves the window
+    carried = abi.Prior()
+    with pytest.raises(RuntimeError):
+        eng.batch_upload_chained(0, bad, carried)
+    same_prior(eng.optimize_finish(), ref[0][2])
