@@ -66,6 +66,7 @@ class HostEstimator:
         L.lfvio_host_set_device_mask.argtypes = [C.c_uint]
         L.lfvio_host_set_local_shards.argtypes = [C.c_int]
         L.lfvio_host_set_split_call.argtypes = [C.c_int]
+        L.lfvio_host_collect_prior.argtypes = [C.c_void_p]
         L.lfvio_host_get_timers.argtypes = [C.c_void_p, _dp, C.c_int]
         L.lfvio_host_uses_group.argtypes = [C.c_void_p]
         L.lfvio_host_triangulate.argtypes = [C.c_void_p]
@@ -150,6 +151,10 @@ class HostEstimator:
 
     def failure_detection(self):
         return bool(self.L.lfvio_host_failure_detection(self.h))
+
+    def collect_prior(self):
+        """Wait for the marginalization a split optimization() left running on the device; 0 or the error code."""
+        return self.L.lfvio_host_collect_prior(self.h)
 
     def timers(self, reset=True):
         """Seconds in the device-backed steps since the last reset: optimization() up to the state, collectPrior(),

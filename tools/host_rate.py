@@ -10,12 +10,16 @@ eng = Engine(0)  # (loads torch's HIP runtime first, see abi.load_hip_library)
 from lfvio.host import HostEstimator
 w = synth.make_window_with_prior(0, 300, lambda x, f: eng.optimize(x, f))[0]
 h = HostEstimator()
-for fused in (True, False):
+for fused, split in ((True, True), (True, False), (False, False)):
+    h.L.lfvio_host_set_split_call(int(split))
     for _ in range(5):
         h.load_window(w); h.pack(); assert h.optimization(abi.MARGIN_OLD, fused=fused) == 0
-    K, t = 50, 0.0
+    K, t, tc = 50, 0.0, 0.0
     for _ in range(K):
         h.load_window(w); h.pack()  # the same input state every time (load + span integration are not timed)
-        t0 = time.perf_counter(); assert h.optimization(abi.MARGIN_OLD, fused=fused) == 0; t += time.perf_counter() - t0
-    print(f"host side WindowEstimator::optimization(), N=300 with prior, {'one upload (fused)' if fused else 'two-call flow'}: "
-          f"{t / K * 1e3:.3f} ms per call = {K / t:.1f} calls/s")
+        t0 = time.perf_counter(); assert h.optimization(abi.MARGIN_OLD, fused=fused) == 0; t1 = time.perf_counter()
+        assert h.collect_prior() == 0  # split call: the marginalization still running when optimization() returned
+        t += t1 - t0; tc += time.perf_counter() - t0
+    how = ("one upload, split call (state first, prior collected later)" if split else "one upload (fused)") if fused else "two-call flow"
+    print(f"host side WindowEstimator::optimization(), N=300 with prior, {how}: "
+          f"{t / K * 1e3:.3f} ms until the state is back ({K / t:.1f} calls/s), {tc / K * 1e3:.3f} ms until the prior is there as well")
