@@ -450,3 +450,50 @@ def test_replay_through_a_group_of_ranks(host, tmp_path):
     d = np.abs(a[:, 1:4] - b[:, 1:4]).max(axis=1)
     assert d[0] < 1e-8 and d.max() < 5e-3, (d[0], d.max())
     assert abs(ate.ate(j1, tp)["rmse"] - ate.ate(j3, tp)["rmse"]) < 0.005
+
+
+def _replay_both_ways(h, tp, tmp_path, tag):
+    out = {}
+    for split in (1, 0):
+        h.L.lfvio_host_set_split_call(split)
+        h.clear_state()
+        h.set_min_parallax(10.0)
+        jp = str(tmp_path / f"traj_{tag}_{split}.txt")
+        rc, st = h.replay(tp, jp)
+        assert rc == 0, st
+        out[split] = (st, open(jp).read())
+    h.L.lfvio_host_set_split_call(1)
+    return out
+
+
+def test_split_call_changes_nothing_on_the_oracle_stack(oracle, tmp_path):
+    """Config::split_call (optimization() returns with the state, the prior is collected by the next upload) against the
+    one synchronous call, on the oracle-backed C-ABI: the same trajectory file byte for byte, reboots included."""
+    from lfvio.host import HostEstimator
+
+    tp = str(tmp_path / "reboot.lfvt")
+    _reboot_recording(tp)
+    h = HostEstimator(oracle.build_host_oracle())
+    try:
+        r = _replay_both_ways(h, tp, tmp_path, "oracle")
+    finally:
+        h.close()
+    assert r[1][0] == r[0][0] and r[1][1] == r[0][1]
+    assert r[1][0]["restarts"] == 1 and r[1][0]["bootstraps"] == 3
+
+
+@pytest.mark.gpu
+def test_split_call_changes_nothing_on_the_product_stack(host, tmp_path):
+    """The same on the GPU: the state pushed through the mailbox and the prior taken by the chained upload are the bits the
+    synchronous call downloads — 60 images of a plain recording and the recording with two reboots (a reset() while a
+    marginalization is in flight)."""
+    from lfvio.engine import Engine  # noqa: F401
+
+    tp = str(tmp_path / "plain.lfvt")
+    trace.make_stream(tp, seed=9, n_frames=60)
+    r = _replay_both_ways(host, tp, tmp_path, "plain")
+    assert r[1][0] == r[0][0] and r[1][1] == r[0][1] and r[1][0]["poses"] >= 45
+    tb = str(tmp_path / "reboot.lfvt")
+    _reboot_recording(tb)
+    r = _replay_both_ways(host, tb, tmp_path, "reboot")
+    assert r[1][0] == r[0][0] and r[1][1] == r[0][1] and r[1][0]["bootstraps"] == 3
