@@ -899,7 +899,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate;
     }
     if (tail_done) *tail_done = false;
-    const bool fuse = fused_flag >= 0 && fused_flag < 3;
+    const bool fuse = fused_flag >= 0 && fused_flag < 2;
     // The first graph carries as many passes as the previous call on this context needed (a stream of windows from one
     // estimator is steady: the bench window takes 4, windows whose steps are mostly accepted 5 to 8), then — fused —
     // the gated gauge fix + marginalization; whatever is still pending afterwards continues in chunks of SOLVE_CHUNK.
@@ -1292,6 +1292,10 @@ int lfvio_batch_upload_chained(lfvio_ctx *c, int slot, const LfvioWindow *in, Lf
 
 static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adaptive, bool early = false) {
   if (!c || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
+  if (marg_flag != LFVIO_MARGIN_OLD && marg_flag != LFVIO_MARGIN_SECOND_NEW) {  // (the flag indexes the slot's two marginalization plans)
+    c->err = "marg_flag is neither LFVIO_MARGIN_OLD nor LFVIO_MARGIN_SECOND_NEW";
+    return LFVIO_ERR_ARG;
+  }
   (void)hipSetDevice(c->device);
   if (int rc = join_inflight(c)) return rc;
   c->has_held = false;  // (a prior nobody collected before the next optimization is dropped, like one left in the slot)
@@ -1313,7 +1317,7 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
     const double t = c->info[s].max_seconds;
     if (t > 0.0 && (max_seconds <= 0.0 || t < max_seconds)) max_seconds = t;
   }
-  const bool fuse = adaptive && c->use_graph && marg_flag >= 0 && marg_flag < 3;
+  const bool fuse = adaptive && c->use_graph;
   bool tail_done = false;
   int rc = enqueue_solve(c, count, max_iter, adaptive, fuse ? marg_flag : -1, &tail_done, max_seconds, early);
   if (rc) return rc;

@@ -265,3 +265,25 @@ def test_a_window_without_information_ends_as_failure_like_the_oracle(eng, oracl
     # the whole optimization() of such a window: nothing to marginalize but the (empty) frame 0 — no error, state as it was
     sol, prior = eng.optimize(w, abi.MARGIN_SECOND_NEW)
     assert sol.c.termination == abi.FAILURE and prior.valid == 0
+
+
+@pytest.mark.gpu
+def test_resident_call_refuses_an_unknown_marginalization_flag(eng):
+    """The flag selects one of the slot's two marginalization plans on the device: anything else is LFVIO_ERR_ARG before a
+    kernel is launched — for the whole call, the enqueue-only form and the split form alike — and the context stays usable."""
+    import ctypes as C
+
+    from lfvio import abi, synth
+
+    w = synth.make_window(0, 40)
+    eng.batch_reserve(1, w.N, w.M)
+    eng.batch_upload(0, w)
+    sol = abi.Solution(w.N)
+    for flag in (2, 3, -1, 77):
+        assert eng.lib.lfvio_batch_optimize(eng.ctx, 1, flag) == -1
+        assert eng.lib.lfvio_batch_optimize_async(eng.ctx, 1, flag) == -1
+        assert eng.lib.lfvio_batch_optimize_begin(eng.ctx, flag, C.byref(sol.c)) == -1
+        assert not eng.optimize_pending()
+    eng.batch_optimize(1, abi.MARGIN_OLD)
+    s, p = eng.batch_download(0, w.N)
+    assert p.valid == 1 and np.isfinite(s.c.final_cost)
