@@ -6,7 +6,10 @@
 
 One "step" = one whole optimization(): trust-region solve (Ceres DENSE_SCHUR + DOGLEG semantics, <= 8 iterations, no
 wall-clock cap), the gauge fix of double2vector(), and MARGIN_OLD marginalization — inputs already resident in HBM when the
-timed region starts.  Workloads (--workload; default window300 at N = 1, window100k_sharded at N > 1):
+timed region starts.  Workloads (--workload; default window300 at every N — one window stream per GPU, the SAME window on every
+rank, no data-path collective: weak scaling, so the values of N = 1, 2, 4, 8 are one curve — and at N > 1 the line also
+carries the strong-scaling figure of configs[3] as `window100k_sharded` (with the same window's one-GPU time and the speed-up)
+and configs[4] as `batch512_weak`):
   window300          BASELINE.json configs[1]: one 10-keyframe / 300-landmark window per rank, prior from a warm-up
                      MARGIN_OLD step; latency-bound (sequential solves of the resident window, synchronous call)
   window300_stream   the same shape as a drop-in sees it: 64 CONSECUTIVE, DISTINCT windows of one estimator stream (each
@@ -181,7 +184,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    workload = args.workload or ("window300" if world == 1 else "window100k_sharded")
+    workload = args.workload or "window300"
     import torch
 
     if not torch.cuda.is_available():
@@ -217,7 +220,7 @@ def main():
     # ---- build the workload of this rank
     if workload == "window300":
         n_lm, batch = 300, 1
-        wins = [synth.make_window_with_prior(1000 * rank, n_lm, hip_optimize)[0]]
+        wins = [synth.make_window_with_prior(0, n_lm, hip_optimize)[0]]  # (the same window on every rank: per-GPU work is fixed as N grows)
         desc = "BASELINE configs[1]: 10-keyframe / 300-landmark window, estimate_extrinsic=1, estimate_td=1, prior from a warm-up MARGIN_OLD step; resident, re-solved every step"
     elif stream_mode:
         n_lm, batch, n_stream = 300, 1, 64
@@ -438,7 +441,77 @@ def main():
             out["one_gpu_same_window"] = dict(ms_per_step=one * 1e3, value=1.0 / one, unit="solves/s",
                                               speedup_of_this_run=(1.0 / one) and value / (1.0 / one))
         barrier()
-    if args.batch_secondary or (sharded and world > 1):
+    if world > 1 and workload == "window300" and not args.no_secondary:
+        # BASELINE configs[3] next to the weak-scaling headline: ONE 100 000-landmark window sharded over the N ranks through
+        # lfvio_group (the C++ driver and the ncclAllReduce inside the library), strong scaling — with the same window's time on
+        # ONE GPU measured in the same run (every rank its own copy, no collective), so the speed-up is read off the line.
+        from lfvio.engine import Group
+        import threading
+
+        # A collective that never completes (a rank lost inside RCCL) must not cost the run its headline: if this section
+        # is still running after five minutes, rank 0 writes the line as it stands and every rank leaves.
+        def give_up():
+            if rank == 0:
+                out["window100k_sharded"] = dict(error="the sharded section did not finish within 300 s")
+                out["cpu_baseline"] = None
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(300.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        big = synth.make_window(0, 100000)
+        e1 = Engine(local_rank)
+        e1.batch_reserve(1, big.N, big.M)
+        e1.batch_upload(0, big)
+        for _ in range(3):
+            e1.batch_optimize(1, flag, sync=True)
+        n1 = 10
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            e1.batch_optimize(1, flag, sync=True)
+        one = (time.perf_counter() - t1) / n1
+        e1.close()
+        box = [Group.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        g2, gerr = None, None
+        try:
+            g2 = Group(rank=rank, world=world, device=local_rank, unique_id=box[0])
+            g2.upload(big)
+        except Exception as ex:  # noqa: BLE001
+            gerr = repr(ex)
+        t = torch.tensor([0.0 if gerr is None else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t.item()) > 0.5:  # some rank has no group: nobody enters a collective of it
+            out["window100k_sharded"] = dict(error=gerr or "another rank could not create its group")
+            watchdog.cancel()
+            g2 = None
+    if world > 1 and workload == "window300" and not args.no_secondary and out.get("window100k_sharded") is None:
+        for _ in range(3):
+            g2.optimize(flag)
+        ns = 20
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(ns):
+            g2.optimize(flag)
+        barrier()
+        es = time.perf_counter() - ts
+        t = torch.tensor([es, one], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        es, one = float(t[0].item()), float(t[1].item())
+        sol_s, prior_s = g2.download()
+        ok_s = bool(prior_s.valid == 1 and np.isfinite(sol_s.c.final_cost))
+        out["window100k_sharded"] = dict(value=ns / es, unit="solves/s", scaling="strong", ms_per_step=es / ns * 1e3, steps=ns,
+                                         one_gpu_ms_per_step=one * 1e3, speedup_over_one_gpu=one / (es / ns), result_valid=ok_s,
+                                         passes_per_step=g2.last_passes(), collectives_per_step=g2.last_collectives(), collective=g2.backend(),
+                                         description=f"BASELINE configs[3]: ONE 10-keyframe / 100 000-landmark window sharded over {world} GPUs by "
+                                                     "contiguous landmark ranges balanced on observation count (lfvio_group: C++ driver, "
+                                                     "ncclAllReduce of the reduced pose system on the library's stream); one_gpu = the same "
+                                                     "window whole on one GPU, slowest rank")
+        g2.close()
+        watchdog.cancel()
+    if args.batch_secondary or world > 1:
         # The other multi-GPU configuration of BASELINE.json (configs[4]): independent windows, 512 resident per GPU, no
         # data-path collective — weak scaling, next to the strong-scaling figure above.  A secondary figure: it never replaces
         # `value`, and a failure here leaves the line as it is.
