@@ -444,6 +444,67 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
         }
     }
   };
+  // Two tiles (tA, tj) and (tB, tj) of ONE block column (tB >= NTL: only the first) take the terms k0 .. k1 - 1 of
+  // A_ij -= sum_k L_ik L_jk^T  with their accumulators in registers across the terms: the two share the B operand L_jk
+  // (12 operand loads per term for two tiles instead of 16), their MFMA chains are independent, and the operands of term
+  // k + 1 are requested before the MFMAs of term k.  Per tile and term the same four MFMAs in the same order as `update`
+  // issues them, so a tile's value does not depend on how its terms are grouped into calls.
+  auto accumulate = [&](int tA, int tB, int tj, int k0, int k1) {
+    const int c = lane & 15, gq = lane >> 4, offA = c * TLD + gq, offC = gq * TLD + c;
+    const bool two = tB < NTL;  // wave-uniform
+    double *TcA = Hs + tile_id(tA, tj) * TSZ + offC, *TcB = Hs + tile_id(two ? tB : tA, tj) * TSZ + offC;
+    // the operand tiles of consecutive terms are consecutive tiles of a block row (tile_id(t, k + 1) = tile_id(t, k) + 1)
+    const double *pA = Hs + tile_id(tA, k0) * TSZ + offA, *pB = Hs + tile_id(two ? tB : tA, k0) * TSZ + offA, *pJ = Hs + tile_id(tj, k0) * TSZ + offA;
+    solve_d4 cA, cB = {0.0, 0.0, 0.0, 0.0};
+    double xA[4], xB[4] = {0, 0, 0, 0}, xJ[4], yA[4] = {0, 0, 0, 0}, yB[4] = {0, 0, 0, 0}, yJ[4] = {0, 0, 0, 0};  // two operand sets: no copies between terms
+#pragma unroll
+    for (int q = 0; q < 4; q++) xA[q] = pA[4 * q], xJ[q] = pJ[4 * q], cA[q] = TcA[4 * TLD * q];
+    if (two) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) xB[q] = pB[4 * q], cB[q] = TcB[4 * TLD * q];
+    }
+    auto fetch = [&](double (&a)[4], double (&b)[4], double (&jv)[4]) {  // the next term's operands
+      pA += TSZ, pB += TSZ, pJ += TSZ;
+#pragma unroll
+      for (int q = 0; q < 4; q++) a[q] = pA[4 * q], jv[q] = pJ[4 * q];
+      if (two) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[q] = pB[4 * q];
+      }
+    };
+    auto term = [&](const double (&a)[4], const double (&b)[4], const double (&jv)[4]) {
+      if (two) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          cA = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], jv[q], cA, 0, 0, 0);
+          cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-b[q], jv[q], cB, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) cA = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], jv[q], cA, 0, 0, 0);
+      }
+    };
+    for (int k = k0; k < k1; k += 2) {
+      const bool more = k + 1 < k1;
+      if (more) fetch(yA, yB, yJ);
+      term(xA, xB, xJ);
+      if (more) {
+        if (k + 2 < k1) fetch(xA, xB, xJ);
+        term(yA, yB, yJ);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) TcA[4 * TLD * r] = cA[r];
+    if (two) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) TcB[4 * TLD * r] = cB[r];
+    }
+  };
+  // a wave's tiles t0, t0 + 3, t0 + 6 (those that exist) of block column tj
+  auto accumulate_column = [&](int t0, int tj, int k0, int k1) {
+    if (t0 < NTL) accumulate(t0, t0 + 3, tj, k0, k1);
+    if (t0 + 6 < NTL) accumulate(t0 + 6, NTL, tj, k0, k1);
+  };
 #ifdef LFVIO_SOLVE_PROFILE
 #define PSTAMP(k, v) do { if (tid == 0) S->dbg[k] = (v); } while (0)
 #define PNOW() ((long long)__builtin_readcyclecounter())
@@ -486,6 +547,29 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
     const long long c1 = PNOW();
     __syncthreads();
     const long long c2 = PNOW();
+#ifndef LFVIO_SOLVE_RIGHT_LOOKING
+    {  // U, left-looking with look-ahead.  A right-looking step would now update ALL trailing tiles with block column kb (55,
+      // 45, 36 ... of them in the first columns, every one read and written through LDS: those columns were bound by that
+      // traffic, 34k of the factorization's 100k cycles).  Only block column kb + 1 is needed next: it takes its LAST term
+      // here — wave 0 the diagonal tile, which it then factors; waves 1..3 the tiles below it, which the next panel solve
+      // reads — and while wave 0 factors, waves 1..3 give block column kb + 2 every term but its last one (the operand
+      // panels 0 .. kb are final), accumulators in registers across the terms, two tiles at a time sharing their B operand:
+      // a third of the LDS traffic per term, and never more than 30 tile-terms between two barriers.  Each tile still receives
+      // its terms in the order 0, 1, 2, ...: same bits.
+      const int j1 = kb + 1, j2 = kb + 2;
+      if (wave == 0) {
+        accumulate(j1, NTL, j1, kb, kb + 1);
+        const long long c3 = PNOW();
+        factor(j1);
+        const long long c4 = PNOW();
+        pu += c3 - c2, pf += c4 - c3;
+        PSTAMP(8 + kb, c4 - c3);
+      } else {
+        accumulate_column(j1 + wave, j1, kb, kb + 1);
+        accumulate_column(j2 + (3 - wave), j2, 0, kb + 1);  // (the wave with the most tiles above starts furthest down here)
+      }
+    }
+#else
     {  // U with look-ahead: wave 0 updates the next diagonal tile first and factors it while waves 1..3 update the rest
       // Wave 0 is on the critical path (next diagonal tile, then its factorization: worth about seven tile updates); in the
       // first block columns the other three would still be updating long after it is done, so it takes the tail of the
@@ -504,6 +588,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
         update(kb, wave, 3, split);
       }
     }
+#endif
     const long long c5 = PNOW();
     __syncthreads();
     const long long c6 = PNOW();

@@ -17,5 +17,5 @@ for name in sys.argv[1:] or ["sprof"]:
         eng.lib.lfvio_debug_read_clocks(eng.ctx, buf)
         t = np.array(buf[:32], dtype=np.int64)
     print(f"{name}: Cholesky {t[4] - t[3]} cycles = factor {t[29]} + panel {t[30]} + next-diagonal update {t[31]} + waits {t[18]}; "
-          f"factor per tile {list(t[8:18])}; back-substitution {t[6] - t[5]}; total {t[7] - t[0]}; k_solve {eng.time_kernel(3, 1, 100) * 1e3:.1f} us")
+          f"factor per tile {[int(v) for v in t[8:18]]}; wave 0 waiting at the second barrier, per column {[int(v) for v in t[19:29]]}; back-substitution {t[6] - t[5]}; total {t[7] - t[0]}; k_solve {eng.time_kernel(3, 1, 100) * 1e3:.1f} us")
     eng.close()
