@@ -449,56 +449,58 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
   // (12 operand loads per term for two tiles instead of 16), their MFMA chains are independent, and the operands of term
   // k + 1 are requested before the MFMAs of term k.  Per tile and term the same four MFMAs in the same order as `update`
   // issues them, so a tile's value does not depend on how its terms are grouped into calls.
-  auto accumulate = [&](int tA, int tB, int tj, int k0, int k1) {
+  // (TWO as a type: the body is straight-line code per variant, and inside the loop nothing is conditional — the operands of
+  // the next term are fetched whether or not there is one (the tile behind the last operand tile exists: k1 <= tj) — so that
+  // the wait in front of a term's MFMAs counts the loads of the NEXT term as still outstanding instead of waiting for them.)
+  auto accumulate_impl = [&](auto two_c, int tA, int tB, int tj, int k0, int k1) {
+    constexpr bool TWO = decltype(two_c)::value;
     const int c = lane & 15, gq = lane >> 4, offA = c * TLD + gq, offC = gq * TLD + c;
-    const bool two = tB < NTL;  // wave-uniform
-    double *TcA = Hs + tile_id(tA, tj) * TSZ + offC, *TcB = Hs + tile_id(two ? tB : tA, tj) * TSZ + offC;
+    double *TcA = Hs + tile_id(tA, tj) * TSZ + offC, *TcB = Hs + tile_id(TWO ? tB : tA, tj) * TSZ + offC;
     // the operand tiles of consecutive terms are consecutive tiles of a block row (tile_id(t, k + 1) = tile_id(t, k) + 1)
-    const double *pA = Hs + tile_id(tA, k0) * TSZ + offA, *pB = Hs + tile_id(two ? tB : tA, k0) * TSZ + offA, *pJ = Hs + tile_id(tj, k0) * TSZ + offA;
+    const double *pA = Hs + tile_id(tA, k0) * TSZ + offA, *pB = Hs + tile_id(TWO ? tB : tA, k0) * TSZ + offA, *pJ = Hs + tile_id(tj, k0) * TSZ + offA;
     solve_d4 cA, cB = {0.0, 0.0, 0.0, 0.0};
-    double xA[4], xB[4] = {0, 0, 0, 0}, xJ[4], yA[4] = {0, 0, 0, 0}, yB[4] = {0, 0, 0, 0}, yJ[4] = {0, 0, 0, 0};  // two operand sets: no copies between terms
-#pragma unroll
-    for (int q = 0; q < 4; q++) xA[q] = pA[4 * q], xJ[q] = pJ[4 * q], cA[q] = TcA[4 * TLD * q];
-    if (two) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) xB[q] = pB[4 * q], cB[q] = TcB[4 * TLD * q];
-    }
-    auto fetch = [&](double (&a)[4], double (&b)[4], double (&jv)[4]) {  // the next term's operands
-      pA += TSZ, pB += TSZ, pJ += TSZ;
+    double xA[4], xB[4] = {0, 0, 0, 0}, xJ[4], yA[4], yB[4] = {0, 0, 0, 0}, yJ[4];  // two operand sets: no copies between terms
+    auto fetch = [&](double (&a)[4], double (&b)[4], double (&jv)[4]) {
 #pragma unroll
       for (int q = 0; q < 4; q++) a[q] = pA[4 * q], jv[q] = pJ[4 * q];
-      if (two) {
+      if (TWO) {
 #pragma unroll
         for (int q = 0; q < 4; q++) b[q] = pB[4 * q];
       }
+      pA += TSZ, pB += TSZ, pJ += TSZ;
     };
     auto term = [&](const double (&a)[4], const double (&b)[4], const double (&jv)[4]) {
-      if (two) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          cA = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], jv[q], cA, 0, 0, 0);
-          cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-b[q], jv[q], cB, 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) cA = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], jv[q], cA, 0, 0, 0);
+      for (int q = 0; q < 4; q++) {
+        cA = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], jv[q], cA, 0, 0, 0);
+        if (TWO) cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-b[q], jv[q], cB, 0, 0, 0);
       }
     };
-    for (int k = k0; k < k1; k += 2) {
-      const bool more = k + 1 < k1;
-      if (more) fetch(yA, yB, yJ);
-      term(xA, xB, xJ);
-      if (more) {
-        if (k + 2 < k1) fetch(xA, xB, xJ);
-        term(yA, yB, yJ);
-      }
+#pragma unroll
+    for (int q = 0; q < 4; q++) cA[q] = TcA[4 * TLD * q];
+    if (TWO) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) cB[q] = TcB[4 * TLD * q];
     }
+    fetch(xA, xB, xJ);
+    int k = k0;
+    for (; k + 1 < k1; k += 2) {
+      fetch(yA, yB, yJ);
+      term(xA, xB, xJ);
+      fetch(xA, xB, xJ);
+      term(yA, yB, yJ);
+    }
+    if (k < k1) term(xA, xB, xJ);
 #pragma unroll
     for (int r = 0; r < 4; r++) TcA[4 * TLD * r] = cA[r];
-    if (two) {
+    if (TWO) {
 #pragma unroll
       for (int r = 0; r < 4; r++) TcB[4 * TLD * r] = cB[r];
     }
+  };
+  auto accumulate = [&](int tA, int tB, int tj, int k0, int k1) {
+    if (tB < NTL) accumulate_impl(std::true_type{}, tA, tB, tj, k0, k1);  // wave-uniform
+    else accumulate_impl(std::false_type{}, tA, tB, tj, k0, k1);
   };
   // a wave's tiles t0, t0 + 3, t0 + 6 (those that exist) of block column tj
   auto accumulate_column = [&](int t0, int tj, int k0, int k1) {
