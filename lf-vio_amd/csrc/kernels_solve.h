@@ -354,7 +354,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
   // accumulator layout D[g + 4 r][c] is the transpose of the ownership, and the tile is symmetric.  30 vector instructions
   // per pivot instead of 47 (tools/micro/f_mfma.hip: 4 900 -> 3 700 cycles per tile); the raw columns are scaled by
   // 1/sqrt(d_k) once at the end.
-  auto factor = [&](int kb) {
+  // last_term: the tile still lacks the term of block column kb - 1 (its panel tile (kb, kb - 1) has just been solved): it
+  // is taken here, on the registers the factorization starts from — the accumulator layout of  A - P P^T  is this very
+  // ownership (the tile is symmetric) — instead of a trip of the tile through LDS in between.
+  auto factor = [&](int kb, bool last_term) {
     const int nb = kb < NTL - 1 ? 16 : KP - 16 * (NTL - 1);  // pivots in this block column (12 in the last)
     double *Td = Hs + tile_id(kb, kb) * TSZ;
     const int c = lane & 15, gq = lane >> 4;
@@ -363,6 +366,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
     for (int i = 0; i < 4; i++) {
       const int col = gq + 4 * i;
       a[i] = col <= c ? Td[tsw(c, col)] : Td[tsw(col, c)];
+    }
+    if (last_term) {
+      const double *Tp = Hs + tile_id(kb, kb - 1) * TSZ + c * TLD + gq;
+      double pv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) pv[q] = Tp[4 * q];
+#pragma unroll
+      for (int q = 0; q < 4; q++) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pv[q], pv[q], a, 0, 0, 0);
     }
     double dsave[4] = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
 #define PSTAMP(k, v) do {} while (0)
 #define PNOW() 0ll
 #endif
-  if (wave == 0) factor(0);
+  if (wave == 0) factor(0, false);
   __syncthreads();
   long long pf = 0, pp = 0, pu = 0, pw = 0;
   for (int kb = 0; kb < NTL - 1; kb++) {
@@ -560,9 +571,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
       // its terms in the order 0, 1, 2, ...: same bits.
       const int j1 = kb + 1, j2 = kb + 2;
       if (wave == 0) {
-        accumulate(j1, NTL, j1, kb, kb + 1);
         const long long c3 = PNOW();
-        factor(j1);
+        factor(j1, true);
         const long long c4 = PNOW();
         pu += c3 - c2, pf += c4 - c3;
         PSTAMP(8 + kb, c4 - c3);
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
       if (wave == 0) {
         update(kb, 0, 1, 1);
         const long long c3 = PNOW();
-        factor(kb + 1);
+        factor(kb + 1, false);
         const long long c4 = PNOW();
         pu += c3 - c2, pf += c4 - c3;
         PSTAMP(8 + kb, c4 - c3);
