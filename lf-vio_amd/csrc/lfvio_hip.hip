@@ -188,6 +188,11 @@ struct lfvio_ctx {
 namespace {
 
 void destroy_graph(lfvio_ctx *c) {
+  // (a graph whose tail is still running behind an early state is not destroyed under it)
+  if (c->stream && (c->inflight || c->unsynced)) {
+    (void)hipStreamSynchronize(c->stream);
+    c->unsynced = false;
+  }
   if (c->graph) {
     (void)hipGraphExecDestroy(c->graph);
     c->graph = nullptr;
@@ -1654,6 +1659,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
 int lfvio_debug_marg_system(lfvio_ctx *c, int n, double *A, double *b) {
   if (!c || !c->d_base) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
+  if (int rc = join_inflight(c)) return rc;
   char *d = c->d_base + c->L.mscr;
   HIPCHK(c, hipMemcpy(A, d + sizeof(double) * (92 * 92 + 96), sizeof(double) * n * n, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(b, d + sizeof(double) * (92 * 92 + 96 + n * n), sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -1662,6 +1668,7 @@ int lfvio_debug_marg_system(lfvio_ctx *c, int n, double *A, double *b) {
 
 int lfvio_debug_read_clocks(lfvio_ctx *c, long long *out32) {
   if (!c || !c->d_base) return LFVIO_ERR_ARG;
+  if (int rc = join_inflight(c)) return rc;
   HIPCHK(c, hipMemcpy(out32, c->d_base + offsetof(Slot, dbg), sizeof(long long) * 32, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(out32 + 32, c->d_base + offsetof(Slot, jtrace), sizeof(double) * 32, hipMemcpyDeviceToHost));
   return LFVIO_OK;
@@ -1673,6 +1680,7 @@ int lfvio_debug_read_clocks(lfvio_ctx *c, long long *out32) {
 int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double *avg_ms) {
   if (!c || !c->d_base || count <= 0 || count > c->batch || reps <= 0) return LFVIO_ERR_ARG;
   (void)hipSetDevice(c->device);
+  if (int rc = join_inflight(c)) return rc;
   const Grid g = grid_for(c, count);
   const size_t st = c->L.total;
   hipEvent_t e0, e1;

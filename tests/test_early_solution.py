@@ -233,3 +233,25 @@ def test_chained_upload_refused_leaves_the_prior_collectable():
     with pytest.raises(RuntimeError):
         eng.batch_upload_chained(0, bad, carried)
     same_prior(eng.optimize_finish(), ref[0][2])
+
+
+def test_context_torn_down_or_reconfigured_with_the_tail_in_flight():
+    """lfvio_destroy and the calls that drop the captured graphs (here lfvio_debug_force_eig) wait for a marginalization
+    still running behind an early state instead of pulling its graph from under it."""
+    w = synth.make_window(0, 300)
+    ref_sol, ref_prior = whole(Engine(0), w, abi.MARGIN_OLD)
+    eng = Engine(0)
+    eng.batch_reserve(1, w.N, w.M)
+    eng.batch_upload(0, w)
+    eng.optimize_begin(abi.MARGIN_OLD, w.N)
+    eng.close()  # with the tail in flight
+    eng = Engine(0)
+    eng.batch_reserve(1, w.N, w.M)
+    for _ in range(3):
+        eng.batch_upload(0, w)
+        sol = eng.optimize_begin(abi.MARGIN_OLD, w.N)
+        eng.force_eig(False)  # drops every captured graph
+        prior = eng.optimize_finish()
+        same_solution(sol, ref_sol)
+        same_prior(prior, ref_prior)
+    eng.close()
