@@ -379,6 +379,39 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       double bop = 0.0;  // this lane's B operand: its panel column times 1/d of that column's pivot
+#ifndef LFVIO_FACTOR_PIVOT_LOOP
+      // The four pivots of a panel without a cross-lane step between them.  Taken one at a time (the loop below), every
+      // pivot is readlane -> reciprocal -> multiply -> multiply-add with a quarter and a row broadcast feeding it: ~250
+      // cycles, most of them the hand-offs.  Instead everything the panel needs from other lanes is fetched FIRST, all of it
+      // independent — the ten entries of its 4 x 4 pivot block (uniform, v_readlane) and this row's four panel entries (one
+      // per quarter) — then every lane runs the block's LDL^T for itself (four reciprocals in a row, the only chain left) and
+      // solves its own row against it: y_k = x_k - sum_{t<k} m_kt y_t, m_kt = Y_kt / d_t.  A panel is whole or absent (nb is
+      // 16 or 12).
+      if (4 * p < nb) {
+        const int l0 = 4 * p;
+        const double B00 = readlane_f64(a[p], l0), B10 = readlane_f64(a[p], l0 + 1), B20 = readlane_f64(a[p], l0 + 2), B30 = readlane_f64(a[p], l0 + 3);
+        const double B11 = readlane_f64(a[p], 16 + l0 + 1), B21 = readlane_f64(a[p], 16 + l0 + 2), B31 = readlane_f64(a[p], 16 + l0 + 3);
+        const double B22 = readlane_f64(a[p], 32 + l0 + 2), B32 = readlane_f64(a[p], 32 + l0 + 3), B33 = readlane_f64(a[p], 48 + l0 + 3);
+        const double x0 = quarter_bcast(a[p], 0), x1 = quarter_bcast(a[p], 1), x2 = quarter_bcast(a[p], 2), x3 = quarter_bcast(a[p], 3);
+        const double d0 = B00, r0 = fast_rcp(d0);
+        const double m10 = B10 * r0, m20 = B20 * r0, m30 = B30 * r0;
+        const double d1 = fma(-m10, B10, B11), Y21 = fma(-m10, B20, B21), Y31 = fma(-m10, B30, B31);
+        const double r1 = fast_rcp(d1);
+        const double m21 = Y21 * r1, m31 = Y31 * r1;
+        const double d2 = fma(-m21, Y21, fma(-m20, B20, B22)), Y32 = fma(-m21, Y31, fma(-m20, B30, B32));
+        const double r2 = fast_rcp(d2);
+        const double m32 = Y32 * r2;
+        const double d3 = fma(-m32, Y32, fma(-m31, Y31, fma(-m30, B30, B33)));
+        const double r3 = fast_rcp(d3);
+        if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) bad = true;
+        const double y1 = fma(-m10, x0, x1), y2 = fma(-m21, y1, fma(-m20, x0, x2)), y3 = fma(-m32, y2, fma(-m31, y1, fma(-m30, x0, x3)));
+        const double yk = gq == 0 ? x0 : gq == 1 ? y1 : gq == 2 ? y2 : y3;
+        const double rk = gq == 0 ? r0 : gq == 1 ? r1 : gq == 2 ? r2 : r3;
+        dsave[p] = gq == 0 ? d0 : gq == 1 ? d1 : gq == 2 ? d2 : d3;
+        a[p] = yk;
+        bop = yk * rk;
+      }
+#else
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const int k = 4 * p + t;
@@ -398,6 +431,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
           }
         }
       }
+#endif
       if (p < 3 && 4 * p < nb) {
         solve_d4 cv = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[p], bop, a, 0, 0, 0);
 #pragma unroll

@@ -233,7 +233,11 @@ def test_wall_clock_cap(eng):
     assert capped.c.termination == abi.NO_CONVERGENCE
     assert 2 <= capped.c.num_iterations < free.c.num_iterations
     k = capped.c.num_iterations
-    assert [t["cost"] for t in capped.trace()] == [t["cost"] for t in free.trace()[:k]]  # the same loop, cut short
+    # the same loop, cut short.  The cost of an accepted step is first the candidate's (summed per landmark block by the
+    # kernel that evaluates the candidates) and is replaced by the cost the NEXT pass's linearization finds at the same point
+    # (k_solve, HandleSuccessfulStep; another summation order): the entry the cap cuts behind keeps the first of the two
+    ct, ft = [t["cost"] for t in capped.trace()], [t["cost"] for t in free.trace()[:k]]
+    assert ct[:-1] == ft[:-1] and abs(ct[-1] - ft[-1]) <= 1e-13 * abs(ft[-1])
     assert np.isfinite(capped.pose).all() and capped.c.final_cost < capped.c.initial_cost
     roomy = eng.solve(w.copy(max_solver_time=10.0))
     assert roomy.c.num_iterations == free.c.num_iterations and np.array_equal(roomy.pose, free.pose)
