@@ -36,6 +36,8 @@ int lfvio_debug_force_eig(lfvio_ctx *ctx, int on);
    and gauge fix + marginalization ran in the same graph) */
 /* microseconds of the last upload: host packing | collecting a chained prior | prior + copies enqueued | final synchronization */
 int lfvio_debug_upload_times(lfvio_ctx *ctx, double *out4);
+/* n > 0: every first graph of the synchronous entry points carries n passes instead of the number the previous call needed; 0: adaptive */
+int lfvio_debug_set_first_passes(lfvio_ctx *ctx, int n);
 int lfvio_debug_last_chunks(lfvio_ctx *ctx);
 /* passes of the trust-region loop the slowest window of the last synchronous call used */
 int lfvio_debug_last_passes(lfvio_ctx *ctx);

@@ -141,6 +141,7 @@ struct lfvio_ctx {
   bool publish = false;
   hipGraphExec_t chunk = nullptr, tail[2][3] = {};
   hipGraphExec_t first[2][4][13] = {};  // [publish][0: solve only, 1 + flag: with the gated tail][passes in the first graph]
+  int fixed_passes = 0;             // debug (LFVIO_FIRST_PASSES / lfvio_debug_set_first_passes): > 0 sizes every first graph with this many passes
   int predict_passes = 4;           // passes the previous synchronous call needed; tail[flag]: force-done + gated gauge fix + marginalization
   double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
@@ -913,7 +914,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     // With a cap the first graph is still the predicted one — a cap of SOLVER_TIME = 0.04 s (the shipped default) is a few
     // hundred passes away and must not cost the call its single launch — unless the cap is so tight that the predicted
     // graph could overrun it: then no more passes than fit (at the measured time per pass), down to a chunk of SOLVE_CHUNK.
-    int first_passes = std::min(std::max(c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
+    int first_passes = std::min(std::max(c->fixed_passes > 0 ? c->fixed_passes : c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
     if (capped) first_passes = std::max(std::min(SOLVE_CHUNK, passes), std::min(first_passes, (int)std::min(max_seconds / c->pass_seconds, 1e6)));
     hipGraphExec_t &first_graph = c->first[c->publish ? 1 : 0][fuse ? 1 + fused_flag : 0][first_passes];
     auto capture = [&](hipGraphExec_t *out, bool setup, int npass, int tail_flag) -> int {
@@ -1217,6 +1218,7 @@ lfvio_ctx *lfvio_create(int device) {
     }
   }
   if (const char *e = getenv("LFVIO_SPARSE_SOLVE")) c->force_dense = e[0] != '1';
+  if (const char *e = getenv("LFVIO_FIRST_PASSES")) c->fixed_passes = std::max(0, atoi(e));
   (void)hipFuncSetAttribute((const void *)k_marg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
   const char *env = getenv("LFVIO_NO_GRAPH");
   if (env && env[0] == '1') c->use_graph = false;
@@ -1721,6 +1723,11 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
 int lfvio_debug_upload_times(lfvio_ctx *c, double *out4) {
   if (!c || !out4) return LFVIO_ERR_ARG;
   for (int k = 0; k < 4; k++) out4[k] = c->up_us[k];
+  return LFVIO_OK;
+}
+int lfvio_debug_set_first_passes(lfvio_ctx *c, int n) {
+  if (!c || n < 0) return LFVIO_ERR_ARG;
+  c->fixed_passes = n;
   return LFVIO_OK;
 }
 int lfvio_debug_last_chunks(lfvio_ctx *c) { return c ? c->stat_chunks : -1; }
