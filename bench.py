@@ -161,6 +161,28 @@ def distinct_windows_with_prior(seeds, optimize):
         return [abi.window_from_dict(d) for d in pool.map(_gen_final, jobs, chunksize=4)]
 
 
+def two_stream_sweeps(device, wins512, flag, sweeps):
+    """The same 512 resident windows as a group of TWO contexts on the device (lfvio_group_create_local: two streams, 256
+    windows each, enqueued side by side by lfvio_group_batch_optimize — no collective in batch mode): the single-workgroup
+    kernels of one half (the dense solve, the marginalization's eigen-solver) overlap the wide ones of the other.  Returns
+    seconds per sweep of all 512."""
+    from lfvio.engine import Group
+
+    g = Group(local_shards=2, device=device)
+    try:
+        g.batch_reserve(len(wins512), max(w.N for w in wins512), max(w.M for w in wins512))
+        for s_, w_ in enumerate(wins512):
+            g.batch_upload(s_, w_)
+        for _ in range(2):
+            g.batch_optimize(len(wins512), flag)
+        t0 = time.perf_counter()
+        for _ in range(sweeps):
+            g.batch_optimize(len(wins512), flag)
+        return (time.perf_counter() - t0) / sweeps
+    finally:
+        g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,6 +397,29 @@ def main():
                roofline=roofline, roofline_k_solve=roofline_solve, kernels_us=extra)
     if lat is not None:
         out["latency"] = lat
+    if workload == "batch512" and not args.no_secondary:
+        # The same 512 windows as two contexts of 256 on the device, two streams side by side (lfvio_group_create_local +
+        # lfvio_group_batch_optimize; no collective in batch mode): the line's value is the better of the two forms, the
+        # single-stream figure — the one the roofline objects and the kernel statistics of profiles/ describe — stays beside it.
+        eb2, err2 = -1.0, None
+        try:
+            eb2 = two_stream_sweeps(local_rank, wins, flag, max(5, min(args.steps, 20)))
+        except Exception as ex:  # noqa: BLE001
+            err2 = repr(ex)
+        if dist is not None:
+            t = torch.tensor([eb2, 1.0 if err2 else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            eb2, bad2 = float(t[0].item()), float(t[1].item()) > 0.5
+        else:
+            bad2 = err2 is not None
+        out["one_stream"] = dict(value=out["value"], ms_per_step=out["ms_per_step"])
+        if not bad2 and eb2 * 1e3 < out["ms_per_step"]:
+            out["value"], out["ms_per_step"], out["streams"] = world * batch / eb2, eb2 * 1e3, 2
+            cfg["parallelism"] += "; on each GPU two contexts of 256 windows (lfvio_group_create_local), two streams side by side"
+        else:
+            out["streams"] = 1
+            if err2:
+                out["two_streams_error"] = err2
     if stream_mode and world == 1 and not args.no_secondary:
         # The same stream through the split call: lfvio_batch_upload_chained (the next window is packed while the marginalization
         # of the previous one is still running, and collects its prior) + lfvio_batch_optimize_begin (returns with the state).
@@ -533,6 +578,10 @@ def main():
             e2.batch_sync()
             eb = time.perf_counter() - tb
             e2.close()
+            try:  # the same windows as two contexts of 256, two streams side by side: the better form counts
+                eb = min(eb, two_stream_sweeps(local_rank, [bw[s_ % n_distinct] for s_ in range(512)], flag, nb_steps) * nb_steps)
+            except Exception:  # noqa: BLE001
+                pass
         except Exception as ex:  # noqa: BLE001
             err = repr(ex)
         ok = 1.0 if err is None else 0.0
@@ -605,15 +654,28 @@ def main():
             flops_lin = sum(2.0e3 * (w_.M - w_.N) + 1.6e3 * w_.N for w_ in bw)  # ~2.0 k per residual block + 1.6 k per landmark
             bytes_lin = sum(algorithmic_bytes(w_.N, w_.M) for w_ in bw)
             flops_sol = nb * (172 ** 3 / 3.0 + 2.0 * 172 ** 2) * 2.0
-            out["batch512"] = dict(value=nb / eb, unit="solves/s", ms_per_sweep=eb * 1e3, windows=nb, distinct_windows=nb,
-                                   description="BASELINE configs[4]: 512 distinct 10-keyframe / 300-landmark windows resident at once, one optimization() each per sweep",
+            e2.close()
+            e2 = None
+            one_stream = dict(value=nb / eb, ms_per_sweep=eb * 1e3)
+            try:  # the same windows on two streams (a group of two contexts on this device)
+                eb2 = two_stream_sweeps(local_rank, bw, flag, nsw)
+            except Exception:  # noqa: BLE001
+                eb2 = None
+            streams = 2 if eb2 is not None and eb2 < eb else 1
+            if streams == 2:
+                eb = eb2
+            out["batch512"] = dict(value=nb / eb, unit="solves/s", ms_per_sweep=eb * 1e3, windows=nb, distinct_windows=nb, streams=streams,
+                                   one_stream=one_stream,
+                                   description="BASELINE configs[4]: 512 distinct 10-keyframe / 300-landmark windows resident at once, one optimization() each per sweep"
+                                               + ("; as two contexts of 256 on the device (lfvio_group_create_local), two streams side by side" if streams == 2 else ""),
                                    roofline=dict(bound="fp64", kernel="k_lin (four role launches over 512 windows)", achieved=flops_lin / lin512 / 1e12,
                                                  peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=flops_lin / lin512 / 1e12 / FP64_PEAK_TFLOPS,
                                                  hbm_gbs=bytes_lin / lin512 / 1e9, hbm_frac=bytes_lin / lin512 / 1e9 / HBM_PEAK_GBS,
                                                  avg_sweep_us=lin512 * 1e6, flops_per_sweep=flops_lin, algorithmic_bytes_per_sweep=bytes_lin),
                                    roofline_k_solve=dict(bound="mfma", achieved=flops_sol / sol512 / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                                                          frac=flops_sol / sol512 / 1e12 / FP64_PEAK_TFLOPS, avg_launch_us=sol512 * 1e6))
-            e2.close()
+            if e2 is not None:
+                e2.close()
         except Exception as ex:  # noqa: BLE001  (a secondary figure: a failure here leaves the headline as it is)
             out["batch512"] = dict(error=repr(ex))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
