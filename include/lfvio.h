@@ -323,7 +323,9 @@ int lfvio_shard_finish(lfvio_ctx *ctx, LfvioSolution *out);
  *   lfvio_group_create_rank(...)   one process per GPU (torchrun / mpirun): ncclCommInitRank; rank 0 obtains the id from
  *                                  lfvio_group_unique_id() and the launcher broadcasts its 128 bytes
  *   lfvio_group_create_local(...)  `shards` ranks on ONE device, the all-reduce a device-side sum in rank order instead
- *                                  of RCCL — for tests on a one-GPU box
+ *                                  of RCCL — for tests of the sharded window on a one-GPU box, and the form of choice for a
+ *                                  resident BATCH that fills the device: two contexts take half of the windows each
+ *                                  (lfvio_group_batch_*, no collective) and their streams run side by side
  * lfvio_group_solve() is what the re-implemented Estimator::optimization() calls in place of lfvio_solve() +
  * lfvio_marginalize(): every rank is handed the same window, rank r linearizes a contiguous landmark range balanced on
  * observation count (IMU factors and prior on rank 0), per trust-region pass the ranks sum-all-reduce
