@@ -348,6 +348,12 @@ const char *lfvio_group_backend(const lfvio_group *g); /* path of the RCCL libra
 /* optimization() of one window, landmark-sharded: upload + optimize + download, or the three steps on their own (the
  * window stays resident: lfvio_group_optimize() may be repeated, which is what bench.py times).  marg_flag < 0: the
  * trust-region solve only. */
+/* One process per GPU (lfvio_group_create_rank): these calls contain collectives, and a collective completes only when every
+ * rank of the group has entered it.  All ranks must therefore make the same sequence of lfvio_group_* calls with the same
+ * window, the same marg_flag and the same choice of sol == NULL / != NULL (sol->inv_depth may be NULL on some ranks and not
+ * on others: the gather of the inverse depths runs either way).  A rank that fails locally (a refused upload, a device
+ * error) returns at once and its peers wait in RCCL: the caller must treat an error from any rank as fatal for the group
+ * (destroy it on every rank) — RCCL has no timeout of its own. */
 int lfvio_group_solve(lfvio_group *g, const LfvioWindow *in, int marg_flag, LfvioSolution *sol, LfvioPrior *prior);
 int lfvio_group_upload(lfvio_group *g, const LfvioWindow *in);
 int lfvio_group_optimize(lfvio_group *g, int marg_flag);

@@ -38,6 +38,10 @@ int lfvio_debug_force_eig(lfvio_ctx *ctx, int on);
 int lfvio_debug_upload_times(lfvio_ctx *ctx, double *out4);
 /* n > 0: every first graph of the synchronous entry points carries n passes instead of the number the previous call needed; 0: adaptive */
 int lfvio_debug_set_first_passes(lfvio_ctx *ctx, int n);
+/* Solver::Options::function_tolerance of the windows uploaded from now on (Ceres' default 1e-6; estimator.cpp:810-822 leaves it
+ * alone).  0 makes the loop run to its iteration cap or another criterion: the diagnostic of tests/tools/fuzz_parity.py, which
+ * asks whether two solvers that disagree in the 6th digit of an inverse depth stopped early in a flat valley. */
+int lfvio_debug_set_function_tolerance(lfvio_ctx *ctx, double tol);
 int lfvio_debug_last_chunks(lfvio_ctx *ctx);
 /* passes of the trust-region loop the slowest window of the last synchronous call used */
 int lfvio_debug_last_passes(lfvio_ctx *ctx);

@@ -112,6 +112,7 @@ constexpr int MAIL_MAX_LM = 8192;  // landmarks a window may have for its soluti
   double xn2_pose_cand; \
   double gmax_pose, lm_bmax; \
   double initial_cost; \
+  double function_tolerance; \
   double q[Q_COUNT]; \
   int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled; \
   int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, new_point; \
@@ -190,6 +191,7 @@ struct Slot {
   long long mail;
   TRDecision dec;
   double g[3], tr_over_row, half_row, sqrt_info;
+  double fn_tol;  // Solver::Options::function_tolerance of this window: Ceres' default 1e-6 unless lfvio_debug_set_function_tolerance() changed it
   FrameState x0;
   LfvioPreintegration imu[LFVIO_WINDOW_SIZE];
   int imu_active[LFVIO_WINDOW_SIZE];

@@ -7,6 +7,7 @@
 #pragma once
 #include "dev_factors.h"
 #include "tr_decide.h"
+#include <type_traits>
 
 #define SLOT(base, stride) ((Slot *)((char *)(base) + (size_t)blockIdx.y * (stride)))
 
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     if (tid == 0) {
       TRState *t = &S->tr;
       t->radius = 1e4;
+      t->function_tolerance = S->fn_tol;
       t->mu = 1e-8;
       t->x_cost = t->cand_cost = t->model_cost_change = t->dogleg_step_norm = t->alpha = 0.0;
       t->iteration = 0;

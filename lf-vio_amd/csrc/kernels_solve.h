@@ -102,8 +102,8 @@ DEV double block_max(double v, double *scratch, int tid) {
   return s;
 }
 
-// What thread 0 of the dense solve leaves in the header once the Gauss-Newton step is there (shared by k_solve_dense and
-// k_solve_sparse): the pose-side sums, and at iteration 0 IterationZero + the first
+// What thread 0 of the dense solve leaves in the header once the Gauss-Newton step is there: the pose-side sums,
+// and at iteration 0 IterationZero + the first
 // FinalizeIterationAndCheckIfMinimizerCanContinue of trust_region_minimizer.cc.
 DEV void solve_epilogue(Slot *S, TRState *tr, const double *ls, double gn2, double ggn, double gG, double gN, double qgn, double qnn) {
   tr->q[Q_GN_SQ] = gn2;

@@ -6,7 +6,20 @@
 // There is NO CPU fallback: without a usable HIP device lfvio_create() fails.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen()ed by group.inc, not linked
+// The few RCCL types group.inc needs, declared here with the values of the public ABI (rccl.h: ncclSuccess = 0, ncclSum = 0,
+// ncclDouble = 8, a 128-byte unique id): librccl is dlopen()ed by group.inc, not linked, and the single-GPU library builds on
+// a ROCm install without the RCCL development headers.
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct {
+  char internal[NCCL_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclRedOp_t ncclSum = 0;
+constexpr ncclDataType_t ncclDouble = 8;
 
 #include <algorithm>
 #include <chrono>
@@ -21,7 +34,7 @@
 #include "../../include/lfvio.h"
 #include "../../include/lfvio_debug.h"
 #include "kernels_marg.h"
-#include "kernels_solve2.h"
+#include "kernels_solve.h"
 #include "kernels_feat.h"
 
 #define HIPCHK(ctx, call)                                                                      \
@@ -107,7 +120,10 @@ struct SlotHostInfo {
   int max_iter = 0;          // LfvioWindow::max_num_iterations of the uploaded window
   double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
   std::vector<int> perm;  // device order -> caller order
-  bool uploaded = false;
+  bool uploaded = false;   // the slot's work-array pointers are on the device (until the next reserve())
+  bool resident = false;   // a window is resident: N, perm, grid sizes below describe what the device holds.  Cleared while an upload
+                           // rewrites them and set again when its copies are enqueued, so a refused upload leaves a slot that every
+                           // later call refuses instead of one described by the wrong sizes
   LfvioPrior in_prior;    // kept for the "prior passes through" case of MARGIN_SECOND_NEW
   bool has_in_prior = false;
   // k_sum's gather lists on the device are a function of the chunks per frame pair alone: kept from one upload of the slot
@@ -132,6 +148,7 @@ struct lfvio_ctx {
   char *h_down = nullptr;   // pinned download buffer
   size_t h_down_bytes = 0;
   std::vector<SlotHostInfo> info;
+  std::vector<int> perm_build;  // upload_window builds the next permutation here and swaps it in at its commit point
   // cached graph of the solve loop
   hipGraphExec_t graph = nullptr;
   int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0;
@@ -165,13 +182,9 @@ struct lfvio_ctx {
   bool has_held = false;
   bool inflight_first = false;  // the flag came out of the first graph: {tail_state, passes_used} land in h_pending[2..3] when it ends
   bool use_graph = true;
-  // the dense solve of a pass: k_solve_dense; LFVIO_SPARSE_SOLVE=1 selects k_solve_sparse (solve_plan.h: the speed/bias
-  // chain by cyclic reduction, then 91 dense unknowns) — measured 69 us against 62 us, so not the
-  // default — unless a resident window's prior has a speed/bias block of a frame other than 0, which the plan has no slot for
-  S2DevTables *d_s2 = nullptr;
-  bool dense_solve = false, force_dense = true;
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
   int last_passes = 0;  // passes of the trust-region loop the last synchronous call used (slowest slot)
+  double fn_tol = 1e-6;  // function_tolerance of the windows uploaded from now on (debug: lfvio_debug_set_function_tolerance)
   bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
   // landmark-sharded mode (multi-GPU)
   bool shard_active = false;
@@ -449,6 +462,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->tr_over_row = w->row > 0.0 ? w->tr / w->row : 0.0;  // only the td factor reads it (row > 0 checked above)
   S->half_row = w->row / 2;
   S->sqrt_info = w->sqrt_info;
+  S->fn_tol = c->fn_tol;
   std::memcpy(S->x0.pose, w->para_pose, sizeof S->x0.pose);
   std::memcpy(S->x0.sb, w->para_speed_bias, sizeof S->x0.sb);
   std::memcpy(S->x0.ex, w->para_ex_pose, sizeof S->x0.ex);
@@ -458,15 +472,17 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     S->imu_active[i] = !(w->imu[i].sum_dt > 10.0);  // estimator.cpp:720
   }
   // ---- landmarks: stable bucket sort by (start_frame, track length)
+  // What the host keeps about the slot (sizes, permutation, grid) is built beside it and committed where the copies are
+  // enqueued: an upload refused on the way — or a chained one, which collects the prior of the window still resident in
+  // between — leaves the slot's description matching what the device holds.
   SlotHostInfo &info = c->info[slot];
-  info.N = N, info.M = M;
-  info.max_iter = w->max_num_iterations, info.max_seconds = w->max_solver_time_in_seconds;
-  info.perm.resize(N);
+  std::vector<int> &perm = c->perm_build;
+  perm.resize(N);
   {
     int count[16 * 16 + 1] = {0};
     for (int l = 0; l < N; l++) count[w->start_frame[l] * 16 + (w->obs_offset[l + 1] - w->obs_offset[l]) + 1]++;
     for (int k = 0; k < 256; k++) count[k + 1] += count[k];
-    for (int l = 0; l < N; l++) info.perm[count[w->start_frame[l] * 16 + (w->obs_offset[l + 1] - w->obs_offset[l])]++] = l;
+    for (int l = 0; l < N; l++) perm[count[w->start_frame[l] * 16 + (w->obs_offset[l + 1] - w->obs_offset[l])]++] = l;
   }
   int *lm_start = (int *)(h + L.lm_start), *lm_cnt = (int *)(h + L.lm_cnt), *lm_obs0 = (int *)(h + L.lm_obs0);
   int *lm_perm = (int *)(h + L.lm_perm), *lm_woff = (int *)(h + L.lm_woff);
@@ -476,7 +492,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   int o = 0, N0 = 0, kmax0 = 0;
   int pair_count[NPAIR + 1] = {0};
   for (int dl = 0; dl < N; dl++) {
-    const int l = info.perm[dl];
+    const int l = perm[dl];
     const int s = w->start_frame[l], k = w->obs_offset[l + 1] - w->obs_offset[l], o0 = w->obs_offset[l];
     lm_start[dl] = s, lm_cnt[dl] = k, lm_obs0[dl] = o, lm_perm[dl] = l;
     lm_woff[dl] = dl == 0 ? 0 : lm_woff[dl - 1] + w_row_len(lm_cnt[dl - 1]);
@@ -526,7 +542,6 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->nLmBlocks = (N + LM_BLOCK - 1) / LM_BLOCK;
   S->schur_lm = SCHUR_LM;  // one part per landmark block: k_lin forms it from its LDS tile
   S->nSchurParts = S->nLmBlocks;
-  info.gLm = S->nLmBlocks, info.gLw = S->nSchurParts, info.gCh = nChunks, info.gSc = S->nSchurParts;
   int used_items = 0;
   bool lists_cached = false;
   // ---- gather lists of k_sum: which Gram entries (chunk or, for large windows, frame pair; local index of the
@@ -624,16 +639,9 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     if (int rc = check_input_prior(c, pr)) return rc;
     t_up1 = lap(1, t_up1);
   }
-  info.has_in_prior = pr != nullptr;
   for (int c2 = 0; c2 < KP; c2++) S->prior_inv[c2] = -1;
   if (pr) {
-    copy_prior(&info.in_prior, pr);
     S->prior_valid = 1, S->prior_n = pr->n, S->prior_nb = pr->num_blocks;
-    for (int i = 0; i < pr->num_blocks; i++)  // the structure k_solve_sparse assumes: the prior reaches no speed/bias block but sb_0
-      if (pr->blocks[i].kind == LFVIO_BLOCK_SPEEDBIAS && pr->blocks[i].frame != 0 && !c->dense_solve) {
-        c->dense_solve = true;
-        destroy_graph(c);  // the captured passes hold the kernel choice
-      }
     for (int i = 0; i < pr->num_blocks; i++) {
       S->prior_kind[i] = pr->blocks[i].kind, S->prior_frame[i] = pr->blocks[i].frame, S->prior_idx[i] = pr->block_idx[i];
       std::memcpy(S->prior_x0[i], pr->block_x0[i], sizeof(double) * 9);
@@ -648,7 +656,6 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   }
   plan_marg(w, pr, LFVIO_MARGIN_OLD, N0, kmax0, S->pair_chunk0[11], true, &S->marg[0]);
   plan_marg(w, pr, LFVIO_MARGIN_SECOND_NEW, 0, 0, 0, true, &S->marg[1]);
-  info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   for (int f = 0; f < 2; f++)
     if (S->marg[f].valid && (S->marg[f].n > 76 || S->marg[f].m15 + S->marg[f].n > 92)) {
       // k_marg_solve keeps the dense system in LDS: sized for what the reference's own marginalization produces
@@ -665,6 +672,15 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->chunk_pair.set(S, L.chunk_pair), S->chunk_begin.set(S, L.chunk_begin), S->chunk_end.set(S, L.chunk_end);
   S->prior_J.set(S, L.prior_J), S->prior_r.set(S, L.prior_r);
   S->sum_off.set(S, L.sum_off), S->sum_end_marg.set(S, L.sum_end_marg), S->sum_items.set(S, L.sum_items);
+  // ---- commit: from here on the device copy changes, and the slot's description with it
+  info.resident = false;
+  info.N = N, info.M = M;
+  info.max_iter = w->max_num_iterations, info.max_seconds = w->max_solver_time_in_seconds;
+  info.perm.swap(perm);
+  info.gLm = S->nLmBlocks, info.gLw = S->nSchurParts, info.gCh = nChunks, info.gSc = S->nSchurParts;
+  info.has_in_prior = pr != nullptr;
+  if (pr) copy_prior(&info.in_prior, pr);
+  info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, (lists_cached ? L.sum_off : L.sum_items + (size_t)used_items * 4) - L.in_begin, hipMemcpyHostToDevice,
@@ -708,6 +724,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   HIPCHK(c, hipEventRecord(c->stage_event, c->stream));
   c->stage_busy = true;
   lap(3, t_up2);
+  info.resident = true;
   return LFVIO_OK;
 }
 
@@ -794,11 +811,7 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
 
 void launch_solve(lfvio_ctx *c, int count) {
   const size_t st = c->L.total;
-  if (c->dense_solve || c->force_dense)
-    hipLaunchKernelGGL(k_solve_dense, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out);
-  else
-    hipLaunchKernelGGL(k_solve_sparse, dim3(1, count), dim3(S2_THREADS), SOLVE2_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out,
-                       (const S2DevTables *)c->d_s2);
+  hipLaunchKernelGGL(k_solve_dense, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out);
 }
 
 // speculate: small windows evaluate the steps for radius, radius / 2, radius / 4 in every pass (dev_types.h, SPEC_EXTRA)
@@ -1045,6 +1058,10 @@ int fetch(lfvio_ctx *c, int slot, bool want_sol, bool want_prior, Fetched *f) {
   const Layout &L = c->L;
   char *d = c->d_base + (size_t)slot * L.total;
   const SlotHostInfo &info = c->info[slot];
+  if (!info.resident) {
+    c->err = "slot not uploaded";
+    return LFVIO_ERR_ARG;
+  }
   char *hd = c->h_down;
   const size_t hdr = sizeof(FrameState) * 2 + sizeof(TRState), lam_bytes = (size_t)info.N * 8;
   char *h_lam0 = hd + hdr, *h_lam1 = h_lam0 + align_up(lam_bytes + 8, 64), *h_prior = h_lam1 + align_up(lam_bytes + 8, 64);
@@ -1200,24 +1217,6 @@ lfvio_ctx *lfvio_create(int device) {
   }
   // kernels that need more than the default 64 KiB of LDS
   (void)hipFuncSetAttribute((const void *)k_solve_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
-  (void)hipFuncSetAttribute((const void *)k_solve_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE2_LDS);
-  {  // where the speed/bias entries of H_pp go in the storage of k_solve_sparse (solve_plan.h)
-    std::vector<int> tab(S2_SB_SLOTS * 256, -1);
-    for (int t = 0; t < 256; t++)
-      for (int q = 0; q < 2; q++)
-        for (int k = 0; k < 9; k++) {
-          int i = 0, j = 0, mirror = -1;
-          if (!s2_combo_entry(t + 256 * q, k, &i, &j)) continue;
-          const int dst = s2_store(i, j, &mirror);
-          if (dst >= 0) tab[(9 * q + k) * 256 + t] = dst | ((mirror + 1) << 16);
-        }
-    if (hipMalloc((void **)&c->d_s2, sizeof(S2DevTables)) != hipSuccess ||
-        hipMemcpy(c->d_s2, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
-      lfvio_destroy(c);
-      return nullptr;
-    }
-  }
-  if (const char *e = getenv("LFVIO_SPARSE_SOLVE")) c->force_dense = e[0] != '1';
   if (const char *e = getenv("LFVIO_FIRST_PASSES")) c->fixed_passes = std::max(0, atoi(e));
   (void)hipFuncSetAttribute((const void *)k_marg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
   const char *env = getenv("LFVIO_NO_GRAPH");
@@ -1234,7 +1233,6 @@ void lfvio_destroy(lfvio_ctx *c) {
   if (c->h_feat) (void)hipHostFree(c->h_feat);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_down) (void)hipHostFree(c->h_down);
-  if (c->d_s2) (void)hipFree(c->d_s2);
   if (c->d_pending) (void)hipFree(c->d_pending);
   if (c->h_pending) (void)hipHostFree(c->h_pending);
   if (c->h_flags) {
@@ -1306,7 +1304,7 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
   (void)hipSetDevice(c->device);
   if (int rc = join_inflight(c)) return rc;
   c->has_held = false;  // (a prior nobody collected before the next optimization is dropped, like one left in the slot)
-  c->publish = early && adaptive && count == 1 && c->h_mail && c->info[0].uploaded && c->info[0].N <= MAIL_MAX_LM;
+  c->publish = early && adaptive && count == 1 && c->h_mail && c->info[0].resident && c->info[0].N <= MAIL_MAX_LM;
   struct PublishOff {
     lfvio_ctx *c;
     ~PublishOff() { c->publish = false; }
@@ -1316,7 +1314,7 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
   int max_iter = 0;
   double max_seconds = -1.0;
   for (int s = 0; s < count; s++) {
-    if (!c->info[s].uploaded) {
+    if (!c->info[s].resident) {
       c->err = "slot not uploaded";
       return LFVIO_ERR_ARG;
     }
@@ -1728,6 +1726,11 @@ int lfvio_debug_upload_times(lfvio_ctx *c, double *out4) {
 int lfvio_debug_set_first_passes(lfvio_ctx *c, int n) {
   if (!c || n < 0) return LFVIO_ERR_ARG;
   c->fixed_passes = n;
+  return LFVIO_OK;
+}
+int lfvio_debug_set_function_tolerance(lfvio_ctx *c, double tol) {
+  if (!c || !(tol >= 0.0)) return LFVIO_ERR_ARG;
+  c->fn_tol = tol;
   return LFVIO_OK;
 }
 int lfvio_debug_last_chunks(lfvio_ctx *c) { return c ? c->stat_chunks : -1; }

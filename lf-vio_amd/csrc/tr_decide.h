@@ -79,7 +79,7 @@ DEV int decide_walk(TRHead &t, const DecideSums &sm, int K, int sharded, int max
     t.skip_step = 1;
     return 0;
   }
-  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double function_tolerance = t.function_tolerance, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;  // (1e-6: k_setup)
   const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
   (void)gradient_tolerance;
   // (the per-candidate numbers are picked by compare-and-select: a run-time index into these small arrays would put them —

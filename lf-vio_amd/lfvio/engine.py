@@ -50,6 +50,11 @@ class Engine:
         self.lib.lfvio_debug_set_decide_merge.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_set_decide_merge(self.ctx, int(on))
 
+    def set_function_tolerance(self, tol):
+        """Diagnostic: function_tolerance of the windows uploaded from now on (1e-6 = Ceres' default; 0 = run to the cap)."""
+        self.lib.lfvio_debug_set_function_tolerance.argtypes = [C.c_void_p, C.c_double]
+        self._check(self.lib.lfvio_debug_set_function_tolerance(self.ctx, float(tol)), "set_function_tolerance")
+
     def last_chunks(self):
         return int(self.lib.lfvio_debug_last_chunks(self.ctx))
 

@@ -187,6 +187,14 @@ def set_eig_mode(mode):
     return L.oracle_set_eig_mode(int(mode))
 
 
+def set_function_tolerance(tol):
+    """Diagnostic knob: Solver::Options::function_tolerance (default 1e-6); 0 lets the loop run to its iteration cap."""
+    L = lib()
+    L.oracle_set_function_tolerance.argtypes = [C.c_double]
+    L.oracle_set_function_tolerance.restype = C.c_double
+    return L.oracle_set_function_tolerance(float(tol))
+
+
 def set_marg_threads(n):
     """4: marginalize() builds A, b on four threads like the reference's ThreadsConstructA (bit-identical sums); 1: serial."""
     L = lib()

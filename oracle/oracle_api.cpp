@@ -156,6 +156,10 @@ int oracle_set_eig_mode(int mode) {  // 0: Jacobi (parity default), 1: tridiagon
   g_eig_mode = mode == 1 ? 1 : 0;
   return g_eig_mode;
 }
+double oracle_set_function_tolerance(double tol) {  // diagnostic (tests/tools/fuzz_parity.py): 0 = run to the cap
+  g_function_tolerance = tol >= 0.0 ? tol : 1e-6;
+  return g_function_tolerance;
+}
 int oracle_set_marg_threads(int n) {
   g_marg_threads = n >= 4 ? 4 : 1;
   return g_marg_threads;

@@ -26,6 +26,8 @@
 
 namespace orc {
 
+double g_function_tolerance = 1e-6;
+
 // ---------------------------------------------------------------------------
 // Problem assembly (estimator.cpp:678-772)
 // ---------------------------------------------------------------------------
@@ -407,7 +409,7 @@ int solve(const LfvioWindow &w, LfvioSolution *out) {
   // Solver::Options (Ceres 1.12 defaults unless set at estimator.cpp:810-822)
   const int max_num_iterations = w.max_num_iterations;
   const double max_time = w.max_solver_time_in_seconds;
-  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double function_tolerance = g_function_tolerance, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;  // (1e-6 unless the diagnostic knob is set)
   const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
   const int max_num_consecutive_invalid_steps = 5;
 

@@ -1,0 +1,83 @@
+"""The cases of the randomized sweep (tests/tools/fuzz_parity.py, profiles/r03/fuzz.md) whose inverse depths were outside
+the 1e-6 bar, taken to ground: each is run (a) as the sweep ran it and (b) with BOTH solvers forced to
+converge — function_tolerance = 0 (lfvio_debug_set_function_tolerance / oracle_set_function_tolerance) and 50 iterations.
+If the two answers then agree to 1e-6 the early stop in a flat valley was the cause; if not, it is a bug.
+
+  python tests/tools/fuzz_outliers.py [case indices ...]     (GPU box; default: the 6 + 2 of profiles/r03/fuzz.md)
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd"))
+import numpy as np
+from lfvio import abi, synth
+from lfvio.engine import Engine
+from oracle import binding as ob
+
+CASES = [int(a) for a in sys.argv[1:]] or [14, 434, 689, 1130, 1537, 1551, 2187, 2344]
+
+
+def sweep_cases(K):
+    """the parameter draws of fuzz_parity.py, replayed (same generator, same order)"""
+    rng = np.random.default_rng(20260928)
+    out = []
+    for case in range(K):
+        seed = int(rng.integers(0, 10_000))
+        n = int(rng.choice([1, 2, 5, 9, 17, 33, 64, 65, 128, 300, 301, 700]))
+        kw = dict(estimate_extrinsic=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)),
+                  tr=float(rng.choice([0.0, 0.02])), max_num_iterations=int(rng.choice([1, 3, 8, 12])))
+        flag = int(rng.choice([abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW]))
+        with_prior = bool(rng.integers(0, 2))
+        out.append((seed, n, kw, flag, with_prior))
+    return out
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def run(eng, seed, n, kw, flag, with_prior, converge):
+    tol = 0.0 if converge else 1e-6
+    ob.set_function_tolerance(1e-6)  # (the window and its own prior are the sweep's: made with the default solver)
+    w = synth.make_window_with_prior(seed, n, lambda x, f: ob.optimize(x, f), **kw)[0] if with_prior else synth.make_window(seed, n, **kw)
+    if converge:
+        w = w.copy(max_num_iterations=50)
+    ob.set_function_tolerance(tol)
+    eng.set_function_tolerance(tol)
+    try:
+        rs = ob.solve(w)
+        gs = eng.solve(w)
+    finally:
+        ob.set_function_tolerance(1e-6)
+        eng.set_function_tolerance(1e-6)
+    a = ob.linearize(abi.apply_solution(w, rs))["a"]
+    return dict(lam=rel(gs.lam, rs.lam) if w.N else 0.0, pose=float(np.abs(gs.pose - rs.pose).max()),
+                it=(gs.c.num_iterations, rs.c.num_iterations), term=(gs.c.termination, rs.c.termination),
+                cost=(gs.c.final_cost, rs.c.final_cost), a_min=float(a.min()) if w.N else 0.0,
+                acc=(sum(t["successful"] for t in gs.trace()), sum(t["successful"] for t in rs.trace())),
+                last_change=abs(rs.trace()[-1]["cost_change"]) / max(rs.c.final_cost, 1e-300) if rs.c.num_iterations else 0.0)
+
+
+def main():
+    eng = Engine(0)
+    table = sweep_cases(max(CASES) + 1)
+    print("| case | seed | landmarks | options | as swept: inv-depth rel, iterations (gpu/oracle), last |cost change|/cost | "
+          "forced to converge (function_tolerance 0, 50 iterations): inv-depth rel, pose abs, iterations, termination, min a_l |")
+    print("|---|---|---|---|---|---|")
+    unexplained = 0
+    for case in CASES:
+        seed, n, kw, flag, wp = table[case]
+        a = run(eng, seed, n, kw, flag, wp, False)
+        b = run(eng, seed, n, kw, flag, wp, True)
+        ok = b["lam"] <= max(1e-6, 3e-11 / max(b["a_min"], 1e-300))
+        unexplained += 0 if ok else 1
+        print(f"| {case} | {seed} | {n} | ex {kw['estimate_extrinsic']} td {kw['estimate_td']} tr {kw['tr']} it {kw['max_num_iterations']}"
+              f"{' prior' if wp else ''} | {a['lam']:.2e}, {a['it'][0]}/{a['it'][1]}, {a['last_change']:.1e} | "
+              f"{b['lam']:.2e}, {b['pose']:.1e}, {b['it'][0]}/{b['it'][1]}, {b['term'][0]}/{b['term'][1]}, {b['a_min']:.2e}"
+              f"{'' if ok else '  <-- STILL OUTSIDE'} |")
+    print(f"\n{unexplained} of {len(CASES)} cases still outside the bar when both solvers run to convergence")
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
