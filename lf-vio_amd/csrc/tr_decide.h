@@ -140,6 +140,11 @@ DEV int decide_walk(TRHead &t, const DecideSums &sm, int K, int sharded, int max
             t.x_norm = sqrt(xn2c + xn_z);
             it.step_is_successful = 1;
             it.cost = candidate_cost;  // replaced by the re-evaluated x_cost when the trace is read
+            // Ceres evaluates the gradient at the accepted point before it looks at the iteration cap (HandleSuccessfulStep ->
+            // EvaluateGradientAndJacobian); here that is the next pass's linearization, and k_dogleg writes its max-norm into
+            // this entry.  A loop that ends with this step never linearizes there: the entry keeps -1 = not evaluated
+            // (include/lfvio.h).
+            it.gradient_max_norm = -1.0;
             if (it.relative_decrease < 0.25) t.radius *= 0.5;
             if (it.relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * snz);
             t.mu = fmax(1e-8, 2.0 * t.mu / 10.0);

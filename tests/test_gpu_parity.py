@@ -64,10 +64,21 @@ TRACE_WORST = {}
 def check_trace_summaries(tr, rt):
     for k, (a, b) in enumerate(zip(tr, rt)):
         assert a["valid"] == b["valid"], k
-        for f in ("gradient_max_norm", "step_norm"):
+        fields = ("gradient_max_norm", "step_norm")
+        if a["gradient_max_norm"] == -1.0:
+            # include/lfvio.h: the gradient at the point of a successful step that ENDED the loop is not evaluated on the
+            # device (it would take one more linearization; test_kkt_residual_at_the_solution compares it through the debug
+            # linearization instead) — legal in the last entry of the trace only
+            assert k == len(rt) - 1 and a["successful"], (k, len(rt))
+            fields = ("step_norm",)
+        for f in fields:
+            # (the gradient is a sum of terms of the size of the start gradient: where it has cancelled to 1e-12 of that —
+            # an IMU-only window solves to cost 1e-17 — what is left is rounding on both sides)
+            floor_f = 1e-12 * rt[0]["gradient_max_norm"] if f == "gradient_max_norm" else 0.0
             err = abs(a[f] - b[f]) / max(abs(b[f]), 1e-300) if b[f] != 0.0 else abs(a[f])
-            TRACE_WORST[f] = max(TRACE_WORST.get(f, 0.0), err)
-            assert err < 1e-6, (k, f, a[f], b[f])
+            if abs(a[f] - b[f]) > floor_f:
+                TRACE_WORST[f] = max(TRACE_WORST.get(f, 0.0), err)
+            assert abs(a[f] - b[f]) <= 1e-6 * abs(b[f]) + floor_f, (k, f, a[f], b[f])
         floor = 1e-10 * abs(b["cost"])
         err = abs(a["cost_change"] - b["cost_change"])
         TRACE_WORST["cost_change"] = max(TRACE_WORST.get("cost_change", 0.0), err / max(abs(b["cost_change"]), floor, 1e-300))
@@ -127,10 +138,9 @@ def test_kkt_residual_at_the_solution(eng, oracle, seed, n, kw):
     solvers minimise is the gradient J^T r of the robustified objective; each side linearizes at ITS OWN solution (the HIP
     path at the HIP solution through the C-ABI, the oracle at the oracle's) and the two residuals are compared — pose side
     g_p (172) and landmark side b (N) — together with the Gauss-Newton diagonal diag(J^T J) there.  Scale of the bar: the
-    gradient at the START state of the same window (the usual relative KKT measure, ||g(x*)|| / ||g(x0)||): the loop stops
-    on Ceres' function tolerance, not on a small gradient, so the residual at the solution itself is a cancellation
-    remainder whose own size is not a scale.  Also held: the max-norm of that residual against the oracle's to 1e-6 of the
-    same scale, and the final gradient_max_norm the solver reports against the one recomputed here."""
+    residual itself (1e-6 relative to ||g(x*)||_inf, the north_star's wording — the loop stops on Ceres' function tolerance,
+    so the residual at the solution is not small: 1e2 ... 2e3 against 1e9 at the start) and, as a second bar, 1e-10 of the
+    gradient at the START state (the usual relative KKT measure ||g(x*)|| / ||g(x0)||)."""
     w = synth.make_window(seed, n, **kw)
     sol, ref = eng.solve(w), oracle.solve(w)
     g0 = oracle.linearize(w)
@@ -142,8 +152,10 @@ def test_kkt_residual_at_the_solution(eng, oracle, seed, n, kw):
     d_g = max(np.abs(lh["g"] - lo["g"]).max(), np.abs(lh["b"] - lo["b"]).max())
     print(f"KKT seed {seed} n {n}: |g(x0)| {scale:.3e}  |g(x*)| hip {kkt_h:.6e} oracle {kkt_o:.6e}  |dg| {d_g:.2e} "
           f"(rel. to start {d_g / scale:.1e}, rel. to |g(x*)| {d_g / kkt_o:.1e})")
-    assert d_g <= 1e-6 * scale
-    assert abs(kkt_h - kkt_o) <= 1e-6 * scale
+    # measured (MI355X, round 4): |dg| / |g(x*)| = 7e-9 ... 7e-7, |dg| / |g(x0)| = 6e-16 ... 2e-12
+    assert d_g <= 1e-6 * kkt_o   # the north_star's bar, relative to the KKT residual itself
+    assert d_g <= 1e-10 * scale  # and what the agreement of the two solutions (1e-9 in the poses) implies
+    assert abs(kkt_h - kkt_o) <= 1e-6 * kkt_o
     assert rel(np.diag(lh["H"]), np.diag(lo["H"])) < 1e-6 and rel(lh["a"], lo["a"]) < 1e-6
     assert abs(lh["cost"] - lo["cost"]) <= 1e-7 * lo["cost"]
     # same linearization point, two implementations: the device's residual at the ORACLE's solution is the oracle's to rounding
