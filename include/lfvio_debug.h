@@ -42,6 +42,15 @@ int lfvio_debug_set_first_passes(lfvio_ctx *ctx, int n);
  * alone).  0 makes the loop run to its iteration cap or another criterion: the diagnostic of tests/tools/fuzz_parity.py, which
  * asks whether two solvers that disagree in the 6th digit of an inverse depth stopped early in a flat valley. */
 int lfvio_debug_set_function_tolerance(lfvio_ctx *ctx, double tol);
+/* How a resident batch is linearized: 1 (default) window-resident (k_linw: one workgroup per window, no partial sums through
+ * HBM) when the launch is a batch and every window carries a plan; 0 never (k_lin role by role + k_sum); 2 for every launch of
+ * planned windows, however few (tests).  Applies to windows uploaded afterwards.  Environment: LFVIO_LINW. */
+int lfvio_debug_set_linw(lfvio_ctx *ctx, int mode);
+/* One linearization + dense solve of the resident slots [0, count) by the path the launch takes; then, of slot `slot`: g_p[172],
+ * the Schur sums (15 x 256, tile layout), lm_sum[5], a[N], b[N] (device landmark order), the pose-side Gauss-Newton step [172], the
+ * dogleg model's quadratic forms [16], the cost.  Any output may be NULL.  Returns 1 if k_linw ran, 0 if k_lin + k_sum, < 0 on error. */
+int lfvio_debug_resident_pass(lfvio_ctx *ctx, int count, int slot, double *gp, double *schur, double *lm_sum, double *a, double *b, double *gn_p, double *q,
+                              double *x_cost);
 int lfvio_debug_last_chunks(lfvio_ctx *ctx);
 /* passes of the trust-region loop the slowest window of the last synchronous call used */
 int lfvio_debug_last_passes(lfvio_ctx *ctx);

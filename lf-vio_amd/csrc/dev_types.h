@@ -150,6 +150,20 @@ struct __attribute__((aligned(8))) TRFlags {
 };
 __device__ __forceinline__ TRFlags tr_flags(const TRState *tr) { return *reinterpret_cast<const TRFlags *>(&tr->iteration); }
 
+// Window-resident linearization of a resident batch (kernels_linw.h): one workgroup owns a window.  The landmarks of one
+// start frame (contiguous in device order) are cut into strips of at most 64; a wave takes whole strips — lane = landmark,
+// step o = the strip's observations in frame start + o, which all belong to ONE frame pair — so every pose-dependent
+// quantity of a step is wave-uniform and the step's <= 64 observations are a complete SYRK operand.
+constexpr int LINW_MAX_STRIPS = 16, LINW_WAVES = 4;
+struct LinwPlan {
+  int ok;         // the window fits the plan (N <= SPEC_MAX_LM, strips <= LINW_MAX_STRIPS) and its extra arrays are uploaded
+  int n_strips;
+  int wave_first[LINW_WAVES + 1];     // wave w takes strips [wave_first[w], wave_first[w + 1]); all strips of a start on one wave
+  short lm0[LINW_MAX_STRIPS], nlm[LINW_MAX_STRIPS], start[LINW_MAX_STRIPS], kmax[LINW_MAX_STRIPS];
+  int pair_obs0[NPAIR + 1];           // first pair-major observation of every frame pair (prefix sums)
+  short firstl[LFVIO_NUM_FRAMES][12];  // [start][o]: first landmark (device order) of that start frame with more than o observations
+};
+
 struct MargPlan {  // structure of the marginalization, computed on the host at upload
   int valid;       // 0: nothing to do (MARGIN_SECOND_NEW without a prior touching Pose[9])
   int m15;         // dropped pose-side dims (15 for MARGIN_OLD, 6 for SECOND_NEW)
@@ -201,12 +215,15 @@ struct Slot {
   int prior_inv[KP];             // tangent column -> prior column (-1: not in the prior)
   int pair_chunk0[NPAIR + 1];    // chunk range per pair slot
   MargPlan marg[2];              // [MARGIN_OLD, MARGIN_SECOND_NEW]
+  LinwPlan linw;
   // ---------------- input arrays (device pointers into the blob)
   GP<int> lm_start, lm_cnt, lm_obs0, lm_perm;
   GP<int> lm_woff;                 // [N + 1] offset of landmark l's row in W: rows are stored over their non-zero span only
   GP<double> lam0;
   GP<double> obs[8];                // px py pz vx vy vz cur_td uv_y, each [M]
   GP<int> pm_obs, pm_lm;           // [NV] pair-major: observation index, landmark index
+  GP<double> anc[8];                // [N] the anchor observation of every landmark, SoA in device order (k_linw)
+  GP<double> pmo[8];                // [NV] the non-anchor observations, SoA in pair-major order (k_linw: a strip step reads 64 consecutive ones)
   GP<int> chunk_pair, chunk_begin, chunk_end;
   GP<double> prior_J, prior_r;     // n*n, n
   GP<int> sum_off, sum_end_marg, sum_items;  // gather lists of k_sum: per H_pp / g_p entry, offsets into gram_part (or pairG)

@@ -32,7 +32,7 @@ DEV int gidx20(int p, int q) { return p * 20 - (p * (p - 1)) / 2 + (q - p); }  /
 // ---------------------------------------------------------------------------
 constexpr int SETUP_PRIOR_WGS = 16;
 constexpr int SETUP_WGS = 1 + LFVIO_WINDOW_SIZE + SETUP_PRIOR_WGS;
-__global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mode) {
+__global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mode, int zero_wt) {
   Slot *S = SLOT(base, stride);
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
@@ -145,6 +145,13 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     // inverse depths of the window: 256 landmarks per workgroup
     const int l = (blockIdx.x - SETUP_WGS) * 256 + tid;
     if (l < S->N) S->lam[0][l] = S->lam0[l];
+    if (zero_wt) {
+      // k_linw writes the transposed rows (Slot::Wt) over the landmarks' own spans only: what lies outside is zero from here
+      // on (the spans do not change during a call)
+      double2 *wt = (double2 *)(double *)S->Wt;
+      const int nw = gridDim.x - SETUP_WGS, w = blockIdx.x - SETUP_WGS;
+      for (int e = w * 256 + tid; e < WT_PAIRS * SPEC_MAX_LM; e += nw * 256) wt[e] = make_double2(0.0, 0.0);
+    }
   } else {
     // prior: A' = J0^T J0, b0 = J0^T r0 (constant over the solve), entries spread over SETUP_PRIOR_WGS workgroups
     if (!S->prior_valid) return;

@@ -162,7 +162,11 @@ DEV void solve_epilogue(Slot *S, TRState *tr, const double *ls, double gn2, doub
 // xch_off / imu_off: byte offsets of the exchange buffer (H_pp | g_p | Schur sums | scalars) and of the IMU factor outputs
 // inside a slot blob — passed by value so that the whole input of the kernel is requested in ONE round of loads, together
 // with the loop flags and before the first branch (a GP<> member would have to be fetched first: one more round trip).
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_t stride, long long xch_off, long long imu_off) {
+// ASSEMBLE (a resident batch linearized by k_linw, kernels_linw.h): the exchange buffer holds only the VISUAL terms of the
+// camera part of H_pp (packed rows 0 .. KC - 1); the (at most two) IMU factors and the prior of every entry are added here,
+// on load, in k_sum's order — the 119 KB packed matrix is never written or read back.  g_p arrives complete.
+template <bool ASSEMBLE>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_t stride, long long xch_off, long long imu_off, long long prior_A_off) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
@@ -179,7 +183,43 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
 #pragma unroll
     for (int t = 0; t < NTILES; t++) {
       const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
-      hreg[t] = (i < KP && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
+      if (!ASSEMBLE) hreg[t] = (i < KP && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
+    }
+    if (ASSEMBLE) {
+      // what this thread needs of the prior's column map: rows 16 a + er, columns 16 b + ek
+      int pinv_r[NTL], pinv_c[NTL];
+      const int prior_ok = S->prior_valid && (!S->sharded || S->pose_side), prior_n = S->prior_n;
+#pragma clang loop unroll(full)
+      for (int a = 0; a < NTL; a++) {
+        const int i = 16 * a + er, j = 16 * a + ek;
+        pinv_r[a] = i < KP ? S->prior_inv[i] : -1, pinv_c[a] = j < KP ? S->prior_inv[j] : -1;
+      }
+      const double *imu_out = (const double *)((const char *)S + imu_off), *prior_A = (const double *)((const char *)S + prior_A_off);
+      const bool ex_on = S->est_ex != 0, td_on = S->est_td != 0;
+#pragma clang loop unroll(full)
+      for (int t = 0; t < NTILES; t++) {
+        const int a = tile_a(t), b = tile_b(t), i = 16 * a + er, j = 16 * b + ek;
+        double h = 0.0;
+        if (i < KP && j <= i) {
+          if (i < KC) h = Hg[i * (i + 1) / 2 + j];
+          const int f0 = col_frame(i);
+          if (f0 >= 0) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const int f = f0 - 1 + u;
+              if (f >= 0 && f < LFVIO_WINDOW_SIZE) {
+                const int pl = imu_local(i, f), ql = imu_local(j, f);
+                if (pl >= 0 && ql >= 0) h += imu_out[(size_t)f * IMU_OUT + pl * 30 + ql];
+              }
+            }
+          }
+          if (prior_ok && pinv_r[a] >= 0 && pinv_c[b] >= 0) h += prior_A[pinv_r[a] * prior_n + pinv_c[b]];
+          const bool act_i = (ex_on || i < off_ex() || i >= off_ex() + 6) && (td_on || i != off_td());
+          const bool act_j = (ex_on || j < off_ex() || j >= off_ex() + 6) && (td_on || j != off_td());
+          if (!(act_i && act_j)) h = 0.0;
+        }
+        hreg[t] = h;
+      }
     }
     if (tid < KP) gval = xch[XOFF_G + tid];
     int n15 = 0;

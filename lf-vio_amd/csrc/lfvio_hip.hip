@@ -36,6 +36,7 @@ constexpr ncclDataType_t ncclDouble = 8;
 #include "kernels_marg.h"
 #include "kernels_solve.h"
 #include "kernels_feat.h"
+#include "kernels_linw.h"
 
 #define HIPCHK(ctx, call)                                                                      \
   do {                                                                                         \
@@ -54,6 +55,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   int maxN = 0, maxM = 0;
   int capLmBlocks = 0, capChunks = 0, capSchurParts = 0;
   size_t in_begin = 0, in_end = 0, total = 0;
+  size_t anc[8], pmo[8], linw_begin = 0, linw_end = 0;  // k_linw's copies of the observations (behind the regular inputs: uploaded on their own, resident batches only)
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lm_woff, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
   size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, Wt, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
@@ -89,6 +91,10 @@ Layout make_layout(int maxN, int maxM) {
   L.sum_items = take((size_t)SUM_ITEMS_CAP * 4);
   L.prior_J = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
   L.in_end = o;
+  L.linw_begin = o;
+  for (int k = 0; k < 8; k++) L.anc[k] = take(N * 8);
+  for (int k = 0; k < 8; k++) L.pmo[k] = take(M * 8);
+  L.linw_end = o;
   L.lam[0] = take(LB * 8), L.lam[1] = take(LB * 8);
   for (int k = 0; k < SPEC_EXTRA; k++) L.lamE[k] = take((size_t)SPEC_MAX_LM * 8);
   L.cost_partE = take((size_t)SPEC_EXTRA * (SPEC_MAX_LM / 64) * LMS * 8);
@@ -120,6 +126,7 @@ struct SlotHostInfo {
   int max_iter = 0;          // LfvioWindow::max_num_iterations of the uploaded window
   double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
   std::vector<int> perm;  // device order -> caller order
+  bool linw_ok = false;    // the window carries a LinwPlan and its arrays (kernels_linw.h)
   bool uploaded = false;   // the slot's work-array pointers are on the device (until the next reserve())
   bool resident = false;   // a window is resident: N, perm, grid sizes below describe what the device holds.  Cleared while an upload
                            // rewrites them and set again when its copies are enqueued, so a refused upload leaves a slot that every
@@ -151,7 +158,7 @@ struct lfvio_ctx {
   std::vector<int> perm_build;  // upload_window builds the next permutation here and swaps it in at its commit point
   // cached graph of the solve loop
   hipGraphExec_t graph = nullptr;
-  int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0;
+  int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0, g_linw = 0;
   // cached graph of one chunk of passes (synchronous entry points: the loop is launched chunk by chunk)
   // [publish]: the variants whose gated gauge fix / marginalization also push state and prior into the caller's mailbox
   // (lfvio_batch_optimize_begin) — a kernel argument, so the plain call pays nothing for the split one
@@ -161,7 +168,7 @@ struct lfvio_ctx {
   int fixed_passes = 0;             // debug (LFVIO_FIRST_PASSES / lfvio_debug_set_first_passes): > 0 sizes every first graph with this many passes
   int predict_passes = 4;           // passes the previous synchronous call needed; tail[flag]: force-done + gated gauge fix + marginalization
   double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
-  int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0;
+  int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0, k_linw = 0;
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   // lfvio_batch_optimize_begin / _finish: the solution of slot 0 arrives in host memory the gated gauge fix writes directly
   // (Slot::mail, dev_types.h MAIL_*) while the marginalization of the same graph is still running; `inflight` from the moment
@@ -184,6 +191,8 @@ struct lfvio_ctx {
   bool use_graph = true;
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
   int last_passes = 0;  // passes of the trust-region loop the last synchronous call used (slowest slot)
+  int linw_mode = 1;     // 1: resident batches linearize with k_linw when every slot of the launch carries a plan; 0: never (k_lin roles + k_sum);
+                         // 2: any launch of planned windows, however few (tests).  LFVIO_LINW / lfvio_debug_set_linw
   double fn_tol = 1e-6;  // function_tolerance of the windows uploaded from now on (debug: lfvio_debug_set_function_tolerance)
   bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
   // landmark-sharded mode (multi-GPU)
@@ -276,7 +285,7 @@ int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
   Layout L = make_layout(maxN + maxN / 4 + 64, maxM + maxM / 4 + 256);
   HIPCHK(c, hipMalloc((void **)&c->d_base, L.total * (size_t)batch));
   HIPCHK(c, hipMemsetAsync(c->d_base, 0, L.total * (size_t)batch, c->stream));
-  HIPCHK(c, hipHostMalloc((void **)&c->h_stage, L.in_end, hipHostMallocDefault));
+  HIPCHK(c, hipHostMalloc((void **)&c->h_stage, L.linw_end, hipHostMallocDefault));
   c->h_down_bytes = down_bytes(L.maxN);
   HIPCHK(c, hipHostMalloc((void **)&c->h_down, c->h_down_bytes, hipHostMallocDefault));
   c->L = L;
@@ -399,6 +408,9 @@ int check_input_prior(lfvio_ctx *c, const LfvioPrior *pr) {
   }
   return LFVIO_OK;
 }
+
+constexpr size_t LIN_SPLIT_WGS = 2048;  // launches of k_lin with more workgroups than this are issued role by role ...
+constexpr int LIN_SPLIT_MIN_BATCH = 8;   // ... when they are a batch: ONE large window (100 000 landmarks: 64 us as one grid, 54 + 35 + 14 role by role) is better off with its roles overlapping
 
 // Pack one window into the pinned staging blob and upload it to slot `slot`.
 // chain (lfvio_batch_upload_chained): the window's prior is *chain, and if a call is still in flight on the context (the
@@ -542,6 +554,71 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->nLmBlocks = (N + LM_BLOCK - 1) / LM_BLOCK;
   S->schur_lm = SCHUR_LM;  // one part per landmark block: k_lin forms it from its LDS tile
   S->nSchurParts = S->nLmBlocks;
+  // ---- k_linw (kernels_linw.h): strips of <= 64 landmarks of one start frame, dealt to the four waves of the window's
+  //      workgroup (all strips of a start frame on one wave: it is the one writer of that frame's pair blocks), and the
+  //      observations once more in the orders its lanes read them — anchors by landmark, the others pair-major.
+  bool linw = c->linw_mode != 0 && !sharded && N <= SPEC_MAX_LM && (c->batch >= LIN_SPLIT_MIN_BATCH || c->linw_mode == 2);
+  if (linw) {
+    LinwPlan &P = S->linw;
+    int begin_s[LFVIO_NUM_FRAMES + 1];
+    {
+      int dl = 0;
+      for (int s = 0; s <= LFVIO_NUM_FRAMES; s++) {
+        while (dl < N && lm_start[dl] < s) dl++;
+        begin_s[s] = dl;
+      }
+    }
+    struct Strip {
+      int lm0, nlm, start, kmax;
+    };
+    std::vector<Strip> by_start[LFVIO_NUM_FRAMES];
+    int cost[LFVIO_NUM_FRAMES] = {0}, n_strips = 0;
+    for (int s = 0; s < LFVIO_NUM_FRAMES; s++) {
+      for (int o2 = 0; o2 < 12; o2++) {
+        int f = begin_s[s];
+        while (f < begin_s[s + 1] && lm_cnt[f] <= o2) f++;
+        P.firstl[s][o2] = (short)f;
+      }
+      for (int l0 = begin_s[s]; l0 < begin_s[s + 1]; l0 += 64) {
+        const int n = std::min(64, begin_s[s + 1] - l0);
+        by_start[s].push_back(Strip{l0, n, s, lm_cnt[l0 + n - 1]});  // (ascending track length inside a start frame: the last one is the longest)
+        cost[s] += lm_cnt[l0 + n - 1] - 1;
+        n_strips++;
+      }
+    }
+    if (n_strips > LINW_MAX_STRIPS) linw = false;
+    else {
+      // longest-processing-time first over the start frames
+      int order[LFVIO_NUM_FRAMES], load[LINW_WAVES] = {0};
+      for (int s = 0; s < LFVIO_NUM_FRAMES; s++) order[s] = s;
+      std::stable_sort(order, order + LFVIO_NUM_FRAMES, [&](int a, int b) { return cost[a] > cost[b]; });
+      std::vector<Strip> per_wave[LINW_WAVES];
+      for (int k = 0; k < LFVIO_NUM_FRAMES; k++) {
+        const int s = order[k];
+        if (by_start[s].empty()) continue;
+        int w = 0;
+        for (int q = 1; q < LINW_WAVES; q++)
+          if (load[q] < load[w]) w = q;
+        load[w] += cost[s];
+        per_wave[w].insert(per_wave[w].end(), by_start[s].begin(), by_start[s].end());
+      }
+      int t = 0;
+      for (int w = 0; w < LINW_WAVES; w++) {
+        P.wave_first[w] = t;
+        for (const Strip &st : per_wave[w]) P.lm0[t] = (short)st.lm0, P.nlm[t] = (short)st.nlm, P.start[t] = (short)st.start, P.kmax[t] = (short)st.kmax, t++;
+      }
+      P.wave_first[LINW_WAVES] = t;
+      P.n_strips = t;
+      for (int p = 0; p <= NPAIR; p++) P.pair_obs0[p] = pair_count[p];
+      double *anc[8], *pmo[8];
+      for (int k = 0; k < 8; k++) anc[k] = (double *)(h + L.anc[k]), pmo[k] = (double *)(h + L.pmo[k]);
+      for (int dl = 0; dl < N; dl++)
+        for (int k = 0; k < 8; k++) anc[k][dl] = obs[k][lm_obs0[dl]];
+      for (int q = 0; q < M - N; q++)
+        for (int k = 0; k < 8; k++) pmo[k][q] = obs[k][pm_obs[q]];
+    }
+    P.ok = linw ? 1 : 0;
+  }
   int used_items = 0;
   bool lists_cached = false;
   // ---- gather lists of k_sum: which Gram entries (chunk or, for large windows, frame pair; local index of the
@@ -669,6 +746,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->lam0.set(S, L.lam0);
   for (int k = 0; k < 8; k++) S->obs[k].set(S, L.obs[k]);
   S->pm_obs.set(S, L.pm_obs), S->pm_lm.set(S, L.pm_lm);
+  for (int k = 0; k < 8; k++) S->anc[k].set(S, L.anc[k]), S->pmo[k].set(S, L.pmo[k]);
   S->chunk_pair.set(S, L.chunk_pair), S->chunk_begin.set(S, L.chunk_begin), S->chunk_end.set(S, L.chunk_end);
   S->prior_J.set(S, L.prior_J), S->prior_r.set(S, L.prior_r);
   S->sum_off.set(S, L.sum_off), S->sum_end_marg.set(S, L.sum_end_marg), S->sum_items.set(S, L.sum_items);
@@ -681,11 +759,13 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   info.has_in_prior = pr != nullptr;
   if (pr) copy_prior(&info.in_prior, pr);
   info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
+  info.linw_ok = linw;
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, (lists_cached ? L.sum_off : L.sum_items + (size_t)used_items * 4) - L.in_begin, hipMemcpyHostToDevice,
                            c->stream));
   if (pr) HIPCHK(c, hipMemcpyAsync(d + L.prior_J, h + L.prior_J, sizeof(double) * pr->n * pr->n, hipMemcpyHostToDevice, c->stream));
+  if (linw) HIPCHK(c, hipMemcpyAsync(d + L.linw_begin, h + L.linw_begin, L.linw_end - L.linw_begin, hipMemcpyHostToDevice, c->stream));
   info.list_items = used_items;  // (only now: an upload refused half-way leaves the key without lists on the device)
   if (!info.uploaded) {
     // work-array pointers: fixed per slot until the next reserve()
@@ -751,8 +831,6 @@ struct Grid {
   int ch_raw;  // largest chunk count of a slot before the rounding of `ch` (what decides the two-level sums: upload_window's pre_gram)
 };
 constexpr int CH_BUCKET = 16;
-constexpr size_t LIN_SPLIT_WGS = 2048;  // launches of k_lin with more workgroups than this are issued role by role ...
-constexpr int LIN_SPLIT_MIN_BATCH = 8;   // ... when they are a batch: ONE large window (100 000 landmarks: 64 us as one grid, 54 + 35 + 14 role by role) is better off with its roles overlapping
 
 Grid grid_for(lfvio_ctx *c, int count) {
   Grid g{1, 1, 1, 1, 1};
@@ -809,9 +887,24 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre, sa);
 }
 
-void launch_solve(lfvio_ctx *c, int count) {
+// lw: the pass was linearized by k_linw — H_pp holds the visual terms of its camera part only, the solve adds the rest on load
+void launch_solve(lfvio_ctx *c, int count, bool lw = false) {
   const size_t st = c->L.total;
-  hipLaunchKernelGGL(k_solve_dense, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out);
+  if (lw)
+    hipLaunchKernelGGL(k_solve_dense<true>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out,
+                       (long long)c->L.prior_A);
+  else
+    hipLaunchKernelGGL(k_solve_dense<false>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out,
+                       (long long)c->L.prior_A);
+}
+
+// A resident batch whose windows all carry a LinwPlan is linearized window by window (kernels_linw.h) instead of role by role.
+bool use_linw(lfvio_ctx *c, int count, const Grid &g, int mode) {
+  if (mode != MODE_SOLVE || c->linw_mode == 0 || c->shard_active) return false;
+  if (c->linw_mode != 2 && !lin_split(count, g)) return false;
+  for (int s = 0; s < count; s++)
+    if (!c->info[s].linw_ok) return false;
+  return true;
 }
 
 // speculate: small windows evaluate the steps for radius, radius / 2, radius / 4 in every pass (dev_types.h, SPEC_EXTRA)
@@ -824,22 +917,31 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   const bool solve = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & MODE_GATED);
   // (latency of few windows only: in a resident batch every workgroup of k_lin repeating the decision costs more of the
   // GPU than the launch it saves)
-  const bool merge = solve && g.lm <= DOGLEG_INLINE_BLOCKS && !c->no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
-  launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
-  launch_sum(c, count, g, mode);
+  const bool lw = use_linw(c, count, g, mode);
+  const bool merge = solve && !lw && g.lm <= DOGLEG_INLINE_BLOCKS && !c->no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
+  if (lw) {
+    // pose-side factors first (IMU evaluations one lane per factor, then the weighting / J^T J role and the prior), then the
+    // window-resident sweep: one workgroup per window, which counts the pass and finishes g_p
+    hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
+    hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
+    hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, (long long)c->L.imu_out);
+  } else {
+    launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
+    launch_sum(c, count, g, mode);
+  }
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
-    launch_solve(c, count);
+    launch_solve(c, count, lw);
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
     const int spec = speculate && inl ? 1 + SPEC_EXTRA : 1;
     const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
     // few small windows: the step and the cost of its candidates in one launch (k_step)
-    const bool split = lin_split(count, g);
+    const bool split = lin_split(count, g) || lw;
     const bool fuse = inl && !split && !c->no_fuse && !c->shard_active && (size_t)count * nb <= 2048;
     if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
     if (fuse) hipLaunchKernelGGL(k_step, dim3(spec * nb, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, g.lm, spec);
     else {
-      if (inl && !split) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(spec, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, spec);
+      if (inl && (!split || lw)) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(spec, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, spec);
       else if (inl) hipLaunchKernelGGL((k_dogleg<true, false>), dim3(spec, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, spec);
       else hipLaunchKernelGGL(k_dogleg<false>, dim3(spec, count), dim3(128), 0, c->stream, c->d_base, st, spec);
     }
@@ -913,9 +1015,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipMalloc((void **)&c->d_pending, 256));
       HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
     }
-    if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate) {
+    const int lwk = use_linw(c, count, g, MODE_SOLVE) ? 1 : 0;
+    if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk) {
       destroy_graph(c);
-      c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate;
+      c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk;
     }
     if (tail_done) *tail_done = false;
     const bool fuse = fused_flag >= 0 && fused_flag < 2;
@@ -936,7 +1039,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       CaptureGuard guard(c->stream);
       if (setup)
-        hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+        hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
       bool gauged = false;
       for (int it = 0; it < npass; it++) gauged = launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1, tail_flag >= 0);
       if (tail_flag >= 0) {
@@ -1006,9 +1109,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     HIPCHK(c, hipGetLastError());
     return LFVIO_OK;
   }
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
   if (c->use_graph) {
-    if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes) {
+    const int lwg = use_linw(c, count, g, MODE_SOLVE) ? 1 : 0;
+    if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes || c->g_linw != lwg) {
       if (c->graph) (void)hipGraphExecDestroy(c->graph), c->graph = nullptr;
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1017,7 +1121,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, guard.end(&graph));
       HIPCHK(c, hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
-      c->g_batch = count, c->g_lm = g.lm, c->g_ch = g.ch, c->g_sc = g.sc, c->g_iters = passes;
+      c->g_batch = count, c->g_lm = g.lm, c->g_ch = g.ch, c->g_sc = g.sc, c->g_iters = passes, c->g_linw = lwg;
     }
     HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
   } else {
@@ -1032,7 +1136,7 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated)
   const Grid g = grid_for(c, count);
   const int mode = (MODE_MARG + flag) | (gated ? MODE_GATED : 0);
   if (standalone)
-    hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode);
+    hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode, 0);
   launch_iteration(c, count, g, mode);
   hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total,
                      flag | (c->force_eig ? 256 : 0) | (gated ? 512 : 0) | (gated && c->publish ? 1024 : 0));
@@ -1216,7 +1320,10 @@ lfvio_ctx *lfvio_create(int device) {
     (void)hipGetLastError();
   }
   // kernels that need more than the default 64 KiB of LDS
-  (void)hipFuncSetAttribute((const void *)k_solve_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
+  (void)hipFuncSetAttribute((const void *)k_solve_dense<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
+  (void)hipFuncSetAttribute((const void *)k_solve_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
+  (void)hipFuncSetAttribute((const void *)k_linw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
+  if (const char *e = getenv("LFVIO_LINW")) c->linw_mode = std::max(0, std::min(2, atoi(e)));
   if (const char *e = getenv("LFVIO_FIRST_PASSES")) c->fixed_passes = std::max(0, atoi(e));
   (void)hipFuncSetAttribute((const void *)k_marg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
   const char *env = getenv("LFVIO_NO_GRAPH");
@@ -1576,7 +1683,7 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   if (rc) return rc;
   if ((rc = upload_window(c, 0, in))) return rc;
   const Grid g = grid_for(c, 1);
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, 1).lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, 1).lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, 0);
   launch_lin(c, 1, g, MODE_SOLVE);
   launch_sum(c, 1, g, MODE_SOLVE);
   launch_solve(c, 1);
@@ -1623,6 +1730,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
   if (rc) return rc;
   if ((rc = upload_window(c, 0, in))) return rc;
   const Grid g = grid_for(c, 1);
+  const bool lw = use_linw(c, 1, g, MODE_SOLVE);  // (lfvio_debug_set_linw(ctx, 2): the window-resident sweep, for one window)
   char *d = c->d_base;
   const size_t o_tr = offsetof(Slot, tr);
   auto poke_int = [&](size_t off, int v) { return hipMemcpy(d + o_tr + off, &v, sizeof v, hipMemcpyHostToDevice); };
@@ -1630,21 +1738,27 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
     HIPCHK(c, hipMemcpy(d + o_tr + offsetof(TRState, mu), &mu, sizeof mu, hipMemcpyHostToDevice));
     HIPCHK(c, poke_int(offsetof(TRState, do_lin), do_lin));
     HIPCHK(c, poke_int(offsetof(TRState, do_schur), 1));
-    launch_lin(c, 1, g, MODE_SOLVE);
-    launch_sum(c, 1, g, MODE_SOLVE);
+    if (lw) {
+      hipLaunchKernelGGL(k_imu_raw, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, 1);
+      hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE | MODE_NOCOUNT, 0, 0);
+      hipLaunchKernelGGL(k_linw, dim3(1, 1), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, (long long)c->L.imu_out);
+    } else {
+      launch_lin(c, 1, g, MODE_SOLVE);
+      launch_sum(c, 1, g, MODE_SOLVE);
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out.resize(SCHUR_LEN);
     HIPCHK(c, hipMemcpy(out.data(), d + c->L.xch + sizeof(double) * XOFF_S, sizeof(double) * SCHUR_LEN, hipMemcpyDeviceToHost));
     return LFVIO_OK;
   };
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE);
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, lw ? 1 : 0);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<double> first, repeat, full;
   const double mu1 = mu;
   mu = 1e-8;
   if ((rc = run(1, first))) return rc;   // ordinary first pass (fixes the Jacobi scaling: k_solve does that, so run it)
-  launch_solve(c, 1);
+  launch_solve(c, 1, lw);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   mu = mu1;
   if ((rc = run(0, repeat))) return rc;  // Schur only, new mu
@@ -1686,10 +1800,17 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
+  const bool lw = use_linw(c, count, g, MODE_SOLVE);
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
   // one full linearization so that every kernel has valid inputs
-  launch_lin(c, count, g, MODE_SOLVE);
-  launch_sum(c, count, g, MODE_SOLVE);
+  if (lw) {
+    hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
+    hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE | MODE_NOCOUNT, 0, 0);
+    hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, (long long)c->L.imu_out);
+  } else {
+    launch_lin(c, count, g, MODE_SOLVE);
+    launch_sum(c, count, g, MODE_SOLVE);
+  }
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
@@ -1703,8 +1824,20 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
       } break;
       case 4: case 5: case 6: case 7: {  // k_setup by role: state + table | + IMU sqrt_info | + prior J0^T J0 | + inverse depths
         const int gx = which == 4 ? 1 : which == 5 ? 1 + LFVIO_WINDOW_SIZE : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
-        hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE);
+        hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
       } break;
+      case 11: case 12:  // the window-resident sweep of a batch: k_linw alone (12), with the pose-side launches in front of it (11)
+        if (!use_linw(c, count, g, MODE_SOLVE)) {
+          c->err = "the resident windows are not linearized by k_linw";
+          return LFVIO_ERR_ARG;
+        }
+        if (which == 11) {
+          hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
+          hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE | MODE_NOCOUNT, 0, 0);
+        }
+        hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, (long long)c->L.imu_out);
+        break;
+      case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;
       default: launch_solve(c, count); break;
     }
   }
@@ -1718,6 +1851,45 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   return LFVIO_OK;
 }
 
+// One linearization + dense solve of the resident slots [0, count) from their uploaded state, by whichever path the launch
+// takes (k_linw or k_lin roles + k_sum: lfvio_debug_set_linw), then what the pass left in slot `slot`:
+// gp[172], schur[15 * 256] (tile layout), lm_sum[5], a[N], b[N], gn_p[172] (pose-side Gauss-Newton step), q[16] (the quadratic
+// forms of the dogleg model), x_cost.  tests/test_linw.py holds the two paths against each other with it.
+int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, double *schur, double *lm_sum, double *a, double *b, double *gn_p, double *q,
+                              double *x_cost) {
+  if (!c || !c->d_base || count <= 0 || count > c->batch || slot < 0 || slot >= count) return LFVIO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (int rc = join_inflight(c)) return rc;
+  for (int s = 0; s < count; s++)
+    if (!c->info[s].resident) return LFVIO_ERR_ARG;
+  const Grid g = grid_for(c, count);
+  const size_t st = c->L.total;
+  const bool lw = use_linw(c, count, g, MODE_SOLVE);
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
+  if (lw) {
+    hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
+    hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE | MODE_NOCOUNT, 0, 0);
+    hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, (long long)c->L.imu_out);
+  } else {
+    launch_lin(c, count, g, MODE_SOLVE);
+    launch_sum(c, count, g, MODE_SOLVE);
+  }
+  launch_solve(c, count, lw);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const char *d = c->d_base + (size_t)slot * st;
+  const int N = c->info[slot].N;
+  auto get = [&](double *dst, size_t off, size_t n) { return !dst || !n ? hipSuccess : hipMemcpy(dst, d + off, n * 8, hipMemcpyDeviceToHost); };
+  HIPCHK(c, get(gp, c->L.xch + (size_t)XOFF_G * 8, KP));
+  HIPCHK(c, get(schur, c->L.xch + (size_t)XOFF_S * 8, SCHUR_LEN));
+  HIPCHK(c, get(lm_sum, offsetof(Slot, lm_sum), 5));
+  HIPCHK(c, get(a, c->L.a, N));
+  HIPCHK(c, get(b, c->L.b, N));
+  HIPCHK(c, get(gn_p, offsetof(Slot, gn_p), KP));
+  HIPCHK(c, get(q, offsetof(Slot, tr) + offsetof(TRState, q), Q_COUNT));
+  HIPCHK(c, get(x_cost, offsetof(Slot, tr) + offsetof(TRState, x_cost), 1));
+  return lw ? 1 : 0;
+}
+
 int lfvio_debug_upload_times(lfvio_ctx *c, double *out4) {
   if (!c || !out4) return LFVIO_ERR_ARG;
   for (int k = 0; k < 4; k++) out4[k] = c->up_us[k];
@@ -1726,6 +1898,13 @@ int lfvio_debug_upload_times(lfvio_ctx *c, double *out4) {
 int lfvio_debug_set_first_passes(lfvio_ctx *c, int n) {
   if (!c || n < 0) return LFVIO_ERR_ARG;
   c->fixed_passes = n;
+  return LFVIO_OK;
+}
+int lfvio_debug_set_linw(lfvio_ctx *c, int mode) {
+  if (!c || mode < 0 || mode > 2) return LFVIO_ERR_ARG;
+  if (int rc = join_inflight(c)) return rc;
+  c->linw_mode = mode;  // (takes effect with the next upload: the plan and its arrays are built there)
+  destroy_graph(c);
   return LFVIO_OK;
 }
 int lfvio_debug_set_function_tolerance(lfvio_ctx *c, double tol) {

@@ -50,6 +50,23 @@ class Engine:
         self.lib.lfvio_debug_set_decide_merge.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_set_decide_merge(self.ctx, int(on))
 
+    def set_linw(self, mode):
+        """How resident batches are linearized (include/lfvio_debug.h): 1 default, 0 never k_linw, 2 every launch of planned windows."""
+        self.lib.lfvio_debug_set_linw.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.lfvio_debug_set_linw(self.ctx, int(mode)), "set_linw")
+
+    def resident_pass(self, count, slot, n_landmarks):
+        """One linearization + dense solve of the resident slots; what it left in `slot` (lfvio_debug_resident_pass)."""
+        out = dict(gp=np.zeros(abi.KP), schur=np.zeros(15 * 256), lm_sum=np.zeros(5), a=np.zeros(max(n_landmarks, 1)),
+                   b=np.zeros(max(n_landmarks, 1)), gn_p=np.zeros(abi.KP), q=np.zeros(16), x_cost=np.zeros(1))
+        dp = C.POINTER(C.c_double)
+        self.lib.lfvio_debug_resident_pass.argtypes = [C.c_void_p, C.c_int, C.c_int] + [dp] * 8
+        rc = self.lib.lfvio_debug_resident_pass(self.ctx, count, slot, *[_p(out[k]) for k in ("gp", "schur", "lm_sum", "a", "b", "gn_p", "q", "x_cost")])
+        if rc < 0:
+            self._check(rc, "resident_pass")
+        out["a"], out["b"], out["linw"] = out["a"][:n_landmarks], out["b"][:n_landmarks], rc
+        return out
+
     def set_function_tolerance(self, tol):
         """Diagnostic: function_tolerance of the windows uploaded from now on (1e-6 = Ceres' default; 0 = run to the cap)."""
         self.lib.lfvio_debug_set_function_tolerance.argtypes = [C.c_void_p, C.c_double]

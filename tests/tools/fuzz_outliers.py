@@ -50,10 +50,22 @@ def run(eng, seed, n, kw, flag, with_prior, converge):
     finally:
         ob.set_function_tolerance(1e-6)
         eng.set_function_tolerance(1e-6)
+    if True:
+        # how far the ORACLE's own answer moves when its input poses move by one or ten units in the last place: the
+        # conditioning of the iteration map itself (an under-determined window — one or two landmarks, extrinsic free —
+        # has directions the data does not fix; where the loop leaves them is decided by rounding in ANY implementation)
+        self_lam = self_ex = 0.0
+        ob.set_function_tolerance(tol)
+        for eps in (1e-15, 1e-14):
+            r2 = ob.solve(w.copy(pose=w.pose * (1 + eps)))
+            self_lam = max(self_lam, rel(r2.lam, rs.lam) if w.N else 0.0)
+            self_ex = max(self_ex, float(np.abs(r2.ex_pose - rs.ex_pose).max()))
+        ob.set_function_tolerance(1e-6)
     a = ob.linearize(abi.apply_solution(w, rs))["a"]
     return dict(lam=rel(gs.lam, rs.lam) if w.N else 0.0, pose=float(np.abs(gs.pose - rs.pose).max()),
                 it=(gs.c.num_iterations, rs.c.num_iterations), term=(gs.c.termination, rs.c.termination),
-                cost=(gs.c.final_cost, rs.c.final_cost), a_min=float(a.min()) if w.N else 0.0,
+                cost=(gs.c.final_cost, rs.c.final_cost), a_min=float(a.min()) if w.N else 0.0, self_lam=self_lam, self_ex=self_ex,
+                ex=float(np.abs(gs.ex_pose - rs.ex_pose).max()),
                 acc=(sum(t["successful"] for t in gs.trace()), sum(t["successful"] for t in rs.trace())),
                 last_change=abs(rs.trace()[-1]["cost_change"]) / max(rs.c.final_cost, 1e-300) if rs.c.num_iterations else 0.0)
 
@@ -61,21 +73,30 @@ def run(eng, seed, n, kw, flag, with_prior, converge):
 def main():
     eng = Engine(0)
     table = sweep_cases(max(CASES) + 1)
-    print("| case | seed | landmarks | options | as swept: inv-depth rel, iterations (gpu/oracle), last |cost change|/cost | "
-          "forced to converge (function_tolerance 0, 50 iterations): inv-depth rel, pose abs, iterations, termination, min a_l |")
-    print("|---|---|---|---|---|---|")
+    print("| case | seed | landmarks | options | as swept: inv-depth rel (oracle's own move under a 1e-15 / 1e-14 input change), iterations gpu/oracle, "
+          "last cost change / cost | forced to converge (function_tolerance 0, 50 iterations): inv-depth rel (oracle's own move), extrinsic abs (own move), "
+          "pose abs, iterations, termination, min a_l | verdict |")
+    print("|---|---|---|---|---|---|---|")
     unexplained = 0
     for case in CASES:
         seed, n, kw, flag, wp = table[case]
         a = run(eng, seed, n, kw, flag, wp, False)
         b = run(eng, seed, n, kw, flag, wp, True)
-        ok = b["lam"] <= max(1e-6, 3e-11 / max(b["a_min"], 1e-300))
-        unexplained += 0 if ok else 1
+        bar = max(1e-6, 3e-11 / max(b["a_min"], 1e-300))
+        if b["lam"] <= 1e-6:
+            verdict = "converged runs agree: the early stop (function tolerance / iteration cap) was the cause"
+        elif b["lam"] <= bar:
+            verdict = "inside the conditioning-scaled bar (1 / min a_l)"
+        elif b["lam"] <= 30 * b["self_lam"] and a["lam"] <= 30 * max(a["self_lam"], b["self_lam"]):
+            verdict = "ill-posed window: the oracle's own answer moves as much under a last-place change of its input"
+        else:
+            verdict = "UNEXPLAINED"
+            unexplained += 1
         print(f"| {case} | {seed} | {n} | ex {kw['estimate_extrinsic']} td {kw['estimate_td']} tr {kw['tr']} it {kw['max_num_iterations']}"
-              f"{' prior' if wp else ''} | {a['lam']:.2e}, {a['it'][0]}/{a['it'][1]}, {a['last_change']:.1e} | "
-              f"{b['lam']:.2e}, {b['pose']:.1e}, {b['it'][0]}/{b['it'][1]}, {b['term'][0]}/{b['term'][1]}, {b['a_min']:.2e}"
-              f"{'' if ok else '  <-- STILL OUTSIDE'} |")
-    print(f"\n{unexplained} of {len(CASES)} cases still outside the bar when both solvers run to convergence")
+              f"{' prior' if wp else ''} | {a['lam']:.2e} ({a['self_lam']:.1e}), {a['it'][0]}/{a['it'][1]}, {a['last_change']:.1e} | "
+              f"{b['lam']:.2e} ({b['self_lam']:.1e}), {b['ex']:.1e} ({b['self_ex']:.1e}), {b['pose']:.1e}, {b['it'][0]}/{b['it'][1]}, {b['term'][0]}/{b['term'][1]}, "
+              f"{b['a_min']:.2e} | {verdict} |")
+    print(f"\n{unexplained} of {len(CASES)} cases unexplained")
     eng.close()
 
 
