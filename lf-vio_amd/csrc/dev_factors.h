@@ -244,7 +244,7 @@ DEV m33 qleft_qright_br(q4 a, q4 b) {
 // raw Jacobian 15 x 30 in local coordinates [pose_i(6) sb_i(9) pose_j(6) sb_j(9)]; Jraw zeroed by caller.
 // imu_factor.h:88-196 (before the sqrt_info multiplication)
 DEV void imu_raw_jacobian(const LfvioPreintegration *pre, const double *G, const double *pose_i, const double *sb_i,
-                          const double *pose_j, const double *sb_j, double *J) {
+                          const double *pose_j, const double *sb_j, double *J, const int LD = 30) {
   d3 g = ld3(G);
   d3 Pi = ld3(pose_i), Pj = ld3(pose_j);
   q4 Qi = q_from_pose(pose_i), Qj = q_from_pose(pose_j);
@@ -259,7 +259,6 @@ DEV void imu_raw_jacobian(const LfvioPreintegration *pre, const double *G, const
   m33 RiT = q2R(Qi_inv);
   m33 I = skewm(mk3(0, 0, 0));
   I.a[0] = I.a[4] = I.a[8] = 1.0;
-  const int LD = 30;
   // pose_i: cols 0..5
   put33(J, LD, 0, 0, RiT, -1.0);
   put33(J, LD, 0, 3, skewm(qrot(Qi_inv, (0.5 * dt * dt) * g + Pj - Pi - dt * Vi)), 1.0);

@@ -27,6 +27,15 @@
 #pragma once
 #include "kernels_lin.h"
 
+#ifdef LFVIO_LINW_PROFILE  // cycle stamps of window 0, wave 0 (tools/linw_clocks.py, a -DLFVIO_LINW_PROFILE build under variants/)
+#define WSTAMP(k) do { if (blockIdx.y == 0 && threadIdx.x == 0) S->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#define WACC(k, t0) do { wacc[(k) - 24] += (long long)__builtin_readcyclecounter() - (t0); } while (0)
+#define WNOW() ((long long)__builtin_readcyclecounter())
+#else
+#define WSTAMP(k) do { } while (0)
+#define WACC(k, t0) do { } while (0)
+#define WNOW() 0ll
+#endif
 typedef const __attribute__((address_space(4))) double cdouble;  // uniform addresses: loads through the scalar cache
 
 constexpr int LW_THREADS = 256;
@@ -43,8 +52,8 @@ constexpr int LW_HC = KC * (KC + 1) / 2 + KC + 3;  // packed camera part + its g
 static_assert(LW_HC <= LW_PRIV0, "Hc fits the stage areas");
 constexpr size_t LW_LDS_BYTES = (size_t)(LW_LDS_P1 > LW_LDS_P2 ? LW_LDS_P1 : LW_LDS_P2) * 8;
 
-DEV int lw_tri(int n, int a, int b) { return a * n - (a * (a - 1)) / 2 + (b - a); }  // upper index, a <= b < n
-DEV int lw_pidx(int i, int j) { return (i * (21 - i)) / 2 + (j - i - 1); }           // i < j <= 10 -> 0 .. 54
+__host__ __device__ inline int lw_tri(int n, int a, int b) { return a * n - (a * (a - 1)) / 2 + (b - a); }  // upper index, a <= b < n
+__host__ __device__ inline int lw_pidx(int i, int j) { return (i * (21 - i)) / 2 + (j - i - 1); }           // i < j <= 10 -> 0 .. 54
 DEV m33 ldm_s(cdouble *p) {
   m33 r;
 #pragma unroll
@@ -59,37 +68,51 @@ DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 DEV int lw_base_row(int p) { return p < 3 ? 0 : p < 6 ? p : p < 9 ? 0 : p < 12 ? p - 3 : p < 15 ? 0 : p < 18 ? p - 6 : p - 6; }
 
 // One expanded entry (p, c), p <= c, of a step's 20 x 20 block lands at  A + Bi i + Bj j (+ 36 pidx(i, j) for the
-// pose-pose off-diagonal block) of the workgroup's LDS: see the header comment.
+// pose-pose off-diagonal block) of the workgroup's LDS: see the header comment.  Packed in two words per entry (a lane keeps
+// four of them for the whole kernel):  w0 = A | Bi << 16 | Bj << 22 | off << 28,  w1 = (16 rp + rc) | p << 8 | c << 16.
 struct LwEntry {
-  int rp, rc, p, c, A, Bi, Bj, off;
+  int w0, w1;
 };
 DEV LwEntry lw_entry(int e, int priv, int off0) {
-  LwEntry d;
   const bool in = e < NG;
   int p = 0, rem = in ? e : 0;
   while (rem >= 20 - p) rem -= 20 - p, p++;
   const int c = p + rem;
-  d.p = p, d.c = c, d.rp = lw_base_row(p), d.rc = lw_base_row(c);
   const int bp = p < 6 ? 0 : p < 12 ? 1 : p < 19 ? 2 : 3, bc = c < 6 ? 0 : c < 12 ? 1 : c < 19 ? 2 : 3;
-  d.Bi = d.Bj = d.off = 0;
-  d.A = priv + LW_DUMMY;
-  if (!in) return d;
-  if (bp == 0 && bc == 0) d.A = priv + LW_D + lw_tri(6, p, c), d.Bi = 21;
-  else if (bp == 0 && bc == 1) d.A = off0 + p * 6 + (c - 6), d.off = 1;
-  else if (bp == 0 && bc == 2) d.A = priv + LW_FX + p * 7 + (c - 12), d.Bi = 42;
-  else if (bp == 0 && bc == 3) d.A = priv + LW_G + p, d.Bi = 6;
-  else if (bp == 1 && bc == 1) d.A = priv + LW_D + lw_tri(6, p - 6, c - 6), d.Bj = 21;
-  else if (bp == 1 && bc == 2) d.A = priv + LW_FX + (p - 6) * 7 + (c - 12), d.Bj = 42;
-  else if (bp == 1 && bc == 3) d.A = priv + LW_G + (p - 6), d.Bj = 6;
-  else if (bp == 2 && bc == 2) d.A = priv + LW_XX + lw_tri(7, p - 12, c - 12);
-  else if (bp == 2 && bc == 3) d.A = priv + LW_G + 66 + (p - 12);
+  int A = priv + LW_DUMMY, Bi = 0, Bj = 0, off = 0;
+  if (in) {
+    if (bp == 0 && bc == 0) A = priv + LW_D + lw_tri(6, p, c), Bi = 21;
+    else if (bp == 0 && bc == 1) A = off0 + p * 6 + (c - 6), off = 1;
+    else if (bp == 0 && bc == 2) A = priv + LW_FX + p * 7 + (c - 12), Bi = 42;
+    else if (bp == 0 && bc == 3) A = priv + LW_G + p, Bi = 6;
+    else if (bp == 1 && bc == 1) A = priv + LW_D + lw_tri(6, p - 6, c - 6), Bj = 21;
+    else if (bp == 1 && bc == 2) A = priv + LW_FX + (p - 6) * 7 + (c - 12), Bj = 42;
+    else if (bp == 1 && bc == 3) A = priv + LW_G + (p - 6), Bj = 6;
+    else if (bp == 2 && bc == 2) A = priv + LW_XX + lw_tri(7, p - 12, c - 12);
+    else if (bp == 2 && bc == 3) A = priv + LW_G + 66 + (p - 12);
+  }
+  LwEntry d;
+  d.w0 = A | (Bi << 16) | (Bj << 22) | (off << 28);
+  d.w1 = (16 * lw_base_row(p) + lw_base_row(c)) | (p << 8) | (c << 16);
   return d;
 }
+
+// Byte offsets, inside a slot blob, of the arrays k_linw touches (the same for every slot of a context), passed BY VALUE: a
+// GP<> member of the slot would be fetched from memory before every use the compiler cannot prove unchanged — one more
+// dependent round trip per step of the sweep.
+struct LinwArgs {
+  long long anc0, anc_stride, pmo0, pmo_stride;  // first channel and distance between the 8 channels of the two observation copies
+  long long Wt, lam[2], a, b, scale_l, diag_l, grad_l, einv_l, imu_out, Hpp, gp, schur_sum;
+  const int *asm_tab;  // static: where every packed camera entry of H_pp is found in the LDS accumulators (build_linw_table)
+};
+template <class T>
+DEV T *lw_at(Slot *S, long long off) { return (T *)((char *)S + off); }
+DEV double lw_sel3(int q, double x0, double x1, double x2) { return q == 0 ? x0 : q == 1 ? x1 : x2; }
 
 // ---------------------------------------------------------------------------
 // phase 1: the strips of this wave
 // ---------------------------------------------------------------------------
-DEV void linw_strips(Slot *S, const LinView &lv, int scaled, double *lw, double part[5]) {
+DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int scaled, double *lw, double part[5]) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   double *my = lw + wv * LW_WAVE;
   double(*stage)[17] = (double(*)[17]) my;
@@ -103,93 +126,112 @@ DEV void linw_strips(Slot *S, const LinView &lv, int scaled, double *lw, double 
   cdouble *TT = (cdouble *)(((unsigned long long)(unsigned)rfl((int)(ta >> 32)) << 32) | (unsigned)rfl((int)ta));
   constexpr int O_M1 = offsetof(Tab, M1) / 8, O_M2 = offsetof(Tab, M2) / 8, O_T = offsetof(Tab, T) / 8, O_C = offsetof(Tab, c) / 8;
   constexpr int O_RIC = offsetof(Tab, ric) / 8, O_RICT = offsetof(Tab, ricT) / 8, O_TIC = offsetof(Tab, tic) / 8;
-  const double *tabv = (const double *)lv.tab;  // (per-lane reads of the same tables: the columns of E)
   // this lane's entries of the expanded block
   LwEntry en[4];
 #pragma unroll
   for (int m = 0; m < 4; m++) en[m] = lw_entry(lane + 64 * m, LW_PRIV0 + wv * LW_PRIV, LW_OFF0);
   // column `lane` of E (lanes 0 .. 19): which of M1 / -M1 / M3 it is a column of, or a unit vector
   const int ekind = lane < 3 ? 1 : (lane >= 6 && lane < 9) ? 2 : (lane >= 12 && lane < 15) ? 3 : 0, eq = lane % 3;
-  const double2 *wt0 = (const double2 *)(const double *)S->Wt;
+  const double *anc = lw_at<const double>(S, A.anc0), *pmo = lw_at<const double>(S, A.pmo0);
+  const size_t ancs = (size_t)A.anc_stride / 8, pmos = (size_t)A.pmo_stride / 8;
+  double2 *wt0 = lw_at<double2>(S, A.Wt);
+  const double *lamv = lw_at<const double>(S, A.lam[cur]);
   double cost_s = 0, g2_s = 0, asv2_s = 0, lam2_s = 0, bmax_s = 0;
+#ifdef LFVIO_LINW_PROFILE
+  long long wacc[5] = {0, 0, 0, 0, 0};
+#endif
   const int t0 = rfl(P->wave_first[wv]), t1 = rfl(P->wave_first[wv + 1]);
+  // the strip descriptors, one per lane, fetched once: a strip reads its own by v_readlane
+  const int tl = lane < LINW_MAX_STRIPS ? lane : 0;
+  const int d_lm0 = P->lm0[tl] | (P->nlm[tl] << 16), d_sk = P->start[tl] | (P->kmax[tl] << 16);
   for (int t = t0; t < t1; t++) {
-    const int lm0 = rfl(P->lm0[t]), nlm = rfl(P->nlm[t]), s = rfl(P->start[t]), kmax = rfl(P->kmax[t]);
+    const long long tp0 = WNOW();
+    (void)tp0;
+    const int dl = __builtin_amdgcn_readlane(d_lm0, t), ds = __builtin_amdgcn_readlane(d_sk, t);
+    const int lm0 = dl & 0xffff, nlm = dl >> 16, s = ds & 0xffff, kmax = ds >> 16;
+    // per step o (lane o holds it): the first landmark of this start frame that has an observation o, and the pair-major index of its observation
+    const int oc = lane < 12 && s + lane < LFVIO_NUM_FRAMES ? lane : 0;
+    const int r_first = P->firstl[s][oc], r_idx0 = P->pair_obs0[s * 11 + s + oc];
     const int l = lm0 + lane;
     const bool valid = lane < nlm;
     const int lc = valid ? l : lm0;
     ObsPair ob;
-    ob.pi = mk3(S->anc[0][lc], S->anc[1][lc], S->anc[2][lc]);
-    ob.vi = mk3(S->anc[3][lc], S->anc[4][lc], S->anc[5][lc]);
-    ob.tdi = S->anc[6][lc], ob.rowi = S->anc[7][lc];
-    const double lam = lv.lam[lc];
+    ob.pi = mk3(anc[lc], anc[ancs + lc], anc[2 * ancs + lc]);
+    ob.vi = mk3(anc[3 * ancs + lc], anc[4 * ancs + lc], anc[5 * ancs + lc]);
+    ob.tdi = anc[6 * ancs + lc], ob.rowi = anc[7 * ancs + lc];
+    const double lam = lamv[lc];
     double a = 0, b = 0, cost = 0, wtd = 0;
     d3 wPi = mk3(0, 0, 0), wTi = wPi, wTic = wPi, wTx = wPi;
-    double2 *wt = (double2 *)wt0 + lc;
-    for (int o = 1; o < kmax; o++) {
-      const int j = s + o, pair = s * 11 + j;
-      const int first = rfl(P->firstl[s][o]);
-      const bool act = valid && l >= first;
-      const int idx = rfl(P->pair_obs0[pair]) + (act ? l - first : 0);
-      ob.pj = mk3(S->pmo[0][idx], S->pmo[1][idx], S->pmo[2][idx]);
-      ob.vj = mk3(S->pmo[3][idx], S->pmo[4][idx], S->pmo[5][idx]);
-      ob.tdj = S->pmo[6][idx], ob.rowj = S->pmo[7][idx];
-      // the column of E this lane will put into LDS (requested here, used behind the SYRK)
-      double ecol[3] = {1.0, 0.0, 0.0};
-      if (ekind) {
+    double2 *wt = wt0 + lc;
+    // the observation of step 1 (every later one is requested a step ahead)
+    double nx[8];
+    int first = __builtin_amdgcn_readlane(r_first, 1);
+    {
+      const int idx = __builtin_amdgcn_readlane(r_idx0, 1) + (valid && l >= first ? l - first : 0);
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const double m1 = tabv[O_M1 + j * 9 + 3 * k + eq];
-          const double m3 = tabv[O_M2 + pair * 9 + 3 * k + eq] - tabv[O_RICT + 3 * k + eq];
-          ecol[k] = ekind == 1 ? m1 : ekind == 2 ? -m1 : m3;
-        }
+      for (int k = 0; k < 8; k++) nx[k] = kmax > 1 ? pmo[k * pmos + idx] : 0.0;
+    }
+    WACC(27, tp0);
+    for (int o = 1; o < kmax; o++) {
+      const long long ts0 = WNOW();
+      (void)ts0;
+      const int j = s + o, pair = s * 11 + j;
+      const bool act = valid && l >= first;
+      const int first_now = first;
+      ob.pj = mk3(nx[0], nx[1], nx[2]), ob.vj = mk3(nx[3], nx[4], nx[5]), ob.tdj = nx[6], ob.rowj = nx[7];
+      if (o + 1 < kmax) {
+        first = __builtin_amdgcn_readlane(r_first, o + 1);
+        const int idx = __builtin_amdgcn_readlane(r_idx0, o + 1) + (valid && l >= first ? l - first : 0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) nx[k] = pmo[k * pmos + idx];
       }
       PairU u;
       u.M2 = ldm_s(TT + O_M2 + pair * 9), u.T = ldm_s(TT + O_T + pair * 9), u.ric = ldm_s(TT + O_RIC), u.ricT = ldm_s(TT + O_RICT);
       u.c = ld3_s(TT + O_C + pair * 3), u.tic = ld3_s(TT + O_TIC);
       const m33 M1 = ldm_s(TT + O_M1 + j * 9);
+      m33 M3 = u.M2;
+#pragma unroll
+      for (int e = 0; e < 9; e++) M3.a[e] -= u.ricT.a[e];
+      // A lane without an observation in this step (a shorter track, a lane past the strip) runs on clamped, finite inputs
+      // with a zero information factor: every basis entry, the residual and log(1 + s) are exact zeros — nothing to mask
+      // in the sums or in the SYRK operand.
       Basis B;
-      visual_basis(ob, lam, td, est_td, tr_over_row, half_row, sqrt_info, u, B);
+      visual_basis(ob, lam, td, est_td, tr_over_row, half_row, act ? sqrt_info : 0.0, u, B);
       {
         const double jl0 = B.jl[0], jl1 = B.jl[1];
         const d3 eR = jl0 * B.red[0] + jl1 * B.red[1];
         const d3 wp = vmul(eR, M1);
         const d3 wtj = jl0 * B.jtj[0] + jl1 * B.jtj[1];
-        m33 M3 = u.M2;
-#pragma unroll
-        for (int e = 0; e < 9; e++) M3.a[e] -= u.ricT.a[e];
+        wPi = wPi + wp;
+        wTi = wTi + (jl0 * B.jti[0] + jl1 * B.jti[1]);
+        wTic = wTic + vmul(eR, M3);
+        wTx = wTx + (jl0 * B.jtx[0] + jl1 * B.jtx[1]);
+        wtd += jl0 * B.jtd[0] + jl1 * B.jtd[1];
+        a += jl0 * jl0 + jl1 * jl1;
+        b += jl0 * B.r[0] + jl1 * B.r[1];
+        cost += 0.5 * B.rho0;
         if (act) {
-          wPi = wPi + wp;
-          wTi = wTi + (jl0 * B.jti[0] + jl1 * B.jti[1]);
-          wTic = wTic + vmul(eR, M3);
-          wTx = wTx + (jl0 * B.jtx[0] + jl1 * B.jtx[1]);
-          wtd += jl0 * B.jtd[0] + jl1 * B.jtd[1];
-          a += jl0 * jl0 + jl1 * jl1;
-          b += jl0 * B.r[0] + jl1 * B.r[1];
-          cost += 0.5 * B.rho0;
           // the pose-j part of the landmark's row: columns 6 j .. 6 j + 5 = pairs 3 j .. 3 j + 2 of the transposed copy
           wt[(size_t)(3 * j) * SPEC_MAX_LM] = make_double2(-wp.x, -wp.y);
           wt[(size_t)(3 * j + 1) * SPEC_MAX_LM] = make_double2(-wp.z, wtj.x);
           wt[(size_t)(3 * j + 2) * SPEC_MAX_LM] = make_double2(wtj.y, wtj.z);
         }
       }
+      WACC(24, ts0);
+      const long long ts1 = WNOW();
+      (void)ts1;
       // ---- Gram of the step: sum over its observations of the two 14-wide basis rows (SYRK on the matrix pipe)
-      double c0[14], c1[14];
-      c0[0] = B.red[0].x, c0[1] = B.red[0].y, c0[2] = B.red[0].z, c1[0] = B.red[1].x, c1[1] = B.red[1].y, c1[2] = B.red[1].z;
-      c0[3] = B.jti[0].x, c0[4] = B.jti[0].y, c0[5] = B.jti[0].z, c1[3] = B.jti[1].x, c1[4] = B.jti[1].y, c1[5] = B.jti[1].z;
-      c0[6] = B.jtj[0].x, c0[7] = B.jtj[0].y, c0[8] = B.jtj[0].z, c1[6] = B.jtj[1].x, c1[7] = B.jtj[1].y, c1[8] = B.jtj[1].z;
-      c0[9] = B.jtx[0].x, c0[10] = B.jtx[0].y, c0[11] = B.jtx[0].z, c1[9] = B.jtx[1].x, c1[10] = B.jtx[1].y, c1[11] = B.jtx[1].z;
-      c0[12] = B.jtd[0], c1[12] = B.jtd[1], c0[13] = B.r[0], c1[13] = B.r[1];
-#pragma unroll
-      for (int e = 0; e < 14; e++) c0[e] = act ? c0[e] : 0.0, c1[e] = act ? c1[e] : 0.0;
       double4_t acc = double4_t{0, 0, 0, 0};
-      const int g_lo = (first > lm0 ? first - lm0 : 0) >> 4, g_hi = (nlm - 1) >> 4;  // lane groups of 16 that hold active lanes
+      const int g_lo = (first_now > lm0 ? first_now - lm0 : 0) >> 4, g_hi = (nlm - 1) >> 4;  // lane groups of 16 that hold active lanes
       for (int r = g_lo; r <= g_hi; r++) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if ((lane >> 4) == r) {
-          const int row = 2 * (lane & 15);
-#pragma unroll
-          for (int e = 0; e < 14; e++) stage[row][e] = c0[e], stage[row + 1][e] = c1[e];
+          double *r0 = stage[2 * (lane & 15)], *r1 = stage[2 * (lane & 15) + 1];
+          r0[0] = B.red[0].x, r0[1] = B.red[0].y, r0[2] = B.red[0].z, r1[0] = B.red[1].x, r1[1] = B.red[1].y, r1[2] = B.red[1].z;
+          r0[3] = B.jti[0].x, r0[4] = B.jti[0].y, r0[5] = B.jti[0].z, r1[3] = B.jti[1].x, r1[4] = B.jti[1].y, r1[5] = B.jti[1].z;
+          r0[6] = B.jtj[0].x, r0[7] = B.jtj[0].y, r0[8] = B.jtj[0].z, r1[6] = B.jtj[1].x, r1[7] = B.jtj[1].y, r1[8] = B.jtj[1].z;
+          r0[9] = B.jtx[0].x, r0[10] = B.jtx[0].y, r0[11] = B.jtx[0].z, r1[9] = B.jtx[1].x, r1[10] = B.jtx[1].y, r1[11] = B.jtx[1].z;
+          r0[12] = B.jtd[0], r1[12] = B.jtd[1], r0[13] = B.r[0], r1[13] = B.r[1];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -198,29 +240,47 @@ DEV void linw_strips(Slot *S, const LinView &lv, int scaled, double *lw, double 
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
         }
       }
+      WACC(25, ts1);
+      const long long ts2 = WNOW();
+      (void)ts2;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
       for (int r = 0; r < 4; r++) Qf[(lane >> 4) + 4 * r][lane & 15] = acc[r];
-      if (lane < 20) Ec[lane][0] = ecol[0], Ec[lane][1] = ecol[1], Ec[lane][2] = ecol[2];
+      if (lane < 20) {
+        // column `lane` of E from the pair's uniform matrices (selects, no memory)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double m1 = lw_sel3(eq, M1.a[3 * k], M1.a[3 * k + 1], M1.a[3 * k + 2]);
+          const double m3 = lw_sel3(eq, M3.a[3 * k], M3.a[3 * k + 1], M3.a[3 * k + 2]);
+          Ec[lane][k] = ekind == 1 ? m1 : ekind == 2 ? -m1 : ekind == 3 ? m3 : (k == 0 ? 1.0 : 0.0);
+        }
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      // ---- E^T Q E by the structure of E, this lane's (up to) four entries, added to the accumulators
+      // ---- E^T Q E by the structure of E: this lane's (up to) four entries — all of them read and formed first, then added
+      //      to the accumulators (a store between two entries would hold the next one's reads back)
       const int offp = 36 * lw_pidx(s, j);
+      double val[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) {
-        const LwEntry &d = en[m];
+        const int w1 = en[m].w1, q0 = w1 & 0xff, p = (w1 >> 8) & 0xff, c = w1 >> 16;
+        const double *qb = &Qf[0][0] + q0;  // Qf[rp][rc]
+        const double ep0 = Ec[p][0], ep1 = Ec[p][1], ep2 = Ec[p][2], ec0 = Ec[c][0], ec1 = Ec[c][1], ec2 = Ec[c][2];
         double tl[3];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          tl[q] = Ec[d.p][0] * Qf[d.rp][d.rc + q];
-          tl[q] = fma(Ec[d.p][1], Qf[d.rp + 1][d.rc + q], tl[q]);
-          tl[q] = fma(Ec[d.p][2], Qf[d.rp + 2][d.rc + q], tl[q]);
-        }
-        const double val = fma(Ec[d.c][2], tl[2], fma(Ec[d.c][1], tl[1], Ec[d.c][0] * tl[0]));
-        double *dst = lw + (d.A + d.Bi * s + d.Bj * j + (d.off ? offp : 0));
-        *dst += val;
+        for (int q = 0; q < 3; q++) tl[q] = fma(ep2, qb[32 + q], fma(ep1, qb[16 + q], ep0 * qb[q]));
+        val[m] = fma(ec2, tl[2], fma(ec1, tl[1], ec0 * tl[0]));
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const int w0 = en[m].w0;
+        double *dst = lw + ((w0 & 0xffff) + ((w0 >> 16) & 63) * s + ((w0 >> 22) & 63) * j + ((w0 >> 28) ? offp : 0));
+        *dst += val[m];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      WACC(26, ts2);
     }
+    const long long te0 = WNOW();
+    (void)te0;
     // ---- the landmark's own sums: anchor pose, extrinsic, td parts of its row; scalars of the trust region
     if (valid) {
       wt[(size_t)(3 * s) * SPEC_MAX_LM] = make_double2(wPi.x, wPi.y);
@@ -232,34 +292,187 @@ DEV void linw_strips(Slot *S, const LinView &lv, int scaled, double *lw, double 
         wt[(size_t)35 * SPEC_MAX_LM] = make_double2(wTx.y, wTx.z);
       }
       wt[(size_t)36 * SPEC_MAX_LM] = make_double2(est_td ? wtd : 0.0, 0.0);
+      double *scale_l = lw_at<double>(S, A.scale_l);
       double sc;
       if (!scaled) {
         sc = 1.0 / (1.0 + sqrt(a));  // jacobi_scaling, fixed at iteration 0
-        S->scale_l[l] = sc;
+        scale_l[l] = sc;
       } else {
-        sc = S->scale_l[l];
+        sc = scale_l[l];
       }
       const double s2a = sc * sc * a;
       const double D2 = fmin(fmax(s2a, 1e-6), 1e32);  // min/max_lm_diagonal
       const double dg = sqrt(D2);
       const double gr = sc * b / dg;  // DoglegStrategy::ComputeGradient
-      S->diag_l[l] = dg;
-      S->grad_l[l] = gr;
+      lw_at<double>(S, A.diag_l)[l] = dg;
+      lw_at<double>(S, A.grad_l)[l] = gr;
       const double v = gr / dg;
       const double eb = s2a + lv.mu * D2;
-      S->einv_l[l] = 1.0 / eb;
-      S->a[l] = a;
-      S->b[l] = b;
+      lw_at<double>(S, A.einv_l)[l] = 1.0 / eb;
+      lw_at<double>(S, A.a)[l] = a;
+      lw_at<double>(S, A.b)[l] = b;
       cost_s += cost, g2_s += gr * gr, asv2_s += s2a * v * v, lam2_s += lam * lam, bmax_s = fmax(bmax_s, fabs(b));
     }
+    WACC(28, te0);
   }
+#ifdef LFVIO_LINW_PROFILE
+  if (blockIdx.y == 0 && threadIdx.x == 0)
+    for (int k = 0; k < 5; k++) S->dbg[24 + k] = wacc[k];
+#endif
   part[0] = wave_sum(cost_s), part[1] = wave_sum(g2_s), part[2] = wave_sum(asv2_s), part[3] = wave_sum(lam2_s), part[4] = wave_max(bmax_s);
 }
 
 // ---------------------------------------------------------------------------
+// phase 0: the pose-side factors.  IMU factor f = wave + 4 q is evaluated by lane q < 3 of the wave (IMUFactor::Evaluate's two
+// serial jobs — residual and Jacobian of integration_base.h:160-186 / imu_factor.h:88-196 — straight into LDS), then the wave
+// weights it with sqrt_info and forms J^T J, J^T r, the cost (what lin_imu_role does with a workgroup per factor).  No
+// workgroup barrier in here: a wave only reads what it wrote itself.
+// ---------------------------------------------------------------------------
+constexpr int LW_JLD = 33;                                   // 16 rows x (32 + 1 pad): columns 0 .. 29 the Jacobian, 30 the residual, row 15 zero
+constexpr int LW_IMU_WAVE = 3 * 16 * LW_JLD + 16 * LW_JLD;   // Jr of the wave's three factors | Jw
+static_assert(LINW_WAVES * LW_IMU_WAVE <= LW_LDS_P1, "phase 0 fits the phase-1 workspace");
+DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  double *my = lw + wv * LW_IMU_WAVE;
+  double *Jr3 = my;
+  double(*Jw)[LW_JLD] = (double(*)[LW_JLD])(my + 3 * 16 * LW_JLD);
+  const FrameState *x = lv.x;
+  const bool pose_rank = !S->sharded || S->pose_side;
+  for (int e = lane; e < 3 * 16 * LW_JLD; e += 64) my[e] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < 3) {
+    const int f = wv + 4 * lane;
+    if (f < LFVIO_WINDOW_SIZE && S->imu_active[f] && pose_rank) {
+      double rr[15];
+      imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
+      double *Jr = Jr3 + 16 * LW_JLD * lane;
+#pragma unroll
+      for (int k = 0; k < 15; k++) Jr[k * LW_JLD + 30] = rr[k];
+      imu_raw_jacobian(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], Jr, LW_JLD);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  WSTAMP(29);
+  // Both products on the FP64 matrix pipe.  Lane (kq, ii) = (lane >> 4, lane & 15) feeds A[ii][4 s + kq] and B[4 s + kq][ii]
+  // of step s and holds D[kq + 4 r][ii], r = 0 .. 3, of a 16 x 16 result tile.
+  //   Jw = sqrt_info [J | r]      (16 x 16 times 16 x 32: 2 tiles x 4 steps; the whitened residual rides as column 30)
+  //   G  = Jw^T Jw                (32 x 32: tiles (0,0), (0,1), (1,1) x 4 steps) = [J^T J, J^T r; . , r^T r]
+  const int kq = lane >> 4, ii = lane & 15;
+  double *imu_out = (double *)((char *)S + imu_off);
+  for (int q = 0; q < 3; q++) {
+    const int f = wv + 4 * q;
+    if (f >= LFVIO_WINDOW_SIZE) break;
+    double *out = imu_out + (size_t)f * IMU_OUT;
+    if (!(S->imu_active[f] && pose_rank)) {
+      for (int e = lane; e < IMU_OUT; e += 64) out[e] = 0.0;
+      continue;
+    }
+    const double(*Jr)[LW_JLD] = (const double(*)[LW_JLD])(Jr3 + 16 * LW_JLD * q);
+    const double *Sq = S->imu_sqrt[f];
+    double sa[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const int k = 4 * s4 + kq;
+      sa[s4] = (ii < 15 && k < 15) ? Sq[ii * 15 + k] : 0.0;
+    }
+    double4_t w0 = double4_t{0, 0, 0, 0}, w1 = w0;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      w0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[s4], Jr[4 * s4 + kq][ii], w0, 0, 0, 0);
+      w1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[s4], Jr[4 * s4 + kq][16 + ii], w1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) Jw[kq + 4 * r][ii] = w0[r], Jw[kq + 4 * r][16 + ii] = w1[r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double4_t g00 = double4_t{0, 0, 0, 0}, g01 = g00, g11 = g00;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const double v0 = Jw[4 * s4 + kq][ii], v1 = Jw[4 * s4 + kq][16 + ii];
+      g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, g00, 0, 0, 0);
+      g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v1, g01, 0, 0, 0);
+      g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, g11, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = kq + 4 * r, c1 = 16 + ii;  // entries G[row][ii], G[row][c1], G[16 + row][c1]
+      out[row * 30 + ii] = g00[r];
+      if (c1 < 30) out[row * 30 + c1] = g01[r], out[c1 * 30 + row] = g01[r];
+      else if (c1 == 30) out[900 + row] = g01[r];  // J^T r, rows 0 .. 15
+      if (16 + row < 30) {
+        if (c1 < 30) out[(16 + row) * 30 + c1] = g11[r];
+        else if (c1 == 30) out[900 + 16 + row] = g11[r];
+      } else if (16 + row == 30 && c1 == 30) out[930] = 0.5 * g11[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+// The prior factor of a pass (MarginalizationFactor::Evaluate, marginalization_factor.cpp:333-381; lin_prior_role of
+// kernels_lin.h with J0 staged in LDS: one batch of coalesced loads instead of a dependent load per term):
+//   r = r0 + J0 dx,  prior_g = J0^T r (tangent columns), cost.  Whole workgroup; ends on a barrier.
+constexpr int LW_PRIOR_MAXN = 88;  // J0 of up to 88 x 88 fits the workspace (the reference's is 76 x 76); larger ones take the global path
+static_assert(LW_PRIOR_MAXN * LW_PRIOR_MAXN + 4 * KP <= LW_LDS_P1, "prior stage fits");
+DEV void linw_prior(Slot *S, const LinView &lv, double *lw) {
+  const int tid = threadIdx.x;
+  const int n = S->prior_n;
+  if (!S->prior_valid || (S->sharded && !S->pose_side) || n > LW_PRIOR_MAXN) {
+    lin_prior_role(S, lv, MODE_SOLVE, lw);  // (zeroes prior_g when there is no prior)
+    __syncthreads();
+    return;
+  }
+  double *Js = lw, *dx = lw + LW_PRIOR_MAXN * LW_PRIOR_MAXN, *r = dx + KP, *part = r + KP;  // part: [2][KP]
+  double *g = S->prior_g;
+  const double *J = S->prior_J;
+  for (int e = tid; e < n * n; e += LW_THREADS) Js[e] = J[e];
+  for (int c = tid; c < KP + 4; c += LW_THREADS) g[c] = 0.0;
+  if (tid < S->prior_nb) prior_block_dx(S, lv.x, tid, dx);
+  __syncthreads();
+  {  // r = r0 + J0 dx: two lanes per row (n <= 128), four independent partial sums each so that the LDS reads overlap
+    const int row = tid >> 1, h = tid & 1;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (row < n) {
+      const double *jr = Js + row * n;
+      int c = h;
+      for (; c + 6 < n; c += 8) s0 = fma(jr[c], dx[c], s0), s1 = fma(jr[c + 2], dx[c + 2], s1), s2 = fma(jr[c + 4], dx[c + 4], s2), s3 = fma(jr[c + 6], dx[c + 6], s3);
+      for (; c < n; c += 2) s0 = fma(jr[c], dx[c], s0);
+    }
+    double sum = (s0 + s1) + (s2 + s3);
+    sum += __shfl_xor(sum, 1, 64);
+    if (row < n && h == 0) r[row] = S->prior_r[row] + sum;
+  }
+  __syncthreads();
+  {  // g = J0^T r: column c, two halves of the rows
+    const int c = tid & 127, h = tid >> 7, k0 = h ? n / 2 : 0, k1 = h ? n : n / 2;
+    if (c < n) {
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      int k = k0;
+      for (; k + 3 < k1; k += 4)
+        s0 = fma(Js[k * n + c], r[k], s0), s1 = fma(Js[(k + 1) * n + c], r[k + 1], s1), s2 = fma(Js[(k + 2) * n + c], r[k + 2], s2), s3 = fma(Js[(k + 3) * n + c], r[k + 3], s3);
+      for (; k < k1; k++) s0 = fma(Js[k * n + c], r[k], s0);
+      part[h * KP + c] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < n; c += LW_THREADS) g[S->prior_cmap[c]] = part[c] + part[KP + c];
+  if (tid < 64) {
+    double cs = 0;
+    for (int row = tid; row < n; row += 64) cs += r[row] * r[row];
+    cs = wave_sum(cs);
+    if (tid == 0) g[KP] = 0.5 * cs;
+  }
+  __syncthreads();
+}
+
+// Static table of phase 3 (built once per context, lfvio_hip.hip): for the packed camera entry e of H_pp (e < SUM_VIS_PACKED)
+// and the camera-side gradient entries behind them, where the value sits in the LDS accumulators —
+//   bits 0..15 the offset (inside a wave's private block, or absolute for the single-writer pose-pose blocks), bit 16 "absolute",
+//   bit 17 the entry touches an extrinsic column, bit 18 it touches the td column.
+constexpr int LWT_ABS = 1 << 16, LWT_EX = 1 << 17, LWT_TD = 1 << 18;
+
+// ---------------------------------------------------------------------------
 // k_linw: grid (1, batch) x 256, dynamic LDS = LW_LDS_BYTES
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t stride, long long imu_off) {
+__global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t stride, const LinwArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lw[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
@@ -271,58 +484,50 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
   if (!fl.done && tid == 0) S->passes_used++;
   if (fl.done | (!fl.do_lin & !fl.do_schur)) return;
   LinView lv;
-  lv.x = &S->x[fl.cur], lv.tab = &S->tab[fl.cur], lv.lam = S->lam[fl.cur], lv.mu = mu;
+  lv.x = &S->x[fl.cur], lv.tab = &S->tab[fl.cur], lv.lam = lw_at<const double>(S, A.lam[fl.cur]), lv.mu = mu;
+  WSTAMP(8);
   if (fl.do_lin) {
+    constexpr int P3_E = (SUM_VIS + LW_THREADS - 1) / LW_THREADS;
+    int p3[P3_E];  // (phase 3's table entries: requested here, used a hundred microseconds later)
+#pragma unroll
+    for (int q = 0; q < P3_E; q++) p3[q] = A.asm_tab[tid + LW_THREADS * q < SUM_VIS ? tid + LW_THREADS * q : 0];
+    linw_imu(S, lv, lw, A.imu_out);
+    WSTAMP(30);
+    __syncthreads();
+    linw_prior(S, lv, lw);
+    WSTAMP(15);
     for (int e = tid; e < LW_LDS_P1; e += LW_THREADS) lw[e] = 0.0;
     __syncthreads();
+    WSTAMP(9);
     double part[5];
-    linw_strips(S, lv, fl.scaled, lw, part);
+    linw_strips(S, lv, A, fl.cur, fl.scaled, lw, part);
+    WSTAMP(10);
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 5; k++) lw[LW_RED0 + 8 * wv + k] = part[k];
     }
     __syncthreads();
+    WSTAMP(11);
     // ---- phase 3: the camera part of H_pp (visual terms only) and the whole of g_p.  Private copies in wave order.
-    double hv[11];
-    const bool act_all = true;
-    (void)act_all;
+    double hv[P3_E];
 #pragma unroll
-    for (int q = 0; q < 11; q++) {
-      const int e = tid + LW_THREADS * q;  // packed entry (r, c), r >= c, then the gradient
-      double v = 0.0;
-      if (e < SUM_VIS) {
-        int r, c;
-        if (e < SUM_VIS_PACKED) {
-          r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-          while ((r + 1) * (r + 2) / 2 <= e) r++;
-          while (r * (r + 1) / 2 > e) r--;
-          c = e - r * (r + 1) / 2;
-        } else {
-          r = c = e - SUM_VIS_PACKED;
-        }
-        const int fr = r < 66 ? r / 6 : 11, fc = c < 66 ? c / 6 : 11, lr = r < 66 ? r - 6 * fr : r - 66, lc = c < 66 ? c - 6 * fc : c - 66;
-        int at, shared = 0;
-        if (e >= SUM_VIS_PACKED) at = LW_G + c;
-        else if (fr == fc && fr < 11) at = LW_D + 21 * fr + lw_tri(6, lc, lr);
-        else if (fr < 11) at = LW_OFF0 + 36 * lw_pidx(fc, fr) + lc * 6 + lr, shared = 1;
-        else if (fc < 11) at = LW_FX + 42 * fc + lc * 7 + lr;
-        else at = LW_XX + lw_tri(7, lc, lr);
-        if (shared) v = lw[at];
-        else {
-          const double *p0 = lw + LW_PRIV0 + at;
-          v = (p0[0] + p0[LW_PRIV]) + (p0[2 * LW_PRIV] + p0[3 * LW_PRIV]);
-        }
-        const bool act_r = !((!est_ex && r >= off_ex() && r < off_ex() + 6) || (!est_td && r == off_td()));
-        const bool act_c = !((!est_ex && c >= off_ex() && c < off_ex() + 6) || (!est_td && c == off_td()));
-        if (!(act_r && act_c)) v = 0.0;
+    for (int q = 0; q < P3_E; q++) {
+      const int d = p3[q], at = d & 0xffff;
+      double v;
+      if (d & LWT_ABS) v = lw[at];
+      else {
+        const double *p0 = lw + LW_PRIV0 + at;
+        v = (p0[0] + p0[LW_PRIV]) + (p0[2 * LW_PRIV] + p0[3 * LW_PRIV]);
       }
+      if (((d & LWT_EX) && !est_ex) || ((d & LWT_TD) && !est_td)) v = 0.0;
       hv[q] = v;
     }
     __syncthreads();  // (the accumulators are read: their LDS is free)
+    double *Hpp = lw_at<double>(S, A.Hpp);
 #pragma unroll
-    for (int q = 0; q < 11; q++) {
+    for (int q = 0; q < P3_E; q++) {
       const int e = tid + LW_THREADS * q;
-      if (e < SUM_VIS_PACKED) S->Hpp[e] = hv[q];
+      if (e < SUM_VIS_PACKED) Hpp[e] = hv[q];
       else if (e < SUM_VIS) lw[e - SUM_VIS_PACKED] = hv[q];  // visual gradient, camera side
     }
     __syncthreads();
@@ -331,7 +536,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
       const int r = tid;
       double val = r < KC ? lw[r] : 0.0;
       const int f0 = col_frame(r);
-      const double *imu_out = (const double *)((const char *)S + imu_off);
+      const double *imu_out = lw_at<const double>(S, A.imu_out);
       if (f0 >= 0) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -344,7 +549,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
       }
       val += S->prior_g[r];
       const bool act_r = !((!est_ex && r >= off_ex() && r < off_ex() + 6) || (!est_td && r == off_td()));
-      S->gp[r] = act_r ? val : 0.0;
+      lw_at<double>(S, A.gp)[r] = act_r ? val : 0.0;
     }
     if (tid < 5) {
       const double *rd = lw + LW_RED0 + tid;
@@ -352,55 +557,71 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
     }
     __syncthreads();
   }
+  WSTAMP(12);
   if (!fl.do_schur) return;
-  // ---- phase 2: Schur SYRK over all landmarks, the tile refilled block by block from the transposed rows
+  // ---- phase 2: Schur SYRK over all landmarks, the tile refilled block by block from the transposed rows; the rows of
+  //      block k + 1 are requested before the matrix pipe starts on block k
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lw;
   double *lcoef = lw + LM_BLOCK * (WLD + 1), *le = lcoef + LM_BLOCK;
   const int kk = lane >> 4, cc = lane & 15;
   double4_t acc[4];
   int ct[4], cu[4];
-  bool scale_k[4], own[4];
+  bool scale_k[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     acc[j] = double4_t{0, 0, 0, 0};
     const int ti = wv + 4 * j;
     const int t = ti < 5 ? 0 : ti < 9 ? 1 : ti < 12 ? 2 : ti < 14 ? 3 : 4;
     const int u = ti - (t * 5 - (t * (t - 1)) / 2) + t;
-    own[j] = ti < NT;
-    ct[j] = own[j] ? 16 * t + cc : 0, cu[j] = own[j] ? 16 * u + cc : 0;
+    ct[j] = ti < NT ? 16 * t + cc : 0, cu[j] = ti < NT ? 16 * u + cc : 0;
     scale_k[j] = cu[j] == COL_K;
   }
-  const double2 *wt0 = (const double2 *)(const double *)S->Wt;
+  const double2 *wt0 = lw_at<const double2>(S, A.Wt);
+  const double *scale_l = lw_at<const double>(S, A.scale_l), *av = lw_at<const double>(S, A.a), *bv = lw_at<const double>(S, A.b);
+  double *einv_l = lw_at<double>(S, A.einv_l);
   const int nblk = (N + LM_BLOCK - 1) / LM_BLOCK;
+  constexpr int WPT = (WT_PAIRS + 3) / 4;  // column pairs per thread
+  double2 wreg[WPT];
+  double w_sc = 0, w_a = 0, w_b = 0;
+  auto request = [&](int blk) {
+    const int l = blk * LM_BLOCK + lane;
+#pragma unroll
+    for (int k = 0; k < WPT; k++) {
+      const int cp = wv + 4 * k;
+      wreg[k] = (cp < WT_PAIRS && l < N) ? wt0[(size_t)cp * SPEC_MAX_LM + l] : make_double2(0.0, 0.0);
+    }
+    if (tid < LM_BLOCK && l < N) w_sc = scale_l[l], w_a = av[l], w_b = bv[l];
+  };
   for (int e = tid; e < LM_BLOCK * 6; e += LW_THREADS) tile[e / 6][75 + e % 6] = 0.0;  // pad columns 75 .. 80
+  if (nblk > 0) request(0);
   for (int blk = 0; blk < nblk; blk++) {
-    __syncthreads();
+    __syncthreads();  // (the matrix pipe is done with the previous block's tile)
     {
       const int l = blk * LM_BLOCK + lane;
 #pragma unroll
-      for (int k = 0; k < (WT_PAIRS + 3) / 4; k++) {
+      for (int k = 0; k < WPT; k++) {
         const int cp = wv + 4 * k;
         if (cp < WT_PAIRS) {
-          const double2 v = l < N ? wt0[(size_t)cp * SPEC_MAX_LM + l] : make_double2(0.0, 0.0);
-          tile[lane][2 * cp] = v.x;
-          if (2 * cp + 1 < KC) tile[lane][2 * cp + 1] = v.y;
+          tile[lane][2 * cp] = wreg[k].x;
+          if (2 * cp + 1 < KC) tile[lane][2 * cp + 1] = wreg[k].y;
         }
       }
       if (tid < LM_BLOCK) {
         double cf = 0.0, eb = 0.0, bl = 0.0, kap = 0.0;
         if (l < N) {
-          const double sc = S->scale_l[l], s2a = sc * sc * S->a[l];
+          const double s2a = w_sc * w_sc * w_a;
           const double D2 = fmin(fmax(s2a, 1e-6), 1e32);
           eb = s2a + mu * D2;  // e-block + lm_diagonal^2
           const double einv = 1.0 / eb;
-          cf = sc * sc * einv;
-          if (!fl.do_lin) S->einv_l[l] = einv;  // (a solve repeated with a larger mu: only the weights change)
-          bl = S->b[l], kap = bl / D2;
+          cf = w_sc * w_sc * einv;
+          if (!fl.do_lin) einv_l[l] = einv;  // (a solve repeated with a larger mu: only the weights change)
+          bl = w_b, kap = bl / D2;
         }
         lcoef[tid] = cf, le[tid] = eb;
         tile[tid][COL_B] = bl, tile[tid][COL_K] = kap;
       }
     }
+    if (blk + 1 < nblk) request(blk + 1);
     __syncthreads();
     int rows = N - blk * LM_BLOCK;
     rows = rows > LM_BLOCK ? LM_BLOCK : rows;
@@ -417,11 +638,13 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
       }
     }
   }
-  double *ss = S->schur_sum;
+  WSTAMP(13);
+  double *ss = lw_at<double>(S, A.schur_sum);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     if (wv + 4 * j >= NT) continue;
 #pragma unroll
     for (int r = 0; r < 4; r++) ss[(wv + 4 * j) * 256 + r * 64 + lane] = acc[j][r];
   }
+  WSTAMP(14);
 }

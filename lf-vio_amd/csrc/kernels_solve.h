@@ -165,8 +165,13 @@ DEV void solve_epilogue(Slot *S, TRState *tr, const double *ls, double gn2, doub
 // ASSEMBLE (a resident batch linearized by k_linw, kernels_linw.h): the exchange buffer holds only the VISUAL terms of the
 // camera part of H_pp (packed rows 0 .. KC - 1); the (at most two) IMU factors and the prior of every entry are added here,
 // on load, in k_sum's order — the 119 KB packed matrix is never written or read back.  g_p arrives complete.
+// Static scatter table of the assembling form (built once per context, lfvio_hip.hip build_asm_table): where the packed visual
+// entry e goes in the LDS tiles (ASM_VIS ints), then for the IMU factors — even ones first, then odd ones: the factors of one
+// parity share no column — every entry of the lower triangle of their 30 x 30 block as (index into imu_out) | (tile address << 16).
+constexpr int ASM_VIS = KC * (KC + 1) / 2, ASM_IMU_F = 30 * 31 / 2, ASM_IMU_HALF = 5 * ASM_IMU_F, ASM_LEN = ASM_VIS + 2 * ASM_IMU_HALF;
+__host__ __device__ constexpr int asm_lidx(int i, int j) { return tile_id(i >> 4, j >> 4) * TSZ + (i & 15) * TLD + (j & 15); }
 template <bool ASSEMBLE>
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_t stride, long long xch_off, long long imu_off, long long prior_A_off) {
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_t stride, long long xch_off, long long imu_off, long long prior_A_off, const int *asm_tab) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
@@ -178,6 +183,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
   // the Schur sums this thread will subtract: entry (er, ek) of the 15 pose-side tiles, the rhs column, z2
   double sreg[15], srhs[5], scross = 0.0, gval = 0.0, cp = 0.0;
   const double *xch = (const double *)((const char *)S + xch_off);
+  if (ASSEMBLE) {
+    // (the assembly below is real work behind barriers: a slot with nothing to solve in this pass leaves first)
+    const TRFlags f0 = tr_flags_decided(S);
+    if ((f0.done | !f0.do_schur) && !S->dec_pending) return;
+  }
   {
     const double *Hg = xch + XOFF_H, *Sg = xch + XOFF_S;
 #pragma unroll
@@ -186,40 +196,96 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
       if (!ASSEMBLE) hreg[t] = (i < KP && j <= i) ? Hg[i * (i + 1) / 2 + j] : 0.0;
     }
     if (ASSEMBLE) {
-      // what this thread needs of the prior's column map: rows 16 a + er, columns 16 b + ek
-      int pinv_r[NTL], pinv_c[NTL];
-      const int prior_ok = S->prior_valid && (!S->sharded || S->pose_side), prior_n = S->prior_n;
-#pragma clang loop unroll(full)
-      for (int a = 0; a < NTL; a++) {
-        const int i = 16 * a + er, j = 16 * a + ek;
-        pinv_r[a] = i < KP ? S->prior_inv[i] : -1, pinv_c[a] = j < KP ? S->prior_inv[j] : -1;
-      }
+      // H_pp is assembled in the LDS tiles the reduced system will be built in, from three contiguous sources read with
+      // coalesced loads — the prior's J0^T J0 (n x n, constant over the call), the visual terms of the camera part (packed,
+      // k_linw), the ten 30 x 30 blocks of the IMU factors — each scattered to its entries by a phase of its own (within a
+      // phase an entry has one writer: the prior's column map is injective, IMU factors f and f + 2 share no column), and
+      // every thread then takes its entries of the tiles into the registers the rest of the kernel works from.
+      double *Ht = smem;
       const double *imu_out = (const double *)((const char *)S + imu_off), *prior_A = (const double *)((const char *)S + prior_A_off);
+      const int prior_ok = S->prior_valid && (!S->sharded || S->pose_side), prior_n = prior_ok ? S->prior_n : 0;
       const bool ex_on = S->est_ex != 0, td_on = S->est_td != 0;
-#pragma clang loop unroll(full)
-      for (int t = 0; t < NTILES; t++) {
-        const int a = tile_a(t), b = tile_b(t), i = 16 * a + er, j = 16 * b + ek;
-        double h = 0.0;
-        if (i < KP && j <= i) {
-          if (i < KC) h = Hg[i * (i + 1) / 2 + j];
-          const int f0 = col_frame(i);
-          if (f0 >= 0) {
+      const int lane64 = tid & 63, wv4 = tid >> 6;
+      // Requests first, in batches with fixed trip counts (a loop that loads, waits and scatters one entry at a time is a
+      // memory round trip per entry): the prior's rows of this thread's two columns and its visual entries, then its IMU
+      // entries; the tiles are cleared while the first batch is in flight.
+      STAMP(S, 16);
+      constexpr int PR_ROWS = 19, VIS_E = (ASM_VIS + SOLVE_THREADS - 1) / SOLVE_THREADS, IMU_E = (ASM_IMU_HALF + SOLVE_THREADS - 1) / SOLVE_THREADS;
+      const int pc0 = lane64, pc1 = lane64 + 64;
+      const int gj0 = pc0 < prior_n ? S->prior_cmap[pc0] : 0, gj1 = pc1 < prior_n ? S->prior_cmap[pc1] : 0;
+      int gi_r[PR_ROWS];
+      double pa0[PR_ROWS], pa1[PR_ROWS], vis[VIS_E];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-              const int f = f0 - 1 + u;
-              if (f >= 0 && f < LFVIO_WINDOW_SIZE) {
-                const int pl = imu_local(i, f), ql = imu_local(j, f);
-                if (pl >= 0 && ql >= 0) h += imu_out[(size_t)f * IMU_OUT + pl * 30 + ql];
-              }
-            }
-          }
-          if (prior_ok && pinv_r[a] >= 0 && pinv_c[b] >= 0) h += prior_A[pinv_r[a] * prior_n + pinv_c[b]];
-          const bool act_i = (ex_on || i < off_ex() || i >= off_ex() + 6) && (td_on || i != off_td());
-          const bool act_j = (ex_on || j < off_ex() || j >= off_ex() + 6) && (td_on || j != off_td());
-          if (!(act_i && act_j)) h = 0.0;
-        }
-        hreg[t] = h;
+      for (int k = 0; k < PR_ROWS; k++) {
+        const int pr = wv4 + 4 * k, prc = pr < prior_n ? pr : 0;
+        gi_r[k] = prior_n > 0 ? S->prior_cmap[prc] : 0;
+        pa0[k] = prior_n > 0 ? prior_A[prc * prior_n + (pc0 < prior_n ? pc0 : 0)] : 0.0;
+        pa1[k] = prior_n > 0 ? prior_A[prc * prior_n + (pc1 < prior_n ? pc1 : 0)] : 0.0;
       }
+      int vdst[VIS_E];
+#pragma unroll
+      for (int k = 0; k < VIS_E; k++) {
+        const int e = tid + SOLVE_THREADS * k, ec = e < ASM_VIS ? e : 0;
+        vis[k] = Hg[ec], vdst[k] = asm_tab[ec];
+      }
+      STAMP(S, 17);
+      for (int e = tid; e < TPACK; e += SOLVE_THREADS) Ht[e] = 0.0;
+      __syncthreads();
+      STAMP(S, 18);
+#pragma unroll
+      for (int k = 0; k < PR_ROWS; k++) {
+        const int pr = wv4 + 4 * k;
+        if (pr < prior_n && pc0 < prior_n && gi_r[k] >= gj0) Ht[lidx(gi_r[k], gj0)] = pa0[k];
+        if (pr < prior_n && pc1 < prior_n && gi_r[k] >= gj1) Ht[lidx(gi_r[k], gj1)] = pa1[k];
+      }
+      // (priors beyond 76 rows or 128 columns — not what the reference's marginalization produces, but legal input: plain loops)
+      for (int pr = wv4 + 4 * PR_ROWS; pr < prior_n; pr += SOLVE_THREADS / 64) {
+        const int gi = S->prior_cmap[pr];
+        if (pc0 < prior_n && gi >= gj0) Ht[lidx(gi, gj0)] = prior_A[pr * prior_n + pc0];
+        if (pc1 < prior_n && gi >= gj1) Ht[lidx(gi, gj1)] = prior_A[pr * prior_n + pc1];
+      }
+      for (int pc = lane64 + 128; pc < prior_n; pc += 64) {
+        const int gj = S->prior_cmap[pc];
+        for (int pr = wv4; pr < prior_n; pr += SOLVE_THREADS / 64) {
+          const int gi = S->prior_cmap[pr];
+          if (gi >= gj) Ht[lidx(gi, gj)] = prior_A[pr * prior_n + pc];
+        }
+      }
+      STAMP(S, 19);
+      double im[2][IMU_E];
+      int idst[2][IMU_E];
+#pragma unroll
+      for (int par = 0; par < 2; par++)
+#pragma unroll
+        for (int k = 0; k < IMU_E; k++) {
+          const int e = tid + SOLVE_THREADS * k;
+          const int d = asm_tab[ASM_VIS + par * ASM_IMU_HALF + (e < ASM_IMU_HALF ? e : 0)];
+          im[par][k] = imu_out[d & 0xffff], idst[par][k] = d >> 16;
+        }
+      __syncthreads();
+      STAMP(S, 20);
+#pragma unroll
+      for (int k = 0; k < VIS_E; k++)
+        if (tid + SOLVE_THREADS * k < ASM_VIS) Ht[vdst[k]] += vis[k];
+      __syncthreads();
+      STAMP(S, 21);
+#pragma unroll
+      for (int par = 0; par < 2; par++) {
+#pragma unroll
+        for (int k = 0; k < IMU_E; k++)
+          if (tid + SOLVE_THREADS * k < ASM_IMU_HALF) Ht[idst[par][k]] += im[par][k];
+        __syncthreads();
+      }
+#pragma unroll
+      for (int t = 0; t < NTILES; t++) {
+        const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
+        const bool act_i = (ex_on || i < off_ex() || i >= off_ex() + 6) && (td_on || i != off_td());
+        const bool act_j = (ex_on || j < off_ex() || j >= off_ex() + 6) && (td_on || j != off_td());
+        const double h = Ht[t * TSZ + esw];
+        hreg[t] = (i < KP && j <= i && act_i && act_j) ? h : 0.0;
+      }
+      __syncthreads();  // (the tiles are rebuilt below, by other threads' schedules too: everyone has its copy first)
+      STAMP(S, 22);
     }
     if (tid < KP) gval = xch[XOFF_G + tid];
     int n15 = 0;

@@ -191,6 +191,8 @@ struct lfvio_ctx {
   bool use_graph = true;
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
   int last_passes = 0;  // passes of the trust-region loop the last synchronous call used (slowest slot)
+  int *d_lwt = nullptr;  // static table of k_linw's phase 3 (kernels_linw.h LWT_*)
+  int *d_asm = nullptr;  // static scatter table of k_solve_dense<true> (kernels_solve.h ASM_*)
   int linw_mode = 1;     // 1: resident batches linearize with k_linw when every slot of the launch carries a plan; 0: never (k_lin roles + k_sum);
                          // 2: any launch of planned windows, however few (tests).  LFVIO_LINW / lfvio_debug_set_linw
   double fn_tol = 1e-6;  // function_tolerance of the windows uploaded from now on (debug: lfvio_debug_set_function_tolerance)
@@ -887,15 +889,31 @@ void launch_sum(lfvio_ctx *c, int count, const Grid &g, int mode) {
   hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, count), dim3(256), 0, c->stream, c->d_base, st, mode, pre, sa);
 }
 
+LinwArgs linw_args(const lfvio_ctx *c) {
+  const Layout &L = c->L;
+  LinwArgs a;
+  a.anc0 = (long long)L.anc[0], a.anc_stride = (long long)(L.anc[1] - L.anc[0]);
+  a.pmo0 = (long long)L.pmo[0], a.pmo_stride = (long long)(L.pmo[1] - L.pmo[0]);
+  a.Wt = (long long)L.Wt, a.lam[0] = (long long)L.lam[0], a.lam[1] = (long long)L.lam[1];
+  a.a = (long long)L.a, a.b = (long long)L.b, a.scale_l = (long long)L.scale_l, a.diag_l = (long long)L.diag_l, a.grad_l = (long long)L.grad_l;
+  a.einv_l = (long long)L.einv_l, a.imu_out = (long long)L.imu_out;
+  a.Hpp = (long long)(L.xch + (size_t)XOFF_H * 8), a.gp = (long long)(L.xch + (size_t)XOFF_G * 8), a.schur_sum = (long long)(L.xch + (size_t)XOFF_S * 8);
+  a.asm_tab = c->d_lwt;
+  return a;
+}
+void launch_linw(lfvio_ctx *c, int count) {
+  hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
+}
+
 // lw: the pass was linearized by k_linw — H_pp holds the visual terms of its camera part only, the solve adds the rest on load
 void launch_solve(lfvio_ctx *c, int count, bool lw = false) {
   const size_t st = c->L.total;
   if (lw)
     hipLaunchKernelGGL(k_solve_dense<true>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out,
-                       (long long)c->L.prior_A);
+                       (long long)c->L.prior_A, (const int *)c->d_asm);
   else
     hipLaunchKernelGGL(k_solve_dense<false>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out,
-                       (long long)c->L.prior_A);
+                       (long long)c->L.prior_A, (const int *)nullptr);
 }
 
 // A resident batch whose windows all carry a LinwPlan is linearized window by window (kernels_linw.h) instead of role by role.
@@ -920,11 +938,8 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   const bool lw = use_linw(c, count, g, mode);
   const bool merge = solve && !lw && g.lm <= DOGLEG_INLINE_BLOCKS && !c->no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
   if (lw) {
-    // pose-side factors first (IMU evaluations one lane per factor, then the weighting / J^T J role and the prior), then the
-    // window-resident sweep: one workgroup per window, which counts the pass and finishes g_p
-    hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
-    hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
-    hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, (long long)c->L.imu_out);
+    // the window-resident sweep: one workgroup per window — pose-side factors, visual sweep, Schur; it counts the pass
+    launch_linw(c, count);
   } else {
     launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
     launch_sum(c, count, g, mode);
@@ -1324,6 +1339,55 @@ lfvio_ctx *lfvio_create(int device) {
   (void)hipFuncSetAttribute((const void *)k_solve_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   (void)hipFuncSetAttribute((const void *)k_linw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   if (const char *e = getenv("LFVIO_LINW")) c->linw_mode = std::max(0, std::min(2, atoi(e)));
+  {  // static table of k_linw's phase 3: where each packed camera entry of H_pp (then each camera-side gradient entry) sits in the LDS accumulators
+    std::vector<int> tab(SUM_VIS);
+    for (int e = 0; e < SUM_VIS; e++) {
+      int r, cc;
+      if (e < SUM_VIS_PACKED) {
+        r = 0;
+        while ((r + 1) * (r + 2) / 2 <= e) r++;
+        cc = e - r * (r + 1) / 2;
+      } else {
+        r = cc = e - SUM_VIS_PACKED;
+      }
+      const int fr = r < 66 ? r / 6 : 11, fc = cc < 66 ? cc / 6 : 11, lr = r < 66 ? r - 6 * fr : r - 66, lc = cc < 66 ? cc - 6 * fc : cc - 66;
+      int at;
+      if (e >= SUM_VIS_PACKED) at = LW_G + cc;
+      else if (fr == fc && fr < 11) at = LW_D + 21 * fr + lw_tri(6, lc, lr);
+      else if (fr < 11) at = (LW_OFF0 + 36 * lw_pidx(fc, fr) + lc * 6 + lr) | LWT_ABS;
+      else if (fc < 11) at = LW_FX + 42 * fc + lc * 7 + lr;
+      else at = LW_XX + lw_tri(7, lc, lr);
+      auto is_ex = [](int q) { return q >= 66 && q < 72; };
+      if (is_ex(r) || is_ex(cc)) at |= LWT_EX;
+      if (r == 72 || cc == 72) at |= LWT_TD;
+      tab[e] = at;
+    }
+    if (hipMalloc((void **)&c->d_lwt, sizeof(int) * tab.size()) != hipSuccess ||
+        hipMemcpy(c->d_lwt, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      lfvio_destroy(c);
+      return nullptr;
+    }
+  }
+  {  // static scatter table of the assembling solve: packed visual entry -> tile address; IMU block entries, even factors then odd
+    std::vector<int> tab(ASM_LEN);
+    for (int r = 0, e = 0; r < KC; r++)
+      for (int cc = 0; cc <= r; cc++, e++) tab[e] = asm_lidx(r, cc);
+    auto glob = [](int p, int f) { return p < 6 ? 6 * f + p : p < 15 ? KC + 9 * f + (p - 6) : p < 21 ? 6 * (f + 1) + (p - 15) : KC + 9 * (f + 1) + (p - 21); };
+    for (int par = 0; par < 2; par++) {
+      std::vector<std::pair<int, int>> ent;  // (tile address, source index)
+      for (int f = par; f < LFVIO_WINDOW_SIZE; f += 2)
+        for (int p = 0; p < 30; p++)
+          for (int q = 0; q < 30; q++)
+            if (glob(p, f) >= glob(q, f)) ent.push_back({asm_lidx(glob(p, f), glob(q, f)), f * IMU_OUT + p * 30 + q});
+      std::sort(ent.begin(), ent.end());
+      for (size_t k = 0; k < ent.size(); k++) tab[ASM_VIS + par * ASM_IMU_HALF + k] = ent[k].second | (ent[k].first << 16);
+    }
+    if (hipMalloc((void **)&c->d_asm, sizeof(int) * tab.size()) != hipSuccess ||
+        hipMemcpy(c->d_asm, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      lfvio_destroy(c);
+      return nullptr;
+    }
+  }
   if (const char *e = getenv("LFVIO_FIRST_PASSES")) c->fixed_passes = std::max(0, atoi(e));
   (void)hipFuncSetAttribute((const void *)k_marg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
   const char *env = getenv("LFVIO_NO_GRAPH");
@@ -1340,6 +1404,8 @@ void lfvio_destroy(lfvio_ctx *c) {
   if (c->h_feat) (void)hipHostFree(c->h_feat);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_down) (void)hipHostFree(c->h_down);
+  if (c->d_asm) (void)hipFree(c->d_asm);
+  if (c->d_lwt) (void)hipFree(c->d_lwt);
   if (c->d_pending) (void)hipFree(c->d_pending);
   if (c->h_pending) (void)hipHostFree(c->h_pending);
   if (c->h_flags) {
@@ -1739,9 +1805,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
     HIPCHK(c, poke_int(offsetof(TRState, do_lin), do_lin));
     HIPCHK(c, poke_int(offsetof(TRState, do_schur), 1));
     if (lw) {
-      hipLaunchKernelGGL(k_imu_raw, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, 1);
-      hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE | MODE_NOCOUNT, 0, 0);
-      hipLaunchKernelGGL(k_linw, dim3(1, 1), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, (long long)c->L.imu_out);
+      launch_linw(c, 1);
     } else {
       launch_lin(c, 1, g, MODE_SOLVE);
       launch_sum(c, 1, g, MODE_SOLVE);
@@ -1804,9 +1868,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
   // one full linearization so that every kernel has valid inputs
   if (lw) {
-    hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
-    hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE | MODE_NOCOUNT, 0, 0);
-    hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, (long long)c->L.imu_out);
+    launch_linw(c, count);
   } else {
     launch_lin(c, count, g, MODE_SOLVE);
     launch_sum(c, count, g, MODE_SOLVE);
@@ -1826,16 +1888,12 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
         const int gx = which == 4 ? 1 : which == 5 ? 1 + LFVIO_WINDOW_SIZE : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
         hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
       } break;
-      case 11: case 12:  // the window-resident sweep of a batch: k_linw alone (12), with the pose-side launches in front of it (11)
+      case 11: case 12:  // the window-resident sweep of a batch (k_linw: pose-side factors, visual sweep, Schur)
         if (!use_linw(c, count, g, MODE_SOLVE)) {
           c->err = "the resident windows are not linearized by k_linw";
           return LFVIO_ERR_ARG;
         }
-        if (which == 11) {
-          hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
-          hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE | MODE_NOCOUNT, 0, 0);
-        }
-        hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, (long long)c->L.imu_out);
+        launch_linw(c, count);
         break;
       case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;
       default: launch_solve(c, count); break;
@@ -1867,9 +1925,7 @@ int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, dou
   const bool lw = use_linw(c, count, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
   if (lw) {
-    hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
-    hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE | MODE_NOCOUNT, 0, 0);
-    hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, (long long)c->L.imu_out);
+    launch_linw(c, count);
   } else {
     launch_lin(c, count, g, MODE_SOLVE);
     launch_sum(c, count, g, MODE_SOLVE);
