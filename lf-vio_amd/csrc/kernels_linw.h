@@ -40,7 +40,7 @@ typedef const __attribute__((address_space(4))) double cdouble;  // uniform addr
 
 constexpr int LW_THREADS = 256;
 constexpr int LW_STAGE = 32 * 17;                  // 32 basis rows x (16 + 1 pad)
-constexpr int LW_WAVE = LW_STAGE + 256 + 64;       // stage | Qf 16 x 16 | Ec 20 x 3 (+4)
+constexpr int LW_WAVE = LW_STAGE + 256 + 64;       // stage | Qf 16 x 16 (rows 0 .. 2 used) | spare
 constexpr int LW_D = 0, LW_FX = 11 * 21, LW_XX = LW_FX + 11 * 42, LW_G = LW_XX + 28, LW_DUMMY = LW_G + 76;
 constexpr int LW_PRIV = 800;                       // D 11 x 21 | FX 11 x 42 | XX 28 | G 76 | dummy
 static_assert(LW_DUMMY < LW_PRIV, "private accumulator layout");
@@ -67,35 +67,30 @@ DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // translation blocks are [M1 | -M1 | M3]^T times the `red` rows 0 .. 2, every other column is one basis row
 DEV int lw_base_row(int p) { return p < 3 ? 0 : p < 6 ? p : p < 9 ? 0 : p < 12 ? p - 3 : p < 15 ? 0 : p < 18 ? p - 6 : p - 6; }
 
-// One expanded entry (p, c), p <= c, of a step's 20 x 20 block lands at  A + Bi i + Bj j (+ 36 pidx(i, j) for the
-// pose-pose off-diagonal block) of the workgroup's LDS: see the header comment.  Packed in two words per entry (a lane keeps
-// four of them for the whole kernel):  w0 = A | Bi << 16 | Bj << 22 | off << 28,  w1 = (16 rp + rc) | p << 8 | c << 16.
-struct LwEntry {
-  int w0, w1;
-};
-DEV LwEntry lw_entry(int e, int priv, int off0) {
-  const bool in = e < NG;
-  int p = 0, rem = in ? e : 0;
-  while (rem >= 20 - p) rem -= 20 - p, p++;
-  const int c = p + rem;
+// Where the entry (p, c), p <= c, of a step's 20 x 20 factor block [Pi th_i Pj th_j tic th_ic td r] lands in the workgroup's
+// LDS accumulators:  A + Bi i + Bj j (+ 36 pidx(i, j) for the pose-pose off-diagonal block) — see the header comment.
+// One word:  A | Bi << 16 | Bj << 22 | off << 28 | negate << 29 | valid << 30.
+constexpr int LWD_NEG = 1 << 29, LWD_VALID = 1 << 30;
+DEV int lw_desc(int p, int c, bool neg, int priv, int off0) {
+  if (p > c) {
+    const int t = p;
+    p = c, c = t;
+  }
   const int bp = p < 6 ? 0 : p < 12 ? 1 : p < 19 ? 2 : 3, bc = c < 6 ? 0 : c < 12 ? 1 : c < 19 ? 2 : 3;
   int A = priv + LW_DUMMY, Bi = 0, Bj = 0, off = 0;
-  if (in) {
-    if (bp == 0 && bc == 0) A = priv + LW_D + lw_tri(6, p, c), Bi = 21;
-    else if (bp == 0 && bc == 1) A = off0 + p * 6 + (c - 6), off = 1;
-    else if (bp == 0 && bc == 2) A = priv + LW_FX + p * 7 + (c - 12), Bi = 42;
-    else if (bp == 0 && bc == 3) A = priv + LW_G + p, Bi = 6;
-    else if (bp == 1 && bc == 1) A = priv + LW_D + lw_tri(6, p - 6, c - 6), Bj = 21;
-    else if (bp == 1 && bc == 2) A = priv + LW_FX + (p - 6) * 7 + (c - 12), Bj = 42;
-    else if (bp == 1 && bc == 3) A = priv + LW_G + (p - 6), Bj = 6;
-    else if (bp == 2 && bc == 2) A = priv + LW_XX + lw_tri(7, p - 12, c - 12);
-    else if (bp == 2 && bc == 3) A = priv + LW_G + 66 + (p - 12);
-  }
-  LwEntry d;
-  d.w0 = A | (Bi << 16) | (Bj << 22) | (off << 28);
-  d.w1 = (16 * lw_base_row(p) + lw_base_row(c)) | (p << 8) | (c << 16);
-  return d;
+  if (bp == 0 && bc == 0) A = priv + LW_D + lw_tri(6, p, c), Bi = 21;
+  else if (bp == 0 && bc == 1) A = off0 + p * 6 + (c - 6), off = 1;
+  else if (bp == 0 && bc == 2) A = priv + LW_FX + p * 7 + (c - 12), Bi = 42;
+  else if (bp == 0 && bc == 3) A = priv + LW_G + p, Bi = 6;
+  else if (bp == 1 && bc == 1) A = priv + LW_D + lw_tri(6, p - 6, c - 6), Bj = 21;
+  else if (bp == 1 && bc == 2) A = priv + LW_FX + (p - 6) * 7 + (c - 12), Bj = 42;
+  else if (bp == 1 && bc == 3) A = priv + LW_G + (p - 6), Bj = 6;
+  else if (bp == 2 && bc == 2) A = priv + LW_XX + lw_tri(7, p - 12, c - 12);
+  else if (bp == 2 && bc == 3) A = priv + LW_G + 66 + (p - 12);
+  return A | (Bi << 16) | (Bj << 22) | (off << 28) | (neg ? LWD_NEG : 0) | LWD_VALID;
 }
+// basis row b (0 .. 13: jP th_i th_j th_ic td r) -> the local column it is (jP -> Pi; its Pj copy is handled apart)
+DEV int lw_pcol(int b) { return b < 6 ? b : b < 9 ? b + 3 : b < 12 ? b + 6 : b + 6; }
 
 // Byte offsets, inside a slot blob, of the arrays k_linw touches (the same for every slot of a context), passed BY VALUE: a
 // GP<> member of the slot would be fetched from memory before every use the compiler cannot prove unchanged — one more
@@ -117,7 +112,6 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
   double *my = lw + wv * LW_WAVE;
   double(*stage)[17] = (double(*)[17]) my;
   double(*Qf)[16] = (double(*)[16])(my + LW_STAGE);
-  double(*Ec)[3] = (double(*)[3])(my + LW_STAGE + 256);
   const LinwPlan *P = &S->linw;
   const int est_td = S->est_td, est_ex = S->est_ex;
   const double td = lv.x->td, tr_over_row = S->tr_over_row, half_row = S->half_row, sqrt_info = S->sqrt_info;
@@ -126,12 +120,45 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
   cdouble *TT = (cdouble *)(((unsigned long long)(unsigned)rfl((int)(ta >> 32)) << 32) | (unsigned)rfl((int)ta));
   constexpr int O_M1 = offsetof(Tab, M1) / 8, O_M2 = offsetof(Tab, M2) / 8, O_T = offsetof(Tab, T) / 8, O_C = offsetof(Tab, c) / 8;
   constexpr int O_RIC = offsetof(Tab, ric) / 8, O_RICT = offsetof(Tab, ricT) / 8, O_TIC = offsetof(Tab, tic) / 8;
-  // this lane's entries of the expanded block
-  LwEntry en[4];
+  // What this lane does with the step's basis Gram Q (its accumulator registers hold Q[kq + 4 r][ii]).  The basis rows are
+  // [jP th_i th_j th_ic td r] with jP = M1^T red, so every column of the factor block but `tic` is a basis row (Pj = -jP):
+  //   prim[r]   where Q[kq + 4 r][ii] itself goes (upper triangle, < 14);
+  //   extra[.]  for r = 0 and a jP row: the Pj copies (negated against other columns; (Pj, Pj) and the two (Pi, Pj) entries when
+  //             the column is a jP column too);
+  //   the tic columns are Kt jP, Kt = M3^T M1 (M1 is orthogonal): lane e < 57 forms ONE entry (tic_a, u) = sum_k Kt[a][k] Q[k][u]
+  //             — or (tic_a, tic_b) — from rows 0 .. 2 of Q, which go through LDS for that.
+  const int kq = lane >> 4, ii = lane & 15, privb = LW_PRIV0 + wv * LW_PRIV;
+  const int nodesc = privb + LW_DUMMY;  // (no valid bit: the slot adds zero to the wave's dummy word)
+  int prim[4], extra[3] = {nodesc, nodesc, nodesc};
 #pragma unroll
-  for (int m = 0; m < 4; m++) en[m] = lw_entry(lane + 64 * m, LW_PRIV0 + wv * LW_PRIV, LW_OFF0);
-  // column `lane` of E (lanes 0 .. 19): which of M1 / -M1 / M3 it is a column of, or a unit vector
-  const int ekind = lane < 3 ? 1 : (lane >= 6 && lane < 9) ? 2 : (lane >= 12 && lane < 15) ? 3 : 0, eq = lane % 3;
+  for (int r = 0; r < 4; r++) {
+    const int R = kq + 4 * r;
+    prim[r] = (R <= ii && ii < 14) ? lw_desc(lw_pcol(R), lw_pcol(ii), false, privb, LW_OFF0) : nodesc;
+  }
+  if (kq < 3 && kq <= ii && ii < 14) {
+    if (ii >= 3) extra[0] = lw_desc(6 + kq, lw_pcol(ii), true, privb, LW_OFF0);
+    else {
+      extra[0] = lw_desc(6 + kq, 6 + ii, false, privb, LW_OFF0);
+      extra[1] = lw_desc(kq, 6 + ii, true, privb, LW_OFF0);
+      if (kq != ii) extra[2] = lw_desc(ii, 6 + kq, true, privb, LW_OFF0);
+    }
+  }
+  // the tic entry of this lane: column a of Kt twice (tic-tic) or once; source basis column bu, sign
+  int tic_desc = nodesc, tic_a = 0, tic_b = 0, tic_u = 0;  // tic_b >= 0: (tic_a, tic_b); else (tic_a, column tic_u of Q)
+  bool tic_neg = false;
+  if (lane < 51) {
+    tic_a = lane / 17;
+    const int ui = lane % 17;  // Pi 0-2 | th_i 3-5 | Pj 6-8 | th_j 9-11 | th_ic 12-14 | td 15 | r 16
+    const int lu = ui < 12 ? ui : ui < 15 ? ui + 3 : ui + 3;  // local column: 0 .. 11, 15 .. 17, 18, 19
+    tic_u = ui < 6 ? ui : ui < 9 ? ui - 6 : ui < 12 ? ui - 3 : ui < 15 ? ui - 3 : ui - 3;  // basis row: Pj -> jP rows 0 .. 2
+    tic_neg = ui >= 6 && ui < 9;
+    tic_b = -1;
+    tic_desc = lw_desc(12 + tic_a, lu, false, privb, LW_OFF0);
+  } else if (lane < 57) {
+    const int e = lane - 51;  // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    tic_a = e < 3 ? 0 : e < 5 ? 1 : 2, tic_b = e < 3 ? e : e < 5 ? e - 2 : 2;
+    tic_desc = lw_desc(12 + tic_a, 12 + tic_b, false, privb, LW_OFF0);
+  }
   const double *anc = lw_at<const double>(S, A.anc0), *pmo = lw_at<const double>(S, A.pmo0);
   const size_t ancs = (size_t)A.anc_stride / 8, pmos = (size_t)A.pmo_stride / 8;
   double2 *wt0 = lw_at<double2>(S, A.Wt);
@@ -220,14 +247,17 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
       WACC(24, ts0);
       const long long ts1 = WNOW();
       (void)ts1;
-      // ---- Gram of the step: sum over its observations of the two 14-wide basis rows (SYRK on the matrix pipe)
+      // ---- Gram of the step: sum over its observations of the two 14-wide basis rows [jP th_i th_j th_ic td r] (SYRK on
+      //      the matrix pipe); the active lanes — a suffix of the strip — are packed from row 0, sixteen observations a round
+      const d3 jP0 = vmul(B.red[0], M1), jP1 = vmul(B.red[1], M1);
       double4_t acc = double4_t{0, 0, 0, 0};
-      const int g_lo = (first_now > lm0 ? first_now - lm0 : 0) >> 4, g_hi = (nlm - 1) >> 4;  // lane groups of 16 that hold active lanes
-      for (int r = g_lo; r <= g_hi; r++) {
+      const int a0 = first_now > lm0 ? first_now - lm0 : 0, rounds = (nlm - a0 + 15) >> 4;
+      const int pk = (lane - a0) & 63;  // packed position: the active lanes first, then the lanes past the strip, then the shorter tracks — all of those carry zero rows
+      for (int r = 0; r < rounds; r++) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if ((lane >> 4) == r) {
-          double *r0 = stage[2 * (lane & 15)], *r1 = stage[2 * (lane & 15) + 1];
-          r0[0] = B.red[0].x, r0[1] = B.red[0].y, r0[2] = B.red[0].z, r1[0] = B.red[1].x, r1[1] = B.red[1].y, r1[2] = B.red[1].z;
+        if ((pk >> 4) == r) {
+          double *r0 = stage[2 * (pk & 15)], *r1 = r0 + 17;
+          r0[0] = jP0.x, r0[1] = jP0.y, r0[2] = jP0.z, r1[0] = jP1.x, r1[1] = jP1.y, r1[2] = jP1.z;
           r0[3] = B.jti[0].x, r0[4] = B.jti[0].y, r0[5] = B.jti[0].z, r1[3] = B.jti[1].x, r1[4] = B.jti[1].y, r1[5] = B.jti[1].z;
           r0[6] = B.jtj[0].x, r0[7] = B.jtj[0].y, r0[8] = B.jtj[0].z, r1[6] = B.jtj[1].x, r1[7] = B.jtj[1].y, r1[8] = B.jtj[1].z;
           r0[9] = B.jtx[0].x, r0[10] = B.jtx[0].y, r0[11] = B.jtx[0].z, r1[9] = B.jtx[1].x, r1[10] = B.jtx[1].y, r1[11] = B.jtx[1].z;
@@ -243,39 +273,47 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
       WACC(25, ts1);
       const long long ts2 = WNOW();
       (void)ts2;
+      // ---- the step's 20 x 20 block into the accumulators.  Rows 0 .. 2 of Q through LDS for the tic entries; everything else
+      //      straight from the accumulator registers.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-      for (int r = 0; r < 4; r++) Qf[(lane >> 4) + 4 * r][lane & 15] = acc[r];
-      if (lane < 20) {
-        // column `lane` of E from the pair's uniform matrices (selects, no memory)
+      if (kq < 3) Qf[kq][ii] = acc[0];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int offp = 36 * lw_pidx(s, j);
+      auto at = [&](int d) { return lw + ((d & 0xffff) + ((d >> 16) & 63) * s + ((d >> 22) & 63) * j + ((d & (1 << 28)) ? offp : 0)); };
+      double tval = 0.0;
+      if (tic_desc & LWD_VALID) {
+        // Kt = M3^T M1: Kt[a][k] = sum_m M3[m][a] M1[m][k] (uniform; this lane needs row a — and row b for a tic-tic entry)
+        double ka[3], kb[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const double m1 = lw_sel3(eq, M1.a[3 * k], M1.a[3 * k + 1], M1.a[3 * k + 2]);
-          const double m3 = lw_sel3(eq, M3.a[3 * k], M3.a[3 * k + 1], M3.a[3 * k + 2]);
-          Ec[lane][k] = ekind == 1 ? m1 : ekind == 2 ? -m1 : ekind == 3 ? m3 : (k == 0 ? 1.0 : 0.0);
+          double ra[3];
+#pragma unroll
+          for (int a2 = 0; a2 < 3; a2++) ra[a2] = fma(M3.a[6 + a2], M1.a[6 + k], fma(M3.a[3 + a2], M1.a[3 + k], M3.a[a2] * M1.a[k]));
+          ka[k] = lw_sel3(tic_a, ra[0], ra[1], ra[2]);
+          kb[k] = lw_sel3(tic_b < 0 ? 0 : tic_b, ra[0], ra[1], ra[2]);
+        }
+        if (tic_b < 0) {
+          tval = fma(ka[2], Qf[2][tic_u], fma(ka[1], Qf[1][tic_u], ka[0] * Qf[0][tic_u]));
+          tval = tic_neg ? -tval : tval;
+        } else {
+          double tl[3];
+#pragma unroll
+          for (int q = 0; q < 3; q++) tl[q] = fma(ka[2], Qf[2][q], fma(ka[1], Qf[1][q], ka[0] * Qf[0][q]));
+          tval = fma(kb[2], tl[2], fma(kb[1], tl[1], kb[0] * tl[0]));
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      // ---- E^T Q E by the structure of E: this lane's (up to) four entries — all of them read and formed first, then added
-      //      to the accumulators (a store between two entries would hold the next one's reads back)
-      const int offp = 36 * lw_pidx(s, j);
-      double val[4];
+      // (all eight read first, then added and stored: a store between two of them would hold the next read back.  An
+      // unused slot points at the wave's dummy word and adds zero.)
+      double *dst[8], old[8], add[8];
 #pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const int w1 = en[m].w1, q0 = w1 & 0xff, p = (w1 >> 8) & 0xff, c = w1 >> 16;
-        const double *qb = &Qf[0][0] + q0;  // Qf[rp][rc]
-        const double ep0 = Ec[p][0], ep1 = Ec[p][1], ep2 = Ec[p][2], ec0 = Ec[c][0], ec1 = Ec[c][1], ec2 = Ec[c][2];
-        double tl[3];
+      for (int r = 0; r < 4; r++) dst[r] = at(prim[r]), add[r] = (prim[r] & LWD_VALID) ? acc[r] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 3; q++) tl[q] = fma(ep2, qb[32 + q], fma(ep1, qb[16 + q], ep0 * qb[q]));
-        val[m] = fma(ec2, tl[2], fma(ec1, tl[1], ec0 * tl[0]));
-      }
+      for (int e = 0; e < 3; e++) dst[4 + e] = at(extra[e]), add[4 + e] = !(extra[e] & LWD_VALID) ? 0.0 : (extra[e] & LWD_NEG) ? -acc[0] : acc[0];
+      dst[7] = at(tic_desc), add[7] = (tic_desc & LWD_VALID) ? tval : 0.0;
 #pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const int w0 = en[m].w0;
-        double *dst = lw + ((w0 & 0xffff) + ((w0 >> 16) & 63) * s + ((w0 >> 22) & 63) * j + ((w0 >> 28) ? offp : 0));
-        *dst += val[m];
-      }
+      for (int e = 0; e < 8; e++) old[e] = *dst[e];
+#pragma unroll
+      for (int e = 0; e < 8; e++) *dst[e] = old[e] + add[e];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       WACC(26, ts2);
     }
@@ -623,20 +661,25 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
     }
     if (blk + 1 < nblk) request(blk + 1);
     __syncthreads();
-    int rows = N - blk * LM_BLOCK;
-    rows = rows > LM_BLOCK ? LM_BLOCK : rows;
-    for (int s4 = 0; 4 * s4 < rows; s4++) {
-      const int row = 4 * s4 + kk;
-      const double coef = lcoef[row], eb = le[row];
+    // all sixteen steps of the block, straight-line (rows past the block's last landmark are zeros with weight zero): the
+    // operand reads of a step are not held behind the previous step's MFMAs
+    auto sweep = [&](auto ntl) {
+      constexpr int NTL4 = decltype(ntl)::value;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (wv + 4 * j >= NT) continue;  // wave-uniform
-        const double xa = tile[row][ct[j]];
-        double xb = tile[row][cu[j]];
-        if (scale_k[j]) xb *= eb;  // b / D2 * e  -> z2 column
-        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(coef * xa, xb, acc[j], 0, 0, 0);
+      for (int s4 = 0; s4 < LM_BLOCK / 4; s4++) {
+        const int row = 4 * s4 + kk;
+        const double coef = lcoef[row], eb = le[row];
+#pragma unroll
+        for (int j = 0; j < NTL4; j++) {
+          const double xa = tile[row][ct[j]];
+          double xb = tile[row][cu[j]];
+          if (scale_k[j]) xb *= eb;  // b / D2 * e  -> z2 column
+          acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(coef * xa, xb, acc[j], 0, 0, 0);
+        }
       }
-    }
+    };
+    if (__builtin_amdgcn_readfirstlane(wv) + 12 < NT) sweep(std::integral_constant<int, 4>{});
+    else sweep(std::integral_constant<int, 3>{});
   }
   WSTAMP(13);
   double *ss = lw_at<double>(S, A.schur_sum);
