@@ -107,13 +107,14 @@ DEV double lw_sel3(int q, double x0, double x1, double x2) { return q == 0 ? x0 
 // ---------------------------------------------------------------------------
 // phase 1: the strips of this wave
 // ---------------------------------------------------------------------------
-DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int scaled, double *lw, double part[5]) {
+DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int scaled, int mode, double *lw, double part[5]) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   double *my = lw + wv * LW_WAVE;
   double(*stage)[17] = (double(*)[17]) my;
   double(*Qf)[16] = (double(*)[16])(my + LW_STAGE);
   const LinwPlan *P = &S->linw;
-  const int est_td = S->est_td, est_ex = S->est_ex;
+  const bool marg = is_marg(mode);
+  const int est_td = S->est_td, est_ex = marg ? 1 : S->est_ex;  // (ResidualBlockInfo::Evaluate asks for every Jacobian)
   const double td = lv.x->td, tr_over_row = S->tr_over_row, half_row = S->half_row, sqrt_info = S->sqrt_info;
   // (the address built from scalars: the tables of this linearization point are read-only here and wave-uniform)
   const unsigned long long ta = (unsigned long long)(const void *)lv.tab;
@@ -176,6 +177,7 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
     (void)tp0;
     const int dl = __builtin_amdgcn_readlane(d_lm0, t), ds = __builtin_amdgcn_readlane(d_sk, t);
     const int lm0 = dl & 0xffff, nlm = dl >> 16, s = ds & 0xffff, kmax = ds >> 16;
+    if (marg && s != 0) continue;  // the marginalization's sweep: the landmarks anchored at frame 0
     // per step o (lane o holds it): the first landmark of this start frame that has an observation o, and the pair-major index of its observation
     const int oc = lane < 12 && s + lane < LFVIO_NUM_FRAMES ? lane : 0;
     const int r_first = P->firstl[s][oc], r_idx0 = P->pair_obs0[s * 11 + s + oc];
@@ -330,26 +332,34 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
         wt[(size_t)35 * SPEC_MAX_LM] = make_double2(wTx.y, wTx.z);
       }
       wt[(size_t)36 * SPEC_MAX_LM] = make_double2(est_td ? wtd : 0.0, 0.0);
-      double *scale_l = lw_at<double>(S, A.scale_l);
-      double sc;
-      if (!scaled) {
-        sc = 1.0 / (1.0 + sqrt(a));  // jacobi_scaling, fixed at iteration 0
-        scale_l[l] = sc;
+      if (marg) {
+        // eps of marginalization_factor.h:70 on the diagonal block; no scaling, no trust-region scalars
+        lw_at<double>(S, A.einv_l)[l] = (a > 1e-8) ? 1.0 / a : 0.0;
+        lw_at<double>(S, A.a)[l] = a;
+        lw_at<double>(S, A.b)[l] = b;
+        cost_s += cost, lam2_s += lam * lam, bmax_s = fmax(bmax_s, fabs(b));
       } else {
-        sc = scale_l[l];
+        double *scale_l = lw_at<double>(S, A.scale_l);
+        double sc;
+        if (!scaled) {
+          sc = 1.0 / (1.0 + sqrt(a));  // jacobi_scaling, fixed at iteration 0
+          scale_l[l] = sc;
+        } else {
+          sc = scale_l[l];
+        }
+        const double s2a = sc * sc * a;
+        const double D2 = fmin(fmax(s2a, 1e-6), 1e32);  // min/max_lm_diagonal
+        const double dg = sqrt(D2);
+        const double gr = sc * b / dg;  // DoglegStrategy::ComputeGradient
+        lw_at<double>(S, A.diag_l)[l] = dg;
+        lw_at<double>(S, A.grad_l)[l] = gr;
+        const double v = gr / dg;
+        const double eb = s2a + lv.mu * D2;
+        lw_at<double>(S, A.einv_l)[l] = 1.0 / eb;
+        lw_at<double>(S, A.a)[l] = a;
+        lw_at<double>(S, A.b)[l] = b;
+        cost_s += cost, g2_s += gr * gr, asv2_s += s2a * v * v, lam2_s += lam * lam, bmax_s = fmax(bmax_s, fabs(b));
       }
-      const double s2a = sc * sc * a;
-      const double D2 = fmin(fmax(s2a, 1e-6), 1e32);  // min/max_lm_diagonal
-      const double dg = sqrt(D2);
-      const double gr = sc * b / dg;  // DoglegStrategy::ComputeGradient
-      lw_at<double>(S, A.diag_l)[l] = dg;
-      lw_at<double>(S, A.grad_l)[l] = gr;
-      const double v = gr / dg;
-      const double eb = s2a + lv.mu * D2;
-      lw_at<double>(S, A.einv_l)[l] = 1.0 / eb;
-      lw_at<double>(S, A.a)[l] = a;
-      lw_at<double>(S, A.b)[l] = b;
-      cost_s += cost, g2_s += gr * gr, asv2_s += s2a * v * v, lam2_s += lam * lam, bmax_s = fmax(bmax_s, fabs(b));
     }
     WACC(28, te0);
   }
@@ -369,18 +379,20 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
 constexpr int LW_JLD = 33;                                   // 16 rows x (32 + 1 pad): columns 0 .. 29 the Jacobian, 30 the residual, row 15 zero
 constexpr int LW_IMU_WAVE = 3 * 16 * LW_JLD + 16 * LW_JLD;   // Jr of the wave's three factors | Jw
 static_assert(LINW_WAVES * LW_IMU_WAVE <= LW_LDS_P1, "phase 0 fits the phase-1 workspace");
-DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off) {
+DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off, int mode) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   double *my = lw + wv * LW_IMU_WAVE;
   double *Jr3 = my;
   double(*Jw)[LW_JLD] = (double(*)[LW_JLD])(my + 3 * 16 * LW_JLD);
   const FrameState *x = lv.x;
   const bool pose_rank = !S->sharded || S->pose_side;
+  // (the marginalization's sweep takes the factor between frames 0 and 1 only, and only if the plan says so)
+  auto factor_on = [&](int f) { return S->imu_active[f] && pose_rank && (mode == MODE_SOLVE || (f == 0 && marg_plan(S, mode)->use_imu0)); };
   for (int e = lane; e < 3 * 16 * LW_JLD; e += 64) my[e] = 0.0;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane < 3) {
     const int f = wv + 4 * lane;
-    if (f < LFVIO_WINDOW_SIZE && S->imu_active[f] && pose_rank) {
+    if (f < LFVIO_WINDOW_SIZE && factor_on(f)) {
       double rr[15];
       imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
       double *Jr = Jr3 + 16 * LW_JLD * lane;
@@ -401,7 +413,7 @@ DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off) {
     const int f = wv + 4 * q;
     if (f >= LFVIO_WINDOW_SIZE) break;
     double *out = imu_out + (size_t)f * IMU_OUT;
-    if (!(S->imu_active[f] && pose_rank)) {
+    if (!factor_on(f)) {
       for (int e = lane; e < IMU_OUT; e += 64) out[e] = 0.0;
       continue;
     }
@@ -510,17 +522,27 @@ constexpr int LWT_ABS = 1 << 16, LWT_EX = 1 << 17, LWT_TD = 1 << 18;
 // ---------------------------------------------------------------------------
 // k_linw: grid (1, batch) x 256, dynamic LDS = LW_LDS_BYTES
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t stride, const LinwArgs A) {
+__global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t stride, const LinwArgs A, int mode_bits) {
   extern __shared__ __attribute__((aligned(16))) double lw[];
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const TRFlags fl = tr_flags(tr);
+  TRFlags fl = tr_flags(tr);
   const double mu = tr->mu;
-  const int N = S->N, est_ex = S->est_ex, est_td = S->est_td;
-  // a pass that starts with the loop still open is a pass this slot needs (k_lin's count)
-  if (!fl.done && tid == 0) S->passes_used++;
-  if (fl.done | (!fl.do_lin & !fl.do_schur)) return;
+  // mode_bits: MODE_SOLVE, or (MODE_MARG + flag) | MODE_GATED — the marginalization's sweep behind the solve passes of the same
+  // graph: the landmarks anchored at frame 0, the IMU factor between frames 0 and 1, the prior; every column active; the
+  // complete packed H_pp written (k_marg_solve reads it), the Schur sums over those landmarks with weights 1 / a_l.
+  const int mode = mode_bits & (MODE_GATED - 1);
+  const bool marg = is_marg(mode);
+  const int N = marg ? marg_plan(S, mode)->N0 : S->N, est_ex = marg ? 1 : S->est_ex, est_td = marg ? 1 : S->est_td;
+  if (marg) {
+    if (!tail_gate(S, fl.done)) return;
+    fl.do_lin = fl.do_schur = 1;
+  } else {
+    // a pass that starts with the loop still open is a pass this slot needs (k_lin's count)
+    if (!fl.done && tid == 0) S->passes_used++;
+    if (fl.done | (!fl.do_lin & !fl.do_schur)) return;
+  }
   LinView lv;
   lv.x = &S->x[fl.cur], lv.tab = &S->tab[fl.cur], lv.lam = lw_at<const double>(S, A.lam[fl.cur]), lv.mu = mu;
   WSTAMP(8);
@@ -529,7 +551,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
     int p3[P3_E];  // (phase 3's table entries: requested here, used a hundred microseconds later)
 #pragma unroll
     for (int q = 0; q < P3_E; q++) p3[q] = A.asm_tab[tid + LW_THREADS * q < SUM_VIS ? tid + LW_THREADS * q : 0];
-    linw_imu(S, lv, lw, A.imu_out);
+    linw_imu(S, lv, lw, A.imu_out, mode);
     WSTAMP(30);
     __syncthreads();
     linw_prior(S, lv, lw);
@@ -538,7 +560,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
     __syncthreads();
     WSTAMP(9);
     double part[5];
-    linw_strips(S, lv, A, fl.cur, fl.scaled, lw, part);
+    linw_strips(S, lv, A, fl.cur, fl.scaled, mode, lw, part);
     WSTAMP(10);
     if (lane == 0) {
 #pragma unroll
@@ -562,13 +584,52 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
     }
     __syncthreads();  // (the accumulators are read: their LDS is free)
     double *Hpp = lw_at<double>(S, A.Hpp);
+    if (!marg) {
 #pragma unroll
-    for (int q = 0; q < P3_E; q++) {
-      const int e = tid + LW_THREADS * q;
-      if (e < SUM_VIS_PACKED) Hpp[e] = hv[q];
-      else if (e < SUM_VIS) lw[e - SUM_VIS_PACKED] = hv[q];  // visual gradient, camera side
+      for (int q = 0; q < P3_E; q++) {
+        const int e = tid + LW_THREADS * q;
+        if (e < SUM_VIS_PACKED) Hpp[e] = hv[q];
+        else if (e < SUM_VIS) lw[e - SUM_VIS_PACKED] = hv[q];  // visual gradient, camera side
+      }
+      __syncthreads();
+    } else {
+      // the marginalization reads the complete packed matrix: visual terms (camera part, from LDS), the IMU factor, the prior
+      // — k_sum's sum per entry, in its order; once per call
+#pragma unroll
+      for (int q = 0; q < P3_E; q++) {
+        const int e = tid + LW_THREADS * q;
+        if (e < SUM_VIS) lw[LW_HC + (e < SUM_VIS_PACKED ? KC + e : e - SUM_VIS_PACKED)] = hv[q];  // [gradient KC | packed camera part]
+      }
+      __syncthreads();
+      const double *imu_out = lw_at<const double>(S, A.imu_out);
+      const double *prior_A = S->prior_A;
+      const int prior_ok = S->prior_valid && (!S->sharded || S->pose_side), prior_n = S->prior_n;
+      for (int e = tid; e < PACKED; e += LW_THREADS) {
+        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= e) r++;
+        while (r * (r + 1) / 2 > e) r--;
+        const int c = e - r * (r + 1) / 2;
+        double val = r < KC ? lw[LW_HC + KC + e] : 0.0;
+        const int f0 = col_frame(r);
+        if (f0 >= 0) {
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int f = f0 - 1 + u;
+            if (f >= 0 && f < LFVIO_WINDOW_SIZE) {
+              const int pl = imu_local(r, f), ql = imu_local(c, f);
+              if (pl >= 0 && ql >= 0) val += imu_out[(size_t)f * IMU_OUT + pl * 30 + ql];
+            }
+          }
+        }
+        if (prior_ok) {
+          const int pr = S->prior_inv[r], pc = S->prior_inv[c];
+          if (pr >= 0 && pc >= 0) val += prior_A[pr * prior_n + pc];
+        }
+        Hpp[e] = val;
+      }
+      if (tid < KC) lw[tid] = lw[LW_HC + tid];
+      __syncthreads();
     }
-    __syncthreads();
     if (tid < KP) {
       // g_p entry: visual part, the (at most two) IMU factors, the prior — k_sum's order
       const int r = tid;
@@ -612,7 +673,7 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
     const int t = ti < 5 ? 0 : ti < 9 ? 1 : ti < 12 ? 2 : ti < 14 ? 3 : 4;
     const int u = ti - (t * 5 - (t * (t - 1)) / 2) + t;
     ct[j] = ti < NT ? 16 * t + cc : 0, cu[j] = ti < NT ? 16 * u + cc : 0;
-    scale_k[j] = cu[j] == COL_K;
+    scale_k[j] = !marg && cu[j] == COL_K;
   }
   const double2 *wt0 = lw_at<const double2>(S, A.Wt);
   const double *scale_l = lw_at<const double>(S, A.scale_l), *av = lw_at<const double>(S, A.a), *bv = lw_at<const double>(S, A.b);
@@ -646,7 +707,9 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
       }
       if (tid < LM_BLOCK) {
         double cf = 0.0, eb = 0.0, bl = 0.0, kap = 0.0;
-        if (l < N) {
+        if (l < N && marg) {
+          cf = (w_a > 1e-8) ? 1.0 / w_a : 0.0, eb = w_a, bl = w_b;
+        } else if (l < N) {
           const double s2a = w_sc * w_sc * w_a;
           const double D2 = fmin(fmax(s2a, 1e-6), 1e32);
           eb = s2a + mu * D2;  // e-block + lm_diagonal^2

@@ -901,8 +901,8 @@ LinwArgs linw_args(const lfvio_ctx *c) {
   a.asm_tab = c->d_lwt;
   return a;
 }
-void launch_linw(lfvio_ctx *c, int count) {
-  hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
+void launch_linw(lfvio_ctx *c, int count, int mode_bits = MODE_SOLVE) {
+  hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c), mode_bits);
 }
 
 // lw: the pass was linearized by k_linw — H_pp holds the visual terms of its camera part only, the solve adds the rest on load
@@ -918,7 +918,10 @@ void launch_solve(lfvio_ctx *c, int count, bool lw = false) {
 
 // A resident batch whose windows all carry a LinwPlan is linearized window by window (kernels_linw.h) instead of role by role.
 bool use_linw(lfvio_ctx *c, int count, const Grid &g, int mode) {
-  if (mode != MODE_SOLVE || c->linw_mode == 0 || c->shard_active) return false;
+  // (the solve passes, and the gated marginalization sweep behind them in the same graph)
+  const int m = mode & (MODE_GATED - 1);
+  const bool solve = mode == MODE_SOLVE, gated_marg = (mode & MODE_GATED) && m >= MODE_MARG && !(mode & (MODE_DECIDE | MODE_NOCOUNT));
+  if (!(solve || gated_marg) || c->linw_mode == 0 || c->shard_active) return false;
   if (c->linw_mode != 2 && !lin_split(count, g)) return false;
   for (int s = 0; s < count; s++)
     if (!c->info[s].linw_ok) return false;
@@ -939,7 +942,7 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   const bool merge = solve && !lw && g.lm <= DOGLEG_INLINE_BLOCKS && !c->no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
   if (lw) {
     // the window-resident sweep: one workgroup per window — pose-side factors, visual sweep, Schur; it counts the pass
-    launch_linw(c, count);
+    launch_linw(c, count, mode);
   } else {
     launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
     launch_sum(c, count, g, mode);
