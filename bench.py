@@ -46,12 +46,16 @@ def algorithmic_bytes(N, M):
     return 68 * (M - N) + 88 * N
 
 
-def pmc_traffic(workload):
-    """HBM bytes per k_lin launch from the committed rocprofv3 --pmc passes of this same command
+def pmc_traffic(workload, kernels):
+    """HBM bytes per launch of the sweep kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/r*/pmc_summary.md, written by tools/collect_profiles.py): FETCH_SIZE + WRITE_SIZE, reported in KB.
+    kernels: the rows that make up ONE sweep of the workload — "k_linw" for a resident batch, "k_lin<7>" (all roles in one
+    grid) for a single window, the role launches "k_lin<1>", "k_lin<2>", "k_lin<8>" for a batch on the role-by-role path.
     None when no summary covers the workload (the counters cannot be collected from inside the timed process)."""
     import glob
     import re
+
+    names = set(kernels)
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.md")), reverse=True):
         section, total, found = None, None, None
@@ -59,10 +63,10 @@ def pmc_traffic(workload):
             m = re.match(r"## (\S+)", line)
             if m:
                 section = m.group(1)
-            elif section == workload and re.match(r"\| (void )?k_lin(<\d+>)? \|", line):
-                # k_lin is a template over its roles: one grid (k_lin<7>) for a single window, one launch per role
-                # (k_lin<1>, <2>, <8>) for a resident batch — a sweep is the sum of the role launches
+            elif section == workload and line.startswith("|"):
                 cells = [c.strip() for c in line.strip().strip("|").split("|")]
+                if cells[0].replace("void ", "") not in names:
+                    continue
                 try:
                     total = (total or 0.0) + (float(cells[2]) + float(cells[3])) * 1024.0
                     found = os.path.relpath(path, ROOT)
@@ -361,16 +365,31 @@ def main():
     #      library's own stream; algorithmic bytes per launch = 68 (M - N) + 88 N over what the launch sweeps
     reps = 200 if n_lm <= 1000 else 20
     tk = grp if sharded else eng  # (the sharded window lives in the group's context)
-    lin_ms = tk.time_kernel(0, batch, reps)
+    # (a resident batch is linearized window by window — k_linw, which also holds what k_sum did; everything else by k_lin)
+    try:
+        lin_ms, linw = tk.time_kernel(12, batch, reps), True
+    except Exception:  # noqa: BLE001  (not a batch the library linearizes with k_linw)
+        lin_ms, linw = tk.time_kernel(0, batch, reps), False
     bytes_per_launch = sum(algorithmic_bytes(w.N, w.M) for w in wins[:batch]) if not sharded else algorithmic_bytes(local_N, local_M)
     achieved = bytes_per_launch / (lin_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(workload if not stream_mode else "window300")
-    roofline = dict(bound="hbm", kernel="k_lin (visual residual/Jacobian sweep: landmark rows + Schur SYRK, Gram chunks, IMU, prior)",
+    rows = ["k_linw"] if linw else (["k_lin<1>", "k_lin<2>", "k_lin<8>"] if batch >= 64 else ["k_lin<7>"])
+    traffic, traffic_src = pmc_traffic(workload if not stream_mode else "window300", rows)
+    kernel_name = ("k_linw (window-resident sweep: IMU + prior factors, every observation once — residual, Jacobian basis, Gram SYRK —, "
+                   "LDS accumulators of H_pp, Schur SYRK; one workgroup per window)") if linw else \
+        "k_lin (visual residual/Jacobian sweep: landmark rows + Schur SYRK, Gram chunks, IMU, prior)"
+    roofline = dict(bound="hbm", kernel=kernel_name,
                     achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                     traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_us=lin_ms * 1e3,
                     note="latency-bound at N=300 (0.1 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep")
-    extra = dict(k_sum_us=tk.time_kernel(2, batch, reps) * 1e3, k_solve_us=tk.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
+    if linw:
+        flops = sum(2.0e3 * (w.M - w.N) + 1.6e3 * w.N for w in wins[:batch])  # ~2.0 k per residual block + 1.6 k per landmark
+        roofline.update(note="FP64-bound (SURVEY section 8(d): 26 FLOP/B against a ridge of 9.8): see fp64_*; the HBM figures are kept because the metric's "
+                             "contract prices this kernel in bytes", fp64_tflops=flops / (lin_ms * 1e-3) / 1e12,
+                        fp64_frac=flops / (lin_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, flops_per_launch=flops)
+        extra = dict(k_solve_us=tk.time_kernel(13, batch, max(reps // 4, 5)) * 1e3)
+    else:
+        extra = dict(k_sum_us=tk.time_kernel(2, batch, reps) * 1e3, k_solve_us=tk.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
     # the dense solve (k_solve: one workgroup = one CU per window) is where a small window spends most of its time; its
     # arithmetic is the Cholesky factorization and two substitutions of the 172 x 172 reduced system
     KP = 172
@@ -649,8 +668,12 @@ def main():
                 e2.batch_optimize(nb, flag, sync=False)
             e2.batch_sync()
             eb = (time.perf_counter() - tb) / nsw
-            lin512 = e2.time_kernel(0, nb, 10) * 1e-3   # one sweep of all four k_lin roles over the 512 windows, seconds
-            sol512 = e2.time_kernel(3, nb, 5) * 1e-3
+            try:  # one linearization sweep of the 512 windows, seconds: k_linw (window-resident), else the four k_lin role launches
+                lin512, lin_name = e2.time_kernel(12, nb, 10) * 1e-3, "k_linw (one workgroup per window, 512 windows)"
+                sol512 = e2.time_kernel(13, nb, 5) * 1e-3
+            except Exception:  # noqa: BLE001
+                lin512, lin_name = e2.time_kernel(0, nb, 10) * 1e-3, "k_lin (four role launches over 512 windows)"
+                sol512 = e2.time_kernel(3, nb, 5) * 1e-3
             flops_lin = sum(2.0e3 * (w_.M - w_.N) + 1.6e3 * w_.N for w_ in bw)  # ~2.0 k per residual block + 1.6 k per landmark
             bytes_lin = sum(algorithmic_bytes(w_.N, w_.M) for w_ in bw)
             flops_sol = nb * (172 ** 3 / 3.0 + 2.0 * 172 ** 2) * 2.0
@@ -668,7 +691,7 @@ def main():
                                    one_stream=one_stream,
                                    description="BASELINE configs[4]: 512 distinct 10-keyframe / 300-landmark windows resident at once, one optimization() each per sweep"
                                                + ("; as two contexts of 256 on the device (lfvio_group_create_local), two streams side by side" if streams == 2 else ""),
-                                   roofline=dict(bound="fp64", kernel="k_lin (four role launches over 512 windows)", achieved=flops_lin / lin512 / 1e12,
+                                   roofline=dict(bound="fp64", kernel=lin_name, achieved=flops_lin / lin512 / 1e12,
                                                  peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=flops_lin / lin512 / 1e12 / FP64_PEAK_TFLOPS,
                                                  hbm_gbs=bytes_lin / lin512 / 1e9, hbm_frac=bytes_lin / lin512 / 1e9 / HBM_PEAK_GBS,
                                                  avg_sweep_us=lin512 * 1e6, flops_per_sweep=flops_lin, algorithmic_bytes_per_sweep=bytes_lin),

@@ -529,14 +529,14 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   TRFlags fl = tr_flags(tr);
   const double mu = tr->mu;
-  // mode_bits: MODE_SOLVE, or (MODE_MARG + flag) | MODE_GATED — the marginalization's sweep behind the solve passes of the same
-  // graph: the landmarks anchored at frame 0, the IMU factor between frames 0 and 1, the prior; every column active; the
+  // mode_bits: MODE_SOLVE, or MODE_MARG + flag (| MODE_GATED behind the solve passes of the same graph) — the marginalization's
+  // sweep: the landmarks anchored at frame 0, the IMU factor between frames 0 and 1, the prior; every column active; the
   // complete packed H_pp written (k_marg_solve reads it), the Schur sums over those landmarks with weights 1 / a_l.
   const int mode = mode_bits & (MODE_GATED - 1);
   const bool marg = is_marg(mode);
   const int N = marg ? marg_plan(S, mode)->N0 : S->N, est_ex = marg ? 1 : S->est_ex, est_td = marg ? 1 : S->est_td;
   if (marg) {
-    if (!tail_gate(S, fl.done)) return;
+    if ((mode_bits & MODE_GATED) && !tail_gate(S, fl.done)) return;
     fl.do_lin = fl.do_schur = 1;
   } else {
     // a pass that starts with the loop still open is a pass this slot needs (k_lin's count)

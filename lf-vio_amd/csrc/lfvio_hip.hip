@@ -918,10 +918,10 @@ void launch_solve(lfvio_ctx *c, int count, bool lw = false) {
 
 // A resident batch whose windows all carry a LinwPlan is linearized window by window (kernels_linw.h) instead of role by role.
 bool use_linw(lfvio_ctx *c, int count, const Grid &g, int mode) {
-  // (the solve passes, and the gated marginalization sweep behind them in the same graph)
+  // (the solve passes, and the marginalization's sweep behind them)
   const int m = mode & (MODE_GATED - 1);
-  const bool solve = mode == MODE_SOLVE, gated_marg = (mode & MODE_GATED) && m >= MODE_MARG && !(mode & (MODE_DECIDE | MODE_NOCOUNT));
-  if (!(solve || gated_marg) || c->linw_mode == 0 || c->shard_active) return false;
+  const bool solve = mode == MODE_SOLVE, marg_sweep = m >= MODE_MARG && !(mode & (MODE_DECIDE | MODE_NOCOUNT));
+  if (!(solve || marg_sweep) || c->linw_mode == 0 || c->shard_active) return false;
   if (c->linw_mode != 2 && !lin_split(count, g)) return false;
   for (int s = 0; s < count; s++)
     if (!c->info[s].linw_ok) return false;
@@ -1154,7 +1154,7 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated)
   const Grid g = grid_for(c, count);
   const int mode = (MODE_MARG + flag) | (gated ? MODE_GATED : 0);
   if (standalone)
-    hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode, 0);
+    hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode, use_linw(c, count, g, mode) ? 1 : 0);
   launch_iteration(c, count, g, mode);
   hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total,
                      flag | (c->force_eig ? 256 : 0) | (gated ? 512 : 0) | (gated && c->publish ? 1024 : 0));

@@ -143,3 +143,24 @@ def test_default_mode_takes_the_new_path_for_a_batch_and_the_old_one_for_few_win
     upload_all(eng, ws, 1)
     assert eng.resident_pass(128, 3, ws[0].N)["linw"] == 1
     assert eng.resident_pass(2, 1, ws[0].N)["linw"] == 0
+
+
+def test_the_literal_calls_of_one_window_through_k_linw(eng, oracle, cases):
+    """lfvio_solve / lfvio_marginalize of ONE window with the window-resident sweep forced (mode 2): the stand-alone
+    marginalization launches its sweep ungated, on a slot k_setup has just re-armed."""
+    w = cases[0]
+    try:
+        eng.set_linw(0)
+        s0 = eng.solve(w)
+        p0 = eng.marginalize(abi.apply_solution(w, s0), abi.MARGIN_OLD)
+        eng.set_linw(2)
+        s2 = eng.solve(w)
+        p2 = eng.marginalize(abi.apply_solution(w, s0), abi.MARGIN_OLD)
+    finally:
+        eng.set_linw(1)
+    assert s0.c.num_iterations == s2.c.num_iterations and np.abs(s0.pose - s2.pose).max() < 1e-8 and rel(s2.lam, s0.lam) < 1e-7
+    assert p0.block_list() == p2.block_list() and (p0.m, p0.n) == (p2.m, p2.n)
+    J0, J2 = p0.J(), p2.J()
+    assert rel(J2.T @ J2, J0.T @ J0) < 1e-8
+    rs = oracle.solve(w)
+    assert np.abs(s2.pose - rs.pose).max() < 1e-6 and rel(s2.lam, rs.lam) < 1e-6
