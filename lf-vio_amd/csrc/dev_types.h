@@ -224,6 +224,7 @@ struct Slot {
   GP<int> pm_obs, pm_lm;           // [NV] pair-major: observation index, landmark index
   GP<double> anc[8];                // [N] the anchor observation of every landmark, SoA in device order (k_linw)
   GP<double> pmo[8];                // [NV] the non-anchor observations, SoA in pair-major order (k_linw: a strip step reads 64 consecutive ones)
+  GP<unsigned char> pm_pair;        // [NV] frame pair (i * 11 + j) of every pair-major observation (k_stepw: one lane per observation)
   GP<int> chunk_pair, chunk_begin, chunk_end;
   GP<double> prior_J, prior_r;     // n*n, n
   GP<int> sum_off, sum_end_marg, sum_items;  // gather lists of k_sum: per H_pp / g_p entry, offsets into gram_part (or pairG)

@@ -1,0 +1,147 @@
+// kernels_stepw.h — the second half of a pass of a resident batch, window-resident like the first (kernels_linw.h):
+//
+//   k_stepw: ONE workgroup per window = k_dogleg (landmark back-substitution inline, dogleg step, candidate state and pair
+//   table) + the cost of the candidate at every factor + the trust-region bookkeeping (k_decide), three launches of the
+//   role-by-role path (four with k_cost_imu) as one.  The dogleg and the bookkeeping are the bodies those kernels run
+//   (dogleg_body, decide_body: kernels_solve.h, tr_decide.h); the cost evaluation is laid out for one workgroup:
+//     visual factors   one LANE per landmark (the window has at most 320), the track's residuals in a loop — ten deep at most
+//     IMU factors      one lane per factor (IntegrationBase::evaluate is a serial chain), on the lanes of the last wave that
+//                      hold no landmark where there are such, then the whitening
+//     prior            four lanes per row of J0 (waves 0 .. 3)
+//   The sums land where k_decide's decide_sums() looks for them (the window's totals in block 0 of cost_part, zeros behind).
+#pragma once
+#include "kernels_solve.h"
+
+constexpr int STEPW_THREADS = DOGLEG_INLINE_THREADS;  // 320: one landmark per thread
+static_assert(STEPW_THREADS == 320 && SPEC_MAX_LM == 320, "one landmark per thread");
+
+DEV void stepw_cost(Slot *S, int cur, double cg, double cn) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nxt = cur ^ 1;
+  const Tab *T = &S->tab[nxt];
+  const FrameState *x = &S->x[nxt];
+  double *lam_out = S->lam[nxt];
+  __shared__ double red[5][8];
+  __shared__ double dxs[KP];
+  __shared__ double lcs[SPEC_MAX_LM];
+  const int N = S->N, NV = S->NV, est_td = S->est_td;
+  const int n = S->prior_valid ? S->prior_n : 0;
+  if (n > 0 && tid < S->prior_nb) prior_block_dx(S, x, tid, dxs);
+  // ---- the landmark part of the candidate and of the model: one lane per landmark
+  double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
+  if (tid < N) {
+    const int l = tid;
+    const double s = S->scale_l[l];
+    const double dl = (cg * S->grad_l[l] + cn * S->gn_l[l]) / S->diag_l[l] * s;
+    const double lc = S->lam[cur][l] + dl;
+    lam_out[l] = lc, lcs[l] = lc;
+    dn = dl * dl, xn = lc * lc;
+    // model: -(delta.g) - 1/2 delta^T H delta, landmark rows / cols
+    const double wd = cg * S->d1[l] + cn * S->d2[l];  // w_l . delta_c
+    mlin = dl * S->b[l];
+    mquad = 2.0 * dl * wd + S->a[l] * dl * dl;
+  }
+  __syncthreads();
+  if (wv < 4) {
+    // ---- visual factors: one lane per OBSERVATION (pair-major: neighbours share the pair's table and sit on neighbouring landmarks)
+    const double td = x->td, tor = S->tr_over_row, hr = S->half_row, si = S->sqrt_info;
+    for (int q = tid; q < NV; q += 256) {
+      const int l = S->pm_lm[q], pair = S->pm_pair[q];
+      ObsPair ob;
+      ob.pi = mk3(S->anc[0][l], S->anc[1][l], S->anc[2][l]), ob.vi = mk3(S->anc[3][l], S->anc[4][l], S->anc[5][l]);
+      ob.tdi = S->anc[6][l], ob.rowi = S->anc[7][l];
+      ob.pj = mk3(S->pmo[0][q], S->pmo[1][q], S->pmo[2][q]), ob.vj = mk3(S->pmo[3][q], S->pmo[4][q], S->pmo[5][q]);
+      ob.tdj = S->pmo[6][q], ob.rowj = S->pmo[7][q];
+      cost += 0.5 * visual_cost(ob, lcs[l], td, est_td, tor, hr, si, ldm(T->T[pair]), ld3(T->c[pair]));
+    }
+  } else if (lane < LFVIO_WINDOW_SIZE) {
+    // ---- IMU factors: one lane per factor (IntegrationBase::evaluate is a serial chain), on the fifth wave beside the visual ones
+    const int f = lane;
+    double c = 0.0;
+    if (S->imu_active[f]) {
+      double rr[15];
+      imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
+      const double *Sq = S->imu_sqrt[f];
+#pragma unroll
+      for (int r = 0; r < 15; r++) {
+        double v = 0;
+#pragma unroll
+        for (int k = r; k < 15; k++) v = fma(Sq[r * 15 + k], rr[k], v);
+        c += v * v;
+      }
+      c *= 0.5;
+    }
+    S->pose_cost[f] = c;
+  }
+  // ---- prior: r = r0 + J0 dx, four lanes per row (rows tid / 4 and that + 64: the reference's prior has at most 76 rows and
+  //      columns; a wider one takes the plain loop)
+  const double *J = S->prior_J;
+  const bool fast = n <= 76, prow = tid < 256;
+  double c = 0.0;
+  if (n > 0 && fast && prow) {
+    const int pq = tid & 3, c0 = pq * 19, r0 = tid >> 2;
+    double jv[2][19], pr[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+      const int row = r0 + 64 * rr;
+      pr[rr] = (pq == 0 && row < n) ? S->prior_r[row] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 19; k++) jv[rr][k] = (row < n && c0 + k < n) ? J[row * n + c0 + k] : 0.0;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+      const int row = r0 + 64 * rr;
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 19; k++)
+        if (c0 + k < n) sum = fma(jv[rr][k], dxs[c0 + k], sum);
+      sum = quad_sum(sum);
+      if (pq == 0 && row < n) {
+        sum += pr[rr];
+        c += sum * sum;
+      }
+    }
+  } else if (n > 0 && !fast) {
+    for (int row = tid; row < n; row += STEPW_THREADS) {
+      double sum = S->prior_r[row];
+      for (int cc = 0; cc < n; cc++) sum = fma(J[row * n + cc], dxs[cc], sum);
+      c += sum * sum;
+    }
+  }
+  cost = wave_sum(cost), mlin = wave_sum(mlin), mquad = wave_sum(mquad), dn = wave_sum(dn), xn = wave_sum(xn), c = wave_sum(c);
+  if (lane == 0) red[wv][0] = cost, red[wv][1] = mlin, red[wv][2] = mquad, red[wv][3] = dn, red[wv][4] = xn, red[wv][5] = c;
+  __syncthreads();
+  if (tid < 6) {
+    double v = red[0][tid];
+    for (int w = 1; w < STEPW_THREADS / 64; w++) v += red[w][tid];
+    if (tid < 5) {
+      double *cp = S->cost_part;
+      cp[tid] = v;
+      for (int b = 1; b < S->nLmBlocks; b++) cp[(size_t)b * LMS + tid] = 0.0;  // (decide_sums adds the blocks: the window's total sits in block 0)
+    } else {
+      S->pose_cost[10] = 0.5 * v;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(STEPW_THREADS) void k_stepw(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  __shared__ double sh2[2 * (1 + SPEC_EXTRA)];
+  const int cur = tr_flags(&S->tr).cur;
+  // (dogleg_body: false when the slot takes no step in this pass — finished, or a failed factorization, which the bookkeeping
+  // below turns into a retry with a larger mu)
+#ifdef LFVIO_LINW_PROFILE
+#define WPST(k) do { if (blockIdx.y == 0 && threadIdx.x == 0) S->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define WPST(k) do { } while (0)
+#endif
+  WPST(16);
+  const bool step = dogleg_body<true, true, true>(S, 0, 1, true, 1, sh2);
+  WPST(17);
+  if (step) stepw_cost(S, cur, sh2[0], sh2[1]);
+  __syncthreads();
+  WPST(18);
+  decide_body(S);
+  WPST(19);
+}

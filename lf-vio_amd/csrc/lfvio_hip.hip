@@ -37,6 +37,7 @@ constexpr ncclDataType_t ncclDouble = 8;
 #include "kernels_solve.h"
 #include "kernels_feat.h"
 #include "kernels_linw.h"
+#include "kernels_stepw.h"
 
 #define HIPCHK(ctx, call)                                                                      \
   do {                                                                                         \
@@ -55,7 +56,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   int maxN = 0, maxM = 0;
   int capLmBlocks = 0, capChunks = 0, capSchurParts = 0;
   size_t in_begin = 0, in_end = 0, total = 0;
-  size_t anc[8], pmo[8], linw_begin = 0, linw_end = 0;  // k_linw's copies of the observations (behind the regular inputs: uploaded on their own, resident batches only)
+  size_t anc[8], pmo[8], pm_pair, linw_begin = 0, linw_end = 0;  // k_linw's copies of the observations (behind the regular inputs: uploaded on their own, resident batches only)
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lm_woff, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
   size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, Wt, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
@@ -94,6 +95,7 @@ Layout make_layout(int maxN, int maxM) {
   L.linw_begin = o;
   for (int k = 0; k < 8; k++) L.anc[k] = take(N * 8);
   for (int k = 0; k < 8; k++) L.pmo[k] = take(M * 8);
+  L.pm_pair = take(M);
   L.linw_end = o;
   L.lam[0] = take(LB * 8), L.lam[1] = take(LB * 8);
   for (int k = 0; k < SPEC_EXTRA; k++) L.lamE[k] = take((size_t)SPEC_MAX_LM * 8);
@@ -618,6 +620,9 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
         for (int k = 0; k < 8; k++) anc[k][dl] = obs[k][lm_obs0[dl]];
       for (int q = 0; q < M - N; q++)
         for (int k = 0; k < 8; k++) pmo[k][q] = obs[k][pm_obs[q]];
+      unsigned char *pm_pair = (unsigned char *)(h + L.pm_pair);
+      for (int p = 0; p < NPAIR; p++)
+        for (int q = pair_count[p]; q < pair_count[p + 1]; q++) pm_pair[q] = (unsigned char)p;
     }
     P.ok = linw ? 1 : 0;
   }
@@ -749,6 +754,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   for (int k = 0; k < 8; k++) S->obs[k].set(S, L.obs[k]);
   S->pm_obs.set(S, L.pm_obs), S->pm_lm.set(S, L.pm_lm);
   for (int k = 0; k < 8; k++) S->anc[k].set(S, L.anc[k]), S->pmo[k].set(S, L.pmo[k]);
+  S->pm_pair.set(S, L.pm_pair);
   S->chunk_pair.set(S, L.chunk_pair), S->chunk_begin.set(S, L.chunk_begin), S->chunk_end.set(S, L.chunk_end);
   S->prior_J.set(S, L.prior_J), S->prior_r.set(S, L.prior_r);
   S->sum_off.set(S, L.sum_off), S->sum_end_marg.set(S, L.sum_end_marg), S->sum_items.set(S, L.sum_items);
@@ -956,6 +962,12 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     // few small windows: the step and the cost of its candidates in one launch (k_step)
     const bool split = lin_split(count, g) || lw;
     const bool fuse = inl && !split && !c->no_fuse && !c->shard_active && (size_t)count * nb <= 2048;
+    // a resident batch on the window-resident path: step, candidate cost and bookkeeping as ONE launch, one workgroup per window
+    const bool stepw = lw && inl && spec == 1 && !c->no_fuse;
+    if (stepw) {
+      hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_THREADS), 0, c->stream, c->d_base, st);
+      return false;
+    }
     if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
     if (fuse) hipLaunchKernelGGL(k_step, dim3(spec * nb, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, g.lm, spec);
     else {
@@ -1876,6 +1888,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     launch_lin(c, count, g, MODE_SOLVE);
     launch_sum(c, count, g, MODE_SOLVE);
   }
+  if (which == 14) launch_solve(c, count, lw);
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
@@ -1899,6 +1912,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
         launch_linw(c, count);
         break;
       case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;
+      case 14: hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_THREADS), 0, c->stream, c->d_base, st); break;  // (not idempotent: a few reps only)
       default: launch_solve(c, count); break;
     }
   }
