@@ -46,6 +46,10 @@ int lfvio_debug_set_function_tolerance(lfvio_ctx *ctx, double tol);
  * HBM) when the launch is a batch and every window carries a plan; 0 never (k_lin role by role + k_sum); 2 for every launch of
  * planned windows, however few (tests).  Applies to windows uploaded afterwards.  Environment: LFVIO_LINW. */
 int lfvio_debug_set_linw(lfvio_ctx *ctx, int mode);
+/* 1: the trust-region loop of a window-resident batch is ONE launch (k_window: every pass of a window by the workgroup that owns
+ * it); 0 (default: faster at 512 windows): three launches per pass (k_linw, k_solve_dense<true>, k_stepw).  Same results.
+ * Environment: LFVIO_WINDOW_KERNEL. */
+int lfvio_debug_set_window(lfvio_ctx *ctx, int on);
 /* One linearization + dense solve of the resident slots [0, count) by the path the launch takes; then, of slot `slot`: g_p[172],
  * the Schur sums (15 x 256, tile layout), lm_sum[5], a[N], b[N] (device landmark order), the pose-side Gauss-Newton step [172], the
  * dogleg model's quadratic forms [16], the cost.  Any output may be NULL.  Returns 1 if k_linw ran, 0 if k_lin + k_sum, < 0 on error. */

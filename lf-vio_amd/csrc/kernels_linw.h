@@ -522,9 +522,8 @@ constexpr int LWT_ABS = 1 << 16, LWT_EX = 1 << 17, LWT_TD = 1 << 18;
 // ---------------------------------------------------------------------------
 // k_linw: grid (1, batch) x 256, dynamic LDS = LW_LDS_BYTES
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t stride, const LinwArgs A, int mode_bits) {
-  extern __shared__ __attribute__((aligned(16))) double lw[];
-  Slot *S = SLOT(base, stride);
+// (the body: k_linw's, and the linearization phase of k_window — kernels_stepw.h)
+DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   TRFlags fl = tr_flags(tr);
@@ -753,4 +752,8 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
     for (int r = 0; r < 4; r++) ss[(wv + 4 * j) * 256 + r * 64 + lane] = acc[j][r];
   }
   WSTAMP(14);
+}
+__global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t stride, const LinwArgs A, int mode_bits) {
+  extern __shared__ __attribute__((aligned(16))) double lw[];
+  linw_body(SLOT(base, stride), lw, A, mode_bits);
 }

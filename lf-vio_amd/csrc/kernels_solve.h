@@ -170,10 +170,9 @@ DEV void solve_epilogue(Slot *S, TRState *tr, const double *ls, double gn2, doub
 // parity share no column — every entry of the lower triangle of their 30 x 30 block as (index into imu_out) | (tile address << 16).
 constexpr int ASM_VIS = KC * (KC + 1) / 2, ASM_IMU_F = 30 * 31 / 2, ASM_IMU_HALF = 5 * ASM_IMU_F, ASM_LEN = ASM_VIS + 2 * ASM_IMU_HALF;
 __host__ __device__ constexpr int asm_lidx(int i, int j) { return tile_id(i >> 4, j >> 4) * TSZ + (i & 15) * TLD + (j & 15); }
+// (the body: k_solve_dense's, and the solve phase of k_window — kernels_stepw.h —, which brings its own workspace)
 template <bool ASSEMBLE>
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_t stride, long long xch_off, long long imu_off, long long prior_A_off, const int *asm_tab) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  Slot *S = SLOT(base, stride);
+DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off, long long prior_A_off, const int *asm_tab) {
   TRState *tr = &S->tr;
   const int tid = threadIdx.x;
   const int er = tid >> 4, ek = tid & 15, esw = tsw(er, ek);  // this thread's entry of every tile
@@ -902,6 +901,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_
     if (tid == 0) solve_epilogue(S, tr, ls, gn2, ggn, gG, gN, qgn, qnn);
   }
 }
+template <bool ASSEMBLE>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve_dense(char *base, size_t stride, long long xch_off, long long imu_off, long long prior_A_off, const int *asm_tab) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  solve_body<ASSEMBLE>(SLOT(base, stride), smem, xch_off, imu_off, prior_A_off, asm_tab);
+}
 
 // ---------------------------------------------------------------------------
 // k_backsub: grid (nLmBlocks, batch) x 64 — landmark part of the Gauss-Newton step
@@ -1057,8 +1061,8 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
     double *ug = cand, *un = cand + WLD;
     for (int c = tid; c < WLD; c += nthr) ug[c] = S->uc_grad[c], un[c] = S->uc_gn[c];
     __syncthreads();
-    const int l = tid;
-    if (l < S->N) {
+    // (one landmark per thread with the 320 threads of k_dogleg / k_step / k_stepw; k_window's 256 take the last 64 in a second trip)
+    for (int l = tid; l < S->N; l += nthr) {
       const double s = S->scale_l[l], bl = S->b[l], einv = S->einv_l[l], dgl = S->diag_l[l], grl = S->grad_l[l];
       double d1 = 0, d2 = 0;
       if (WT) {
@@ -1108,8 +1112,8 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
         S->d1[l] = d1;
         S->d2[l] = d2;
       }
-      a = gn * gn;
-      b = grl * gn;
+      a += gn * gn;
+      b += grl * gn;
     }
     __syncthreads();  // ug / un alias cand
   }

@@ -15,37 +15,39 @@
 constexpr int STEPW_THREADS = DOGLEG_INLINE_THREADS;  // 320: one landmark per thread
 static_assert(STEPW_THREADS == 320 && SPEC_MAX_LM == 320, "one landmark per thread");
 
-DEV void stepw_cost(Slot *S, int cur, double cg, double cn) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// ws: >= 5 * 8 + KP + SPEC_MAX_LM doubles of LDS.  320 threads: the visual factors on waves 0 .. 3, the IMU factors on wave 4;
+// 256 threads (k_window): the IMU factors on wave 0, the visual ones on waves 1 .. 3.
+constexpr int STEPW_WS = 5 * 8 + KP + 4 + SPEC_MAX_LM;
+DEV void stepw_cost(Slot *S, int cur, double cg, double cn, double *ws) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nthr = blockDim.x, nwv = nthr >> 6;
+  const int imu_wave = nthr > 256 ? 4 : 0, vis0 = nthr > 256 ? 0 : 64, vis_n = nthr > 256 ? 256 : 192;
   const int nxt = cur ^ 1;
   const Tab *T = &S->tab[nxt];
   const FrameState *x = &S->x[nxt];
   double *lam_out = S->lam[nxt];
-  __shared__ double red[5][8];
-  __shared__ double dxs[KP];
-  __shared__ double lcs[SPEC_MAX_LM];
+  double(*red)[8] = (double(*)[8])ws;
+  double *dxs = ws + 40, *lcs = ws + 40 + KP + 4;
   const int N = S->N, NV = S->NV, est_td = S->est_td;
   const int n = S->prior_valid ? S->prior_n : 0;
   if (n > 0 && tid < S->prior_nb) prior_block_dx(S, x, tid, dxs);
   // ---- the landmark part of the candidate and of the model: one lane per landmark
   double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
-  if (tid < N) {
-    const int l = tid;
+  for (int l = tid; l < N; l += nthr) {
     const double s = S->scale_l[l];
     const double dl = (cg * S->grad_l[l] + cn * S->gn_l[l]) / S->diag_l[l] * s;
     const double lc = S->lam[cur][l] + dl;
     lam_out[l] = lc, lcs[l] = lc;
-    dn = dl * dl, xn = lc * lc;
+    dn += dl * dl, xn += lc * lc;
     // model: -(delta.g) - 1/2 delta^T H delta, landmark rows / cols
     const double wd = cg * S->d1[l] + cn * S->d2[l];  // w_l . delta_c
-    mlin = dl * S->b[l];
-    mquad = 2.0 * dl * wd + S->a[l] * dl * dl;
+    mlin += dl * S->b[l];
+    mquad += 2.0 * dl * wd + S->a[l] * dl * dl;
   }
   __syncthreads();
-  if (wv < 4) {
+  if (wv != imu_wave) {
     // ---- visual factors: one lane per OBSERVATION (pair-major: neighbours share the pair's table and sit on neighbouring landmarks)
     const double td = x->td, tor = S->tr_over_row, hr = S->half_row, si = S->sqrt_info;
-    for (int q = tid; q < NV; q += 256) {
+    for (int q = tid - vis0; q < NV; q += vis_n) {
       const int l = S->pm_lm[q], pair = S->pm_pair[q];
       ObsPair ob;
       ob.pi = mk3(S->anc[0][l], S->anc[1][l], S->anc[2][l]), ob.vi = mk3(S->anc[3][l], S->anc[4][l], S->anc[5][l]);
@@ -102,7 +104,7 @@ DEV void stepw_cost(Slot *S, int cur, double cg, double cn) {
       }
     }
   } else if (n > 0 && !fast) {
-    for (int row = tid; row < n; row += STEPW_THREADS) {
+    for (int row = tid; row < n; row += nthr) {
       double sum = S->prior_r[row];
       for (int cc = 0; cc < n; cc++) sum = fma(J[row * n + cc], dxs[cc], sum);
       c += sum * sum;
@@ -113,7 +115,7 @@ DEV void stepw_cost(Slot *S, int cur, double cg, double cn) {
   __syncthreads();
   if (tid < 6) {
     double v = red[0][tid];
-    for (int w = 1; w < STEPW_THREADS / 64; w++) v += red[w][tid];
+    for (int w = 1; w < nwv; w++) v += red[w][tid];
     if (tid < 5) {
       double *cp = S->cost_part;
       cp[tid] = v;
@@ -125,23 +127,58 @@ DEV void stepw_cost(Slot *S, int cur, double cg, double cn) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(STEPW_THREADS) void k_stepw(char *base, size_t stride) {
-  Slot *S = SLOT(base, stride);
-  __shared__ double sh2[2 * (1 + SPEC_EXTRA)];
-  const int cur = tr_flags(&S->tr).cur;
-  // (dogleg_body: false when the slot takes no step in this pass — finished, or a failed factorization, which the bookkeeping
-  // below turns into a retry with a larger mu)
 #ifdef LFVIO_LINW_PROFILE
 #define WPST(k) do { if (blockIdx.y == 0 && threadIdx.x == 0) S->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define WPST(k) do { } while (0)
 #endif
+DEV void stepw_body(Slot *S, double *ws) {
+  __shared__ double sh2[2 * (1 + SPEC_EXTRA)];
+  const int cur = tr_flags(&S->tr).cur;
+  // (dogleg_body: false when the slot takes no step in this pass — finished, or a failed factorization, which the bookkeeping
+  // below turns into a retry with a larger mu)
   WPST(16);
   const bool step = dogleg_body<true, true, true>(S, 0, 1, true, 1, sh2);
   WPST(17);
-  if (step) stepw_cost(S, cur, sh2[0], sh2[1]);
+  if (step) stepw_cost(S, cur, sh2[0], sh2[1], ws);
   __syncthreads();
   WPST(18);
   decide_body(S);
   WPST(19);
+}
+__global__ __launch_bounds__(STEPW_THREADS) void k_stepw(char *base, size_t stride) {
+  __shared__ double ws[STEPW_WS];
+  stepw_body(SLOT(base, stride), ws);
+}
+
+// ---------------------------------------------------------------------------
+// k_window: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS — the whole trust-region loop of a window in ONE launch: up to
+// `npass` passes of [ k_linw | k_solve_dense<true> | k_stepw ] by the workgroup that owns the window, no launch boundary and no
+// other window in between.  A batch no longer waits, pass by pass, for its slowest window: a window whose step is rejected
+// goes straight on to the next radius, a finished one leaves the CU to the next window of the grid.  Same bodies, same
+// arithmetic, same results as the three launches.  What a launch boundary did implicitly is explicit here: a workgroup
+// barrier between the phases (the phases hand data over through the slot in global memory: coherent inside one CU), and the
+// scalar cache is invalidated before a linearization (it reads the pair tables through it, and the step phase of the pass
+// before has rewritten them with vector stores).
+// ---------------------------------------------------------------------------
+// (out of line: inlined into one loop the three phases share a register allocation — loop-invariant pieces of each are hoisted
+// over the others and 700 registers spill; as calls every phase is allocated as the kernel it came from)
+__device__ __noinline__ void window_lin(Slot *S, double *smem, const LinwArgs *A) { linw_body(S, smem, *A, MODE_SOLVE); }
+__device__ __noinline__ void window_solve(Slot *S, double *smem, long long xch_off, long long imu_off, long long prior_A_off, const int *asm_tab) {
+  solve_body<true>(S, smem, xch_off, imu_off, prior_A_off, asm_tab);
+}
+__device__ __noinline__ void window_step(Slot *S, double *smem) { stepw_body(S, smem); }
+__global__ __launch_bounds__(LW_THREADS) void k_window(char *base, size_t stride, const LinwArgs A, long long xch_off, long long prior_A_off, const int *asm_tab, int npass) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  Slot *S = SLOT(base, stride);
+  for (int p = 0; p < npass; p++) {
+    if (tr_flags(&S->tr).done) break;  // (wave-uniform, workgroup-uniform: the header was written in front of the last barrier)
+    __builtin_amdgcn_s_dcache_inv();
+    window_lin(S, smem, &A);
+    __syncthreads();
+    window_solve(S, smem, xch_off, A.imu_out, prior_A_off, asm_tab);
+    __syncthreads();
+    window_step(S, smem);
+    __syncthreads();
+  }
 }

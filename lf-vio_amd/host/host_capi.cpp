@@ -39,6 +39,9 @@ void lfvio_host_set_extrinsic(const double *tic, const double *ric) {
   std::memcpy(config().tic, tic, sizeof config().tic);
   std::memcpy(config().ric, ric, sizeof config().ric);
 }
+// SOLVER_TIME on its own (<= 0: no wall-clock cap — what a test on a loaded machine wants: Ceres' max_solver_time_in_seconds makes the
+// number of iterations depend on the clock)
+void lfvio_host_set_solver_time(double seconds) { config().solver_time = seconds; }
 void lfvio_host_set_min_parallax(double keyframe_parallax_px) { config().min_parallax = keyframe_parallax_px / FOCAL_LENGTH; }
 
 void lfvio_host_set_state(void *h, const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs,

@@ -50,6 +50,11 @@ class Engine:
         self.lib.lfvio_debug_set_decide_merge.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_set_decide_merge(self.ctx, int(on))
 
+    def set_window(self, on):
+        """k_window (the whole loop of a window as one launch) on / off (include/lfvio_debug.h)."""
+        self.lib.lfvio_debug_set_window.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.lfvio_debug_set_window(self.ctx, int(on)), "set_window")
+
     def set_linw(self, mode):
         """How resident batches are linearized (include/lfvio_debug.h): 1 default, 0 never k_linw, 2 every launch of planned windows."""
         self.lib.lfvio_debug_set_linw.argtypes = [C.c_void_p, C.c_int]

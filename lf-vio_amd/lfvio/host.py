@@ -116,6 +116,11 @@ class HostEstimator:
     def clear_state(self):
         self.L.lfvio_host_clear_state(self.h)
 
+    def set_solver_time(self, seconds):
+        """SOLVER_TIME (parameters.cpp:133); <= 0 switches the wall-clock cap of the solve off."""
+        self.L.lfvio_host_set_solver_time.argtypes = [C.c_double]
+        self.L.lfvio_host_set_solver_time(float(seconds))
+
     def set_min_parallax(self, keyframe_parallax_px):
         self.L.lfvio_host_set_min_parallax(float(keyframe_parallax_px))
 
