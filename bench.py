@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=None,
                     choices=["window300", "window300_stream", "batch512", "window100k", "window100k_sharded"])
+    ap.add_argument("--landmarks", type=int, default=100000,
+                    help="window100k / window100k_sharded only: landmarks of the one large window (DESIGN.md section 6: at 100 000 the replicated part "
+                         "of a pass caps 8 ranks near 1.8x; the landmark-sharded part reaches 6x from about 2 400 000 landmarks on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="window300 only: skip the default-cap variant and the batch512 second headline")
     ap.add_argument("--batch-secondary", action="store_true",
@@ -267,13 +270,13 @@ def main():
         wins = distinct_windows_with_prior([100000 * rank + s for s in range(batch)], hip_optimize)
         desc = "BASELINE configs[4]: 512 independent 10-keyframe / 300-landmark windows, 512 distinct seeds, each with the prior of its own warm-up MARGIN_OLD step, solved side by side"
     elif workload == "window100k":
-        n_lm, batch = 100000, 1
+        n_lm, batch = args.landmarks, 1
         wins = [synth.make_window(1000 * rank, n_lm)]
-        desc = "10-keyframe / 100 000-landmark window (no prior), whole window on one GPU"
+        desc = f"10-keyframe / {n_lm}-landmark window (no prior), whole window on one GPU"
     else:
-        n_lm, batch = 100000, 1
+        n_lm, batch = args.landmarks, 1
         wins = [synth.make_window(0, n_lm)]  # the SAME window on every rank: each keeps its landmark range
-        desc = (f"BASELINE configs[3]: ONE 10-keyframe / 100 000-landmark window sharded over {world} GPU(s) by contiguous landmark "
+        desc = (f"BASELINE configs[3]: ONE 10-keyframe / {n_lm}-landmark window sharded over {world} GPU(s) by contiguous landmark "
                 "ranges balanced on observation count; RCCL sum-all-reduce of the reduced pose system per pass")
 
     grp = None
