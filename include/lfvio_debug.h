@@ -58,6 +58,9 @@ int lfvio_debug_resident_pass(lfvio_ctx *ctx, int count, int slot, double *gp, d
 int lfvio_debug_last_chunks(lfvio_ctx *ctx);
 /* passes of the trust-region loop the slowest window of the last synchronous call used */
 int lfvio_debug_last_passes(lfvio_ctx *ctx);
+/* out3 = {passes, iterations} of the last synchronous call on one window and the number of speculative candidates per pass the next one
+ * will prepare (3, or 4 where a pass of the previous call covered two iterations or more) */
+int lfvio_debug_speculation(lfvio_ctx *ctx, int *out3);
 #ifdef __cplusplus
 }
 #endif

@@ -99,7 +99,7 @@ enum {
 // them in Ceres' order.  Candidate 0 lives in x[cur ^ 1] / tab[cur ^ 1] / lam[cur ^ 1] as always, candidates 1, 2 in
 // the *E slots and are copied over when one of them is the accepted step.
 #ifndef LFVIO_SPEC_EXTRA
-#define LFVIO_SPEC_EXTRA 2
+#define LFVIO_SPEC_EXTRA 3
 #endif
 constexpr int SPEC_EXTRA = LFVIO_SPEC_EXTRA, SPEC_MAX_LM = 320;
 constexpr int WT_PAIRS = (KC + 1) / 2;
@@ -194,7 +194,7 @@ struct Slot {
   // ---------------- header: sizes, flags, constants
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
   int max_iter, prior_valid, prior_n, prior_nb;
-  int tail_state, passes_used;  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
+  int tail_state, passes_used, iters_done, hdr_pad_;  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
   int dec_pending, dec_pad_;     // dec holds a decision k_solve has not moved into the header yet

@@ -77,7 +77,7 @@ DEV void publish_prior(Slot *S) {
   }
   for (int k = tid; k < n * n; k += nthr) dst->linearized_jacobians[k] = src->linearized_jacobians[k];
   for (int k = tid; k < n; k += nthr) dst->linearized_residuals[k] = src->linearized_residuals[k];
-  if (tid == 0) ((int *)m)[2] = S->passes_used;
+  if (tid == 0) ((int *)m)[2] = S->passes_used | (S->tr.iteration << 8);
   __threadfence_system();
   __syncthreads();
   if (tid == 0) __hip_atomic_store((int *)m + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   if (!mp->valid) {
     // MARGIN_SECOND_NEW with no prior touching Pose[WINDOW_SIZE-1]: the prior is left as it is
     if (tid == 0) out->valid = -1;  // host copies the input prior through
-    if (gated && tid == 0) S->tail_state = 2;
+    if (gated && tid == 0) S->iters_done = tr->iteration, S->tail_state = 2;
     if (gated && publish) {
       __syncthreads();
       publish_prior(S);
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     out->m = m15 + (S->sharded ? (int)(S->xch[XOFF_C + XS_N0] + 0.5) : mp->N0);
     out->n = n;
     out->num_blocks = mp->nb;
-    if (gated) S->tail_state = 2;
+    if (gated) S->iters_done = tr->iteration, S->tail_state = 2;
   }
   if (gated && publish) {
     __syncthreads();

@@ -165,8 +165,8 @@ struct lfvio_ctx {
   // [publish]: the variants whose gated gauge fix / marginalization also push state and prior into the caller's mailbox
   // (lfvio_batch_optimize_begin) — a kernel argument, so the plain call pays nothing for the split one
   bool publish = false;
-  hipGraphExec_t chunk = nullptr, tail[2][3] = {};
-  hipGraphExec_t first[2][4][13] = {};  // [publish][0: solve only, 1 + flag: with the gated tail][passes in the first graph]
+  hipGraphExec_t chunk[2] = {}, tail[2][3] = {};  // chunk[speculation variant]
+  hipGraphExec_t first[2][2][4][13] = {};  // [speculation variant: 0 three candidates (or none), 1 four][publish][0: solve only, 1 + flag: with the gated tail][passes in the first graph]
   int fixed_passes = 0;             // debug (LFVIO_FIRST_PASSES / lfvio_debug_set_first_passes): > 0 sizes every first graph with this many passes
   int predict_passes = 4;           // passes the previous synchronous call needed; tail[flag]: force-done + gated gauge fix + marginalization
   double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
@@ -193,6 +193,9 @@ struct lfvio_ctx {
   bool use_graph = true;
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
   int last_passes = 0;  // passes of the trust-region loop the last synchronous call used (slowest slot)
+  int last_iters = 0;   // ... and, for one window, the iterations they covered: a window whose steps are mostly rejected gets more speculative candidates per pass
+  bool fixed_spec = false;  // LFVIO_SPEC_COUNT: a fixed number of candidates (measurements)
+  int spec_count = 3;   // candidates per pass of a speculating launch: radius, radius / 2, radius / 4 (, radius / 8)
   int *d_lwt = nullptr;  // static table of k_linw's phase 3 (kernels_linw.h LWT_*)
   int *d_asm = nullptr;  // static scatter table of k_solve_dense<true> (kernels_solve.h ASM_*)
   bool window_kernel = false;  // the loop of a window-resident batch as ONE launch (k_window).  Off: measured 120 000 solves/s against 143 000 for three launches per
@@ -227,17 +230,16 @@ void destroy_graph(lfvio_ctx *c) {
     (void)hipGraphExecDestroy(c->graph);
     c->graph = nullptr;
   }
-  if (c->chunk) {
-    (void)hipGraphExecDestroy(c->chunk);
-    c->chunk = nullptr;
-  }
+  for (auto &t : c->chunk)
+    if (t) (void)hipGraphExecDestroy(t), t = nullptr;
   for (auto &row : c->tail)
     for (auto &t : row)
       if (t) (void)hipGraphExecDestroy(t), t = nullptr;
-  for (auto &plane : c->first)
-    for (auto &row : plane)
-      for (auto &t : row)
-        if (t) (void)hipGraphExecDestroy(t), t = nullptr;
+  for (auto &var : c->first)
+    for (auto &plane : var)
+      for (auto &row : plane)
+        for (auto &t : row)
+          if (t) (void)hipGraphExecDestroy(t), t = nullptr;
 }
 
 // The tail of a call whose solution went out early (lfvio_batch_optimize_begin) is still on the stream: wait for it and
@@ -251,7 +253,7 @@ int join_inflight(lfvio_ctx *c) {
   c->inflight = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->inflight_first) {
-    c->last_passes = std::max(c->h_pending[3], 1);
+    c->last_passes = std::max(c->h_pending[3], 1), c->last_iters = c->h_pending[4];
     c->predict_passes = c->last_passes;
     if (c->h_pending[2] != 2) {
       c->err = "the marginalization behind an early solution did not finish";
@@ -970,7 +972,7 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     launch_solve(c, count, lw);
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
-    const int spec = speculate && inl ? 1 + SPEC_EXTRA : 1;
+    const int spec = speculate && inl ? c->spec_count : 1;
     const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
     // few small windows: the step and the cost of its candidates in one launch (k_step)
     const bool split = lin_split(count, g) || lw;
@@ -1054,6 +1056,11 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
   const int passes = std::max(max_iter, 0) + 4;
   if (adaptive && c->use_graph) {
     const bool speculate = (size_t)count * (g.lm + LFVIO_WINDOW_SIZE + 1) <= 512;
+    // How many candidates a pass prepares follows the previous call (a stream of windows from one estimator is steady): where a
+    // pass covered two iterations or more — most steps rejected: the bench window's nine iterations take four passes with three
+    // candidates, three with four — the fourth candidate saves a pass; where nearly every step is accepted it would only be
+    // evaluated (measured with a fixed count: 0.532 / 0.511 ms resident with 3 / 4, 0.950 / 0.963 ms on the stream).
+    if (speculate && !c->fixed_spec) c->spec_count = (c->last_iters > 0 && c->last_iters >= 2 * c->last_passes) ? std::min(4, 1 + SPEC_EXTRA) : 3;
     if (!c->d_pending) {
       HIPCHK(c, hipMalloc((void **)&c->d_pending, 256));
       HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
@@ -1075,7 +1082,8 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     // graph could overrun it: then no more passes than fit (at the measured time per pass), down to a chunk of SOLVE_CHUNK.
     int first_passes = std::min(std::max(c->fixed_passes > 0 ? c->fixed_passes : c->predict_passes, 1), std::min(passes, MAX_FIRST_PASSES));
     if (capped) first_passes = std::max(std::min(SOLVE_CHUNK, passes), std::min(first_passes, (int)std::min(max_seconds / c->pass_seconds, 1e6)));
-    hipGraphExec_t &first_graph = c->first[c->publish ? 1 : 0][fuse ? 1 + fused_flag : 0][first_passes];
+    const int sv = speculate && c->spec_count > 3 ? 1 : 0;  // (both variants stay captured: a stream may alternate)
+    hipGraphExec_t &first_graph = c->first[sv][c->publish ? 1 : 0][fuse ? 1 + fused_flag : 0][first_passes];
     auto capture = [&](hipGraphExec_t *out, bool setup, int npass, int tail_flag) -> int {
       hipGraph_t graph;
       int rc = LFVIO_OK;
@@ -1096,7 +1104,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       }
       if (tail_flag >= 0 && count == 1) {
         // one window: its {tail_state, passes_used} pair is the answer — copied as it is, no k_pending launch
-        HIPCHK(c, hipMemcpyAsync(c->h_pending + 2, c->d_base + offsetof(Slot, tail_state), 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_pending + 2, c->d_base + offsetof(Slot, tail_state), 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       } else {
         hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, tail_flag >= 0 ? 1 : 0);
         HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1114,8 +1122,8 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       const int rc = capture(&first_graph, true, first_passes, fuse ? fused_flag : -1);
       if (rc) return rc;
     }
-    if (!c->chunk) {
-      const int rc = capture(&c->chunk, false, SOLVE_CHUNK, -1);
+    if (!c->chunk[sv]) {
+      const int rc = capture(&c->chunk[sv], false, SOLVE_CHUNK, -1);
       if (rc) return rc;
     }
     c->stat_chunks = 0;
@@ -1124,7 +1132,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       const auto t_launch = std::chrono::steady_clock::now();
       const bool watch = early && done_passes == 0 && fuse && c->publish;
       if (watch) __atomic_store_n((int *)c->h_mail + 1, 0, __ATOMIC_RELAXED), __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
-      HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk, c->stream));
+      HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk[sv], c->stream));
       if (watch && wait_early(c)) {  // the window was done inside the first graph: its tail follows in the same graph
         c->inflight = true, c->inflight_first = true;
         if (tail_done) *tail_done = true;
@@ -1137,7 +1145,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
         c->pass_seconds = 0.75 * c->pass_seconds + 0.25 * dt;
       }
       done_passes += first ? first_passes : SOLVE_CHUNK;
-      if (first && fuse && count == 1) c->h_pending[0] = c->h_pending[2] == 2 ? 0 : 1, c->h_pending[1] = c->h_pending[3];
+      if (first && fuse && count == 1) c->h_pending[0] = c->h_pending[2] == 2 ? 0 : 1, c->h_pending[1] = c->h_pending[3], c->last_iters = c->h_pending[4];
       if (c->h_pending[0] == 0) {
         if (tail_done && fuse && first) *tail_done = true;
         break;
@@ -1424,6 +1432,8 @@ lfvio_ctx *lfvio_create(int device) {
       return nullptr;
     }
   }
+  if (const char *e = getenv("LFVIO_SPEC_COUNT"))
+    if (e[0]) c->spec_count = std::max(1, std::min(1 + SPEC_EXTRA, atoi(e))), c->fixed_spec = true;
   if (const char *e = getenv("LFVIO_FIRST_PASSES")) c->fixed_passes = std::max(0, atoi(e));
   (void)hipFuncSetAttribute((const void *)k_marg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
   const char *env = getenv("LFVIO_NO_GRAPH");
@@ -1628,7 +1638,7 @@ int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
     }
     if (there) {
       c->inflight = false, c->unsynced = true;  // (what is left of the graph is a copy of two words: the next join waits for it)
-      c->last_passes = std::max(((const int *)c->h_mail)[2], 1);
+      c->last_passes = std::max(((const int *)c->h_mail)[2] & 255, 1), c->last_iters = ((const int *)c->h_mail)[2] >> 8;
       if (c->inflight_first) c->predict_passes = c->last_passes;
       Fetched f{};
       f.prior = (LfvioPrior *)(c->h_mail + MAIL_PRIOR);
@@ -2015,6 +2025,11 @@ int lfvio_debug_set_function_tolerance(lfvio_ctx *c, double tol) {
 }
 int lfvio_debug_last_chunks(lfvio_ctx *c) { return c ? c->stat_chunks : -1; }
 int lfvio_debug_last_passes(lfvio_ctx *c) { return c ? c->last_passes : -1; }
+int lfvio_debug_speculation(lfvio_ctx *c, int *out3) {
+  if (!c || !out3) return LFVIO_ERR_ARG;
+  out3[0] = c->last_passes, out3[1] = c->last_iters, out3[2] = c->spec_count;
+  return LFVIO_OK;
+}
 
 int lfvio_debug_force_eig(lfvio_ctx *c, int on) {
   if (!c) return LFVIO_ERR_ARG;

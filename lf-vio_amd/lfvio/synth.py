@@ -290,8 +290,38 @@ class Scene:
         return self.acc_m[k0], self.gyr_m[k0], np.full(SAMPLES, IMU_DT), self.acc_m[ks], self.gyr_m[ks]
 
 
-def _landmarks(rng, scene, kf0, n_landmarks, td_frames, min_track=2):
-    """CSR landmark/observation arrays for the window kf0..kf0+10 (vectorised)."""
+# The PAL camera of the reference (Scaramuzza / OCam model, README.md:85-118; OCAMCamera::liftProjective / spaceToPlane,
+# camera_model/src/camera_models/ScaramuzzaCamera.cc:623-674): pixel -> ray by the polynomial in the pixel radius, ray -> pixel by
+# the inverse polynomial in the elevation angle; affine part the identity, 1280 x 960.  The pair is consistent to < 0.011 deg over
+# the 40-120 deg annulus the windows are sampled on.
+OCAM_POLY = (-2.445239e+02, 0.0, 1.748610e-03, -1.757770e-06, 4.475965e-09)
+OCAM_INV = (376.845565, 246.746504, 19.035187, 23.840497, 18.991943, 6.066253, 1.560387, 5.854280, 3.458320, -1.995166, -1.509264,
+            1.089614, 1.340245, 0.255323)
+OCAM_CX, OCAM_CY, OCAM_W, OCAM_H = 645.107791, 486.025172, 1280, 960
+
+
+def ocam_space_to_plane(P):
+    n = np.hypot(P[..., 0], P[..., 1])
+    th = np.arctan2(-P[..., 2], n)
+    rho = sum(c * th ** i for i, c in enumerate(OCAM_INV))
+    return np.stack([P[..., 0] / n * rho + OCAM_CX, P[..., 1] / n * rho + OCAM_CY], axis=-1)
+
+
+def ocam_lift_projective(p):
+    x, y = p[..., 0] - OCAM_CX, p[..., 1] - OCAM_CY
+    phi = np.hypot(x, y)
+    z = sum(c * phi ** i for i, c in enumerate(OCAM_POLY))
+    return np.stack([x, y, -z], axis=-1)
+
+
+def _landmarks(rng, scene, kf0, n_landmarks, td_frames, min_track=2, camera="sphere"):
+    """CSR landmark/observation arrays for the window kf0..kf0+10 (vectorised).
+
+    camera = "sphere": bearings sampled on the sphere with 1 px / 160 of tangent noise, image rows drawn at random (immaterial
+    with TR = 0: the default, and what every committed figure and fixture was generated with).  camera = "ocam": every observation
+    goes through the reference's camera model — projected to the pixel (spaceToPlane), 1 px of noise added there, lifted back
+    (liftProjective) and normalized as the tracker does; uv.y is that pixel's row, so the rolling-shutter term of the td factor
+    (TR / ROW * row) is geometrically consistent when TR != 0."""
     N = n_landmarks
     start = rng.integers(0, 8, size=N)                    # start_frame U{0..7}
     kmax = abi.NUM_FRAMES - start
@@ -345,12 +375,25 @@ def _landmarks(rng, scene, kf0, n_landmarks, td_frames, min_track=2):
     velocity = ((b - b_prev) / KF_DT).astype(np.float32).astype(np.float64)
     cur_td = td_frames[frame_of_obs]
     uv_y = rng.uniform(100.0, 860.0, size=M).astype(np.float32).astype(np.float64)
+    if camera == "ocam":
+        px = ocam_space_to_plane(pc) + rng.normal(0, 1.0, size=(M, 2))
+        px_prev = ocam_space_to_plane(pc_prev)
+        ray = ocam_lift_projective(px)
+        bo = ray / np.linalg.norm(ray, axis=1, keepdims=True)
+        point = _bearing_f32(bo)
+        ray_prev = ocam_lift_projective(px_prev)
+        bo_prev = ray_prev / np.linalg.norm(ray_prev, axis=1, keepdims=True)
+        ray_now = ocam_lift_projective(ocam_space_to_plane(pc))
+        velocity = ((ray_now / np.linalg.norm(ray_now, axis=1, keepdims=True) - bo_prev) / KF_DT).astype(np.float32).astype(np.float64)
+        uv_y = np.clip(px[:, 1], 0.0, OCAM_H - 1.0).astype(np.float32).astype(np.float64)
+    elif camera != "sphere":
+        raise ValueError(camera)
     return dict(start=start.astype(np.int32), obs_offset=obs_offset.astype(np.int32), point=point, velocity=velocity,
                 cur_td=cur_td, uv_y=uv_y, true_depth=true_depth_anchor)
 
 
 def make_window(seed, n_landmarks=300, kf0=0, scene=None, prior=None, init_state=None, estimate_extrinsic=1,
-                estimate_td=1, tr=0.0, max_num_iterations=8, pose_noise=(0.02, np.deg2rad(0.5)), n_total=12, motion="full"):
+                estimate_td=1, tr=0.0, max_num_iterations=8, pose_noise=(0.02, np.deg2rad(0.5)), n_total=12, motion="full", camera="sphere"):
     """One LfvioWindow over keyframes kf0..kf0+10 of Scene(seed).
 
     init_state: optional dict(pose[11,7], speed_bias[11,9], ex_pose, td) to continue a previous solve;
@@ -359,7 +402,7 @@ def make_window(seed, n_landmarks=300, kf0=0, scene=None, prior=None, init_state
     scene = scene or Scene(seed, n_total=n_total, motion=motion)
     rng = np.random.default_rng([seed, 7919, kf0, n_landmarks])
     td_frames = TD0 + rng.normal(0, 2e-4, size=abi.NUM_FRAMES)
-    lm = _landmarks(rng, scene, kf0, n_landmarks, td_frames)
+    lm = _landmarks(rng, scene, kf0, n_landmarks, td_frames, camera=camera)
     N = n_landmarks
     if init_state is None:
         pose = np.zeros((abi.NUM_FRAMES, 7))

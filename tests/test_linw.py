@@ -46,7 +46,8 @@ def make_cases(oracle):
           synth.make_window(4, 120, tr=0.02),
           synth.make_window(5, 64), synth.make_window(6, 65), synth.make_window(3, 7), synth.make_window(8, 1),
           synth.make_window(9, 320),
-          all_start_zero(10, 300)]
+          all_start_zero(10, 300),
+          synth.make_window(12, 300, camera="ocam", tr=0.02)]  # the reference's camera model, rolling shutter on
     w = synth.make_window(11, 1)
     ws.append(w.copy(start_frame=np.zeros(0, np.int32), obs_offset=np.zeros(1, np.int32), inv_depth=np.zeros(0), obs_point=np.zeros((0, 3)),
                      obs_velocity=np.zeros((0, 3)), obs_cur_td=np.zeros(0), obs_uv_y=np.zeros(0)))  # IMU factors only
