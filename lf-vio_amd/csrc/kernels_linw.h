@@ -445,13 +445,21 @@ DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off, int
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = kq + 4 * r, c1 = 16 + ii;  // entries G[row][ii], G[row][c1], G[16 + row][c1]
-      out[row * 30 + ii] = g00[r];
-      if (c1 < 30) out[row * 30 + c1] = g01[r], out[c1 * 30 + row] = g01[r];
-      else if (c1 == 30) out[900 + row] = g01[r];  // J^T r, rows 0 .. 15
-      if (16 + row < 30) {
-        if (c1 < 30) out[(16 + row) * 30 + c1] = g11[r];
-        else if (c1 == 30) out[900 + 16 + row] = g11[r];
-      } else if (16 + row == 30 && c1 == 30) out[930] = 0.5 * g11[r];
+      // Of the symmetric 30 x 30 block only the entries (p, q) whose tangent columns satisfy col(p) >= col(q) are stored — the
+      // ones the packed lower H_pp takes (k_solve_dense<true>'s table, the marginalization's assembly): 465 of 900.  Local
+      // order is pose_f, sb_f, pose_f+1, sb_f+1; tangent order pose_f, pose_f+1, sb_f, sb_f+1.
+      auto ord = [](int p) { return p < 6 ? p : p < 15 ? p + 6 : p < 21 ? p - 9 : p; };
+      const int r2 = 16 + row;
+      if (ord(row) >= ord(ii)) out[row * 30 + ii] = g00[r];
+      if (c1 < 30) {
+        if (ord(row) >= ord(c1)) out[row * 30 + c1] = g01[r];
+        else out[c1 * 30 + row] = g01[r];
+      } else if (c1 == 30) out[900 + row] = g01[r];  // J^T r, rows 0 .. 15
+      if (r2 < 30) {
+        if (c1 < 30) {
+          if (ord(r2) >= ord(c1)) out[r2 * 30 + c1] = g11[r];
+        } else if (c1 == 30) out[900 + r2] = g11[r];
+      } else if (r2 == 30 && c1 == 30) out[930] = 0.5 * g11[r];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
@@ -683,10 +691,13 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
   double w_sc = 0, w_a = 0, w_b = 0;
   auto request = [&](int blk) {
     const int l = blk * LM_BLOCK + lane;
+    // (landmarks are sorted by start frame: no row of the block has an entry in the columns of frames before its first
+    // landmark's start — those pairs are zeros without a load)
+    const int pmin = 3 * rfl(S->lm_start[blk * LM_BLOCK]);
 #pragma unroll
     for (int k = 0; k < WPT; k++) {
       const int cp = wv + 4 * k;
-      wreg[k] = (cp < WT_PAIRS && l < N) ? wt0[(size_t)cp * SPEC_MAX_LM + l] : make_double2(0.0, 0.0);
+      wreg[k] = (cp < WT_PAIRS && cp >= pmin && l < N) ? wt0[(size_t)cp * SPEC_MAX_LM + l] : make_double2(0.0, 0.0);
     }
     if (tid < LM_BLOCK && l < N) w_sc = scale_l[l], w_a = av[l], w_b = bv[l];
   };
