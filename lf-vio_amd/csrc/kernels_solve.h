@@ -1062,7 +1062,8 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
     for (int c = tid; c < WLD; c += nthr) ug[c] = S->uc_grad[c], un[c] = S->uc_gn[c];
     __syncthreads();
     // (one landmark per thread with the 320 threads of k_dogleg / k_step / k_stepw; k_window's 256 take the last 64 in a second trip)
-    for (int l = tid; l < S->N; l += nthr) {
+    // (written as two guarded trips, not a loop: with one trip known the loads above stay in one batch with these)
+    auto row = [&](const int l) {
       const double s = S->scale_l[l], bl = S->b[l], einv = S->einv_l[l], dgl = S->diag_l[l], grl = S->grad_l[l];
       double d1 = 0, d2 = 0;
       if (WT) {
@@ -1114,7 +1115,9 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
       }
       a += gn * gn;
       b += grl * gn;
-    }
+    };
+    if (tid < S->N) row(tid);
+    if (nthr < SPEC_MAX_LM && tid + nthr < S->N) row(tid + nthr);
     __syncthreads();  // ug / un alias cand
   }
   GSTAMP(9);
