@@ -212,8 +212,8 @@ constexpr int LIN_THREADS = 256;
 constexpr int LIN_LDS = LM_BLOCK * (WLD + 1) + 64 + 2 * LM_BLOCK;  // doubles: W tile of the landmark role, reduction scratch, Schur weights
 
 DEV double quad_sum(double v) {  // sum over the 4 lanes of a quad, same value and same order in every lane
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
+  v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]  (DPP moves: a __shfl_xor is a ds_bpermute round trip per dword)
+  v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
   return v;
 }
 DEV d3 quad_sum3(d3 v) { return mk3(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z)); }

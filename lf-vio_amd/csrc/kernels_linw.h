@@ -495,7 +495,7 @@ DEV void linw_prior(Slot *S, const LinView &lv, double *lw) {
       for (; c < n; c += 2) s0 = fma(jr[c], dx[c], s0);
     }
     double sum = (s0 + s1) + (s2 + s3);
-    sum += __shfl_xor(sum, 1, 64);
+    sum += dpp_f64<0xB1>(sum);  // quad_perm [1,0,3,2]: the other half of the row
     if (row < n && h == 0) r[row] = S->prior_r[row] + sum;
   }
   __syncthreads();
