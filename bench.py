@@ -384,7 +384,8 @@ def main():
                     achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                     traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_us=lin_ms * 1e3,
-                    note="latency-bound at N=300 (0.1 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep")
+                    note=("latency-bound at N=300 (0.1 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep" if n_lm <= 1000 else
+                          "FP64-issue-bound, not HBM-bound (26 FLOP/B against a ridge of 9.8): VALU issue share and counter traffic in profiles/, DESIGN.md section 5"))
     if linw:
         flops = sum(2.0e3 * (w.M - w.N) + 1.6e3 * w.N for w in wins[:batch])  # ~2.0 k per residual block + 1.6 k per landmark
         roofline.update(note="FP64-bound (SURVEY section 8(d): 26 FLOP/B against a ridge of 9.8): see fp64_*; the HBM figures are kept because the metric's "

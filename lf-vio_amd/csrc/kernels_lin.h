@@ -157,9 +157,14 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     if (!S->prior_valid) return;
     const int n = S->prior_n;
     const int part = blockIdx.x - (LFVIO_WINDOW_SIZE + 1);
+    // (as many of the SETUP_PRIOR_WGS workgroups as the entries need at PRIOR_EPT per thread — three for the usual n = 76 —: every
+    // one of them stages all of J0, and a resident batch pays that for every window)
+    constexpr int PRIOR_EPT = 8;
+    const int np = min(SETUP_PRIOR_WGS, (n * n + 256 * PRIOR_EPT - 1) / (256 * PRIOR_EPT));
+    if (part >= np) return;
     // J0 goes through LDS in slabs of rows (all of it for the usual n = 76): one batch of independent loads instead of
     // a dependent load per term.  A thread owns up to PRIOR_EPT entries of A' (n <= 172: 29 584 entries over 4 096 threads).
-    constexpr int PRIOR_SLAB = 2048, PRIOR_EPT = 8;  // 16 KB: k_setup keeps 5 workgroups per CU for resident batches
+    constexpr int PRIOR_SLAB = 2048;  // 16 KB: k_setup keeps 5 workgroups per CU for resident batches
     __shared__ double Js[PRIOR_SLAB + LFVIO_MAX_PRIOR_DIM];
     const double *J = S->prior_J;
     const int rows_per = PRIOR_SLAB / n;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < PRIOR_EPT; q++) {
-        const int e = part * 256 + tid + q * 256 * SETUP_PRIOR_WGS;
+        const int e = part * 256 + tid + q * 256 * np;
         if (e < n * n) {
           const int r = e / n, c = e % n;
           double s = acc[q];
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     }
 #pragma unroll
     for (int q = 0; q < PRIOR_EPT; q++) {
-      const int e = part * 256 + tid + q * 256 * SETUP_PRIOR_WGS;
+      const int e = part * 256 + tid + q * 256 * np;
       if (e < n * n) S->prior_A[e] = acc[q];
     }
     if (part == 0 && tid < n) S->prior_b0[tid] = accb;

@@ -9,7 +9,7 @@ from lfvio.engine import Engine
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 distinct = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-eng = Engine(0)
+eng = Engine(0, os.environ.get("LFVIO_TOOL_LIB") or None)
 wins = [synth.make_window_with_prior(s, 300, lambda x, f: eng.optimize(x, f))[0] for s in range(distinct)]
 for mode, names in ((1, {12: "k_linw", 13: "k_solve_dense<true>"}),
                     (0, {8: "k_lin landmark role", 9: "k_lin Gram role", 10: "k_lin pose roles", 0: "k_lin (role by role, as launched)", 2: "k_sum", 3: "k_solve_dense<false>"})):

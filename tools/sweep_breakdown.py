@@ -10,15 +10,23 @@ d = "/tmp/prof_sweep"
 subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "batch512",
                 "--no-secondary", "--no-cpu-baseline", "--steps", str(steps), "--warmup", str(warm)], cwd="/tmp", capture_output=True, text=True)
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if int(r["Grid_Size_Y"]) == windows]
+rows = sorted((r for r in csv.DictReader(open(f)) if int(r["Grid_Size_Y"]) == windows), key=lambda r: int(r["Start_Timestamp"]))
+# (the bench's own kernel timings — lfvio_debug_time_kernel — launch ONE kernel over the whole batch many times in a row: runs of
+# three or more launches of the same kernel are those, not passes of a sweep, and are left out)
+runs, i = [], 0
+while i < len(rows):
+    j = i
+    while j + 1 < len(rows) and rows[j + 1]["Kernel_Name"] == rows[i]["Kernel_Name"]:
+        j += 1
+    runs.append((i, j))
+    i = j + 1
+rows = [rows[k] for a, b in runs if b - a + 1 < 3 for k in range(a, b + 1)]
 t0 = min(int(r["Start_Timestamp"]) for r in rows)
 t1 = max(int(r["End_Timestamp"]) for r in rows)
 by = collections.defaultdict(list)
 for r in rows:
     by[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 sweeps = steps + warm
-# (the bench's own kernel timings — lfvio_debug_time_kernel — launch the same kernels over the whole batch: they are the launches
-# in excess of the sweeps' and are reported apart by the reps they come in)
 lines = [f"# one sweep of {windows} resident windows (bench.py --workload batch512, one stream), kernel time per sweep from rocprofv3 --kernel-trace",
          "", "| kernel | launches per sweep | us per sweep | mean us of the launches that did work | share |", "|---|---|---|---|---|"]
 tot = sum(sum(v) for v in by.values())
