@@ -157,10 +157,11 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     if (!S->prior_valid) return;
     const int n = S->prior_n;
     const int part = blockIdx.x - (LFVIO_WINDOW_SIZE + 1);
-    // (as many of the SETUP_PRIOR_WGS workgroups as the entries need at PRIOR_EPT per thread — three for the usual n = 76 —: every
-    // one of them stages all of J0, and a resident batch pays that for every window)
+    // (a resident batch: as few of the SETUP_PRIOR_WGS workgroups as the entries need at PRIOR_EPT per thread — three for the usual
+    // n = 76 —, because every one of them stages all of J0 and the batch pays that for every window; few windows: all of them,
+    // 1.4 entries per thread — the latency of the call)
     constexpr int PRIOR_EPT = 8;
-    const int np = min(SETUP_PRIOR_WGS, (n * n + 256 * PRIOR_EPT - 1) / (256 * PRIOR_EPT));
+    const int np = gridDim.y >= 8 ? min(SETUP_PRIOR_WGS, (n * n + 256 * PRIOR_EPT - 1) / (256 * PRIOR_EPT)) : SETUP_PRIOR_WGS;
     if (part >= np) return;
     // J0 goes through LDS in slabs of rows (all of it for the usual n = 76): one batch of independent loads instead of
     // a dependent load per term.  A thread owns up to PRIOR_EPT entries of A' (n <= 172: 29 584 entries over 4 096 threads).
