@@ -1005,7 +1005,7 @@ DEV void dogleg_coeffs(double grad_sq_total, double gn_sq_total, double grad_gn_
 // Returns false when the slot takes no step in this pass.
 // WT: the inline back-substitution reads Slot::Wt (launches whose k_lin has all roles in one grid and writes it); a resident
 // batch, whose landmark role is a launch of its own and whose sweeps are throughput, keeps the compact rows of W.
-template <bool FUSED, bool inline_backsub, bool WT>
+template <bool FUSED, bool inline_backsub, bool WT, int WT_PARTS = 1>
 DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *sh2) {
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
@@ -1071,14 +1071,24 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
         // a wave share line by line, all in flight before the first product (a wave holds 63 loads in flight at most; from
         // the compact rows of W it is KC loads of 64 lines each: 10 500 cycles for this block, 5 900 like this).  The entries
         // outside the track's span are zeros, which leave the sums as they are: same products, same order.
+        // (WT_PARTS > 1 — k_stepw, whose workgroups are throughput: the row in that many batches of loads, so that the 148
+        // registers of a whole row do not decide how many workgroups share a CU; same products, same order)
         const double2 *wt = (const double2 *)(const double *)S->Wt + l;
-        double2 wv[WT_PAIRS];
+        constexpr int PER = (WT_PAIRS + WT_PARTS - 1) / WT_PARTS;
 #pragma unroll
-        for (int cp = 0; cp < WT_PAIRS; cp++) wv[cp] = wt[(size_t)cp * SPEC_MAX_LM];
+        for (int part = 0; part < WT_PARTS; part++) {
+          double2 wv[PER];
 #pragma unroll
-        for (int c = 0; c < KC; c++) {
-          const double w = (c & 1) ? wv[c >> 1].y : wv[c >> 1].x;
-          d1 = fma(w, ug[c], d1), d2 = fma(w, un[c], d2);
+          for (int k = 0; k < PER; k++) {
+            const int cp = part * PER + k;
+            wv[k] = cp < WT_PAIRS ? wt[(size_t)cp * SPEC_MAX_LM] : make_double2(0.0, 0.0);
+          }
+#pragma unroll
+          for (int k = 0; k < PER; k++) {
+            const int c0 = 2 * (part * PER + k);
+            if (c0 < KC) d1 = fma(wv[k].x, ug[c0], d1), d2 = fma(wv[k].x, un[c0], d2);
+            if (c0 + 1 < KC) d1 = fma(wv[k].y, ug[c0 + 1], d1), d2 = fma(wv[k].y, un[c0 + 1], d2);
+          }
         }
       } else {
         // the compact row: all eleven frame slots of it at once (a shorter track reads on into the rows behind it, which are

@@ -132,13 +132,14 @@ DEV void stepw_cost(Slot *S, int cur, double cg, double cn, double *ws) {
 #else
 #define WPST(k) do { } while (0)
 #endif
+template <int STEPW_WT_PARTS>
 DEV void stepw_body(Slot *S, double *ws) {
   __shared__ double sh2[2 * (1 + SPEC_EXTRA)];
   const int cur = tr_flags(&S->tr).cur;
   // (dogleg_body: false when the slot takes no step in this pass — finished, or a failed factorization, which the bookkeeping
   // below turns into a retry with a larger mu)
   WPST(16);
-  const bool step = dogleg_body<true, true, true>(S, 0, 1, true, 1, sh2);
+  const bool step = dogleg_body<true, true, true, STEPW_WT_PARTS>(S, 0, 1, true, 1, sh2);
   WPST(17);
   if (step) stepw_cost(S, cur, sh2[0], sh2[1], ws);
   __syncthreads();
@@ -146,9 +147,13 @@ DEV void stepw_body(Slot *S, double *ws) {
   decide_body(S);
   WPST(19);
 }
-__global__ __launch_bounds__(STEPW_THREADS) void k_stepw(char *base, size_t stride) {
+// 256 threads, not the 320 of one landmark per thread: four waves sit one per SIMD, and at two waves per SIMD (256 registers) TWO
+// workgroups share a CU; five-wave workgroups did not pair up on a CU at any register count (measured: the time of a launch
+// doubles from 256 to 257 windows either way), and 512 windows were two rounds.
+constexpr int STEPW_LAUNCH_THREADS = 256;
+__global__ __launch_bounds__(STEPW_LAUNCH_THREADS, 2) void k_stepw(char *base, size_t stride) {
   __shared__ double ws[STEPW_WS];
-  stepw_body(SLOT(base, stride), ws);
+  stepw_body<1>(SLOT(base, stride), ws);
 }
 
 // ---------------------------------------------------------------------------
@@ -167,7 +172,7 @@ __device__ __noinline__ void window_lin(Slot *S, double *smem, const LinwArgs *A
 __device__ __noinline__ void window_solve(Slot *S, double *smem, long long xch_off, long long imu_off, long long prior_A_off, const int *asm_tab) {
   solve_body<true>(S, smem, xch_off, imu_off, prior_A_off, asm_tab);
 }
-__device__ __noinline__ void window_step(Slot *S, double *smem) { stepw_body(S, smem); }
+__device__ __noinline__ void window_step(Slot *S, double *smem) { stepw_body<1>(S, smem); }
 __global__ __launch_bounds__(LW_THREADS) void k_window(char *base, size_t stride, const LinwArgs A, long long xch_off, long long prior_A_off, const int *asm_tab, int npass) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   Slot *S = SLOT(base, stride);

@@ -980,7 +980,7 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     // a resident batch on the window-resident path: step, candidate cost and bookkeeping as ONE launch, one workgroup per window
     const bool stepw = lw && inl && spec == 1 && !c->no_fuse;
     if (stepw) {
-      hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_THREADS), 0, c->stream, c->d_base, st);
+      hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_LAUNCH_THREADS), 0, c->stream, c->d_base, st);
       return false;
     }
     if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
@@ -1943,7 +1943,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
         launch_linw(c, count);
         break;
       case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;
-      case 14: hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_THREADS), 0, c->stream, c->d_base, st); break;  // (not idempotent: a few reps only)
+      case 14: hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_LAUNCH_THREADS), 0, c->stream, c->d_base, st); break;  // (not idempotent: a few reps only)
       default: launch_solve(c, count); break;
     }
   }
