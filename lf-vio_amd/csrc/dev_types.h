@@ -161,7 +161,11 @@ struct LinwPlan {
   int wave_first[LINW_WAVES + 1];     // wave w takes strips [wave_first[w], wave_first[w + 1]); all strips of a start on one wave
   short lm0[LINW_MAX_STRIPS], nlm[LINW_MAX_STRIPS], start[LINW_MAX_STRIPS], kmax[LINW_MAX_STRIPS];
   int pair_obs0[NPAIR + 1];           // first pair-major observation of every frame pair (prefix sums)
-  short firstl[LFVIO_NUM_FRAMES][12];  // [start][o]: first landmark (device order) of that start frame with more than o observations
+  int firstl[LFVIO_NUM_FRAMES][12];   // [start][o]: first landmark (device order) of that start frame with more than o observations
+  // A large single window (k_linb, kernels_linw.h): the same strips, four of ONE start frame to a workgroup ("group"), as many
+  // groups as the window has; strips, waves and lm0 .. kmax above are not used then
+  int big;        // 1: the plan is a group list (Slot::linb_lm0 / linb_ns), ng groups; Wt rows are wt_ld apart
+  int ng, wt_ld, pad_;
 };
 
 struct MargPlan {  // structure of the marginalization, computed on the host at upload
@@ -225,6 +229,7 @@ struct Slot {
   GP<double> anc[8];                // [N] the anchor observation of every landmark, SoA in device order (k_linw)
   GP<double> pmo[8];                // [NV] the non-anchor observations, SoA in pair-major order (k_linw: a strip step reads 64 consecutive ones)
   GP<unsigned char> pm_pair;        // [NV] frame pair (i * 11 + j) of every pair-major observation (k_stepw: one lane per observation)
+  GP<int> linb_lm0, linb_ns;        // [ng] k_linb's groups: first landmark; landmarks | start frame << 16 (longest first)
   GP<int> chunk_pair, chunk_begin, chunk_end;
   GP<double> prior_J, prior_r;     // n*n, n
   GP<int> sum_off, sum_end_marg, sum_items;  // gather lists of k_sum: per H_pp / g_p entry, offsets into gram_part (or pairG)

@@ -51,6 +51,10 @@ constexpr int LW_LDS_P2 = LM_BLOCK * (WLD + 1) + 2 * LM_BLOCK;
 constexpr int LW_HC = KC * (KC + 1) / 2 + KC + 3;  // packed camera part + its gradient, aliased over the stage areas
 static_assert(LW_HC <= LW_PRIV0, "Hc fits the stage areas");
 constexpr size_t LW_LDS_BYTES = (size_t)(LW_LDS_P1 > LW_LDS_P2 ? LW_LDS_P1 : LW_LDS_P2) * 8;
+// k_linb (a large single window: the four strips of a workgroup share their start frame s): the pose-pose off-diagonal blocks are
+// the ten (s, j) ones, private per wave like everything else
+constexpr int LB_OFF = 10 * 36, LB_PRIVSZ = LW_PRIV + LB_OFF, LB_RED0 = LW_PRIV0 + LINW_WAVES * LB_PRIVSZ;
+static_assert(LB_RED0 + LINW_WAVES * 8 <= LW_LDS_P1, "k_linb's accumulators fit k_linw's workspace");
 
 __host__ __device__ inline int lw_tri(int n, int a, int b) { return a * n - (a * (a - 1)) / 2 + (b - a); }  // upper index, a <= b < n
 __host__ __device__ inline int lw_pidx(int i, int j) { return (i * (21 - i)) / 2 + (j - i - 1); }           // i < j <= 10 -> 0 .. 54
@@ -98,6 +102,8 @@ DEV int lw_pcol(int b) { return b < 6 ? b : b < 9 ? b + 3 : b < 12 ? b + 6 : b +
 struct LinwArgs {
   long long anc0, anc_stride, pmo0, pmo_stride;  // first channel and distance between the 8 channels of the two observation copies
   long long Wt, lam[2], a, b, scale_l, diag_l, grad_l, einv_l, imu_out, Hpp, gp, schur_sum;
+  long long part;  // k_linb: the groups' partial sums (LINB_LEN doubles each; the role-by-role path's Schur partials live there)
+  int wt_ld;       // k_linb: distance between the column pairs of Slot::Wt (landmarks, padded)
   const int *asm_tab;  // static: where every packed camera entry of H_pp is found in the LDS accumulators (build_linw_table)
 };
 template <class T>
@@ -107,7 +113,13 @@ DEV double lw_sel3(int q, double x0, double x1, double x2) { return q == 0 ? x0 
 // ---------------------------------------------------------------------------
 // phase 1: the strips of this wave
 // ---------------------------------------------------------------------------
-DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int scaled, int mode, double *lw, double part[5]) {
+// BIG (k_linb): the wave's strips come from the caller (t0 .. t1, descriptors in the lanes' d_lm0 / d_nsk), Wt rows are A.wt_ld
+// apart and every entry of a strip's span is WRITTEN (nothing zero-fills a large window's Wt), the pose-pose blocks are private.
+// o1 / ostep (BIG): the wave takes the steps o1, o1 + ostep, ... of its strip — ostep waves share a strip whose tracks are long
+// (the steps of a strip are a serial chain; a workgroup with one or two strips splits them) and the landmark's sums meet in LDS.
+template <bool BIG>
+DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int scaled, int mode, double *lw, double part[5], int t0, int t1, int d_lm0,
+                     int d_nsk, int o1 = 1, int ostep = 1) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   double *my = lw + wv * LW_WAVE;
   double(*stage)[17] = (double(*)[17]) my;
@@ -128,20 +140,21 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
   //             the column is a jP column too);
   //   the tic columns are Kt jP, Kt = M3^T M1 (M1 is orthogonal): lane e < 57 forms ONE entry (tic_a, u) = sum_k Kt[a][k] Q[k][u]
   //             — or (tic_a, tic_b) — from rows 0 .. 2 of Q, which go through LDS for that.
-  const int kq = lane >> 4, ii = lane & 15, privb = LW_PRIV0 + wv * LW_PRIV;
+  const int kq = lane >> 4, ii = lane & 15, privb = LW_PRIV0 + wv * (BIG ? LB_PRIVSZ : LW_PRIV), off0 = BIG ? privb + LW_PRIV : LW_OFF0;
+  const size_t wld = BIG ? (size_t)A.wt_ld : (size_t)SPEC_MAX_LM;
   const int nodesc = privb + LW_DUMMY;  // (no valid bit: the slot adds zero to the wave's dummy word)
   int prim[4], extra[3] = {nodesc, nodesc, nodesc};
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int R = kq + 4 * r;
-    prim[r] = (R <= ii && ii < 14) ? lw_desc(lw_pcol(R), lw_pcol(ii), false, privb, LW_OFF0) : nodesc;
+    prim[r] = (R <= ii && ii < 14) ? lw_desc(lw_pcol(R), lw_pcol(ii), false, privb, off0) : nodesc;
   }
   if (kq < 3 && kq <= ii && ii < 14) {
-    if (ii >= 3) extra[0] = lw_desc(6 + kq, lw_pcol(ii), true, privb, LW_OFF0);
+    if (ii >= 3) extra[0] = lw_desc(6 + kq, lw_pcol(ii), true, privb, off0);
     else {
-      extra[0] = lw_desc(6 + kq, 6 + ii, false, privb, LW_OFF0);
-      extra[1] = lw_desc(kq, 6 + ii, true, privb, LW_OFF0);
-      if (kq != ii) extra[2] = lw_desc(ii, 6 + kq, true, privb, LW_OFF0);
+      extra[0] = lw_desc(6 + kq, 6 + ii, false, privb, off0);
+      extra[1] = lw_desc(kq, 6 + ii, true, privb, off0);
+      if (kq != ii) extra[2] = lw_desc(ii, 6 + kq, true, privb, off0);
     }
   }
   // the tic entry of this lane: column a of Kt twice (tic-tic) or once; source basis column bu, sign
@@ -154,11 +167,11 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
     tic_u = ui < 6 ? ui : ui < 9 ? ui - 6 : ui < 12 ? ui - 3 : ui < 15 ? ui - 3 : ui - 3;  // basis row: Pj -> jP rows 0 .. 2
     tic_neg = ui >= 6 && ui < 9;
     tic_b = -1;
-    tic_desc = lw_desc(12 + tic_a, lu, false, privb, LW_OFF0);
+    tic_desc = lw_desc(12 + tic_a, lu, false, privb, off0);
   } else if (lane < 57) {
     const int e = lane - 51;  // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
     tic_a = e < 3 ? 0 : e < 5 ? 1 : 2, tic_b = e < 3 ? e : e < 5 ? e - 2 : 2;
-    tic_desc = lw_desc(12 + tic_a, 12 + tic_b, false, privb, LW_OFF0);
+    tic_desc = lw_desc(12 + tic_a, 12 + tic_b, false, privb, off0);
   }
   const double *anc = lw_at<const double>(S, A.anc0), *pmo = lw_at<const double>(S, A.pmo0);
   const size_t ancs = (size_t)A.anc_stride / 8, pmos = (size_t)A.pmo_stride / 8;
@@ -168,15 +181,12 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
 #ifdef LFVIO_LINW_PROFILE
   long long wacc[5] = {0, 0, 0, 0, 0};
 #endif
-  const int t0 = rfl(P->wave_first[wv]), t1 = rfl(P->wave_first[wv + 1]);
-  // the strip descriptors, one per lane, fetched once: a strip reads its own by v_readlane
-  const int tl = lane < LINW_MAX_STRIPS ? lane : 0;
-  const int d_lm0 = P->lm0[tl] | (P->nlm[tl] << 16), d_sk = P->start[tl] | (P->kmax[tl] << 16);
+  // (the strip descriptors, one per lane: a strip reads its own by v_readlane)
   for (int t = t0; t < t1; t++) {
     const long long tp0 = WNOW();
     (void)tp0;
-    const int dl = __builtin_amdgcn_readlane(d_lm0, t), ds = __builtin_amdgcn_readlane(d_sk, t);
-    const int lm0 = dl & 0xffff, nlm = dl >> 16, s = ds & 0xffff, kmax = ds >> 16;
+    const int lm0 = __builtin_amdgcn_readlane(d_lm0, t), ds = __builtin_amdgcn_readlane(d_nsk, t);
+    const int nlm = ds & 0xff, s = (ds >> 8) & 0xff, kmax = ds >> 16;
     if (marg && s != 0) continue;  // the marginalization's sweep: the landmarks anchored at frame 0
     // per step o (lane o holds it): the first landmark of this start frame that has an observation o, and the pair-major index of its observation
     const int oc = lane < 12 && s + lane < LFVIO_NUM_FRAMES ? lane : 0;
@@ -194,23 +204,24 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
     double2 *wt = wt0 + lc;
     // the observation of step 1 (every later one is requested a step ahead)
     double nx[8];
-    int first = __builtin_amdgcn_readlane(r_first, 1);
+    int first = __builtin_amdgcn_readlane(r_first, BIG ? min(o1, 11) : 1);
     {
-      const int idx = __builtin_amdgcn_readlane(r_idx0, 1) + (valid && l >= first ? l - first : 0);
+      const int idx = __builtin_amdgcn_readlane(r_idx0, BIG ? min(o1, 11) : 1) + (valid && l >= first ? l - first : 0);
 #pragma unroll
-      for (int k = 0; k < 8; k++) nx[k] = kmax > 1 ? pmo[k * pmos + idx] : 0.0;
+      for (int k = 0; k < 8; k++) nx[k] = kmax > (BIG ? o1 : 1) ? pmo[k * pmos + idx] : 0.0;
     }
     WACC(27, tp0);
-    for (int o = 1; o < kmax; o++) {
+    for (int o = BIG ? o1 : 1; o < kmax; o += BIG ? ostep : 1) {
       const long long ts0 = WNOW();
       (void)ts0;
       const int j = s + o, pair = s * 11 + j;
       const bool act = valid && l >= first;
       const int first_now = first;
       ob.pj = mk3(nx[0], nx[1], nx[2]), ob.vj = mk3(nx[3], nx[4], nx[5]), ob.tdj = nx[6], ob.rowj = nx[7];
-      if (o + 1 < kmax) {
-        first = __builtin_amdgcn_readlane(r_first, o + 1);
-        const int idx = __builtin_amdgcn_readlane(r_idx0, o + 1) + (valid && l >= first ? l - first : 0);
+      const int on = o + (BIG ? ostep : 1);
+      if (on < kmax) {
+        first = __builtin_amdgcn_readlane(r_first, on);
+        const int idx = __builtin_amdgcn_readlane(r_idx0, on) + (valid && l >= first ? l - first : 0);
 #pragma unroll
         for (int k = 0; k < 8; k++) nx[k] = pmo[k * pmos + idx];
       }
@@ -239,11 +250,11 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
         a += jl0 * jl0 + jl1 * jl1;
         b += jl0 * B.r[0] + jl1 * B.r[1];
         cost += 0.5 * B.rho0;
-        if (act) {
+        if (BIG ? valid : act) {
           // the pose-j part of the landmark's row: columns 6 j .. 6 j + 5 = pairs 3 j .. 3 j + 2 of the transposed copy
-          wt[(size_t)(3 * j) * SPEC_MAX_LM] = make_double2(-wp.x, -wp.y);
-          wt[(size_t)(3 * j + 1) * SPEC_MAX_LM] = make_double2(-wp.z, wtj.x);
-          wt[(size_t)(3 * j + 2) * SPEC_MAX_LM] = make_double2(wtj.y, wtj.z);
+          wt[(size_t)(3 * j) * wld] = make_double2(-wp.x, -wp.y);
+          wt[(size_t)(3 * j + 1) * wld] = make_double2(-wp.z, wtj.x);
+          wt[(size_t)(3 * j + 2) * wld] = make_double2(wtj.y, wtj.z);
         }
       }
       WACC(24, ts0);
@@ -280,7 +291,7 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (kq < 3) Qf[kq][ii] = acc[0];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      const int offp = 36 * lw_pidx(s, j);
+      const int offp = BIG ? 36 * (o - 1) : 36 * lw_pidx(s, j);
       auto at = [&](int d) { return lw + ((d & 0xffff) + ((d >> 16) & 63) * s + ((d >> 22) & 63) * j + ((d & (1 << 28)) ? offp : 0)); };
       double tval = 0.0;
       if (tic_desc & LWD_VALID) {
@@ -321,17 +332,44 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
     }
     const long long te0 = WNOW();
     (void)te0;
-    // ---- the landmark's own sums: anchor pose, extrinsic, td parts of its row; scalars of the trust region
-    if (valid) {
-      wt[(size_t)(3 * s) * SPEC_MAX_LM] = make_double2(wPi.x, wPi.y);
-      wt[(size_t)(3 * s + 1) * SPEC_MAX_LM] = make_double2(wPi.z, wTi.x);
-      wt[(size_t)(3 * s + 2) * SPEC_MAX_LM] = make_double2(wTi.y, wTi.z);
-      if (est_ex) {
-        wt[(size_t)33 * SPEC_MAX_LM] = make_double2(wTic.x, wTic.y);
-        wt[(size_t)34 * SPEC_MAX_LM] = make_double2(wTic.z, wTx.x);
-        wt[(size_t)35 * SPEC_MAX_LM] = make_double2(wTx.y, wTx.z);
+    bool owner = true;
+    if (BIG && ostep > 1) {
+      // the waves that shared the strip's steps: their sums over the track meet in the first one, in wave order (two rounds of
+      // eight values through the stage areas, which are free now; workgroup-uniform: every wave of such a group has a strip)
+      owner = (wv % ostep) == 0;
+      double v[16] = {a, b, cost, wtd, wPi.x, wPi.y, wPi.z, wTi.x, wTi.y, wTi.z, wTic.x, wTic.y, wTic.z, wTx.x, wTx.y, wTx.z};
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        __syncthreads();
+        if (!owner) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) my[k * 64 + lane] = v[8 * h + k];
+        }
+        __syncthreads();
+        if (owner) {
+          for (int pw = 1; pw < ostep; pw++) {
+            const double *src = lw + (wv + pw) * LW_WAVE;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[8 * h + k] += src[k * 64 + lane];
+          }
+        }
       }
-      wt[(size_t)36 * SPEC_MAX_LM] = make_double2(est_td ? wtd : 0.0, 0.0);
+      a = v[0], b = v[1], cost = v[2], wtd = v[3];
+      wPi = mk3(v[4], v[5], v[6]), wTi = mk3(v[7], v[8], v[9]), wTic = mk3(v[10], v[11], v[12]), wTx = mk3(v[13], v[14], v[15]);
+    }
+    // ---- the landmark's own sums: anchor pose, extrinsic, td parts of its row; scalars of the trust region
+    if (valid && owner) {
+      wt[(size_t)(3 * s) * wld] = make_double2(wPi.x, wPi.y);
+      wt[(size_t)(3 * s + 1) * wld] = make_double2(wPi.z, wTi.x);
+      wt[(size_t)(3 * s + 2) * wld] = make_double2(wTi.y, wTi.z);
+      if (est_ex) {
+        wt[(size_t)33 * wld] = make_double2(wTic.x, wTic.y);
+        wt[(size_t)34 * wld] = make_double2(wTic.z, wTx.x);
+        wt[(size_t)35 * wld] = make_double2(wTx.y, wTx.z);
+      } else if (BIG) {
+        wt[(size_t)33 * wld] = wt[(size_t)34 * wld] = wt[(size_t)35 * wld] = make_double2(0.0, 0.0);
+      }
+      wt[(size_t)36 * wld] = make_double2(est_td ? wtd : 0.0, 0.0);
       if (marg) {
         // eps of marginalization_factor.h:70 on the diagonal block; no scaling, no trust-region scalars
         lw_at<double>(S, A.einv_l)[l] = (a > 1e-8) ? 1.0 / a : 0.0;
@@ -364,7 +402,7 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
     WACC(28, te0);
   }
 #ifdef LFVIO_LINW_PROFILE
-  if (blockIdx.y == 0 && threadIdx.x == 0)
+  if (blockIdx.y == 0 && threadIdx.x == 0 && (!BIG || blockIdx.x == LFVIO_LINB_GROUP))
     for (int k = 0; k < 5; k++) S->dbg[24 + k] = wacc[k];
 #endif
   part[0] = wave_sum(cost_s), part[1] = wave_sum(g2_s), part[2] = wave_sum(asv2_s), part[3] = wave_sum(lam2_s), part[4] = wave_max(bmax_s);
@@ -524,7 +562,7 @@ DEV void linw_prior(Slot *S, const LinView &lv, double *lw) {
 // Static table of phase 3 (built once per context, lfvio_hip.hip): for the packed camera entry e of H_pp (e < SUM_VIS_PACKED)
 // and the camera-side gradient entries behind them, where the value sits in the LDS accumulators —
 //   bits 0..15 the offset (inside a wave's private block, or absolute for the single-writer pose-pose blocks), bit 16 "absolute",
-//   bit 17 the entry touches an extrinsic column, bit 18 it touches the td column.
+//   bit 17 the entry touches an extrinsic column, bit 18 it touches the td column; bits 20..23 / 24..27 the frames (i, j) of a pose-pose block.
 constexpr int LWT_ABS = 1 << 16, LWT_EX = 1 << 17, LWT_TD = 1 << 18;
 
 // ---------------------------------------------------------------------------
@@ -567,7 +605,12 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
     __syncthreads();
     WSTAMP(9);
     double part[5];
-    linw_strips(S, lv, A, fl.cur, fl.scaled, mode, lw, part);
+    {
+      const LinwPlan *P = &S->linw;
+      const int tl = lane < LINW_MAX_STRIPS ? lane : 0;
+      linw_strips<false>(S, lv, A, fl.cur, fl.scaled, mode, lw, part, rfl(P->wave_first[wv]), rfl(P->wave_first[wv + 1]), P->lm0[tl],
+                         P->nlm[tl] | (P->start[tl] << 8) | (P->kmax[tl] << 16));
+    }
     WSTAMP(10);
     if (lane == 0) {
 #pragma unroll
@@ -767,4 +810,293 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
 __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t stride, const LinwArgs A, int mode_bits) {
   extern __shared__ __attribute__((aligned(16))) double lw[];
   linw_body(SLOT(base, stride), lw, A, mode_bits);
+}
+
+// ---------------------------------------------------------------------------
+// k_linb: grid (groups + 1, batch) x 256, dynamic LDS = LW_LDS_BYTES — the strip sweep of k_linw for ONE LARGE window (thousands
+// of landmarks; LinwPlan::big).  A start frame of such a window has hundreds of strips, all of them full: workgroup g takes a
+// GROUP — one to eight consecutive strips of one start frame s: a strip (or two) per wave where the tracks are short, two or four
+// waves sharing the steps of a strip where they are long — and does with its <= 512 landmarks what k_linw
+// does with a window: every observation once (residual, Jacobian basis, rows of W into Slot::Wt, Gram SYRK per step into LDS
+// accumulators), then the camera part of H_pp and of g_p summed over its waves, then the Schur SYRK over its landmarks from the
+// transposed rows — and leaves ONE partial of LINB_LEN doubles ([camera H_pp packed | camera gradient | Schur tiles | landmark
+// scalars]); k_sumb adds the partials up in group order.  Against the role-by-role sweep (k_lin): an observation is evaluated once
+// instead of twice, the per-pair tables come through the scalar cache, a quarter of the Schur partials and no Gram partials per
+// chunk.  The last workgroup of the grid takes the pose side (IMU factors, prior) like phase 0 of k_linw.
+// Differences to k_linw inside a group: all four waves share s, so the pose-pose blocks (s, j) are private per wave like the
+// rest (LB_OFF); nothing zero-fills a large window's Wt, so a strip writes every entry of its span (a shorter track's zeros
+// too) and the Schur phase takes from a block only the pairs its longest track reaches.
+// ---------------------------------------------------------------------------
+constexpr int LINB_LEN = SUM_VIS + SCHUR_LEN + 8;
+#ifdef LFVIO_LINW_PROFILE  // cycle stamps of group LFVIO_LINB_GROUP (default 0: the most expensive one), tools/linb_clocks.py
+#ifndef LFVIO_LINB_GROUP
+#define LFVIO_LINB_GROUP 0
+#endif
+#define BSTAMP(k) do { if (blockIdx.x == LFVIO_LINB_GROUP && blockIdx.y == 0 && threadIdx.x == 0) S->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BSTAMP(k) do { } while (0)
+#endif
+DEV void linb_body(Slot *S, double *lw, const LinwArgs &A) {
+  TRState *tr = &S->tr;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const TRFlags fl = tr_flags(tr);
+  const double mu = tr->mu;
+  const LinwPlan *P = &S->linw;
+  const int ng = P->ng, g = blockIdx.x;
+  if (g > ng) return;
+  // a pass that starts with the loop still open is a pass this slot needs (k_lin's count)
+  if (g == 0 && tid == 0 && !fl.done) S->passes_used++;
+  if (fl.done | (!fl.do_lin & !fl.do_schur)) return;
+  LinView lv;
+  lv.x = &S->x[fl.cur], lv.tab = &S->tab[fl.cur], lv.lam = lw_at<const double>(S, A.lam[fl.cur]), lv.mu = mu;
+  if (g == ng) {  // the pose side
+    if (!fl.do_lin) return;
+    linw_imu(S, lv, lw, A.imu_out, MODE_SOLVE);
+    __syncthreads();
+    linw_prior(S, lv, lw);
+    return;
+  }
+  const int L0 = rfl(S->linb_lm0[g]), ns = rfl(S->linb_ns[g]), s = ns >> 16, L1 = L0 + (ns & 0xffff);
+  const int est_ex = S->est_ex, est_td = S->est_td;
+  double *out = lw_at<double>(S, A.part) + (size_t)g * LINB_LEN;
+  if (fl.do_lin) {
+    constexpr int P3_E = (SUM_VIS + LW_THREADS - 1) / LW_THREADS;
+    int p3[P3_E];
+#pragma unroll
+    for (int q = 0; q < P3_E; q++) p3[q] = A.asm_tab[tid + LW_THREADS * q < SUM_VIS ? tid + LW_THREADS * q : 0];
+    // one, two, (three,) four strips: four, two, one wave(s) per strip, sharing its steps; five to eight: two strips per wave
+    // (wave w takes strips w and w + 4; lane t of the wave holds the descriptor of its t-th strip)
+    const int nstr = (L1 - L0 + LM_BLOCK - 1) / LM_BLOCK, split = nstr <= 1 ? 4 : nstr <= 2 ? 2 : 1;
+    const int mine = wv / split + (lane == 1 ? 4 : 0);
+    const int lm0w = L0 + LM_BLOCK * mine, nw = min(max(L1 - lm0w, 0), LM_BLOCK);
+    const int kmaxw = nw > 0 ? S->lm_cnt[lm0w + nw - 1] : 0;  // (ascending track length inside a start frame: the last one is the longest)
+    const int nmine = (wv / split < nstr ? 1 : 0) + (wv / split + 4 < nstr ? 1 : 0);
+    BSTAMP(8);
+    for (int e = tid; e < LB_RED0 + LINW_WAVES * 8; e += LW_THREADS) lw[e] = 0.0;
+    __syncthreads();
+    BSTAMP(9);
+    double part[5];
+    linw_strips<true>(S, lv, A, fl.cur, fl.scaled, MODE_SOLVE, lw, part, 0, nmine, lm0w, nw | (s << 8) | (kmaxw << 16), 1 + wv % split, split);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) lw[LB_RED0 + 8 * wv + k] = part[k];
+    }
+    __syncthreads();
+    BSTAMP(10);
+    // ---- the group's camera part of H_pp and of the gradient: the waves' private copies in wave order
+#pragma unroll
+    for (int q = 0; q < P3_E; q++) {
+      const int e = tid + LW_THREADS * q, d = p3[q];
+      int at = d & 0xffff;
+      bool live = true;
+      if (d & LWT_ABS) {
+        // a pose-pose block (i, j): this group has the ten (s, j) ones, at 36 (j - s - 1) behind every wave's private block
+        const int i = (d >> 20) & 15, j = (d >> 24) & 15;  // (the block's frames ride in the table word)
+        live = i == s;
+        at = LW_PRIV + 36 * (j - s - 1) + (at - LW_OFF0 - 36 * lw_pidx(i, j));
+      }
+      const double *p0 = lw + LW_PRIV0 + (live ? at : 0);
+      double v = (p0[0] + p0[LB_PRIVSZ]) + (p0[2 * LB_PRIVSZ] + p0[3 * LB_PRIVSZ]);
+      if (!live || ((d & LWT_EX) && !est_ex) || ((d & LWT_TD) && !est_td)) v = 0.0;
+      if (e < SUM_VIS) out[e] = v;
+    }
+    if (tid < 5) {
+      const double *rd = lw + LB_RED0 + tid;
+      out[SUM_VIS + SCHUR_LEN + tid] = tid < 4 ? ((rd[0] + rd[8]) + (rd[16] + rd[24])) : fmax(fmax(rd[0], rd[8]), fmax(rd[16], rd[24]));
+    }
+    __syncthreads();  // (the accumulators are read: their LDS is free)
+    BSTAMP(11);
+  }
+  if (!fl.do_schur) return;
+  // ---- the Schur SYRK over the group's landmarks (phase 2 of k_linw over [L0, L1): a block is a strip)
+  double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lw;
+  double *lcoef = lw + LM_BLOCK * (WLD + 1), *le = lcoef + LM_BLOCK;
+  const int kk = lane >> 4, cc = lane & 15;
+  double4_t acc[4];
+  int ct[4], cu[4];
+  bool scale_k[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    acc[j] = double4_t{0, 0, 0, 0};
+    const int ti = wv + 4 * j;
+    const int t = ti < 5 ? 0 : ti < 9 ? 1 : ti < 12 ? 2 : ti < 14 ? 3 : 4;
+    const int u = ti - (t * 5 - (t * (t - 1)) / 2) + t;
+    ct[j] = ti < NT ? 16 * t + cc : 0, cu[j] = ti < NT ? 16 * u + cc : 0;
+    scale_k[j] = cu[j] == COL_K;
+  }
+  const double2 *wt0 = lw_at<const double2>(S, A.Wt);
+  const size_t wld = (size_t)A.wt_ld;
+  const double *scale_l = lw_at<const double>(S, A.scale_l), *av = lw_at<const double>(S, A.a), *bv = lw_at<const double>(S, A.b);
+  double *einv_l = lw_at<double>(S, A.einv_l);
+  const int nblk = (L1 - L0 + LM_BLOCK - 1) / LM_BLOCK;
+  constexpr int WPT = (WT_PAIRS + 3) / 4;  // column pairs per thread
+  double2 wreg[WPT];
+  double w_sc = 0, w_a = 0, w_b = 0;
+  int pmax_next = 0;
+  auto request = [&](int blk) {
+    const int l = L0 + blk * LM_BLOCK + lane;
+    // the pairs the block's rows reach: frames s .. s + (longest track of the block) - 1, then extrinsic and td
+    const int last = min(L0 + blk * LM_BLOCK + LM_BLOCK, L1) - 1;
+    const int pmin = 3 * s, pmax = 3 * (s + rfl(S->lm_cnt[last]));
+    pmax_next = pmax;
+#pragma unroll
+    for (int k = 0; k < WPT; k++) {
+      const int cp = wv + 4 * k;
+      wreg[k] = (cp < WT_PAIRS && ((cp >= pmin && cp < pmax) || cp >= 33) && l < L1) ? wt0[(size_t)cp * wld + l] : make_double2(0.0, 0.0);
+    }
+    if (tid < LM_BLOCK && l < L1) w_sc = scale_l[l], w_a = av[l], w_b = bv[l];
+  };
+  for (int e = tid; e < LM_BLOCK * 6; e += LW_THREADS) tile[e / 6][75 + e % 6] = 0.0;  // pad columns 75 .. 80
+  if (nblk > 0) request(0);
+  for (int blk = 0; blk < nblk; blk++) {
+    __syncthreads();  // (the matrix pipe is done with the previous block's tile)
+    // Every row of the block is zero outside the columns of frames s .. s + (its longest track) - 1 and of extrinsic / td / b / kappa
+    // (64 .. 74: column block 4): a 16 x 16 tile of the SYRK whose column blocks are not among those is zero and is skipped.
+    const int cb_lo = (6 * s) >> 4, cb_hi = (2 * pmax_next - 1) >> 4;  // column blocks of the pose part, from the pairs just requested for this block
+    {
+      const int l = L0 + blk * LM_BLOCK + lane;
+#pragma unroll
+      for (int k = 0; k < WPT; k++) {
+        const int cp = wv + 4 * k;
+        if (cp < WT_PAIRS) {
+          tile[lane][2 * cp] = wreg[k].x;
+          if (2 * cp + 1 < KC) tile[lane][2 * cp + 1] = wreg[k].y;
+        }
+      }
+      if (tid < LM_BLOCK) {
+        double cf = 0.0, eb = 0.0, bl = 0.0, kap = 0.0;
+        if (l < L1) {
+          const double s2a = w_sc * w_sc * w_a;
+          const double D2 = fmin(fmax(s2a, 1e-6), 1e32);
+          eb = s2a + mu * D2;  // e-block + lm_diagonal^2
+          const double einv = 1.0 / eb;
+          cf = w_sc * w_sc * einv;
+          if (!fl.do_lin) einv_l[l] = einv;  // (a solve repeated with a larger mu: only the weights change)
+          bl = w_b, kap = bl / D2;
+        }
+        lcoef[tid] = cf, le[tid] = eb;
+        tile[tid][COL_B] = bl, tile[tid][COL_K] = kap;
+      }
+    }
+    if (blk + 1 < nblk) request(blk + 1);
+    __syncthreads();
+    auto block_live = [&](int cb) { return cb == 4 || (cb >= cb_lo && cb <= cb_hi); };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int ti = __builtin_amdgcn_readfirstlane(wv) + 4 * j;
+      if (ti >= NT) continue;
+      const int t = ti < 5 ? 0 : ti < 9 ? 1 : ti < 12 ? 2 : ti < 14 ? 3 : 4, u = ti - (t * 5 - (t * (t - 1)) / 2) + t;
+      if (!(block_live(t) && block_live(u))) continue;  // (wave-uniform)
+#pragma unroll
+      for (int s4 = 0; s4 < LM_BLOCK / 4; s4++) {
+        const int row = 4 * s4 + kk;
+        const double xa = tile[row][ct[j]];
+        double xb = tile[row][cu[j]];
+        if (scale_k[j]) xb *= le[row];  // b / D2 * e  -> z2 column
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(lcoef[row] * xa, xb, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  BSTAMP(12);
+  double *ss = out + SUM_VIS;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (wv + 4 * j >= NT) continue;
+#pragma unroll
+    for (int r = 0; r < 4; r++) ss[(wv + 4 * j) * 256 + r * 64 + lane] = acc[j][r];
+  }
+  BSTAMP(13);
+}
+__global__ __launch_bounds__(LW_THREADS, 2) void k_linb(char *base, size_t stride, const LinwArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lw[];
+  linb_body(SLOT(base, stride), lw, A);
+}
+
+// ---------------------------------------------------------------------------
+// k_sumb: grid (LINB_SUM_WGS + 1, batch) x 1024 — the groups' partials added up in a fixed order (sixteen waves per workgroup: lane e
+// of wave q adds entry e of the groups q, q + 16, ..., eight loads in flight; then the sixteen sums in wave order), into the places
+// k_linw leaves a window's sums: the packed camera part of H_pp, the Schur sums, then — the last workgroup — g_p (camera
+// gradient + IMU factors + prior, k_sum's order), the landmark scalars (totals in block 0 of lm_part, zeros behind).
+// ---------------------------------------------------------------------------
+constexpr int LINB_SUM_WGS = (SUM_VIS_PACKED + SCHUR_LEN + 63) / 64, LINB_SUM_THREADS = 1024, LINB_SUM_Q = LINB_SUM_THREADS / 64;
+__global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t stride, const LinwArgs A) {
+  Slot *S = SLOT(base, stride);
+  const TRFlags fl = tr_flags(&S->tr);
+  if (fl.done | (!fl.do_lin & !fl.do_schur)) return;
+  __shared__ double red[LINB_SUM_Q][64];
+  const int tid = threadIdx.x, q = tid >> 6, lane = tid & 63, ng = S->linw.ng;
+  const double *part = lw_at<const double>(S, A.part);
+  // entry idx of the partials over the groups q, q + 16, ...: eight loads in flight; a fixed order whatever the timing
+  auto some = [&](int idx, bool on, bool is_max) {
+    double acc = 0.0;
+    if (on) {
+      int g = q;
+      for (; g + 7 * LINB_SUM_Q < ng; g += 8 * LINB_SUM_Q) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = part[(size_t)(g + k * LINB_SUM_Q) * LINB_LEN + idx];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
+      }
+      for (; g < ng; g += LINB_SUM_Q) {
+        const double v0 = part[(size_t)g * LINB_LEN + idx];
+        acc = is_max ? fmax(acc, v0) : acc + v0;
+      }
+    }
+    return acc;
+  };
+  auto all = [&](bool is_max) {  // (lanes of wave 0, after the barrier)
+    double t = red[0][lane];
+#pragma unroll
+    for (int k = 1; k < LINB_SUM_Q; k++) t = is_max ? fmax(t, red[k][lane]) : t + red[k][lane];
+    return t;
+  };
+  if ((int)blockIdx.x < LINB_SUM_WGS) {
+    // entry e of [packed camera H_pp | Schur tiles]
+    const int e = blockIdx.x * 64 + lane;
+    const bool on = e < SUM_VIS_PACKED + SCHUR_LEN && (e < SUM_VIS_PACKED ? fl.do_lin : fl.do_schur);
+    const int idx = e < SUM_VIS_PACKED ? e : SUM_VIS + (e - SUM_VIS_PACKED);
+    red[q][lane] = some(on ? idx : 0, on, false);
+    __syncthreads();
+    if (q == 0 && on) {
+      const double v = all(false);
+      if (e < SUM_VIS_PACKED) lw_at<double>(S, A.Hpp)[e] = v;
+      else lw_at<double>(S, A.schur_sum)[e - SUM_VIS_PACKED] = v;
+    }
+    return;
+  }
+  if (!fl.do_lin) return;
+  // ---- the last workgroup: camera gradient (KC entries, lanes 0 .. 72 in two trips) and the five landmark scalars
+  __shared__ double gv[KC + 8];
+  for (int trip = 0; trip < 2; trip++) {
+    const int c = trip * 64 + lane;
+    const bool on = c < KC + 5;
+    const int idx = c < KC ? SUM_VIS_PACKED + c : SUM_VIS + SCHUR_LEN + (c - KC);
+    red[q][lane] = some(on ? idx : 0, on, c == KC + 4);
+    __syncthreads();
+    if (q == 0 && on) gv[c] = all(c == KC + 4);
+    __syncthreads();
+  }
+  const int est_ex = S->est_ex, est_td = S->est_td;
+  if (tid < KP) {
+    // g_p entry: visual part, the (at most two) IMU factors, the prior — k_sum's order
+    const int r = tid;
+    double val = r < KC ? gv[r] : 0.0;
+    const int f0 = col_frame(r);
+    const double *imu_out = lw_at<const double>(S, A.imu_out);
+    if (f0 >= 0) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int f = f0 - 1 + u;
+        if (f >= 0 && f < LFVIO_WINDOW_SIZE) {
+          const int pl = imu_local(r, f);
+          if (pl >= 0) val += imu_out[(size_t)f * IMU_OUT + 900 + pl];
+        }
+      }
+    }
+    val += S->prior_g[r];
+    const bool act_r = !((!est_ex && r >= off_ex() && r < off_ex() + 6) || (!est_td && r == off_td()));
+    lw_at<double>(S, A.gp)[r] = act_r ? val : 0.0;
+  }
+  if (tid < 5) S->lm_sum[tid] = gv[KC + tid];
 }

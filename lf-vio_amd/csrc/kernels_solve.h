@@ -962,6 +962,52 @@ __global__ __launch_bounds__(64) void k_backsub(char *base, size_t stride) {
 // k_dogleg<INLINE, WT>: grid (spec, batch) x 128 (INLINE: x DOGLEG_INLINE_THREADS) — ComputeTraditionalDoglegStep, candidate
 // pose-side state, per-pair table of the candidate.  The body (dogleg_body) is also the prologue of k_step.
 // ---------------------------------------------------------------------------
+// k_backsub_wt: the same from the TRANSPOSED rows (Slot::Wt, column pairs wt_ld apart) — what k_linb leaves of a large window
+// instead of the compact rows: a lane's row is at most WT_PAIRS coalesced 16-byte loads, taken over its own span only (frames
+// start .. start + count - 1, then extrinsic and td: nothing outside it is defined).  Same products in the same order.
+__global__ __launch_bounds__(64) void k_backsub_wt(char *base, size_t stride, int wt_ld) {
+  Slot *S = SLOT(base, stride);
+  const TRState *tr = &S->tr;
+  {
+    const TRFlags fl = tr_flags(tr);
+    if (fl.done | !fl.do_schur | fl.chol_fail) return;
+  }
+  __shared__ double ug[WLD], un[WLD];
+  const int lane = threadIdx.x;
+  for (int c = lane; c < WLD; c += 64) ug[c] = S->uc_grad[c], un[c] = S->uc_gn[c];
+  __syncthreads();
+  const int l = blockIdx.x * LM_BLOCK + lane;
+  double gn2 = 0, ggn = 0;
+  if (l < S->N) {
+    const int lo = 3 * S->lm_start[l], hi = lo + 3 * S->lm_cnt[l];
+    const double s = S->scale_l[l], bl = S->b[l], einv = S->einv_l[l], dgl = S->diag_l[l], grl = S->grad_l[l];
+    const double2 *wt = (const double2 *)(const double *)S->Wt + l;
+    double2 wv[WT_PAIRS];
+#pragma unroll
+    for (int cp = 0; cp < WT_PAIRS; cp++) wv[cp] = ((cp >= lo && cp < hi) || cp >= 33) ? wt[(size_t)cp * wt_ld] : make_double2(0.0, 0.0);
+    double d1 = 0, d2 = 0;
+#pragma unroll
+    for (int c = 0; c < KC; c++) {
+      const double w = (c & 1) ? wv[c >> 1].y : wv[c >> 1].x;
+      d1 = fma(w, ug[c], d1), d2 = fma(w, un[c], d2);
+    }
+    // s_l w_l . (S_c y_c) = -s_l d2   (N_c = -S_c y_c)
+    const double y = (s * bl + s * d2) * einv;
+    const double gn = -dgl * y;
+    S->gn_l[l] = gn;
+    S->d1[l] = d1;
+    S->d2[l] = d2;
+    gn2 = gn * gn;
+    ggn = grl * gn;
+  }
+  gn2 = wave_sum(gn2);
+  ggn = wave_sum(ggn);
+  if (lane == 0) {
+    double *p = S->lm_part + (size_t)blockIdx.x * LMS;
+    p[8] = gn2, p[9] = ggn;
+  }
+}
+
 // INLINE (windows of at most DOGLEG_INLINE_BLOCKS landmark blocks): the landmark part of the Gauss-Newton step (k_backsub)
 // is formed here, one landmark per thread, and that launch is left out of the pass — at this size a kernel is a few
 // microseconds of launch and first-load latency whatever it does.

@@ -56,7 +56,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   int maxN = 0, maxM = 0;
   int capLmBlocks = 0, capChunks = 0, capSchurParts = 0;
   size_t in_begin = 0, in_end = 0, total = 0;
-  size_t anc[8], pmo[8], pm_pair, linw_begin = 0, linw_end = 0;  // k_linw's copies of the observations (behind the regular inputs: uploaded on their own, resident batches only)
+  size_t anc[8], pmo[8], pm_pair, linb_lm0, linb_ns, linw_begin = 0, linw_end = 0;  // k_linw's copies of the observations (behind the regular inputs: uploaded on their own, resident batches only)
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lm_woff, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
   size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, Wt, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
@@ -96,18 +96,19 @@ Layout make_layout(int maxN, int maxM) {
   for (int k = 0; k < 8; k++) L.anc[k] = take(N * 8);
   for (int k = 0; k < 8; k++) L.pmo[k] = take(M * 8);
   L.pm_pair = take(M);
+  L.linb_lm0 = take(((size_t)L.capLmBlocks + LFVIO_NUM_FRAMES + 1) * 4), L.linb_ns = take(((size_t)L.capLmBlocks + LFVIO_NUM_FRAMES + 1) * 4);  // (at most a group per strip)
   L.linw_end = o;
   L.lam[0] = take(LB * 8), L.lam[1] = take(LB * 8);
   for (int k = 0; k < SPEC_EXTRA; k++) L.lamE[k] = take((size_t)SPEC_MAX_LM * 8);
   L.cost_partE = take((size_t)SPEC_EXTRA * (SPEC_MAX_LM / 64) * LMS * 8);
   L.prior_A = take((size_t)LFVIO_MAX_PRIOR_DIM * LFVIO_MAX_PRIOR_DIM * 8);
   L.a = take(LB * 8), L.b = take(LB * 8), L.W = take(LB * WLD * 8);
-  L.Wt = take((size_t)WT_PAIRS * SPEC_MAX_LM * 16);
+  L.Wt = take((size_t)WT_PAIRS * std::max((size_t)SPEC_MAX_LM, LB) * 16);  // (a large window's rows are LB apart: k_linb)
   L.scale_l = take(LB * 8), L.grad_l = take(LB * 8), L.gn_l = take(LB * 8), L.diag_l = take(LB * 8);
   L.einv_l = take(LB * 8), L.d1 = take(LB * 8), L.d2 = take(LB * 8);
   L.gram_part = take((size_t)L.capChunks * NGP * 8);
   L.pairG = take((size_t)NPAIR * NGP * 8);
-  L.schur_part = take((size_t)L.capSchurParts * SCHUR_LEN * 8);
+  L.schur_part = take((size_t)L.capSchurParts * LINB_LEN * 8);  // (k_linb's partials live there too: LINB_LEN > SCHUR_LEN doubles per group, at most a group per strip)
   L.xch = take((size_t)XCH_LEN * 8);
   L.lm_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.cost_part = take((size_t)L.capLmBlocks * LMS * 8);
@@ -129,6 +130,8 @@ struct SlotHostInfo {
   double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
   std::vector<int> perm;  // device order -> caller order
   bool linw_ok = false;    // the window carries a LinwPlan and its arrays (kernels_linw.h)
+  bool linb_ok = false;    // ... as a group list: a large single window (k_linb)
+  int linb_ng = 0;
   bool uploaded = false;   // the slot's work-array pointers are on the device (until the next reserve())
   bool resident = false;   // a window is resident: N, perm, grid sizes below describe what the device holds.  Cleared while an upload
                            // rewrites them and set again when its copies are enqueued, so a refused upload leaves a slot that every
@@ -419,6 +422,11 @@ int check_input_prior(lfvio_ctx *c, const LfvioPrior *pr) {
 }
 
 constexpr size_t LIN_SPLIT_WGS = 2048;  // launches of k_lin with more workgroups than this are issued role by role ...
+constexpr int LINB_MAX_GROUPS = 500;     // ... in at most this many groups (two workgroups per CU: 512 at once, one of them the pose side's)
+// A single window from this many landmarks on is linearized group by group (k_linb, kernels_linw.h).  A group is a latency of ~60 us
+// however few there are; the role-by-role sweep grows with the window (measured, whole optimization(): 20 000 landmarks 1.28 ms role by
+// role / 1.40 by groups, 50 000: 1.57 / 1.55, 100 000: 1.95 / 1.70, 200 000: 3.22 / 2.44).
+constexpr int LINB_MIN_LM = 65536;
 constexpr int LIN_SPLIT_MIN_BATCH = 8;   // ... when they are a batch: ONE large window (100 000 landmarks: 64 us as one grid, 54 + 35 + 14 role by role) is better off with its roles overlapping
 
 // Pack one window into the pinned staging blob and upload it to slot `slot`.
@@ -567,7 +575,10 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   //      workgroup (all strips of a start frame on one wave: it is the one writer of that frame's pair blocks), and the
   //      observations once more in the orders its lanes read them — anchors by landmark, the others pair-major.
   bool linw = c->linw_mode != 0 && !sharded && N <= SPEC_MAX_LM && (c->batch >= LIN_SPLIT_MIN_BATCH || c->linw_mode == 2);
-  if (linw) {
+  // a large single window: the same strips as groups of four of one start frame, one workgroup each (k_linb)
+  bool linb = c->linw_mode != 0 && !sharded && !linw && N >= (c->linw_mode == 2 ? SPEC_MAX_LM + 1 : LINB_MIN_LM);
+  int linb_ng = 0;
+  if (linw || linb) {
     LinwPlan &P = S->linw;
     int begin_s[LFVIO_NUM_FRAMES + 1];
     {
@@ -583,19 +594,80 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     std::vector<Strip> by_start[LFVIO_NUM_FRAMES];
     int cost[LFVIO_NUM_FRAMES] = {0}, n_strips = 0;
     for (int s = 0; s < LFVIO_NUM_FRAMES; s++) {
-      for (int o2 = 0; o2 < 12; o2++) {
-        int f = begin_s[s];
-        while (f < begin_s[s + 1] && lm_cnt[f] <= o2) f++;
-        P.firstl[s][o2] = (short)f;
+      {
+        int f = begin_s[s];  // (ascending track length inside a start frame)
+        for (int o2 = 0; o2 < 12; o2++) {
+          while (f < begin_s[s + 1] && lm_cnt[f] <= o2) f++;
+          P.firstl[s][o2] = f;
+        }
       }
-      for (int l0 = begin_s[s]; l0 < begin_s[s + 1]; l0 += 64) {
+      for (int l0 = begin_s[s]; l0 < begin_s[s + 1] && !linb; l0 += 64) {
         const int n = std::min(64, begin_s[s + 1] - l0);
         by_start[s].push_back(Strip{l0, n, s, lm_cnt[l0 + n - 1]});  // (ascending track length inside a start frame: the last one is the longest)
         cost[s] += lm_cnt[l0 + n - 1] - 1;
         n_strips++;
       }
     }
-    if (n_strips > LINW_MAX_STRIPS) linw = false;
+    auto observation_copies = [&] {
+      for (int p = 0; p <= NPAIR; p++) P.pair_obs0[p] = pair_count[p];
+      double *anc[8], *pmo[8];
+      for (int k = 0; k < 8; k++) anc[k] = (double *)(h + L.anc[k]), pmo[k] = (double *)(h + L.pmo[k]);
+      for (int dl = 0; dl < N; dl++)
+        for (int k = 0; k < 8; k++) anc[k][dl] = obs[k][lm_obs0[dl]];
+      for (int q = 0; q < M - N; q++)
+        for (int k = 0; k < 8; k++) pmo[k][q] = obs[k][pm_obs[q]];
+      unsigned char *pm_pair = (unsigned char *)(h + L.pm_pair);
+      for (int p = 0; p < NPAIR; p++)
+        for (int q = pair_count[p]; q < pair_count[p + 1]; q++) pm_pair[q] = (unsigned char)p;
+    };
+    if (linb) {
+      // Groups of consecutive strips of one start frame, sized by a cost model of k_linb's phases (thousands of cycles, measured
+      // with two workgroups per CU: 18 fixed — zeroing, the sums out —, 6.5 per strip a wave takes, 9 per step of it, 11 per block
+      // of the Schur phase, 3 where waves share a strip): up to eight strips where the tracks are short, two or one where they
+      // are long (their steps are a serial chain; the waves of a workgroup with fewer strips than waves split them).  The budget
+      // is the smallest one that leaves at most LINB_MAX_GROUPS groups: all of them resident at once (two per CU), none of them
+      // much longer than the others.  The most expensive groups first.
+      struct Group {
+        int lm0, n, s, cost;
+      };
+      std::vector<Group> groups;
+      auto build = [&](int budget) {
+        groups.clear();
+        for (int s = 0; s < LFVIO_NUM_FRAMES; s++) {
+          const int b0 = begin_s[s], b1 = begin_s[s + 1], nst = (b1 - b0 + LM_BLOCK - 1) / LM_BLOCK;
+          auto steps_of = [&](int strip) { return lm_cnt[std::min(b0 + (std::min(strip, nst - 1) + 1) * LM_BLOCK, b1) - 1] - 1; };  // its longest track
+          auto cost_of = [&](int i, int nstr) {
+            const int split = nstr <= 1 ? 4 : nstr <= 2 ? 2 : 1;
+            const int wave = nstr <= 4 ? 13 + 18 * ((steps_of(i + nstr - 1) + split - 1) / split) : 26 + 18 * (steps_of(i + 3) + steps_of(i + nstr - 1));
+            return 36 + wave + 22 * nstr + (split > 1 ? 6 : 0);  // (half thousands)
+          };
+          for (int i = 0; i < nst;) {
+            int nstr = 1;
+            for (int cand : {8, 7, 6, 5, 4, 3, 2})
+              if (cand <= nst - i && cost_of(i, cand) <= budget) {
+                nstr = cand;
+                break;
+              }
+            const int l0 = b0 + i * LM_BLOCK, n = std::min(nstr * LM_BLOCK, b1 - l0);
+            groups.push_back(Group{l0, n, s, cost_of(i, nstr)});
+            i += nstr;
+          }
+        }
+      };
+      for (int budget = 100; budget <= 2000; budget += 10) {
+        build(budget);
+        if ((int)groups.size() <= LINB_MAX_GROUPS) break;
+      }
+      std::stable_sort(groups.begin(), groups.end(), [](const Group &a, const Group &b) { return a.cost > b.cost; });
+      int *g_lm0 = (int *)(h + L.linb_lm0), *g_ns = (int *)(h + L.linb_ns);
+      linb_ng = (int)groups.size();
+      if (linb_ng > L.capSchurParts) linb = false, linb_ng = 0;  // (the partials live in the Schur partials' space)
+      else {
+        for (int g2 = 0; g2 < linb_ng; g2++) g_lm0[g2] = groups[g2].lm0, g_ns[g2] = groups[g2].n | (groups[g2].s << 16);
+        P.big = 1, P.ng = linb_ng, P.wt_ld = L.capLmBlocks * LM_BLOCK;
+        observation_copies();
+      }
+    } else if (n_strips > LINW_MAX_STRIPS) linw = false;
     else {
       // longest-processing-time first over the start frames
       int order[LFVIO_NUM_FRAMES], load[LINW_WAVES] = {0};
@@ -618,18 +690,9 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
       }
       P.wave_first[LINW_WAVES] = t;
       P.n_strips = t;
-      for (int p = 0; p <= NPAIR; p++) P.pair_obs0[p] = pair_count[p];
-      double *anc[8], *pmo[8];
-      for (int k = 0; k < 8; k++) anc[k] = (double *)(h + L.anc[k]), pmo[k] = (double *)(h + L.pmo[k]);
-      for (int dl = 0; dl < N; dl++)
-        for (int k = 0; k < 8; k++) anc[k][dl] = obs[k][lm_obs0[dl]];
-      for (int q = 0; q < M - N; q++)
-        for (int k = 0; k < 8; k++) pmo[k][q] = obs[k][pm_obs[q]];
-      unsigned char *pm_pair = (unsigned char *)(h + L.pm_pair);
-      for (int p = 0; p < NPAIR; p++)
-        for (int q = pair_count[p]; q < pair_count[p + 1]; q++) pm_pair[q] = (unsigned char)p;
+      observation_copies();
     }
-    P.ok = linw ? 1 : 0;
+    P.ok = (linw || linb) ? 1 : 0;
   }
   int used_items = 0;
   bool lists_cached = false;
@@ -760,6 +823,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->pm_obs.set(S, L.pm_obs), S->pm_lm.set(S, L.pm_lm);
   for (int k = 0; k < 8; k++) S->anc[k].set(S, L.anc[k]), S->pmo[k].set(S, L.pmo[k]);
   S->pm_pair.set(S, L.pm_pair);
+  S->linb_lm0.set(S, L.linb_lm0), S->linb_ns.set(S, L.linb_ns);
   S->chunk_pair.set(S, L.chunk_pair), S->chunk_begin.set(S, L.chunk_begin), S->chunk_end.set(S, L.chunk_end);
   S->prior_J.set(S, L.prior_J), S->prior_r.set(S, L.prior_r);
   S->sum_off.set(S, L.sum_off), S->sum_end_marg.set(S, L.sum_end_marg), S->sum_items.set(S, L.sum_items);
@@ -773,12 +837,13 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   if (pr) copy_prior(&info.in_prior, pr);
   info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   info.linw_ok = linw;
+  info.linb_ok = linb, info.linb_ng = linb_ng;
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, (lists_cached ? L.sum_off : L.sum_items + (size_t)used_items * 4) - L.in_begin, hipMemcpyHostToDevice,
                            c->stream));
   if (pr) HIPCHK(c, hipMemcpyAsync(d + L.prior_J, h + L.prior_J, sizeof(double) * pr->n * pr->n, hipMemcpyHostToDevice, c->stream));
-  if (linw) HIPCHK(c, hipMemcpyAsync(d + L.linw_begin, h + L.linw_begin, L.linw_end - L.linw_begin, hipMemcpyHostToDevice, c->stream));
+  if (linw || linb) HIPCHK(c, hipMemcpyAsync(d + L.linw_begin, h + L.linw_begin, L.linw_end - L.linw_begin, hipMemcpyHostToDevice, c->stream));
   info.list_items = used_items;  // (only now: an upload refused half-way leaves the key without lists on the device)
   if (!info.uploaded) {
     // work-array pointers: fixed per slot until the next reserve()
@@ -909,6 +974,7 @@ LinwArgs linw_args(const lfvio_ctx *c) {
   a.a = (long long)L.a, a.b = (long long)L.b, a.scale_l = (long long)L.scale_l, a.diag_l = (long long)L.diag_l, a.grad_l = (long long)L.grad_l;
   a.einv_l = (long long)L.einv_l, a.imu_out = (long long)L.imu_out;
   a.Hpp = (long long)(L.xch + (size_t)XOFF_H * 8), a.gp = (long long)(L.xch + (size_t)XOFF_G * 8), a.schur_sum = (long long)(L.xch + (size_t)XOFF_S * 8);
+  a.part = (long long)L.schur_part, a.wt_ld = L.capLmBlocks * LM_BLOCK;
   a.asm_tab = c->d_lwt;
   return a;
 }
@@ -939,6 +1005,21 @@ bool use_linw(lfvio_ctx *c, int count, const Grid &g, int mode) {
   return true;
 }
 
+// A large single window that carries a group list is linearized group by group (k_linb + k_sumb) instead of role by role; the
+// marginalization's sweep of such a window stays with the roles (one launch per call).
+bool use_linb(lfvio_ctx *c, int count, const Grid &g, int mode) {
+  if (mode != MODE_SOLVE || c->linw_mode == 0 || c->shard_active) return false;
+  for (int s = 0; s < count; s++)
+    if (!c->info[s].linb_ok) return false;
+  return count > 0;
+}
+void launch_linb(lfvio_ctx *c, int count) {
+  int ng = 0;
+  for (int s = 0; s < count; s++) ng = std::max(ng, c->info[s].linb_ng);
+  hipLaunchKernelGGL(k_linb, dim3(ng + 1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
+  hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_WGS + 1, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, c->L.total, linw_args(c));
+}
+
 // The whole trust-region loop of a resident batch as ONE launch (k_window, kernels_stepw.h): every condition of the
 // window-resident sweep and of k_stepw, i.e. planned windows of at most 320 landmarks, one candidate per pass.
 bool use_window(lfvio_ctx *c, int count, const Grid &g, bool speculate) {
@@ -959,17 +1040,19 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   const bool solve = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & MODE_GATED);
   // (latency of few windows only: in a resident batch every workgroup of k_lin repeating the decision costs more of the
   // GPU than the launch it saves)
-  const bool lw = use_linw(c, count, g, mode);
+  const bool lw = use_linw(c, count, g, mode), lb = !lw && use_linb(c, count, g, mode);
   const bool merge = solve && !lw && g.lm <= DOGLEG_INLINE_BLOCKS && !c->no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
   if (lw) {
     // the window-resident sweep: one workgroup per window — pose-side factors, visual sweep, Schur; it counts the pass
     launch_linw(c, count, mode);
+  } else if (lb) {
+    launch_linb(c, count);
   } else {
     launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
     launch_sum(c, count, g, mode);
   }
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
-    launch_solve(c, count, lw);
+    launch_solve(c, count, lw || lb);
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
     const int spec = speculate && inl ? c->spec_count : 1;
@@ -983,7 +1066,8 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
       hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_LAUNCH_THREADS), 0, c->stream, c->d_base, st);
       return false;
     }
-    if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
+    if (!inl && lb) hipLaunchKernelGGL(k_backsub_wt, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st, c->L.capLmBlocks * LM_BLOCK);
+    else if (!inl) hipLaunchKernelGGL(k_backsub, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st);
     if (fuse) hipLaunchKernelGGL(k_step, dim3(spec * nb, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, g.lm, spec);
     else {
       if (inl && (!split || lw)) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(spec, count), dim3(DOGLEG_INLINE_THREADS), 0, c->stream, c->d_base, st, spec);
@@ -1065,7 +1149,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipMalloc((void **)&c->d_pending, 256));
       HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
     }
-    const int lwk = use_linw(c, count, g, MODE_SOLVE) ? 1 : 0;
+    const int lwk = use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 : 0;
     if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk) {
       destroy_graph(c);
       c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk;
@@ -1164,7 +1248,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
   }
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
   if (c->use_graph) {
-    const int lwg = use_linw(c, count, g, MODE_SOLVE) ? 1 : 0;
+    const int lwg = use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 : 0;
     if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes || c->g_linw != lwg) {
       if (c->graph) (void)hipGraphExecDestroy(c->graph), c->graph = nullptr;
       hipGraph_t graph;
@@ -1380,6 +1464,7 @@ lfvio_ctx *lfvio_create(int device) {
   (void)hipFuncSetAttribute((const void *)k_solve_dense<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   (void)hipFuncSetAttribute((const void *)k_solve_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   (void)hipFuncSetAttribute((const void *)k_linw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void *)k_linb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   (void)hipFuncSetAttribute((const void *)k_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   if (const char *e = getenv("LFVIO_WINDOW_KERNEL")) c->window_kernel = e[0] == '1';
   if (const char *e = getenv("LFVIO_LINW")) c->linw_mode = std::max(0, std::min(2, atoi(e)));
@@ -1398,7 +1483,7 @@ lfvio_ctx *lfvio_create(int device) {
       int at;
       if (e >= SUM_VIS_PACKED) at = LW_G + cc;
       else if (fr == fc && fr < 11) at = LW_D + 21 * fr + lw_tri(6, lc, lr);
-      else if (fr < 11) at = (LW_OFF0 + 36 * lw_pidx(fc, fr) + lc * 6 + lr) | LWT_ABS;
+      else if (fr < 11) at = (LW_OFF0 + 36 * lw_pidx(fc, fr) + lc * 6 + lr) | LWT_ABS | (fc << 20) | (fr << 24);  // (frames of the block: k_linb)
       else if (fc < 11) at = LW_FX + 42 * fc + lc * 7 + lr;
       else at = LW_XX + lw_tri(7, lc, lr);
       auto is_ex = [](int q) { return q >= 66 && q < 72; };
@@ -1843,6 +1928,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
   if ((rc = upload_window(c, 0, in))) return rc;
   const Grid g = grid_for(c, 1);
   const bool lw = use_linw(c, 1, g, MODE_SOLVE);  // (lfvio_debug_set_linw(ctx, 2): the window-resident sweep, for one window)
+  const bool lb = !lw && use_linb(c, 1, g, MODE_SOLVE);
   char *d = c->d_base;
   const size_t o_tr = offsetof(Slot, tr);
   auto poke_int = [&](size_t off, int v) { return hipMemcpy(d + o_tr + off, &v, sizeof v, hipMemcpyHostToDevice); };
@@ -1852,6 +1938,8 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
     HIPCHK(c, poke_int(offsetof(TRState, do_schur), 1));
     if (lw) {
       launch_linw(c, 1);
+    } else if (lb) {
+      launch_linb(c, 1);
     } else {
       launch_lin(c, 1, g, MODE_SOLVE);
       launch_sum(c, 1, g, MODE_SOLVE);
@@ -1868,7 +1956,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
   const double mu1 = mu;
   mu = 1e-8;
   if ((rc = run(1, first))) return rc;   // ordinary first pass (fixes the Jacobi scaling: k_solve does that, so run it)
-  launch_solve(c, 1, lw);
+  launch_solve(c, 1, lw || lb);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   mu = mu1;
   if ((rc = run(0, repeat))) return rc;  // Schur only, new mu
@@ -1913,13 +2001,23 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   const bool lw = use_linw(c, count, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
   // one full linearization so that every kernel has valid inputs
+  const bool lb = !lw && use_linb(c, count, g, MODE_SOLVE);
   if (lw) {
     launch_linw(c, count);
+  } else if (lb && which >= 15) {
+    launch_linb(c, count);
   } else {
     launch_lin(c, count, g, MODE_SOLVE);
     launch_sum(c, count, g, MODE_SOLVE);
   }
   if (which == 14) launch_solve(c, count, lw);
+  if (which >= 15 && !lb) {
+    c->err = "the resident window is not linearized by k_linb";
+    return LFVIO_ERR_ARG;
+  }
+  if (which == 17) launch_solve(c, count, true);
+  int ngmax = 0;
+  for (int s2 = 0; s2 < count; s2++) ngmax = std::max(ngmax, c->info[s2].linb_ng);
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
@@ -1944,6 +2042,11 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
         break;
       case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;
       case 14: hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_LAUNCH_THREADS), 0, c->stream, c->d_base, st); break;  // (not idempotent: a few reps only)
+      // a large single window, group by group: 15 the strip sweep (k_linb), 16 the sum of its partials (k_sumb), 17 the landmark
+      // back-substitution from the transposed rows (k_backsub_wt)
+      case 15: hipLaunchKernelGGL(k_linb, dim3(ngmax + 1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, linw_args(c)); break;
+      case 16: hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_WGS + 1, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, st, linw_args(c)); break;
+      case 17: hipLaunchKernelGGL(k_backsub_wt, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st, c->L.capLmBlocks * LM_BLOCK); break;
       default: launch_solve(c, count); break;
     }
   }
@@ -1970,15 +2073,17 @@ int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, dou
     if (!c->info[s].resident) return LFVIO_ERR_ARG;
   const Grid g = grid_for(c, count);
   const size_t st = c->L.total;
-  const bool lw = use_linw(c, count, g, MODE_SOLVE);
+  const bool lw = use_linw(c, count, g, MODE_SOLVE), lb = !lw && use_linb(c, count, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
   if (lw) {
     launch_linw(c, count);
+  } else if (lb) {
+    launch_linb(c, count);
   } else {
     launch_lin(c, count, g, MODE_SOLVE);
     launch_sum(c, count, g, MODE_SOLVE);
   }
-  launch_solve(c, count, lw);
+  launch_solve(c, count, lw || lb);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const char *d = c->d_base + (size_t)slot * st;
   const int N = c->info[slot].N;
@@ -1991,7 +2096,7 @@ int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, dou
   HIPCHK(c, get(gn_p, offsetof(Slot, gn_p), KP));
   HIPCHK(c, get(q, offsetof(Slot, tr) + offsetof(TRState, q), Q_COUNT));
   HIPCHK(c, get(x_cost, offsetof(Slot, tr) + offsetof(TRState, x_cost), 1));
-  return lw ? 1 : 0;
+  return lw ? 1 : lb ? 2 : 0;
 }
 
 int lfvio_debug_upload_times(lfvio_ctx *c, double *out4) {
