@@ -369,16 +369,23 @@ def main():
     reps = 200 if n_lm <= 1000 else 20
     tk = grp if sharded else eng  # (the sharded window lives in the group's context)
     # (a resident batch is linearized window by window — k_linw, which also holds what k_sum did; everything else by k_lin)
+    # (... and a large single window group by group — k_linb, the same strip sweep)
+    linb = False
     try:
         lin_ms, linw = tk.time_kernel(12, batch, reps), True
     except Exception:  # noqa: BLE001  (not a batch the library linearizes with k_linw)
-        lin_ms, linw = tk.time_kernel(0, batch, reps), False
+        try:
+            lin_ms, linw, linb = tk.time_kernel(15, batch, reps), False, True
+        except Exception:  # noqa: BLE001  (nor a window it linearizes with k_linb)
+            lin_ms, linw = tk.time_kernel(0, batch, reps), False
     bytes_per_launch = sum(algorithmic_bytes(w.N, w.M) for w in wins[:batch]) if not sharded else algorithmic_bytes(local_N, local_M)
     achieved = bytes_per_launch / (lin_ms * 1e-3) / 1e9
-    rows = ["k_linw"] if linw else (["k_lin<1>", "k_lin<2>", "k_lin<8>"] if batch >= 64 else ["k_lin<7>"])
+    rows = ["k_linw"] if linw else ["k_linb"] if linb else (["k_lin<1>", "k_lin<2>", "k_lin<8>"] if batch >= 64 else ["k_lin<7>"])
     traffic, traffic_src = pmc_traffic(workload if not stream_mode else "window300", rows)
     kernel_name = ("k_linw (window-resident sweep: IMU + prior factors, every observation once — residual, Jacobian basis, Gram SYRK —, "
                    "LDS accumulators of H_pp, Schur SYRK; one workgroup per window)") if linw else \
+        ("k_linb (the strip sweep of k_linw over one large window: a workgroup per group of strips of one start frame — every observation once, "
+         "Gram SYRK into LDS accumulators, Schur SYRK over the group —, partial sums added by k_sumb)") if linb else \
         "k_lin (visual residual/Jacobian sweep: landmark rows + Schur SYRK, Gram chunks, IMU, prior)"
     roofline = dict(bound="hbm", kernel=kernel_name,
                     achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic,
@@ -386,12 +393,14 @@ def main():
                     algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_us=lin_ms * 1e3,
                     note=("latency-bound at N=300 (0.1 MB per sweep); see DESIGN.md for the FP64-VALU roofline and the 100k-landmark sweep" if n_lm <= 1000 else
                           "FP64-issue-bound, not HBM-bound (26 FLOP/B against a ridge of 9.8): VALU issue share and counter traffic in profiles/, DESIGN.md section 5"))
-    if linw:
+    if linw or linb:
         flops = sum(2.0e3 * (w.M - w.N) + 1.6e3 * w.N for w in wins[:batch])  # ~2.0 k per residual block + 1.6 k per landmark
         roofline.update(note="FP64-bound (SURVEY section 8(d): 26 FLOP/B against a ridge of 9.8): see fp64_*; the HBM figures are kept because the metric's "
                              "contract prices this kernel in bytes", fp64_tflops=flops / (lin_ms * 1e-3) / 1e12,
                         fp64_frac=flops / (lin_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, flops_per_launch=flops)
-        extra = dict(k_solve_us=tk.time_kernel(13, batch, max(reps // 4, 5)) * 1e3)
+        extra = dict(k_solve_us=tk.time_kernel(13 if linw else 3, batch, max(reps // 4, 5)) * 1e3)
+        if linb:
+            extra.update(k_sumb_us=tk.time_kernel(16, batch, reps) * 1e3, k_backsub_wt_us=tk.time_kernel(17, batch, reps) * 1e3)
     else:
         extra = dict(k_sum_us=tk.time_kernel(2, batch, reps) * 1e3, k_solve_us=tk.time_kernel(3, batch, max(reps // 4, 5)) * 1e3)
     # the dense solve (k_solve: one workgroup = one CU per window) is where a small window spends most of its time; its

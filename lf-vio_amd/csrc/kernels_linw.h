@@ -1013,12 +1013,13 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linb(char *base, size_t strid
 }
 
 // ---------------------------------------------------------------------------
-// k_sumb: grid (LINB_SUM_WGS + 1, batch) x 1024 — the groups' partials added up in a fixed order (sixteen waves per workgroup: lane e
+// k_sumb: grid (LINB_SUM_GRID, batch) x 1024 — the groups' partials added up in a fixed order (sixteen waves per workgroup: lane e
 // of wave q adds entry e of the groups q, q + 16, ..., eight loads in flight; then the sixteen sums in wave order), into the places
-// k_linw leaves a window's sums: the packed camera part of H_pp, the Schur sums, then — the last workgroup — g_p (camera
-// gradient + IMU factors + prior, k_sum's order), the landmark scalars (totals in block 0 of lm_part, zeros behind).
+// k_sum leaves a window's sums: the COMPLETE packed H_pp (camera part + IMU factors + prior; the rows below the camera part by
+// workgroups of their own), the Schur sums, g_p (camera gradient + IMU factors + prior, k_sum's order), the landmark scalars.
 // ---------------------------------------------------------------------------
 constexpr int LINB_SUM_WGS = (SUM_VIS_PACKED + SCHUR_LEN + 63) / 64, LINB_SUM_THREADS = 1024, LINB_SUM_Q = LINB_SUM_THREADS / 64;
+constexpr int LINB_SUM_GRID = LINB_SUM_WGS + 1 + (PACKED - SUM_VIS_PACKED + LINB_SUM_THREADS - 1) / LINB_SUM_THREADS;  // sums | gradient + scalars | the speed / bias rows of H_pp
 __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t stride, const LinwArgs A) {
   Slot *S = SLOT(base, stride);
   const TRFlags fl = tr_flags(&S->tr);
@@ -1051,6 +1052,34 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
     for (int k = 1; k < LINB_SUM_Q; k++) t = is_max ? fmax(t, red[k][lane]) : t + red[k][lane];
     return t;
   };
+  // what the IMU factors and the prior add to packed entry e of H_pp (k_sum's terms in its order; zero in an inactive column): the
+  // matrix leaves COMPLETE, for the plain dense solve — assembling it on load costs a single large window 10 us per pass
+  const double *imu_out = lw_at<const double>(S, A.imu_out);
+  auto pose_terms = [&](int e) {
+    int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= e) r++;
+    while (r * (r + 1) / 2 > e) r--;
+    const int c = e - r * (r + 1) / 2;
+    const bool ex_off = !S->est_ex, td_off = !S->est_td;
+    if ((ex_off && ((r >= off_ex() && r < off_ex() + 6) || (c >= off_ex() && c < off_ex() + 6))) || (td_off && (r == off_td() || c == off_td()))) return 0.0;
+    double val = 0.0;
+    const int f0 = col_frame(r);
+    if (f0 >= 0) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int f = f0 - 1 + u;
+        if (f >= 0 && f < LFVIO_WINDOW_SIZE) {
+          const int pl = imu_local(r, f), ql = imu_local(c, f);
+          if (pl >= 0 && ql >= 0) val += imu_out[(size_t)f * IMU_OUT + pl * 30 + ql];
+        }
+      }
+    }
+    if (S->prior_valid) {
+      const int pr = S->prior_inv[r], pc = S->prior_inv[c];
+      if (pr >= 0 && pc >= 0) val += S->prior_A[pr * S->prior_n + pc];
+    }
+    return val;
+  };
   if ((int)blockIdx.x < LINB_SUM_WGS) {
     // entry e of [packed camera H_pp | Schur tiles]
     const int e = blockIdx.x * 64 + lane;
@@ -1060,12 +1089,18 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
     __syncthreads();
     if (q == 0 && on) {
       const double v = all(false);
-      if (e < SUM_VIS_PACKED) lw_at<double>(S, A.Hpp)[e] = v;
+      if (e < SUM_VIS_PACKED) lw_at<double>(S, A.Hpp)[e] = v + pose_terms(e);  // (the camera part is masked where it is formed)
       else lw_at<double>(S, A.schur_sum)[e - SUM_VIS_PACKED] = v;
     }
     return;
   }
   if (!fl.do_lin) return;
+  if ((int)blockIdx.x > LINB_SUM_WGS) {
+    // the rows of H_pp below the camera part (speed / bias): IMU factors and prior only
+    const int e = SUM_VIS_PACKED + ((int)blockIdx.x - LINB_SUM_WGS - 1) * LINB_SUM_THREADS + tid;
+    if (e < PACKED) lw_at<double>(S, A.Hpp)[e] = pose_terms(e);
+    return;
+  }
   // ---- the last workgroup: camera gradient (KC entries, lanes 0 .. 72 in two trips) and the five landmark scalars
   __shared__ double gv[KC + 8];
   for (int trip = 0; trip < 2; trip++) {
@@ -1083,7 +1118,6 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
     const int r = tid;
     double val = r < KC ? gv[r] : 0.0;
     const int f0 = col_frame(r);
-    const double *imu_out = lw_at<const double>(S, A.imu_out);
     if (f0 >= 0) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {

@@ -1017,7 +1017,7 @@ void launch_linb(lfvio_ctx *c, int count) {
   int ng = 0;
   for (int s = 0; s < count; s++) ng = std::max(ng, c->info[s].linb_ng);
   hipLaunchKernelGGL(k_linb, dim3(ng + 1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
-  hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_WGS + 1, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, c->L.total, linw_args(c));
+  hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_GRID, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, c->L.total, linw_args(c));
 }
 
 // The whole trust-region loop of a resident batch as ONE launch (k_window, kernels_stepw.h): every condition of the
@@ -1052,7 +1052,7 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     launch_sum(c, count, g, mode);
   }
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
-    launch_solve(c, count, lw || lb);
+    launch_solve(c, count, lw);  // (k_sumb leaves the complete matrix)
     // small windows: the landmark back-substitution rides inside k_dogleg (one launch less per pass)
     const bool inl = g.lm <= DOGLEG_INLINE_BLOCKS;
     const int spec = speculate && inl ? c->spec_count : 1;
@@ -1956,7 +1956,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
   const double mu1 = mu;
   mu = 1e-8;
   if ((rc = run(1, first))) return rc;   // ordinary first pass (fixes the Jacobi scaling: k_solve does that, so run it)
-  launch_solve(c, 1, lw || lb);
+  launch_solve(c, 1, lw);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   mu = mu1;
   if ((rc = run(0, repeat))) return rc;  // Schur only, new mu
@@ -2015,7 +2015,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     c->err = "the resident window is not linearized by k_linb";
     return LFVIO_ERR_ARG;
   }
-  if (which == 17) launch_solve(c, count, true);
+  if (which == 17) launch_solve(c, count, false);
   int ngmax = 0;
   for (int s2 = 0; s2 < count; s2++) ngmax = std::max(ngmax, c->info[s2].linb_ng);
   HIPCHK(c, hipEventRecord(e0, c->stream));
@@ -2045,7 +2045,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
       // a large single window, group by group: 15 the strip sweep (k_linb), 16 the sum of its partials (k_sumb), 17 the landmark
       // back-substitution from the transposed rows (k_backsub_wt)
       case 15: hipLaunchKernelGGL(k_linb, dim3(ngmax + 1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, linw_args(c)); break;
-      case 16: hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_WGS + 1, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, st, linw_args(c)); break;
+      case 16: hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_GRID, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, st, linw_args(c)); break;
       case 17: hipLaunchKernelGGL(k_backsub_wt, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st, c->L.capLmBlocks * LM_BLOCK); break;
       default: launch_solve(c, count); break;
     }
@@ -2083,7 +2083,7 @@ int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, dou
     launch_lin(c, count, g, MODE_SOLVE);
     launch_sum(c, count, g, MODE_SOLVE);
   }
-  launch_solve(c, count, lw || lb);
+  launch_solve(c, count, lw);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const char *d = c->d_base + (size_t)slot * st;
   const int N = c->info[slot].N;
