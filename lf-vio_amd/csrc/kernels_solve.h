@@ -1090,6 +1090,7 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
   }
   double a = 0, b = 0;
   if (do_schur && !inline_backsub && !sharded)
+#pragma unroll 4
     for (int k = tid; k < nLmBlocks; k += nthr) {
       a += S->lm_part[(size_t)k * LMS + 8];
       b += S->lm_part[(size_t)k * LMS + 9];

@@ -45,8 +45,8 @@ DEV void decide_sums(const Slot *S, const TRHead &t, int K, int sharded, int nLm
     const double *pcz = z == 0 ? pc0 : (const double *)S->pose_costE[z > 0 ? z - 1 : 0];
     const int nbz = z == 0 ? nLmBlocks : min(nLmBlocks, SPEC_MAX_LM / 64);
     c[z] = l[z] = q[z] = d[z] = x[z] = 0.0;
-#pragma unroll 4
-    for (int k = lane; k < nbz; k += 64) {  // (unrolled: the partials of four blocks are requested together)
+#pragma unroll 8
+    for (int k = lane; k < nbz; k += 64) {  // (unrolled: the partials of eight blocks are requested together)
       const double *p = cp + (size_t)k * LMS;
       c[z] += p[0], l[z] += p[1], q[z] += p[2], d[z] += p[3], x[z] += p[4];
     }
