@@ -1013,10 +1013,15 @@ bool use_linb(lfvio_ctx *c, int count, const Grid &g, int mode) {
     if (!c->info[s].linb_ok) return false;
   return count > 0;
 }
-void launch_linb(lfvio_ctx *c, int count) {
+// (grid of k_linb: the groups of the largest resident window and the pose side's workgroup, rounded up so that a captured graph
+// serves the next window of about that size too — a workgroup past a slot's own count returns at once; part of the graphs' key)
+int linb_grid(const lfvio_ctx *c, int count) {
   int ng = 0;
   for (int s = 0; s < count; s++) ng = std::max(ng, c->info[s].linb_ng);
-  hipLaunchKernelGGL(k_linb, dim3(ng + 1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
+  return (ng + 1 + 63) / 64 * 64;
+}
+void launch_linb(lfvio_ctx *c, int count) {
+  hipLaunchKernelGGL(k_linb, dim3(linb_grid(c, count), count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
   hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_GRID, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, c->L.total, linw_args(c));
 }
 
@@ -1149,7 +1154,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipMalloc((void **)&c->d_pending, 256));
       HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
     }
-    const int lwk = use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 : 0;
+    const int lwk = use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0;
     if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk) {
       destroy_graph(c);
       c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk;
@@ -1248,7 +1253,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
   }
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
   if (c->use_graph) {
-    const int lwg = use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 : 0;
+    const int lwg = use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0;
     if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes || c->g_linw != lwg) {
       if (c->graph) (void)hipGraphExecDestroy(c->graph), c->graph = nullptr;
       hipGraph_t graph;
@@ -2016,8 +2021,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     return LFVIO_ERR_ARG;
   }
   if (which == 17) launch_solve(c, count, false);
-  int ngmax = 0;
-  for (int s2 = 0; s2 < count; s2++) ngmax = std::max(ngmax, c->info[s2].linb_ng);
+
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
@@ -2044,7 +2048,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
       case 14: hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_LAUNCH_THREADS), 0, c->stream, c->d_base, st); break;  // (not idempotent: a few reps only)
       // a large single window, group by group: 15 the strip sweep (k_linb), 16 the sum of its partials (k_sumb), 17 the landmark
       // back-substitution from the transposed rows (k_backsub_wt)
-      case 15: hipLaunchKernelGGL(k_linb, dim3(ngmax + 1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, linw_args(c)); break;
+      case 15: hipLaunchKernelGGL(k_linb, dim3(linb_grid(c, count), count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, linw_args(c)); break;
       case 16: hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_GRID, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, st, linw_args(c)); break;
       case 17: hipLaunchKernelGGL(k_backsub_wt, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st, c->L.capLmBlocks * LM_BLOCK); break;
       default: launch_solve(c, count); break;

@@ -9,7 +9,7 @@ from lfvio.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 w = synth.make_window(0, n)
 eng = Engine(0)
-for mode in (0, 1):
+for mode in (0, 2):
     eng.set_linw(mode)
     eng.batch_reserve(1, w.N, w.M)
     eng.batch_upload(0, w)
