@@ -424,9 +424,9 @@ int check_input_prior(lfvio_ctx *c, const LfvioPrior *pr) {
 constexpr size_t LIN_SPLIT_WGS = 2048;  // launches of k_lin with more workgroups than this are issued role by role ...
 constexpr int LINB_MAX_GROUPS = 500;     // ... in at most this many groups (two workgroups per CU: 512 at once, one of them the pose side's)
 // A single window from this many landmarks on is linearized group by group (k_linb, kernels_linw.h).  A group is a latency of ~60 us
-// however few there are; the role-by-role sweep grows with the window (measured, whole optimization(): 20 000 landmarks 1.28 ms role by
-// role / 1.40 by groups, 50 000: 1.57 / 1.55, 100 000: 1.95 / 1.70, 200 000: 3.22 / 2.44).
-constexpr int LINB_MIN_LM = 65536;
+// however few there are; the role-by-role sweep grows with the window (measured, whole optimization(), profiles/r04/linb_times.txt:
+// 20 000 landmarks 1.29 ms role by role / 1.34 by groups, 50 000: 1.58 / 1.48, 100 000: 1.94 / 1.63, 200 000: 3.17 / 2.39).
+constexpr int LINB_MIN_LM = 40960;
 constexpr int LIN_SPLIT_MIN_BATCH = 8;   // ... when they are a batch: ONE large window (100 000 landmarks: 64 us as one grid, 54 + 35 + 14 role by role) is better off with its roles overlapping
 
 // Pack one window into the pinned staging blob and upload it to slot `slot`.

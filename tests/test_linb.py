@@ -6,7 +6,7 @@ Tolerances as in test_linw.py: the two device paths run the same per-observation
   * linearization outputs (g_p, Schur sums, a, b, landmark scalars, cost)      1e-10 relative to the array's largest entry
   * the dense solve behind them                                               1e-6
   * whole calls: identical iteration counts and terminations, states 1e-6, the oracle's bars of test_gpu_parity.
-Default mode takes the path from 65 536 landmarks on (where it is faster); lfvio_debug_set_linw(2) from 321 on (how the small cases here reach it).
+Default mode takes the path from 40 960 landmarks on (where it is faster); lfvio_debug_set_linw(2) from 321 on (how the small cases here reach it).
 """
 import numpy as np
 import pytest
@@ -95,7 +95,7 @@ def test_whole_calls_against_the_old_path_and_the_oracle(eng, oracle, wins, sync
         eng.set_linw(1)
 
 
-def test_the_literal_calls_take_the_path_by_default_from_65536_landmarks_on(eng, oracle):
+def test_the_literal_calls_take_the_path_by_default_from_40960_landmarks_on(eng, oracle):
     w = synth.make_window(7, 4200)
     eng.batch_reserve(1, w.N, w.M)
     eng.batch_upload(0, w)
