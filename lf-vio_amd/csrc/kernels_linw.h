@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
         }
       }
     }
-    if (S->prior_valid) {
+    if (S->prior_valid && (!S->sharded || S->pose_side)) {  // (a landmark-sharded window: the pose side on ONE rank)
       const int pr = S->prior_inv[r], pc = S->prior_inv[c];
       if (pr >= 0 && pc >= 0) val += S->prior_A[pr * S->prior_n + pc];
     }
@@ -1133,4 +1133,21 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
     lw_at<double>(S, A.gp)[r] = act_r ? val : 0.0;
   }
   if (tid < 5) S->lm_sum[tid] = gv[KC + tid];
+  if (S->sharded) {
+    // exchange scalars of phase A (k_sum's): local cost (pose-side factors on the owning rank only), gradient norms, Cauchy
+    // landmark term, ||lambda||^2; the max is sent as a sum (upper bound, only feeds the 1e-10 gradient tolerance)
+    __syncthreads();
+    double *sc = S->xch + XOFF_C;
+    if (tid < 16) sc[tid] = 0.0;
+    __syncthreads();
+    if (tid == 0) {
+      double cost = gv[KC];
+      if (S->pose_side) {
+        cost += S->prior_g[KP];
+        for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += imu_out[(size_t)f * IMU_OUT + 930];
+      }
+      sc[XS_COST] = cost;
+      sc[XS_G2] = gv[KC + 1], sc[XS_ASV2] = gv[KC + 2], sc[XS_LAM2] = gv[KC + 3], sc[XS_BMAX] = gv[KC + 4];
+    }
+  }
 }

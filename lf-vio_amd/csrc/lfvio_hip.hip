@@ -576,7 +576,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   //      observations once more in the orders its lanes read them — anchors by landmark, the others pair-major.
   bool linw = c->linw_mode != 0 && !sharded && N <= SPEC_MAX_LM && (c->batch >= LIN_SPLIT_MIN_BATCH || c->linw_mode == 2);
   // a large single window: the same strips as groups of four of one start frame, one workgroup each (k_linb)
-  bool linb = c->linw_mode != 0 && !sharded && !linw && N >= (c->linw_mode == 2 ? SPEC_MAX_LM + 1 : LINB_MIN_LM);
+  bool linb = c->linw_mode != 0 && !linw && N >= (c->linw_mode == 2 ? SPEC_MAX_LM + 1 : LINB_MIN_LM);  // (a rank's share of a sharded window too)
   int linb_ng = 0;
   if (linw || linb) {
     LinwPlan &P = S->linw;
@@ -2006,7 +2006,8 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   const bool lw = use_linw(c, count, g, MODE_SOLVE);
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
   // one full linearization so that every kernel has valid inputs
-  const bool lb = !lw && use_linb(c, count, g, MODE_SOLVE);
+  // (a rank of a sharded window sweeps its share group by group under the same condition: shard.inc)
+  const bool lb = !lw && (c->shard_active ? (c->linw_mode != 0 && count == 1 && c->info[0].linb_ok) : use_linb(c, count, g, MODE_SOLVE));
   if (lw) {
     launch_linw(c, count);
   } else if (lb && which >= 15) {

@@ -118,3 +118,30 @@ def test_mu_retry_redoes_only_the_schur_phase(eng, n, mu):
         assert eng.schur_repeat(synth.make_window(5, n), mu) == 0.0
     finally:
         eng.set_linw(1)
+
+
+@pytest.mark.parametrize("shards,n,force", [(1, 100000, False), (2, 100000, False), (3, 3000, True), (1, 700, True)])
+def test_ranks_of_a_sharded_window_sweep_their_share_group_by_group(oracle, shards, n, force):
+    """lfvio_group: a rank whose share of the window carries a group list (>= 40 960 landmarks of its own; LFVIO_LINW=2: > 320)
+    linearizes it with k_linb + k_sumb — the sums land in the exchange buffer like k_sum's — and back-substitutes from the
+    transposed rows.  Against the unsharded optimization() role by role."""
+    import os
+    from lfvio.engine import Engine, Group
+    from test_group import _compare
+
+    ref = Engine(0)
+    ref.set_linw(0)
+    warm = (lambda x, f: oracle.optimize(x, f)) if n <= 1000 else (lambda x, f: ref.optimize(x, f))
+    w = synth.make_window_with_prior(4, n, warm)[0]
+    want, want_prior = ref.optimize(w, abi.MARGIN_OLD)
+    ref.close()
+    if force:
+        os.environ["LFVIO_LINW"] = "2"
+    try:
+        g = Group(local_shards=shards)
+    finally:
+        os.environ.pop("LFVIO_LINW", None)
+    sol, prior = g.solve(w, abi.MARGIN_OLD)
+    _compare(sol, prior, want, want_prior)
+    assert sol.c.num_iterations == want.c.num_iterations
+    g.close()
