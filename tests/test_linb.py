@@ -145,3 +145,45 @@ def test_ranks_of_a_sharded_window_sweep_their_share_group_by_group(oracle, shar
     _compare(sol, prior, want, want_prior)
     assert sol.c.num_iterations == want.c.num_iterations
     g.close()
+
+
+def test_two_large_windows_resident_side_by_side(eng, wins):
+    """Slots with different group counts in one launch: the grid is sized for the larger one, a workgroup past a slot's own count
+    (and the pose side's, which sits behind the slot's last group) returns at once."""
+    a, b = wins[0], wins[2]  # 2 500 and 1 300 landmarks
+    try:
+        eng.set_linw(2)
+        single = []
+        for w in (a, b):
+            eng.batch_reserve(1, w.N, w.M)
+            eng.batch_upload(0, w)
+            eng.batch_optimize(1, abi.MARGIN_OLD)
+            single.append(eng.batch_download(0, w.N))
+        eng.batch_reserve(2, max(a.N, b.N), max(a.M, b.M))
+        eng.batch_upload(0, a)
+        eng.batch_upload(1, b)
+        assert eng.resident_pass(2, 1, b.N)["linw"] == 2
+        eng.batch_upload(0, a)
+        eng.batch_upload(1, b)
+        eng.batch_optimize(2, abi.MARGIN_OLD)
+        for s, w in enumerate((a, b)):
+            sol, prior = eng.batch_download(s, w.N)
+            ref, rprior = single[s]
+            assert sol.c.num_iterations == ref.c.num_iterations and np.array_equal(sol.pose, ref.pose) and np.array_equal(sol.lam, ref.lam), s
+            assert np.array_equal(prior.J(), rprior.J()), s
+    finally:
+        eng.set_linw(1)
+
+
+def test_marginalizing_the_second_newest_frame_behind_the_group_sweep(eng, oracle, wins):
+    w = wins[0]
+    try:
+        eng.set_linw(2)
+        eng.batch_reserve(1, w.N, w.M)
+        eng.batch_upload(0, w)
+        eng.batch_optimize(1, abi.MARGIN_SECOND_NEW)
+        sol, prior = eng.batch_download(0, w.N)
+    finally:
+        eng.set_linw(1)
+    rsol, rprior = oracle.optimize(w, abi.MARGIN_SECOND_NEW)
+    check_against(sol, prior, rsol, rprior, "MARGIN_SECOND_NEW")
