@@ -828,6 +828,35 @@ __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t strid
 // too) and the Schur phase takes from a block only the pairs its longest track reaches.
 // ---------------------------------------------------------------------------
 constexpr int LINB_LEN = SUM_VIS + SCHUR_LEN + 8;
+// k_linb_gather: grid (ceil(max(N, NV) / 256), batch) x 256, once per upload of a large window — the copies of the observations in
+// the orders the strips read them (anchors by landmark, the others pair-major with their frame pair), made on the device from the
+// arrays the upload carries anyway: 36 MB less over PCIe and no host loop over half a million observations at 100 000 landmarks.
+__global__ __launch_bounds__(256) void k_linb_gather(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  if (!S->linw.big) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < S->N) {
+    const int o = S->lm_obs0[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) S->anc[k][i] = S->obs[k][o];
+  }
+  if (i < S->NV) {
+    const int o = S->pm_obs[i];
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = S->obs[k][o];
+#pragma unroll
+    for (int k = 0; k < 8; k++) S->pmo[k][i] = v[k];
+    // the frame pair whose range [pair_obs0[p], pair_obs0[p + 1]) holds i
+    int lo = 0, hi = NPAIR;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (S->linw.pair_obs0[mid] <= i) lo = mid;
+      else hi = mid;
+    }
+    S->pm_pair[i] = (unsigned char)lo;
+  }
+}
 #ifdef LFVIO_LINW_PROFILE  // cycle stamps of group LFVIO_LINB_GROUP (default 0: the most expensive one), tools/linb_clocks.py
 #ifndef LFVIO_LINB_GROUP
 #define LFVIO_LINB_GROUP 0

@@ -665,7 +665,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
       else {
         for (int g2 = 0; g2 < linb_ng; g2++) g_lm0[g2] = groups[g2].lm0, g_ns[g2] = groups[g2].n | (groups[g2].s << 16);
         P.big = 1, P.ng = linb_ng, P.wt_ld = L.capLmBlocks * LM_BLOCK;
-        observation_copies();
+        for (int p = 0; p <= NPAIR; p++) P.pair_obs0[p] = pair_count[p];  // (the observations' copies are made on the device: k_linb_gather)
       }
     } else if (n_strips > LINW_MAX_STRIPS) linw = false;
     else {
@@ -843,7 +843,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, (lists_cached ? L.sum_off : L.sum_items + (size_t)used_items * 4) - L.in_begin, hipMemcpyHostToDevice,
                            c->stream));
   if (pr) HIPCHK(c, hipMemcpyAsync(d + L.prior_J, h + L.prior_J, sizeof(double) * pr->n * pr->n, hipMemcpyHostToDevice, c->stream));
-  if (linw || linb) HIPCHK(c, hipMemcpyAsync(d + L.linw_begin, h + L.linw_begin, L.linw_end - L.linw_begin, hipMemcpyHostToDevice, c->stream));
+  if (linw) HIPCHK(c, hipMemcpyAsync(d + L.linw_begin, h + L.linw_begin, L.pm_pair + (size_t)std::max(M - N, 0) - L.linw_begin, hipMemcpyHostToDevice, c->stream));
+  if (linb) HIPCHK(c, hipMemcpyAsync(d + L.linb_lm0, h + L.linb_lm0, L.linw_end - L.linb_lm0, hipMemcpyHostToDevice, c->stream));
   info.list_items = used_items;  // (only now: an upload refused half-way leaves the key without lists on the device)
   if (!info.uploaded) {
     // work-array pointers: fixed per slot until the next reserve()
@@ -875,6 +876,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     HIPCHK(c, hipStreamSynchronize(c->stream));  // W is on the stack
     info.uploaded = true;
   }
+  if (linb) hipLaunchKernelGGL(k_linb_gather, dim3((std::max(N, M - N) + 255) / 256, 1), dim3(256), 0, c->stream, d, L.total);  // (the slot's own blob as base)
   // The staging block is reused by the next upload: that one waits for these copies (an event), this one does not — what
   // follows an upload is an optimization on the same stream, and a round trip to the device saved here is ~30 us of the call.
   const auto t_up2 = lap(2, t_up1);
