@@ -20,7 +20,9 @@ int lfvio_debug_marg_system(lfvio_ctx *ctx, int n, double *A, double *b);
 /* shader-clock stamps written by the last k_solve of slot 0 (bring-up instrumentation) */
 int lfvio_debug_read_clocks(lfvio_ctx *ctx, long long *out32);
 /* Average ms of `reps` launches of one pipeline kernel over slots [0,count) (HIP events on the context stream).
- * which: 0 k_lin (residual/Jacobian sweep + Schur SYRK of the landmark blocks), 2 k_sum (+ k_presum), 3 k_solve. */
+ * which: 0 k_lin (residual/Jacobian sweep + Schur SYRK of the landmark blocks), 2 k_sum (+ k_presum), 3 k_solve_dense;
+ * 4 .. 7 k_setup by role, 8 .. 10 k_lin by role; a resident batch on the strip sweep: 12 k_linw, 13 k_solve_dense<true>, 14 k_stepw;
+ * a large window group by group: 15 k_linb, 16 k_sumb, 17 k_backsub_wt (an error where the launch does not take that path). */
 int lfvio_debug_time_kernel(lfvio_ctx *ctx, int which, int count, int reps, double *avg_ms);
 /* 0: launch kernels directly, 1: replay the captured hipGraph (default). */
 int lfvio_debug_set_graph(lfvio_ctx *ctx, int on);
@@ -42,9 +44,11 @@ int lfvio_debug_set_first_passes(lfvio_ctx *ctx, int n);
  * alone).  0 makes the loop run to its iteration cap or another criterion: the diagnostic of tests/tools/fuzz_parity.py, which
  * asks whether two solvers that disagree in the 6th digit of an inverse depth stopped early in a flat valley. */
 int lfvio_debug_set_function_tolerance(lfvio_ctx *ctx, double tol);
-/* How a resident batch is linearized: 1 (default) window-resident (k_linw: one workgroup per window, no partial sums through
- * HBM) when the launch is a batch and every window carries a plan; 0 never (k_lin role by role + k_sum); 2 for every launch of
- * planned windows, however few (tests).  Applies to windows uploaded afterwards.  Environment: LFVIO_LINW. */
+/* Where the strip sweep (kernels_linw.h) replaces the role-by-role one (k_lin + k_sum): 1 (default) for a resident batch whose
+ * windows all carry a plan (k_linw: one workgroup per window, no partial sums through HBM) and for a single window — or a rank's
+ * share of a sharded one — of at least 40 960 landmarks (k_linb + k_sumb: one workgroup per group of strips); 0 never; 2 for every
+ * launch, however few or small the windows (<= 320 landmarks: k_linw, more: k_linb; tests).  Applies to windows uploaded
+ * afterwards.  Environment: LFVIO_LINW. */
 int lfvio_debug_set_linw(lfvio_ctx *ctx, int mode);
 /* 1: the trust-region loop of a window-resident batch is ONE launch (k_window: every pass of a window by the workgroup that owns
  * it); 0 (default: faster at 512 windows): three launches per pass (k_linw, k_solve_dense<true>, k_stepw).  Same results.
@@ -52,7 +56,8 @@ int lfvio_debug_set_linw(lfvio_ctx *ctx, int mode);
 int lfvio_debug_set_window(lfvio_ctx *ctx, int on);
 /* One linearization + dense solve of the resident slots [0, count) by the path the launch takes; then, of slot `slot`: g_p[172],
  * the Schur sums (15 x 256, tile layout), lm_sum[5], a[N], b[N] (device landmark order), the pose-side Gauss-Newton step [172], the
- * dogleg model's quadratic forms [16], the cost.  Any output may be NULL.  Returns 1 if k_linw ran, 0 if k_lin + k_sum, < 0 on error. */
+ * dogleg model's quadratic forms [16], the cost.  Any output may be NULL.  Returns 1 if k_linw ran, 2 if k_linb + k_sumb, 0 if k_lin + k_sum,
+ * < 0 on error. */
 int lfvio_debug_resident_pass(lfvio_ctx *ctx, int count, int slot, double *gp, double *schur, double *lm_sum, double *a, double *b, double *gn_p, double *q,
                               double *x_cost);
 int lfvio_debug_last_chunks(lfvio_ctx *ctx);
