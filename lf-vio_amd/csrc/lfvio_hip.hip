@@ -37,6 +37,7 @@ constexpr ncclDataType_t ncclDouble = 8;
 #include "kernels_solve.h"
 #include "kernels_feat.h"
 #include "kernels_linw.h"
+#include "linb_plan.h"
 #include "kernels_stepw.h"
 
 #define HIPCHK(ctx, call)                                                                      \
@@ -621,44 +622,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
         for (int q = pair_count[p]; q < pair_count[p + 1]; q++) pm_pair[q] = (unsigned char)p;
     };
     if (linb) {
-      // Groups of consecutive strips of one start frame, sized by a cost model of k_linb's phases (thousands of cycles, measured
-      // with two workgroups per CU: 18 fixed — zeroing, the sums out —, 6.5 per strip a wave takes, 9 per step of it, 11 per block
-      // of the Schur phase, 3 where waves share a strip): up to eight strips where the tracks are short, two or one where they
-      // are long (their steps are a serial chain; the waves of a workgroup with fewer strips than waves split them).  The budget
-      // is the smallest one that leaves at most LINB_MAX_GROUPS groups: all of them resident at once (two per CU), none of them
-      // much longer than the others.  The most expensive groups first.
-      struct Group {
-        int lm0, n, s, cost;
-      };
-      std::vector<Group> groups;
-      auto build = [&](int budget) {
-        groups.clear();
-        for (int s = 0; s < LFVIO_NUM_FRAMES; s++) {
-          const int b0 = begin_s[s], b1 = begin_s[s + 1], nst = (b1 - b0 + LM_BLOCK - 1) / LM_BLOCK;
-          auto steps_of = [&](int strip) { return lm_cnt[std::min(b0 + (std::min(strip, nst - 1) + 1) * LM_BLOCK, b1) - 1] - 1; };  // its longest track
-          auto cost_of = [&](int i, int nstr) {
-            const int split = nstr <= 1 ? 4 : nstr <= 2 ? 2 : 1;
-            const int wave = nstr <= 4 ? 13 + 18 * ((steps_of(i + nstr - 1) + split - 1) / split) : 26 + 18 * (steps_of(i + 3) + steps_of(i + nstr - 1));
-            return 36 + wave + 22 * nstr + (split > 1 ? 6 : 0);  // (half thousands)
-          };
-          for (int i = 0; i < nst;) {
-            int nstr = 1;
-            for (int cand : {8, 7, 6, 5, 4, 3, 2})
-              if (cand <= nst - i && cost_of(i, cand) <= budget) {
-                nstr = cand;
-                break;
-              }
-            const int l0 = b0 + i * LM_BLOCK, n = std::min(nstr * LM_BLOCK, b1 - l0);
-            groups.push_back(Group{l0, n, s, cost_of(i, nstr)});
-            i += nstr;
-          }
-        }
-      };
-      for (int budget = 100; budget <= 2000; budget += 10) {
-        build(budget);
-        if ((int)groups.size() <= LINB_MAX_GROUPS) break;
-      }
-      std::stable_sort(groups.begin(), groups.end(), [](const Group &a, const Group &b) { return a.cost > b.cost; });
+      // the groups of k_linb: consecutive strips of one start frame sized by a cost model, the most expensive first (linb_plan.h)
+      const std::vector<LinbGroup> groups = linb_plan_groups(begin_s, LFVIO_NUM_FRAMES, lm_cnt, LM_BLOCK, LINB_MAX_GROUPS);
       int *g_lm0 = (int *)(h + L.linb_lm0), *g_ns = (int *)(h + L.linb_ns);
       linb_ng = (int)groups.size();
       if (linb_ng > L.capSchurParts) linb = false, linb_ng = 0;  // (the partials live in the Schur partials' space)
