@@ -370,14 +370,10 @@ def main():
     tk = grp if sharded else eng  # (the sharded window lives in the group's context)
     # (a resident batch is linearized window by window — k_linw, which also holds what k_sum did; everything else by k_lin)
     # (... and a large single window group by group — k_linb, the same strip sweep)
-    linb = False
-    try:
-        lin_ms, linw = tk.time_kernel(12, batch, reps), True
-    except Exception:  # noqa: BLE001  (not a batch the library linearizes with k_linw)
-        try:
-            lin_ms, linw, linb = tk.time_kernel(15, batch, reps), False, True
-        except Exception:  # noqa: BLE001  (nor a window it linearizes with k_linb)
-            lin_ms, linw = tk.time_kernel(0, batch, reps), False
+    # (the library says which one the launch takes; a failure of the timing call itself is a failure of the bench)
+    sweep = tk.sweep_kernel(batch)
+    linw, linb = sweep == 1, sweep == 2
+    lin_ms = tk.time_kernel({0: 0, 1: 12, 2: 15}[sweep], batch, reps)
     bytes_per_launch = sum(algorithmic_bytes(w.N, w.M) for w in wins[:batch]) if not sharded else algorithmic_bytes(local_N, local_M)
     achieved = bytes_per_launch / (lin_ms * 1e-3) / 1e9
     rows = ["k_linw"] if linw else ["k_linb"] if linb else (["k_lin<1>", "k_lin<2>", "k_lin<8>"] if batch >= 64 else ["k_lin<7>"])
@@ -690,10 +686,12 @@ def main():
                 e2.batch_optimize(nb, flag, sync=False)
             e2.batch_sync()
             eb = (time.perf_counter() - tb) / nsw
-            try:  # one linearization sweep of the 512 windows, seconds: k_linw (window-resident), else the four k_lin role launches
+            # one linearization sweep of the 512 windows, seconds: k_linw (window-resident) where the library says the launch takes
+            # it, else the four k_lin role launches
+            if e2.sweep_kernel(nb) == 1:
                 lin512, lin_name = e2.time_kernel(12, nb, 10) * 1e-3, "k_linw (one workgroup per window, 512 windows)"
                 sol512 = e2.time_kernel(13, nb, 5) * 1e-3
-            except Exception:  # noqa: BLE001
+            else:
                 lin512, lin_name = e2.time_kernel(0, nb, 10) * 1e-3, "k_lin (four role launches over 512 windows)"
                 sol512 = e2.time_kernel(3, nb, 5) * 1e-3
             flops_lin = sum(2.0e3 * (w_.M - w_.N) + 1.6e3 * w_.N for w_ in bw)  # ~2.0 k per residual block + 1.6 k per landmark

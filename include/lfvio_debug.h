@@ -24,6 +24,9 @@ int lfvio_debug_read_clocks(lfvio_ctx *ctx, long long *out32);
  * 4 .. 7 k_setup by role, 8 .. 10 k_lin by role; a resident batch on the strip sweep: 12 k_linw, 13 k_solve_dense<true>, 14 k_stepw;
  * a large window group by group: 15 k_linb, 16 k_sumb, 17 k_backsub_wt (an error where the launch does not take that path). */
 int lfvio_debug_time_kernel(lfvio_ctx *ctx, int which, int count, int reps, double *avg_ms);
+/* Which kernel linearizes a launch over the resident slots [0, count): 0 k_lin (+ k_sum), 1 k_linw (a resident batch), 2 k_linb
+ * (+ k_sumb: a large single window); < 0 on error.  bench.py asks before it times a sweep kernel. */
+int lfvio_debug_sweep_kernel(lfvio_ctx *ctx, int count);
 /* 0: launch kernels directly, 1: replay the captured hipGraph (default). */
 int lfvio_debug_set_graph(lfvio_ctx *ctx, int on);
 /* The launches a pass of few small windows saves by fusion.  on = 1 (default): the trust-region bookkeeping of a pass rides

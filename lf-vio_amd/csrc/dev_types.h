@@ -29,8 +29,6 @@ constexpr int NPAIR = 121; // pair slot = i * 11 + j
 constexpr int NT = 15;     // upper tiles of the 5x5 tiling of the 80x80 Schur accumulator
 constexpr int SCHUR_LEN = NT * 256;
 constexpr int PACKED = KP * (KP + 1) / 2;
-constexpr int JLOG_LD = 48;      // rotation slots per logged Jacobi step (>= ceil(n/2), n <= 96)
-constexpr int JLOG_STEPS = 1600;  // >= JMAX_SWEEPS * (n - 1)
 constexpr int JMAX_SWEEPS = 20;
 constexpr int PRE_CHUNK_LIMIT = 2 * 121;  // windows with more Gram chunks reduce them per frame pair first (k_presum)
 constexpr int SUM_ITEMS_CAP = PRE_CHUNK_LIMIT * 209 + 64;
@@ -262,13 +260,11 @@ struct Slot {
   double pose_cost[16];          // candidate costs of imu[0..9], prior [10]
   GP<double> Hpp;                   // packed lower KP (assembled by k_sum) = xch + XOFF_H
   GP<double> mscr;                  // dense scratch of the marginalization (HPP_CAP)
-  GP<double2> rotlog;               // [JLOG_STEPS][JLOG_LD] (cos, sin) of every Jacobi step of the n x n eigen-problem
   GP<double> eig_aux;               // eigenvalues[96] | sorted b'[96] | (int) diagonal-sort permutation[96]
   double scale_p[KP], diag_p[KP], grad_p[KP], gn_p[KP], step_p[KP];
   double uc_grad[WLD], uc_gn[WLD];  // camera-side Cauchy / Gauss-Newton directions (unscaled), zero-padded to WLD
   long long dbg[32];
-  double jtrace[32];             // off/diag mass per Jacobi sweep (instrumentation)             // shader-clock stamps (bring-up instrumentation)
-  int eig_steps, eig_pad;        // Jacobi steps logged in rotlog
+  double jtrace[32];             // second half of lfvio_debug_read_clocks' record (bring-up instrumentation)
   // marginalization outputs
   LfvioPrior prior_out;
 };

@@ -126,6 +126,7 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
   double(*Qf)[16] = (double(*)[16])(my + LW_STAGE);
   const LinwPlan *P = &S->linw;
   const bool marg = is_marg(mode);
+  const int marg_n0 = marg ? rfl(marg_plan(S, mode)->N0) : 0;  // landmarks the marginalization eliminates (0: MARGIN_SECOND_NEW)
   const int est_td = S->est_td, est_ex = marg ? 1 : S->est_ex;  // (ResidualBlockInfo::Evaluate asks for every Jacobian)
   const double td = lv.x->td, tr_over_row = S->tr_over_row, half_row = S->half_row, sqrt_info = S->sqrt_info;
   // (the address built from scalars: the tables of this linearization point are read-only here and wave-uniform)
@@ -187,7 +188,9 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
     (void)tp0;
     const int lm0 = __builtin_amdgcn_readlane(d_lm0, t), ds = __builtin_amdgcn_readlane(d_nsk, t);
     const int nlm = ds & 0xff, s = (ds >> 8) & 0xff, kmax = ds >> 16;
-    if (marg && s != 0) continue;  // the marginalization's sweep: the landmarks anchored at frame 0
+    // the marginalization's sweep: the landmarks anchored at frame 0 — and none at all where the plan has no visual part
+    // (MARGIN_SECOND_NEW drops a pose no landmark is anchored at: estimator.cpp:942-953 adds the prior factor only)
+    if (marg && (s != 0 || marg_n0 == 0)) continue;
     // per step o (lane o holds it): the first landmark of this start frame that has an observation o, and the pair-major index of its observation
     const int oc = lane < 12 && s + lane < LFVIO_NUM_FRAMES ? lane : 0;
     const int r_first = P->firstl[s][oc], r_idx0 = P->pair_obs0[s * 11 + s + oc];

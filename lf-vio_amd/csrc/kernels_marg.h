@@ -15,14 +15,12 @@
 #pragma once
 #include "kernels_solve.h"
 
-constexpr int MARG_THREADS = 768;   // 12 waves: one 2x2 block of the 38 x 39 / 2 = 741 lower blocks per thread
+constexpr int MARG_THREADS = 768;   // 12 waves: the gather, the Schur step and the back-transformation (eight lanes per eigenvector) use them all
 constexpr int MARG_MAXD = 96;  // 15 dropped + 76 kept, padded
-constexpr int LDN = 80;              // LDS row stride of the n x n (n <= 76) eigen-problem, see jacobi_systolic
-constexpr double JACOBI_TOL = 1e-19;  // off-diagonal mass / diagonal mass at which the n x n Jacobi stops, see jacobi_systolic
+constexpr int LDN = 80;              // LDS row stride of the n x n (n <= 76) eigen-problem
+constexpr double JACOBI_TOL = 1e-19;  // off-diagonal mass / diagonal mass at which the Jacobi of the dropped block stops (jacobi_small)
 constexpr size_t MARG_LDS = (size_t)19072 * sizeof(double);  // >= LPACK + KP + 64 and >= the eigen-phase carve below
 constexpr int BT_GROUP = 4;          // reflectors per step of the back-transformation (bt_apply)
-constexpr bool EIG_TRIDIAG = true;  // n x n eigen-problem: Householder tridiagonalization + multisection + twisted factorization
-                                    // (eig_tridiag below); false: the systolic Jacobi + k_marg_vecs
 
 // setDepth / getDepthVector round trip (feature_manager.cpp:148,191), landmarks [l0, l0 + 128)
 DEV void gauge_landmarks(Slot *S, int l0) {
@@ -260,230 +258,8 @@ DEV void jacobi_angle(double app, double aqq, double apq, double &c, double &s) 
   }
 }
 
-// The n x n eigen-problem of the prior (n = 76), eigenvalues only; the rotations are logged and the eigenvectors are
-// accumulated from the log by k_marg_vecs, whose rows are independent and therefore spread over many CUs.
-//
-// Brent-Luk arrangement: the matrix is kept in "position space".  Slot k always rotates positions (top k, bot k); after
-// every step the indices move one place round the tournament ring (top row towards slot 0, bottom row away from it,
-// bot 0 fixed), so the pairing of step g is (p_k, q_k) = rr_pair(k, g mod (np-1)).  Thread (ka >= kb) keeps the 2x2 block
-// [top ka, bot ka] x [top kb, bot kb] of the symmetric matrix in registers: the angle comes from the registers of the
-// diagonal threads, the rotation is applied in registers, and the ring move is one LDS round trip through addresses
-// that never change (4 stores to the blocks the elements move to, 4 loads of the own block).  Blocks above the diagonal
-// are not stored: an element that moves there is written to its mirror place.
-// B: np x np doubles, row stride ldb, memory index of position (bot, k) = bot * half + k.
-#if defined(JAC_TIMING)  // bring-up: cycles of thread 0 per segment of the Jacobi step, summed into trace[12 + segment]
-#define JT(k)                                                            \
-  do {                                                                   \
-    const long long t_ = __builtin_readcyclecounter();                   \
-    if (tid == 0 && (k) > 0) trace[12 + (k)] += (double)(t_ - jt_last);  \
-    jt_last = t_;                                                        \
-  } while (0)
-#else
-#define JT(k)
-#endif
-DEV int jacobi_systolic(const double *As, int lda, const int *perm, double *B, int ldb, int n, int tid, int nthreads,
-                        double2 *cs, double *scratch, double2 *rotlog, double *ev_out, double *trace) {
-  const int np = n + (n & 1), half = np / 2;
-  // position space at step 0: top k <- index k, bot k <- index np-1-k  (= rr_pair(k, 0))
-  for (int e = tid; e < np * np; e += nthreads) {
-    const int mi = e / np, mj = e % np;
-    const int i = mi < half ? mi : np - 1 - (mi - half), j = mj < half ? mj : np - 1 - (mj - half);
-    B[mi * ldb + mj] = (i < n && j < n) ? As[perm[i] * lda + perm[j]] : 0.0;
-  }
-  __syncthreads();
-  const int nblk = half * (half + 1) / 2;
-  const bool own = tid < nblk;
-  // the diagonal blocks go to the first lanes (one wave computes all rotation angles, the others skip that code),
-  // the strictly lower blocks follow in triangular order
-  int ka = 0, kb = 0;
-  if (tid < half) {
-    ka = kb = tid;
-  } else if (own) {
-    const int t = tid - half;
-    ka = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((ka + 1) * (ka + 2) / 2 <= t) ka++;
-    while (ka * (ka + 1) / 2 > t) ka--;
-    kb = t - ka * (ka + 1) / 2;
-    ka += 1;
-  }
-  const bool diag = own && ka == kb;
-  const int r00 = ka * ldb + kb, r01 = ka * ldb + half + kb, r10 = (half + ka) * ldb + kb, r11 = (half + ka) * ldb + half + kb;
-  // where the four elements go in the ring move
-  auto sigma = [&](int bot, int k, int &nb, int &nk) {
-    if (!bot) {
-      if (k >= 1) nb = 0, nk = k - 1;
-      else nb = 1, nk = 1;
-    } else {
-      if (k == 0) nb = 1, nk = 0;
-      else if (k <= half - 2) nb = 1, nk = k + 1;
-      else nb = 0, nk = half - 1;
-    }
-  };
-  auto dest = [&](int bx, int by) {
-    int dbx, dkx, dby, dky;
-    sigma(bx, ka, dbx, dkx);
-    sigma(by, kb, dby, dky);
-    bool flip = dkx < dky || (dkx == dky && dbx < dby);  // keep block row >= block column, (bot, top) inside a diagonal block
-    const int mr = flip ? dby * half + dky : dbx * half + dkx, mc = flip ? dbx * half + dkx : dby * half + dky;
-    return mr * ldb + mc;
-  };
-  const int w00 = dest(0, 0), w01 = diag ? -1 : dest(0, 1), w10 = dest(1, 0), w11 = dest(1, 1);
-  double b00 = 0, b01 = 0, b10 = 0, b11 = 0;
-  if (own) {
-    b00 = B[r00], b10 = B[r10], b11 = B[r11];
-    b01 = diag ? b10 : B[r01];
-  }
-  __syncthreads();
-  int sweeps = 0, g = 0;
-  double prev_off = 1e300;
-#if defined(JAC_TIMING)
-  long long jt_last = 0;
-  if (tid == 0)
-    for (int k = 12; k < 20; k++) trace[k] = 0.0;
-#endif
-  for (int sweep = 0; sweep < JMAX_SWEEPS; sweep++) {
-    double off = 0, dia = 0;
-    if (diag) dia = b00 * b00 + b11 * b11, off = 2.0 * b10 * b10;
-    else if (own) off = 2.0 * (b00 * b00 + b01 * b01 + b10 * b10 + b11 * b11);
-    off = wave_sum(off), dia = wave_sum(dia);
-    if ((tid & 63) == 0) scratch[tid >> 6] = off, scratch[16 + (tid >> 6)] = dia;
-    __syncthreads();
-    double so = 0, sd = 0;
-    for (int w = 0; w < nthreads / 64; w++) so += scratch[w], sd += scratch[16 + w];
-    __syncthreads();
-    if (trace && tid == 0 && sweep < 12) trace[sweep] = so / sd;
-    if (so <= JACOBI_TOL * sd || so == 0.0) break;
-    if (sweep >= 4 && so > 0.25 * prev_off) break;  // rounding floor reached
-    prev_off = so;
-    sweeps++;
-    for (int step = 0; step < np - 1; step++, g++) {
-      JT(0);
-      if (diag) {
-        double c = 1.0, s = 0.0;
-        if (ka > 0 || np == n) jacobi_angle(b00, b11, b10, c, s);  // slot 0 of an odd n holds the dummy index
-        const double2 r = make_double2(c, s);
-        cs[ka] = r;
-        rotlog[(size_t)g * JLOG_LD + ka] = r;
-      }
-      JT(1);
-      __syncthreads();
-      JT(2);
-      if (own) {
-        const double2 ra = cs[ka], rb = cs[kb];
-        // (explicit fma: the step is bound by the instructions a wave can issue)
-        const double t00 = fma(rb.x, b00, -(rb.y * b01)), t01 = fma(rb.y, b00, rb.x * b01);
-        const double t10 = fma(rb.x, b10, -(rb.y * b11)), t11 = fma(rb.y, b10, rb.x * b11);
-        B[w00] = fma(ra.x, t00, -(ra.y * t10));
-        if (w01 >= 0) B[w01] = fma(ra.x, t01, -(ra.y * t11));
-        B[w10] = fma(ra.y, t00, ra.x * t10);
-        B[w11] = fma(ra.y, t01, ra.x * t11);
-      }
-      JT(3);
-      __syncthreads();
-      JT(4);
-      if (own) {
-        b00 = B[r00], b10 = B[r10], b11 = B[r11];
-        b01 = diag ? b10 : B[r01];
-      }
-      JT(5);
-    }
-  }
-  if (diag) {
-    int p, q;
-    rr_pair(ka, g % (np - 1), np, n, p, q);
-    ev_out[p] = b00;
-    if (q >= 0) ev_out[q] = b11;
-  }
-  __syncthreads();
-  return sweeps;
-}
-
-// whole-wave shifts by one lane as DPP moves (wave_shl:1 / wave_shr:1): a few cycles instead of the LDS-crossbar round
-// trip of ds_bpermute, and the eigenvector recurrence below is one dependent chain per wave
-DEV double wave_from_next(double v) {  // lane i <- lane i+1
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-DEV double wave_from_prev(double v, double lane0) {  // lane i <- lane i-1; lane 0 (no source) keeps `lane0`
-  int lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), __double2loint(v), 0x138, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), __double2hiint(v), 0x138, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
-// Eigenvectors of the prior's eigen-problem from the rotation log, and with them the outputs of
-// marginalization_factor.cpp:283-291:  J0 = sqrt(S) V^T,  r0 = sqrt(1/S) V^T b'.
-// V = J_1 J_2 ... J_G applied to the rows of the identity: one wave per row, lane k = tournament slot k holding the row's
-// entries in columns (p_k, q_k); a step is one in-register rotation and the ring move by two lane shifts.  Row n carries
-// b' instead of a unit vector, which gives V^T b' without a reduction.
-// grid (MARG_VEC_WGS, batch) x 256
-constexpr int MARG_VEC_WGS = 20;  // 4 rows per workgroup, rows 0 .. n (n <= 79)
-__global__ __launch_bounds__(256) void k_marg_vecs(char *base, size_t stride, int flag) {
-  Slot *S = SLOT(base, stride);
-  const MargPlan *mp = &S->marg[flag];
-  if (!mp->valid) return;
-  const int n = mp->n, np = n + (n & 1), half = np / 2;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row > n) return;
-  const int k = threadIdx.x & 63;
-  const int kc = k < half ? k : half - 1;
-  const double *ev = S->eig_aux, *brp = S->eig_aux + 96;
-  const int *perm = (const int *)(S->eig_aux + 192);
-  const int G = S->eig_steps;
-  const double2 *log = S->rotlog + kc;
-  int p0, q0;
-  rr_pair(kc, 0, np, n, p0, q0);
-  double vp, vq;
-  if (row < n) vp = p0 == row ? 1.0 : 0.0, vq = q0 == row ? 1.0 : 0.0;
-  else vp = brp[p0], vq = q0 >= 0 ? brp[q0] : 0.0;
-  constexpr int UB = 16;
-  double2 cur[UB], nxt[UB];
-#pragma unroll
-  for (int u = 0; u < UB; u++) cur[u] = log[(size_t)min(u, JLOG_STEPS - 1) * JLOG_LD];
-  for (int g0 = 0; g0 < G; g0 += UB) {
-#pragma unroll
-    for (int u = 0; u < UB; u++) nxt[u] = log[(size_t)min(g0 + UB + u, JLOG_STEPS - 1) * JLOG_LD];
-#pragma unroll
-    for (int u = 0; u < UB; u++) {
-      if (g0 + u < G) {
-        const double c = cur[u].x, s = cur[u].y;
-        const double np_ = fma(c, vp, -(s * vq)), nq = fma(s, vp, c * vq);
-        // ring move: top row one slot towards slot 0, bottom row one slot away from it; top 0 -> bot 1,
-        // bot (half-1) -> top (half-1), bot 0 stays (lane 0 has no source lane in the shift and keeps its own)
-        const double up = wave_from_next(np_);
-        vq = wave_from_prev(k == 0 ? np_ : nq, nq);
-        vp = k == half - 1 ? nq : up;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UB; u++) cur[u] = nxt[u];
-  }
-  if (k >= half) return;
-  int p, q;
-  rr_pair(k, G % (np - 1), np, n, p, q);
-  LfvioPrior *out = &S->prior_out;
-  const double eps = 1e-8;
-  if (row < n) {
-    const int col = perm[row];
-    const double e0 = ev[p];
-    out->linearized_jacobians[p * n + col] = e0 > eps ? sqrt(e0) * vp : 0.0;
-    if (q >= 0) {
-      const double e1 = ev[q];
-      out->linearized_jacobians[q * n + col] = e1 > eps ? sqrt(e1) * vq : 0.0;
-    }
-  } else {
-    const double e0 = ev[p];
-    out->linearized_residuals[p] = e0 > eps ? sqrt(1.0 / e0) * vp : 0.0;
-    if (q >= 0) {
-      const double e1 = ev[q];
-      out->linearized_residuals[q] = e1 > eps ? sqrt(1.0 / e1) * vq : 0.0;
-    }
-  }
-}
-
 // Eigen-decomposition of a small symmetric matrix (n <= 16: the dropped pose-side block of the marginalization).
-// Same tournament as jacobi_systolic, one thread per matrix ELEMENT: thread (u, v) of the first np^2 threads forms
+// Round-robin tournament (rr_pair), one thread per matrix ELEMENT: thread (u, v) of the first np^2 threads forms
 // element (u, v) of J^T A J and of V J from the 2x2 blocks it sits in and stores it at its place after the ring move
 // (double-buffered position space: one LDS round trip and two barriers per step, a few dozen instructions per thread).
 // On return Am holds the eigenvalues on its diagonal and Vm the eigenvectors in its columns (row stride n).
@@ -1108,7 +884,6 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   double *Ag = S->mscr;  // global scratch: A', b' are kept there for parity checks
   // LDS re-use (16.7k doubles): A dies once A' is formed, so the second eigenvector matrix aliases it
   double *A = smem;                        // D x D           (<= 92*92 = 8464)
-  double *V2 = smem;                       // n x n (row stride LDN), aliases A after the Schur step
   double *bv = A + 92 * 92;                // D
   double *Am = bv + 96;                    // m15 x m15 (then its eigenvalues on the diagonal)
   double *Vm = Am + 256;                   // m15 x m15
@@ -1220,30 +995,9 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   // The matrix is strongly graded (eigenvalues 1e-6 .. 1e6): cyclic Jacobi converges markedly faster when the
   // diagonal is sorted in decreasing order first (de Rijk), which is a permutation similarity.
   STAMP(S, 13);
-  int sw2 = 0;
-  if (EIG_TRIDIAG) {
-    eig_tridiag(Ar, br, n, tid, RV, DMs, vec8, scr, (double *)cs, S->eig_aux, out, 1e-8, S->dbg);
-    if (tid == 0) S->eig_steps = 0;
-  } else {
-    if (tid < n) {
-      const double di = Ar[tid * LDN + tid];
-      int rank = 0;
-      for (int j = 0; j < n; j++) {
-        const double dj = Ar[j * LDN + j];
-        rank += (dj > di) || (dj == di && j < tid);
-      }
-      perm[rank] = tid;
-    }
-    __syncthreads();
-    double *ev = S->eig_aux, *brp = S->eig_aux + 96;
-    int *gperm = (int *)(S->eig_aux + 192);
-    if (tid < n) gperm[tid] = perm[tid], brp[tid] = br[perm[tid]];
-    sw2 = jacobi_systolic(Ar, LDN, perm, V2, LDN, n, tid, MARG_THREADS, cs, scr, S->rotlog, ev, S->jtrace);  // V2 aliases the dead A
-    if (tid == 0) S->eig_steps = sw2 * (n + (n & 1) - 1);
-  }
-  if (tid == 0) S->dbg[24] = sw1, S->dbg[25] = sw2;
+  eig_tridiag(Ar, br, n, tid, RV, DMs, vec8, scr, (double *)cs, S->eig_aux, out, 1e-8, S->dbg);
+  if (tid == 0) S->dbg[24] = sw1;
   STAMP(S, 14);
-  // J0 and r0 follow in k_marg_vecs
   // ---- getParameterBlocks + addr_shift
   const FrameState *x = &S->x[tr->cur];
   if (tid < mp->nb) {

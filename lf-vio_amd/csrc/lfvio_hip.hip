@@ -61,7 +61,7 @@ struct Layout {  // byte offsets inside one slot blob, by capacity
   size_t lm_start, lm_cnt, lm_obs0, lm_perm, lm_woff, lam0, obs[8], pm_obs, pm_lm, chunk_pair, chunk_begin, chunk_end, sum_off, sum_end_marg, sum_items, prior_J,
       prior_r;
   size_t lam[2], lamE[SPEC_EXTRA], cost_partE, prior_A, a, b, W, Wt, scale_l, grad_l, gn_l, diag_l, einv_l, d1, d2, gram_part, pairG, schur_part,
-      xch, lm_part, cost_part, imu_out, imu_raw, mscr, rotlog, eig_aux;
+      xch, lm_part, cost_part, imu_out, imu_raw, mscr, eig_aux;
 };
 
 Layout make_layout(int maxN, int maxM) {
@@ -116,7 +116,6 @@ Layout make_layout(int maxN, int maxM) {
   L.imu_out = take((size_t)LFVIO_WINDOW_SIZE * IMU_OUT * 8);
   L.imu_raw = take((size_t)LFVIO_WINDOW_SIZE * IMU_RAW * 8);
   L.mscr = take((size_t)HPP_CAP * 8);
-  L.rotlog = take((size_t)JLOG_STEPS * JLOG_LD * 16);
   L.eig_aux = take(4096);
   L.total = align_up(o, 4096);
   return L;
@@ -828,7 +827,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     W.schur_sum.set(&W, L.xch + (size_t)XOFF_S * 8), W.gp.set(&W, L.xch + (size_t)XOFF_G * 8), W.Hpp.set(&W, L.xch + (size_t)XOFF_H * 8);
     W.lm_part.set(&W, L.lm_part), W.cost_part.set(&W, L.cost_part), W.imu_out.set(&W, L.imu_out), W.imu_raw.set(&W, L.imu_raw);
     W.mscr.set(&W, L.mscr);
-    W.rotlog.set(&W, L.rotlog), W.eig_aux.set(&W, L.eig_aux);
+    W.eig_aux.set(&W, L.eig_aux);
     // field-by-field so that only pointer members are touched
 #define PUTP(field) HIPCHK(c, hipMemcpyAsync(d + offsetof(Slot, field), &W.field, sizeof W.field, hipMemcpyHostToDevice, c->stream))
     PUTP(lam); PUTP(lamE); PUTP(cost_partE);
@@ -836,7 +835,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     PUTP(a); PUTP(b); PUTP(W); PUTP(Wt); PUTP(scale_l); PUTP(grad_l); PUTP(gn_l); PUTP(diag_l); PUTP(einv_l); PUTP(d1); PUTP(d2);
     PUTP(gram_part); PUTP(pairG); PUTP(schur_part); PUTP(schur_sum); PUTP(xch); PUTP(gp); PUTP(lm_part); PUTP(cost_part); PUTP(imu_out); PUTP(imu_raw);
     PUTP(Hpp);
-    PUTP(mscr); PUTP(rotlog); PUTP(eig_aux);
+    PUTP(mscr); PUTP(eig_aux);
 #undef PUTP
     HIPCHK(c, hipStreamSynchronize(c->stream));  // W is on the stack
     info.uploaded = true;
@@ -1253,7 +1252,6 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated)
   launch_iteration(c, count, g, mode);
   hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total,
                      flag | (c->force_eig ? 256 : 0) | (gated ? 512 : 0) | (gated && c->publish ? 1024 : 0));
-  if (!EIG_TRIDIAG) hipLaunchKernelGGL(k_marg_vecs, dim3(MARG_VEC_WGS, count), dim3(256), 0, c->stream, c->d_base, c->L.total, flag);
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
 }
@@ -1967,14 +1965,26 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   if (int rc = join_inflight(c)) return rc;
   const Grid g = grid_for(c, count);
   const size_t st = c->L.total;
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0));
-  HIPCHK(c, hipEventCreate(&e1));
   const bool lw = use_linw(c, count, g, MODE_SOLVE);
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
-  // one full linearization so that every kernel has valid inputs
   // (a rank of a sharded window sweeps its share group by group under the same condition: shard.inc)
   const bool lb = !lw && (c->shard_active ? (c->linw_mode != 0 && count == 1 && c->info[0].linb_ok) : use_linb(c, count, g, MODE_SOLVE));
+  // which kernel the launch would take is settled before anything is created or enqueued
+  if ((which == 11 || which == 12) && !lw) {
+    c->err = "the resident windows are not linearized by k_linw";
+    return LFVIO_ERR_ARG;
+  }
+  if (which >= 15 && !lb) {
+    c->err = "the resident window is not linearized by k_linb";
+    return LFVIO_ERR_ARG;
+  }
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  if (hipError_t e = hipEventCreate(&e1); e != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    HIPCHK(c, e);
+  }
+  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
+  // one full linearization so that every kernel has valid inputs
   if (lw) {
     launch_linw(c, count);
   } else if (lb && which >= 15) {
@@ -1984,10 +1994,6 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     launch_sum(c, count, g, MODE_SOLVE);
   }
   if (which == 14) launch_solve(c, count, lw);
-  if (which >= 15 && !lb) {
-    c->err = "the resident window is not linearized by k_linb";
-    return LFVIO_ERR_ARG;
-  }
   if (which == 17) launch_solve(c, count, false);
 
   HIPCHK(c, hipEventRecord(e0, c->stream));
@@ -2005,13 +2011,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
         const int gx = which == 4 ? 1 : which == 5 ? 1 + LFVIO_WINDOW_SIZE : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
         hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
       } break;
-      case 11: case 12:  // the window-resident sweep of a batch (k_linw: pose-side factors, visual sweep, Schur)
-        if (!use_linw(c, count, g, MODE_SOLVE)) {
-          c->err = "the resident windows are not linearized by k_linw";
-          return LFVIO_ERR_ARG;
-        }
-        launch_linw(c, count);
-        break;
+      case 11: case 12: launch_linw(c, count); break;  // the window-resident sweep of a batch (k_linw: pose-side factors, visual sweep, Schur)
       case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;
       case 14: hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_LAUNCH_THREADS), 0, c->stream, c->d_base, st); break;  // (not idempotent: a few reps only)
       // a large single window, group by group: 15 the strip sweep (k_linb), 16 the sum of its partials (k_sumb), 17 the landmark
@@ -2030,6 +2030,15 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return LFVIO_OK;
+}
+
+// Which kernel linearizes a launch over the resident slots [0, count): 0 k_lin (+ k_sum), 1 k_linw, 2 k_linb (+ k_sumb).
+int lfvio_debug_sweep_kernel(lfvio_ctx *c, int count) {
+  if (!c || !c->d_base || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
+  const Grid g = grid_for(c, count);
+  if (use_linw(c, count, g, MODE_SOLVE)) return 1;
+  const bool lb = c->shard_active ? (c->linw_mode != 0 && count == 1 && c->info[0].linb_ok) : use_linb(c, count, g, MODE_SOLVE);
+  return lb ? 2 : 0;
 }
 
 // One linearization + dense solve of the resident slots [0, count) from their uploaded state, by whichever path the launch

@@ -212,6 +212,14 @@ class Engine:
         self._check(self.lib.lfvio_debug_time_kernel(self.ctx, which, count, reps, _p(ms)), "time_kernel")
         return float(ms[0])
 
+    def sweep_kernel(self, count):
+        """which kernel linearizes a launch over slots [0, count): 0 k_lin, 1 k_linw, 2 k_linb"""
+        self.lib.lfvio_debug_sweep_kernel.argtypes = [C.c_void_p, C.c_int]
+        rc = self.lib.lfvio_debug_sweep_kernel(self.ctx, count)
+        if rc < 0:
+            self._check(rc, "sweep_kernel")
+        return rc
+
     # ---- landmark-sharded API (multi-GPU)
     def shard_begin(self, win, lm_begin, lm_end, add_pose_side):
         self._shard_win = win  # keep the arrays alive
@@ -372,6 +380,13 @@ class Group:
         if rc != 0:
             raise RuntimeError(f"time_kernel failed rc={rc}")
         return float(ms[0])
+
+    def sweep_kernel(self, count, i=0):
+        self.lib.lfvio_debug_sweep_kernel.argtypes = [C.c_void_p, C.c_int]
+        rc = self.lib.lfvio_debug_sweep_kernel(self.ctx(i), count)
+        if rc < 0:
+            raise RuntimeError(f"sweep_kernel failed rc={rc}")
+        return rc
 
     # independent windows split over the local devices
     def batch_reserve(self, batch, max_landmarks, max_observations):

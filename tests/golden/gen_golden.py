@@ -59,7 +59,7 @@ def gen_factors():
     np.savez_compressed(os.path.join(HERE, "factors.npz"), **out)
 
 
-def gen_window(name, seed, n, **kw):
+def gen_window(name, seed, n, marg_flag=0, **kw):
     w = synth.make_window(seed, n, **kw)
     d = {"win_" + k: v for k, v in abi.window_to_dict(w).items()}
     lin = nr.linearize(w)
@@ -72,11 +72,12 @@ def gen_window(name, seed, n, **kw):
     d["sol_radius"] = np.array([t["radius"] for t in trace])
     d["sol_successful"] = np.array([t["successful"] for t in trace])
     d["sol_term"] = np.array(term)
-    # gauge fix + MARGIN_OLD marginalization at the solved state
+    # gauge fix + marginalization (MARGIN_OLD unless the fixture says otherwise) at the solved state
     st = nr.gauge_fix(w.pose[0], x.copy())
     d["gauge_pose"], d["gauge_sb"], d["gauge_ex"], d["gauge_lam"] = st.pose, st.sb, st.ex, st.lam
     w2 = w.copy(pose=st.pose, speed_bias=st.sb, ex_pose=st.ex, td=st.td, inv_depth=st.lam)
-    mg = nr.marginalize(w2, 0)
+    mg = nr.marginalize(w2, marg_flag)
+    d["marg_flag"] = np.array(marg_flag)
     d["marg_m"], d["marg_n"] = np.array(mg["m"]), np.array(mg["n"])
     d["marg_blocks"] = np.array([[k, f, i] for (k, f), i in zip(mg["shifted"], mg["idx"])])
     d["marg_A"], d["marg_b"] = mg["A"], mg["b"]
@@ -98,16 +99,16 @@ def prior_from_marg(w2, mg):
     return abi.prior_from_dict(d)
 
 
-def gen_chained(name, seed, n):
+def gen_chained(name, seed, n, marg_flag=0, **kw):
     """second window of a sequence: prior produced by the numpy marginalization itself"""
     scene = synth.Scene(seed)
-    w1 = synth.make_window(seed, n, kf0=0, scene=scene)
+    w1 = synth.make_window(seed, n, kf0=0, scene=scene, **kw)
     x, _, _ = nr.solve(w1)
     st = nr.gauge_fix(w1.pose[0], x.copy())
     w1s = w1.copy(pose=st.pose, speed_bias=st.sb, ex_pose=st.ex, td=st.td, inv_depth=st.lam)
     prior = prior_from_marg(w1s, nr.marginalize(w1s, 0))
     nxt = synth.continue_state(scene, 1, st.pose, st.sb, st.ex, st.td, np.random.default_rng(seed))
-    return gen_window(name, seed, n, kf0=1, scene=scene, prior=prior, init_state=nxt)
+    return gen_window(name, seed, n, marg_flag=marg_flag, kf0=1, scene=scene, prior=prior, init_state=nxt, **kw)
 
 
 def gen_feature(name, seed, n):
@@ -140,6 +141,11 @@ if __name__ == "__main__":
     gen_chained("window_n24_prior.npz", 104, 24)
     gen_window("window_n24_notd_noex.npz", 102, 24, estimate_td=0, estimate_extrinsic=0)
     gen_window("window_n24_rs.npz", 103, 24, tr=0.02)
+    # round 5: the shape the metric is quoted on (BASELINE configs[1]: 300 landmarks, a prior from the previous window), a window
+    # drawn through the reference's camera model with a rolling shutter, and a MARGIN_SECOND_NEW case (the prior touches Pose[9])
+    gen_chained("window_n300_prior.npz", 106, 300)
+    gen_window("window_n120_ocam_rs.npz", 107, 120, camera="ocam", tr=0.02)
+    gen_chained("window_n64_prior_second_new.npz", 108, 64, marg_flag=1)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -127,6 +127,35 @@ def test_whole_calls_against_the_old_path_and_the_oracle(eng, oracle, cases, syn
         assert np.abs(sn.pose - so.pose).max() < 1e-7 and (sn.lam.size == 0 or rel(sn.lam, so.lam) < 1e-7), s
 
 
+@pytest.mark.parametrize("sync", [True, False])
+def test_second_new_marginalization_of_a_batch_takes_the_prior_only(eng, oracle, sync):
+    """MARGIN_SECOND_NEW (estimator.cpp:942-953) marginalizes the prior factor alone: no visual factor, no IMU factor, no
+    landmark.  The window-resident sweep used to run its frame-0 strips there and put their Gram into H_pp:
+    a batch through k_linw (mode 2) against the role-by-role sweep (mode 0) and the oracle, windows WITH a prior that touches
+    Pose[9] (the plan is valid) and one without (nothing to do)."""
+    opt = lambda x, f: oracle.optimize(x, f)  # noqa: E731
+    ws = [synth.make_window_with_prior(s, n, opt)[0] for s, n in ((0, 300), (3, 120), (7, 64), (2, 300))] + [synth.make_window(5, 200)]
+    ws = ws * 2
+    out = {}
+    try:
+        for mode in (0, 2):
+            upload_all(eng, ws, mode)
+            eng.batch_optimize(len(ws), abi.MARGIN_SECOND_NEW, sync=sync)
+            eng.batch_sync()
+            out[mode] = [eng.batch_download(s, w.N) for s, w in enumerate(ws)]
+    finally:
+        eng.set_linw(1)
+    for s, w in enumerate(ws):
+        rsol, rprior = oracle.optimize(w, abi.MARGIN_SECOND_NEW)
+        (so, po), (sn, pn) = out[0][s], out[2][s]
+        check_against(sn, pn, rsol, rprior, ("k_linw SECOND_NEW vs oracle", s))
+        check_against(sn, pn, so, po, ("k_linw SECOND_NEW vs k_lin + k_sum", s))
+        if rprior.valid == 1:
+            J, Jo, Jr = pn.J(), po.J(), rprior.J()
+            assert rel(J.T @ J, Jo.T @ Jo) < 1e-9, s
+            assert rel(J.T @ pn.r(), Jr.T @ rprior.r()) < 1e-6, s
+
+
 @pytest.mark.parametrize("seed,n,mu", [(0, 300, 1e-3), (5, 65, 1e-5), (9, 320, 1e-2)])
 def test_mu_retry_redoes_only_the_schur_phase(eng, seed, n, mu):
     """A pass with do_schur and without do_lin (Ceres repeats the solve with a larger mu after a failed factorization or an
