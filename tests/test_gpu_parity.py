@@ -45,7 +45,15 @@ def test_linearization_vs_golden(eng, golden_dir, name):
     w, d = load_window(golden_dir, name)
     lin = eng.linearize(w)
     ref = dict(H=d["lin_H"], g=d["lin_g"], a=d["lin_a"], b=d["lin_b"], W=d["lin_W"], cost=float(d["lin_cost"]))
-    check_linearization(lin, ref)
+    # A chained window's newest frame is IMU-propagated with unnormalised delta quaternions like the reference does it
+    # (estimator.cpp:107-116), so its quaternion sits off the unit sphere (2e-11 in window_n64_prior_second_new).  The reference —
+    # and both CPU statements — rotate back with Eigen's Quaternion::inverse() = conjugate / |q|^2 in the residual chain
+    # (projection_td_factor.cpp:57-60) and with R^T in the Jacobians; the device uses R^T in both.  For |q| = 1 + e the two differ
+    # by ~4e in the back-rotation, and the landmark terms amplify that by depth / baseline (~100: reduce projects the radial
+    # direction out): 4e-9 relative in a_l at e = 2e-11, measured.  Only the start point of a call can carry such a quaternion
+    # (PoseLocalParameterization::Plus normalises from the first step on); the bar follows the defect and is 1e-10 without one.
+    defect = np.abs(np.linalg.norm(w.pose[:, 3:], axis=1) - 1.0).max()
+    check_linearization(lin, ref, tol=1e-10 + 500.0 * defect)
 
 
 @pytest.mark.parametrize("seed,n", [(0, 300), (1, 300), (2, 1000), (3, 7), (4, 3000)])
