@@ -57,6 +57,13 @@ int lfvio_debug_set_linw(lfvio_ctx *ctx, int mode);
  * it); 0 (default: faster at 512 windows): three launches per pass (k_linw, k_solve_dense<true>, k_stepw).  Same results.
  * Environment: LFVIO_WINDOW_KERNEL. */
 int lfvio_debug_set_window(lfvio_ctx *ctx, int on);
+/* 1: the reduced pose system is solved along its block structure — the speed/bias chain eliminated block by block, a
+ * dense 73-wide camera block left (k_solve_block, 78 KB of LDS: two windows of a batch per CU) — where every window of the launch
+ * has that structure (a prior with no SpeedBias block but frame 0's: what the reference's marginalization produces); 0 (default:
+ * the block form measured slower on MI355X): always the dense 172 x 172 solve (k_solve_dense).  Same semantics, a different elimination order.  Environment: LFVIO_BLOCK_SOLVE. */
+int lfvio_debug_set_block_solve(lfvio_ctx *ctx, int on);
+/* 1: a launch over the resident slots [0, count) takes k_solve_block, 0: k_solve_dense; < 0 on error */
+int lfvio_debug_solve_kernel(lfvio_ctx *ctx, int count);
 /* One linearization + dense solve of the resident slots [0, count) by the path the launch takes; then, of slot `slot`: g_p[172],
  * the Schur sums (15 x 256, tile layout), lm_sum[5], a[N], b[N] (device landmark order), the pose-side Gauss-Newton step [172], the
  * dogleg model's quadratic forms [16], the cost.  Any output may be NULL.  Returns 1 if k_linw ran, 2 if k_linb + k_sumb, 0 if k_lin + k_sum,

@@ -102,6 +102,299 @@ DEV double block_max(double v, double *scratch, int tid) {
   return s;
 }
 
+// ---------------------------------------------------------------------------
+// Blocked Cholesky and back-substitution of a symmetric system held in LDS as the lower 16 x 16 tiles of a 16 TN x 16 TN matrix
+// (tile layout above), TK pivots, the rhs as row TK (so the forward substitution rides along).  Shared by the dense solve of the
+// whole reduced system (TN = 11, TK = 172: solve_body) and by the camera block that is left once the speed/bias chain is
+// eliminated along its block structure (TN = 5, TK = 76: kernels_solveb.h).  Whole workgroup of SOLVE_THREADS threads; both end
+// on a barrier.  tile_cholesky returns this thread's view of "a pivot was not positive" (or-ed into `bad`).
+// ---------------------------------------------------------------------------
+template <int TN, int TK>
+DEV bool tile_cholesky(double *Hs, double *invd, int tid, bool bad) {
+  // ---- blocked right-looking Cholesky, TN block columns of 16.  Per block column:
+  //   F  wave 0 factors the diagonal tile, one ROW per lane, fully unrolled: pivot and column entries travel by
+  //      v_readlane, the update uses the raw column (a_ik a_jk / d_k: the reciprocal runs beside the broadcasts), the
+  //      columns are scaled by 1/sqrt(d_k) once at the end;
+  //   P  the rows below solve  x L_kk^T = a  — one thread per row, L_kk read from a plain copy with uniform addresses;
+  //   U  the trailing tiles take  A_ij -= L_ik L_jk^T  on the FP64 matrix pipe (4 v_mfma_f64_16x16x4_f64 per tile),
+  //      tiles dealt round-robin to the four waves; operands and accumulators go straight between LDS and the MFMA
+  //      register layouts.
+  // The rhs row rides along as row TK - 16 (TN - 1) of the last block row (never a pivot), which is the forward substitution.
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave in an SGPR: scalar loop control below
+  // F: factor diagonal tile kb in wave 0.  Lane (row c, quarter g) owns columns g, g + 4, g + 8, g + 12 of its row of the FULL
+  // symmetric tile (a[i] = A[c][g + 4 i]).  The four pivots of a panel are eliminated on the vector pipe inside the panel only
+  // (pivot by v_readlane, the pivot column for every quarter by v_permlane16/32_swap, the pivot row by DPP row_newbcast — all
+  // requested before the reciprocal they run beside); the columns behind the panel take the rank-4 update
+  // C -= P diag(1/d) P^T in ONE v_mfma_f64_16x16x4_f64 whose A, B and C operands are the registers as they stand: the
+  // accumulator layout D[g + 4 r][c] is the transpose of the ownership, and the tile is symmetric.  30 vector instructions
+  // per pivot instead of 47 (tools/micro/f_mfma.hip: 4 900 -> 3 700 cycles per tile); the raw columns are scaled by
+  // 1/sqrt(d_k) once at the end.
+  // last_term: the tile still lacks the term of block column kb - 1 (its panel tile (kb, kb - 1) has just been solved): it
+  // is taken here, on the registers the factorization starts from — the accumulator layout of  A - P P^T  is this very
+  // ownership (the tile is symmetric) — instead of a trip of the tile through LDS in between.
+  auto factor = [&](int kb, bool last_term) {
+    const int nb = kb < TN - 1 ? 16 : TK - 16 * (TN - 1);  // pivots in this block column (12 in the last)
+    double *Td = Hs + tile_id(kb, kb) * TSZ;
+    const int c = lane & 15, gq = lane >> 4;
+    solve_d4 a;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int col = gq + 4 * i;
+      a[i] = col <= c ? Td[tsw(c, col)] : Td[tsw(col, c)];
+    }
+    if (last_term) {
+      const double *Tp = Hs + tile_id(kb, kb - 1) * TSZ + c * TLD + gq;
+      double pv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) pv[q] = Tp[4 * q];
+#pragma unroll
+      for (int q = 0; q < 4; q++) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pv[q], pv[q], a, 0, 0, 0);
+    }
+    double dsave[4] = {1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      double bop = 0.0;  // this lane's B operand: its panel column times 1/d of that column's pivot
+      // The four pivots of a panel without a cross-lane step between them.  Taken one at a time (the loop below), every
+      // pivot is readlane -> reciprocal -> multiply -> multiply-add with a quarter and a row broadcast feeding it: ~250
+      // cycles, most of them the hand-offs.  Instead everything the panel needs from other lanes is fetched FIRST, all of it
+      // independent — the ten entries of its 4 x 4 pivot block (uniform, v_readlane) and this row's four panel entries (one
+      // per quarter) — then every lane runs the block's LDL^T for itself (four reciprocals in a row, the only chain left) and
+      // solves its own row against it: y_k = x_k - sum_{t<k} m_kt y_t, m_kt = Y_kt / d_t.  A panel is whole or absent (nb is
+      // 16 or 12).
+      if (4 * p < nb) {
+        const int l0 = 4 * p;
+        const double B00 = readlane_f64(a[p], l0), B10 = readlane_f64(a[p], l0 + 1), B20 = readlane_f64(a[p], l0 + 2), B30 = readlane_f64(a[p], l0 + 3);
+        const double B11 = readlane_f64(a[p], 16 + l0 + 1), B21 = readlane_f64(a[p], 16 + l0 + 2), B31 = readlane_f64(a[p], 16 + l0 + 3);
+        const double B22 = readlane_f64(a[p], 32 + l0 + 2), B32 = readlane_f64(a[p], 32 + l0 + 3), B33 = readlane_f64(a[p], 48 + l0 + 3);
+        const double x0 = quarter_bcast(a[p], 0), x1 = quarter_bcast(a[p], 1), x2 = quarter_bcast(a[p], 2), x3 = quarter_bcast(a[p], 3);
+        const double d0 = B00, r0 = fast_rcp(d0);
+        const double m10 = B10 * r0, m20 = B20 * r0, m30 = B30 * r0;
+        const double d1 = fma(-m10, B10, B11), Y21 = fma(-m10, B20, B21), Y31 = fma(-m10, B30, B31);
+        const double r1 = fast_rcp(d1);
+        const double m21 = Y21 * r1, m31 = Y31 * r1;
+        const double d2 = fma(-m21, Y21, fma(-m20, B20, B22)), Y32 = fma(-m21, Y31, fma(-m20, B30, B32));
+        const double r2 = fast_rcp(d2);
+        const double m32 = Y32 * r2;
+        const double d3 = fma(-m32, Y32, fma(-m31, Y31, fma(-m30, B30, B33)));
+        const double r3 = fast_rcp(d3);
+        if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) bad = true;
+        const double y1 = fma(-m10, x0, x1), y2 = fma(-m21, y1, fma(-m20, x0, x2)), y3 = fma(-m32, y2, fma(-m31, y1, fma(-m30, x0, x3)));
+        const double yk = gq == 0 ? x0 : gq == 1 ? y1 : gq == 2 ? y2 : y3;
+        const double rk = gq == 0 ? r0 : gq == 1 ? r1 : gq == 2 ? r2 : r3;
+        dsave[p] = gq == 0 ? d0 : gq == 1 ? d1 : gq == 2 ? d2 : d3;
+        a[p] = yk;
+        bop = yk * rk;
+      }
+      if (p < 3 && 4 * p < nb) {
+        solve_d4 cv = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[p], bop, a, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (i > p) a[i] = cv[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int col = gq + 4 * i;
+      const double rs = fast_rsqrt(dsave[i]);
+      double v = 0.0;
+      if (col < nb) v = c > col ? a[i] * rs : (c == col ? dsave[i] * rs : 0.0);
+      Td[tsw(c, col)] = v;
+      if (c == col && col < nb) invd[16 * kb + col] = rs;
+    }
+  };
+  // Two tiles (tA, tj) and (tB, tj) of ONE block column (tB >= TN: only the first) take the terms k0 .. k1 - 1 of
+  // A_ij -= sum_k L_ik L_jk^T  with their accumulators in registers across the terms: the two share the B operand L_jk
+  // (12 operand loads per term for two tiles instead of 16), their MFMA chains are independent, and the operands of term
+  // k + 1 are requested before the MFMAs of term k.  Per tile and term the same four MFMAs in the same order as `update`
+  // issues them, so a tile's value does not depend on how its terms are grouped into calls.
+  // (TWO as a type: the body is straight-line code per variant, and inside the loop nothing is conditional — the operands of
+  // the next term are fetched whether or not there is one (the tile behind the last operand tile exists: k1 <= tj) — so that
+  // the wait in front of a term's MFMAs counts the loads of the NEXT term as still outstanding instead of waiting for them.)
+  auto accumulate_impl = [&](auto two_c, int tA, int tB, int tj, int k0, int k1) {
+    constexpr bool TWO = decltype(two_c)::value;
+    const int c = lane & 15, gq = lane >> 4, offA = c * TLD + gq, offC = gq * TLD + c;
+    double *TcA = Hs + tile_id(tA, tj) * TSZ + offC, *TcB = Hs + tile_id(TWO ? tB : tA, tj) * TSZ + offC;
+    // the operand tiles of consecutive terms are consecutive tiles of a block row (tile_id(t, k + 1) = tile_id(t, k) + 1)
+    const double *pA = Hs + tile_id(tA, k0) * TSZ + offA, *pB = Hs + tile_id(TWO ? tB : tA, k0) * TSZ + offA, *pJ = Hs + tile_id(tj, k0) * TSZ + offA;
+    solve_d4 cA, cB = {0.0, 0.0, 0.0, 0.0};
+    double xA[4], xB[4] = {0, 0, 0, 0}, xJ[4], yA[4], yB[4] = {0, 0, 0, 0}, yJ[4];  // two operand sets: no copies between terms
+    auto fetch = [&](double (&a)[4], double (&b)[4], double (&jv)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) a[q] = pA[4 * q], jv[q] = pJ[4 * q];
+      if (TWO) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[q] = pB[4 * q];
+      }
+      pA += TSZ, pB += TSZ, pJ += TSZ;
+    };
+    auto term = [&](const double (&a)[4], const double (&b)[4], const double (&jv)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        cA = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], jv[q], cA, 0, 0, 0);
+        if (TWO) cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-b[q], jv[q], cB, 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; q++) cA[q] = TcA[4 * TLD * q];
+    if (TWO) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) cB[q] = TcB[4 * TLD * q];
+    }
+    fetch(xA, xB, xJ);
+    int k = k0;
+    for (; k + 1 < k1; k += 2) {
+      fetch(yA, yB, yJ);
+      term(xA, xB, xJ);
+      fetch(xA, xB, xJ);
+      term(yA, yB, yJ);
+    }
+    if (k < k1) term(xA, xB, xJ);
+#pragma unroll
+    for (int r = 0; r < 4; r++) TcA[4 * TLD * r] = cA[r];
+    if (TWO) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) TcB[4 * TLD * r] = cB[r];
+    }
+  };
+  auto accumulate = [&](int tA, int tB, int tj, int k0, int k1) {
+    if (tB < TN) accumulate_impl(std::true_type{}, tA, tB, tj, k0, k1);  // wave-uniform
+    else accumulate_impl(std::false_type{}, tA, tB, tj, k0, k1);
+  };
+  // a wave's tiles t0, t0 + 3, t0 + 6 (those that exist) of block column tj
+  auto accumulate_column = [&](int t0, int tj, int k0, int k1) {
+    if (t0 < TN) accumulate(t0, t0 + 3, tj, k0, k1);
+    if (t0 + 6 < TN) accumulate(t0 + 6, TN, tj, k0, k1);
+  };
+  if (wave == 0) factor(0, false);
+  __syncthreads();
+  for (int kb = 0; kb < TN - 1; kb++) {
+    {  // P: the rows below solve x L_kk^T = a, one thread per row
+      const int ta = kb + 1 + (tid >> 4), r = tid & 15;
+      if (ta < TN) {
+        double *Tp = Hs + tile_id(ta, kb) * TSZ;
+        const double *Tk = Hs + tile_id(kb, kb) * TSZ;
+        double x[16], dv[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = Tp[tsw(r, j)], dv[j] = invd[16 * kb + j];
+        // column j of L_kk (uniform addresses) is requested one step ahead: LDS reads complete in order, so a read issued
+        // inside the step that uses it would cost that step a round trip
+        double lc[16], ln[16];
+#pragma unroll
+        for (int t = 1; t < 16; t++) lc[t] = Tk[tsw(t, 0)];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+#pragma unroll
+          for (int t = j + 2; t < 16; t++) ln[t] = Tk[tsw(t, j + 1)];
+          x[j] *= dv[j];
+#pragma unroll
+          for (int t = j + 1; t < 16; t++) x[t] = fma(-x[j], lc[t], x[t]);
+#pragma unroll
+          for (int t = j + 2; t < 16; t++) lc[t] = ln[t];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) Tp[tsw(r, j)] = x[j];
+      }
+    }
+    __syncthreads();
+    {  // U, left-looking with look-ahead.  A right-looking step would now update ALL trailing tiles with block column kb (55,
+      // 45, 36 ... of them in the first columns, every one read and written through LDS: those columns were bound by that
+      // traffic, 34k of the factorization's 100k cycles).  Only block column kb + 1 is needed next: it takes its LAST term
+      // here — wave 0 the diagonal tile, which it then factors; waves 1..3 the tiles below it, which the next panel solve
+      // reads — and while wave 0 factors, waves 1..3 give block column kb + 2 every term but its last one (the operand
+      // panels 0 .. kb are final), accumulators in registers across the terms, two tiles at a time sharing their B operand:
+      // a third of the LDS traffic per term, and never more than 30 tile-terms between two barriers.  Each tile still receives
+      // its terms in the order 0, 1, 2, ...: same bits.
+      const int j1 = kb + 1, j2 = kb + 2;
+      if (wave == 0) {
+        factor(j1, true);
+      } else {
+        accumulate_column(j1 + wave, j1, kb, kb + 1);
+        accumulate_column(j2 + (3 - wave), j2, 0, kb + 1);  // (the wave with the most tiles above starts furthest down here)
+      }
+    }
+    __syncthreads();
+  }
+  return bad;
+}
+
+// L^T y = z in place: z is the rhs row of the factored tiles, the result is left in yv[0, TK).
+template <int TN, int TK>
+DEV void tile_backsub(double *Hs, double *yv, const double *invd, int tid) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // ---- blocked back-substitution  L^T y = z  (TN diagonal blocks of 16), right-looking, from the last block to the
+  //      first.  The diagonal tiles are inverted first, ALL of them at once — four tiles per wave, one column per lane,
+  //      X = L_kk^-1 by forward substitution with the tile's entries as LDS broadcasts (120 fma per lane, no cross-lane
+  //      traffic) — so that a block of the solution is a 16 x 16 product  y_k = X^T z_k  (16 independent fma per lane)
+  //      instead of a chain of sixteen dependent broadcast steps; then every earlier block takes z_j -= L_kj^T y_k at
+  //      once (thread (j, c): one column of one tile).  29 k -> 9 k cycles.
+  if (tid < TK) yv[tid] = Hs[lidx(TK, tid)];  // z = the rhs row (it sits in the last diagonal tile: copied out before that tile is overwritten)
+  __syncthreads();
+  {
+    const int tsel = 4 * wave + (lane >> 4), c = lane & 15;
+    if (tsel < TN) {
+      const int nb = tsel < TN - 1 ? 16 : TK - 16 * (TN - 1);
+      double *Tk = Hs + tile_id(tsel, tsel) * TSZ;
+      double x[16], dv[16], lr[16], ln[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) dv[r] = invd[16 * tsel + (r < nb ? r : 0)];
+      lr[0] = Tk[tsw(1, 0)];
+      x[0] = (0 >= c && 0 < nb) ? dv[0] : 0.0;
+#pragma unroll
+      for (int r = 1; r < 16; r++) {
+        // row r + 1 of L is requested while row r is in work (an LDS read issued inside the chain costs it a round trip)
+        if (r + 1 < 16) {
+#pragma unroll
+          for (int j = 0; j <= r; j++) ln[j] = Tk[tsw(r + 1, j)];
+        }
+        double acc = r == c ? 1.0 : 0.0, acc1 = 0.0;  // two accumulators: half the dependent chain
+#pragma unroll
+        for (int j = 0; j + 1 < r; j += 2) acc = fma(-lr[j], x[j], acc), acc1 = fma(-lr[j + 1], x[j + 1], acc1);  // x[j] = 0 above the diagonal
+        if (r & 1) acc = fma(-lr[r - 1], x[r - 1], acc);
+        x[r] = (r >= c && r < nb) ? (acc + acc1) * dv[r] : 0.0;
+        if (r + 1 < 16) {
+#pragma unroll
+          for (int j = 0; j <= r; j++) lr[j] = ln[j];
+        }
+      }
+      // the LDS operations of one wave complete in program order: every read above precedes these writes
+#pragma unroll
+      for (int r = 0; r < 16; r++) Tk[tsw(r, c)] = x[r];
+    }
+  }
+  __syncthreads();
+  auto tile_solve = [&](int blk) {  // 16 lanes of wave 0: y_blk = X^T z_blk, in place
+    const int o = 16 * blk, nb = (TK - o) < 16 ? (TK - o) : 16, c = lane & 15;
+    const double *Tk = Hs + tile_id(blk, blk) * TSZ;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r & 3] = fma(Tk[tsw(r, c)], r < nb ? yv[o + r] : 0.0, acc[r & 3]);
+    if (c < nb) yv[o + c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  };
+  auto apply = [&](int blk, int j, int c) {  // z_j[c] -= (L_kj^T y_k)[c]
+    const int o = 16 * blk, nb = (TK - o) < 16 ? (TK - o) : 16;
+    const double *Tj = Hs + tile_id(blk, j) * TSZ;
+    double acc[4] = {yv[16 * j + c], 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      if (r < nb) acc[r & 3] = fma(-Tj[tsw(r, c)], yv[o + r], acc[r & 3]);
+    yv[16 * j + c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  };
+  if (wave == 0 && lane < 16) tile_solve(TN - 1);
+  __syncthreads();
+  for (int blk = TN - 1; blk >= 1; blk--) {
+    if (wave == 0) {  // look-ahead: the next block to be solved gets its update first
+      if (lane < 16) {
+        apply(blk, blk - 1, lane);
+        tile_solve(blk - 1);
+      }
+    } else {
+      const int j = (tid - 64) >> 4;
+      if (j < blk - 1) apply(blk, j, tid & 15);
+    }
+    __syncthreads();
+  }
+}
+
 // What thread 0 of the dense solve leaves in the header once the Gauss-Newton step is there: the pose-side sums,
 // and at iteration 0 IterationZero + the first
 // FinalizeIterationAndCheckIfMinimizerCanContinue of trust_region_minimizer.cc.
@@ -440,316 +733,10 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
   __syncthreads();
   STAMP(S, 3);
 
-  // ---- blocked right-looking Cholesky, 11 block columns of 16.  Per block column:
-  //   F  wave 0 factors the diagonal tile, one ROW per lane, fully unrolled: pivot and column entries travel by
-  //      v_readlane, the update uses the raw column (a_ik a_jk / d_k: the reciprocal runs beside the broadcasts), the
-  //      columns are scaled by 1/sqrt(d_k) once at the end;
-  //   P  the rows below solve  x L_kk^T = a  — one thread per row, L_kk read from a plain copy with uniform addresses;
-  //   U  the trailing tiles take  A_ij -= L_ik L_jk^T  on the FP64 matrix pipe (4 v_mfma_f64_16x16x4_f64 per tile),
-  //      tiles dealt round-robin to the four waves; operands and accumulators go straight between LDS and the MFMA
-  //      register layouts.
-  // The rhs row rides along as row 12 of block row 10 (never a pivot), which is the forward substitution.
-  bool bad = !(mu < 1.0);  // ComputeGaussNewtonStep: `while (mu_ < max_mu_)` — no attempt at mu >= 1
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave in an SGPR: scalar loop control below
-  // F: factor diagonal tile kb in wave 0.  Lane (row c, quarter g) owns columns g, g + 4, g + 8, g + 12 of its row of the FULL
-  // symmetric tile (a[i] = A[c][g + 4 i]).  The four pivots of a panel are eliminated on the vector pipe inside the panel only
-  // (pivot by v_readlane, the pivot column for every quarter by v_permlane16/32_swap, the pivot row by DPP row_newbcast — all
-  // requested before the reciprocal they run beside); the columns behind the panel take the rank-4 update
-  // C -= P diag(1/d) P^T in ONE v_mfma_f64_16x16x4_f64 whose A, B and C operands are the registers as they stand: the
-  // accumulator layout D[g + 4 r][c] is the transpose of the ownership, and the tile is symmetric.  30 vector instructions
-  // per pivot instead of 47 (tools/micro/f_mfma.hip: 4 900 -> 3 700 cycles per tile); the raw columns are scaled by
-  // 1/sqrt(d_k) once at the end.
-  // last_term: the tile still lacks the term of block column kb - 1 (its panel tile (kb, kb - 1) has just been solved): it
-  // is taken here, on the registers the factorization starts from — the accumulator layout of  A - P P^T  is this very
-  // ownership (the tile is symmetric) — instead of a trip of the tile through LDS in between.
-  auto factor = [&](int kb, bool last_term) {
-    const int nb = kb < NTL - 1 ? 16 : KP - 16 * (NTL - 1);  // pivots in this block column (12 in the last)
-    double *Td = Hs + tile_id(kb, kb) * TSZ;
-    const int c = lane & 15, gq = lane >> 4;
-    solve_d4 a;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int col = gq + 4 * i;
-      a[i] = col <= c ? Td[tsw(c, col)] : Td[tsw(col, c)];
-    }
-    if (last_term) {
-      const double *Tp = Hs + tile_id(kb, kb - 1) * TSZ + c * TLD + gq;
-      double pv[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) pv[q] = Tp[4 * q];
-#pragma unroll
-      for (int q = 0; q < 4; q++) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-pv[q], pv[q], a, 0, 0, 0);
-    }
-    double dsave[4] = {1.0, 1.0, 1.0, 1.0};
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      double bop = 0.0;  // this lane's B operand: its panel column times 1/d of that column's pivot
-#ifndef LFVIO_FACTOR_PIVOT_LOOP
-      // The four pivots of a panel without a cross-lane step between them.  Taken one at a time (the loop below), every
-      // pivot is readlane -> reciprocal -> multiply -> multiply-add with a quarter and a row broadcast feeding it: ~250
-      // cycles, most of them the hand-offs.  Instead everything the panel needs from other lanes is fetched FIRST, all of it
-      // independent — the ten entries of its 4 x 4 pivot block (uniform, v_readlane) and this row's four panel entries (one
-      // per quarter) — then every lane runs the block's LDL^T for itself (four reciprocals in a row, the only chain left) and
-      // solves its own row against it: y_k = x_k - sum_{t<k} m_kt y_t, m_kt = Y_kt / d_t.  A panel is whole or absent (nb is
-      // 16 or 12).
-      if (4 * p < nb) {
-        const int l0 = 4 * p;
-        const double B00 = readlane_f64(a[p], l0), B10 = readlane_f64(a[p], l0 + 1), B20 = readlane_f64(a[p], l0 + 2), B30 = readlane_f64(a[p], l0 + 3);
-        const double B11 = readlane_f64(a[p], 16 + l0 + 1), B21 = readlane_f64(a[p], 16 + l0 + 2), B31 = readlane_f64(a[p], 16 + l0 + 3);
-        const double B22 = readlane_f64(a[p], 32 + l0 + 2), B32 = readlane_f64(a[p], 32 + l0 + 3), B33 = readlane_f64(a[p], 48 + l0 + 3);
-        const double x0 = quarter_bcast(a[p], 0), x1 = quarter_bcast(a[p], 1), x2 = quarter_bcast(a[p], 2), x3 = quarter_bcast(a[p], 3);
-        const double d0 = B00, r0 = fast_rcp(d0);
-        const double m10 = B10 * r0, m20 = B20 * r0, m30 = B30 * r0;
-        const double d1 = fma(-m10, B10, B11), Y21 = fma(-m10, B20, B21), Y31 = fma(-m10, B30, B31);
-        const double r1 = fast_rcp(d1);
-        const double m21 = Y21 * r1, m31 = Y31 * r1;
-        const double d2 = fma(-m21, Y21, fma(-m20, B20, B22)), Y32 = fma(-m21, Y31, fma(-m20, B30, B32));
-        const double r2 = fast_rcp(d2);
-        const double m32 = Y32 * r2;
-        const double d3 = fma(-m32, Y32, fma(-m31, Y31, fma(-m30, B30, B33)));
-        const double r3 = fast_rcp(d3);
-        if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) bad = true;
-        const double y1 = fma(-m10, x0, x1), y2 = fma(-m21, y1, fma(-m20, x0, x2)), y3 = fma(-m32, y2, fma(-m31, y1, fma(-m30, x0, x3)));
-        const double yk = gq == 0 ? x0 : gq == 1 ? y1 : gq == 2 ? y2 : y3;
-        const double rk = gq == 0 ? r0 : gq == 1 ? r1 : gq == 2 ? r2 : r3;
-        dsave[p] = gq == 0 ? d0 : gq == 1 ? d1 : gq == 2 ? d2 : d3;
-        a[p] = yk;
-        bop = yk * rk;
-      }
-#else
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int k = 4 * p + t;
-        if (k < nb) {  // wave-uniform
-          double colk = 0.0, u = 0.0;
-          if (t < 3) {
-            colk = quarter_bcast(a[p], t);
-            u = row_bcast_k(a[p], k);
-          }
-          const double d = readlane_f64(a[p], 16 * t + k);  // pivot: row k in quarter t
-          if (!(d > 0.0)) bad = true;
-          const double rc = fast_rcp(d);
-          if (gq == t) dsave[p] = d, bop = a[p] * rc;
-          if (t < 3) {
-            const double upd = fma(c > k ? -(colk * rc) : 0.0, u, a[p]);
-            if (gq > t) a[p] = upd;
-          }
-        }
-      }
-#endif
-      if (p < 3 && 4 * p < nb) {
-        solve_d4 cv = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[p], bop, a, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (i > p) a[i] = cv[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int col = gq + 4 * i;
-      const double rs = fast_rsqrt(dsave[i]);
-      double v = 0.0;
-      if (col < nb) v = c > col ? a[i] * rs : (c == col ? dsave[i] * rs : 0.0);
-      Td[tsw(c, col)] = v;
-      if (c == col && col < nb) invd[16 * kb + col] = rs;
-    }
-  };
-  // U: tiles [first, first + count) of the enumeration (ti, tj), kb < tj <= ti, every `step`-th; four tiles in flight
-  auto update = [&](int kb, int first, int step, int last) {
-    const int c = lane & 15, gq = lane >> 4, offA = c * TLD + gq, offC = gq * TLD + c;
-    int ti = kb + 1, tj = kb + 1, u = 0;
-    auto advance = [&](int n) {
-      for (int q = 0; q < n; q++, u++)
-        if (++tj > ti) ti++, tj = kb + 1;
-    };
-    advance(first);
-    while (u < last) {
-      double av[4][4], bv[4][4];
-      solve_d4 cv[4];
-      double *Tc[4];
-      int nt = 0;
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        Tc[t] = nullptr;
-        if (u < last) {
-          const double *Ta = Hs + tile_id(ti, kb) * TSZ + offA, *Tb = Hs + tile_id(tj, kb) * TSZ + offA;
-          Tc[t] = Hs + tile_id(ti, tj) * TSZ + offC;
-#pragma unroll
-          for (int q = 0; q < 4; q++) av[t][q] = Ta[4 * q], bv[t][q] = Tb[4 * q], cv[t][q] = Tc[t][4 * TLD * q];
-          nt = t + 1;
-          advance(step);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; t++)
-        if (t < nt) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) cv[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[t][q], bv[t][q], cv[t], 0, 0, 0);
-        }
-#pragma unroll
-      for (int t = 0; t < 4; t++)
-        if (t < nt) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) Tc[t][4 * TLD * r] = cv[t][r];
-        }
-    }
-  };
-  // Two tiles (tA, tj) and (tB, tj) of ONE block column (tB >= NTL: only the first) take the terms k0 .. k1 - 1 of
-  // A_ij -= sum_k L_ik L_jk^T  with their accumulators in registers across the terms: the two share the B operand L_jk
-  // (12 operand loads per term for two tiles instead of 16), their MFMA chains are independent, and the operands of term
-  // k + 1 are requested before the MFMAs of term k.  Per tile and term the same four MFMAs in the same order as `update`
-  // issues them, so a tile's value does not depend on how its terms are grouped into calls.
-  // (TWO as a type: the body is straight-line code per variant, and inside the loop nothing is conditional — the operands of
-  // the next term are fetched whether or not there is one (the tile behind the last operand tile exists: k1 <= tj) — so that
-  // the wait in front of a term's MFMAs counts the loads of the NEXT term as still outstanding instead of waiting for them.)
-  auto accumulate_impl = [&](auto two_c, int tA, int tB, int tj, int k0, int k1) {
-    constexpr bool TWO = decltype(two_c)::value;
-    const int c = lane & 15, gq = lane >> 4, offA = c * TLD + gq, offC = gq * TLD + c;
-    double *TcA = Hs + tile_id(tA, tj) * TSZ + offC, *TcB = Hs + tile_id(TWO ? tB : tA, tj) * TSZ + offC;
-    // the operand tiles of consecutive terms are consecutive tiles of a block row (tile_id(t, k + 1) = tile_id(t, k) + 1)
-    const double *pA = Hs + tile_id(tA, k0) * TSZ + offA, *pB = Hs + tile_id(TWO ? tB : tA, k0) * TSZ + offA, *pJ = Hs + tile_id(tj, k0) * TSZ + offA;
-    solve_d4 cA, cB = {0.0, 0.0, 0.0, 0.0};
-    double xA[4], xB[4] = {0, 0, 0, 0}, xJ[4], yA[4], yB[4] = {0, 0, 0, 0}, yJ[4];  // two operand sets: no copies between terms
-    auto fetch = [&](double (&a)[4], double (&b)[4], double (&jv)[4]) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) a[q] = pA[4 * q], jv[q] = pJ[4 * q];
-      if (TWO) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) b[q] = pB[4 * q];
-      }
-      pA += TSZ, pB += TSZ, pJ += TSZ;
-    };
-    auto term = [&](const double (&a)[4], const double (&b)[4], const double (&jv)[4]) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        cA = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q], jv[q], cA, 0, 0, 0);
-        if (TWO) cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-b[q], jv[q], cB, 0, 0, 0);
-      }
-    };
-#pragma unroll
-    for (int q = 0; q < 4; q++) cA[q] = TcA[4 * TLD * q];
-    if (TWO) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) cB[q] = TcB[4 * TLD * q];
-    }
-    fetch(xA, xB, xJ);
-    int k = k0;
-    for (; k + 1 < k1; k += 2) {
-      fetch(yA, yB, yJ);
-      term(xA, xB, xJ);
-      fetch(xA, xB, xJ);
-      term(yA, yB, yJ);
-    }
-    if (k < k1) term(xA, xB, xJ);
-#pragma unroll
-    for (int r = 0; r < 4; r++) TcA[4 * TLD * r] = cA[r];
-    if (TWO) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) TcB[4 * TLD * r] = cB[r];
-    }
-  };
-  auto accumulate = [&](int tA, int tB, int tj, int k0, int k1) {
-    if (tB < NTL) accumulate_impl(std::true_type{}, tA, tB, tj, k0, k1);  // wave-uniform
-    else accumulate_impl(std::false_type{}, tA, tB, tj, k0, k1);
-  };
-  // a wave's tiles t0, t0 + 3, t0 + 6 (those that exist) of block column tj
-  auto accumulate_column = [&](int t0, int tj, int k0, int k1) {
-    if (t0 < NTL) accumulate(t0, t0 + 3, tj, k0, k1);
-    if (t0 + 6 < NTL) accumulate(t0 + 6, NTL, tj, k0, k1);
-  };
-#ifdef LFVIO_SOLVE_PROFILE
-#define PSTAMP(k, v) do { if (tid == 0) S->dbg[k] = (v); } while (0)
-#define PNOW() ((long long)__builtin_readcyclecounter())
-#else
-#define PSTAMP(k, v) do {} while (0)
-#define PNOW() 0ll
-#endif
-  if (wave == 0) factor(0, false);
-  __syncthreads();
-  long long pf = 0, pp = 0, pu = 0, pw = 0;
-  for (int kb = 0; kb < NTL - 1; kb++) {
-    const long long c0 = PNOW();
-    {  // P: the rows below solve x L_kk^T = a, one thread per row
-      const int ta = kb + 1 + (tid >> 4), r = tid & 15;
-      if (ta < NTL) {
-        double *Tp = Hs + tile_id(ta, kb) * TSZ;
-        const double *Tk = Hs + tile_id(kb, kb) * TSZ;
-        double x[16], dv[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = Tp[tsw(r, j)], dv[j] = invd[16 * kb + j];
-        // column j of L_kk (uniform addresses) is requested one step ahead: LDS reads complete in order, so a read issued
-        // inside the step that uses it would cost that step a round trip
-        double lc[16], ln[16];
-#pragma unroll
-        for (int t = 1; t < 16; t++) lc[t] = Tk[tsw(t, 0)];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-#pragma unroll
-          for (int t = j + 2; t < 16; t++) ln[t] = Tk[tsw(t, j + 1)];
-          x[j] *= dv[j];
-#pragma unroll
-          for (int t = j + 1; t < 16; t++) x[t] = fma(-x[j], lc[t], x[t]);
-#pragma unroll
-          for (int t = j + 2; t < 16; t++) lc[t] = ln[t];
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) Tp[tsw(r, j)] = x[j];
-      }
-    }
-    const long long c1 = PNOW();
-    __syncthreads();
-    const long long c2 = PNOW();
-#ifndef LFVIO_SOLVE_RIGHT_LOOKING
-    {  // U, left-looking with look-ahead.  A right-looking step would now update ALL trailing tiles with block column kb (55,
-      // 45, 36 ... of them in the first columns, every one read and written through LDS: those columns were bound by that
-      // traffic, 34k of the factorization's 100k cycles).  Only block column kb + 1 is needed next: it takes its LAST term
-      // here — wave 0 the diagonal tile, which it then factors; waves 1..3 the tiles below it, which the next panel solve
-      // reads — and while wave 0 factors, waves 1..3 give block column kb + 2 every term but its last one (the operand
-      // panels 0 .. kb are final), accumulators in registers across the terms, two tiles at a time sharing their B operand:
-      // a third of the LDS traffic per term, and never more than 30 tile-terms between two barriers.  Each tile still receives
-      // its terms in the order 0, 1, 2, ...: same bits.
-      const int j1 = kb + 1, j2 = kb + 2;
-      if (wave == 0) {
-        const long long c3 = PNOW();
-        factor(j1, true);
-        const long long c4 = PNOW();
-        pu += c3 - c2, pf += c4 - c3;
-        PSTAMP(8 + kb, c4 - c3);
-      } else {
-        accumulate_column(j1 + wave, j1, kb, kb + 1);
-        accumulate_column(j2 + (3 - wave), j2, 0, kb + 1);  // (the wave with the most tiles above starts furthest down here)
-      }
-    }
-#else
-    {  // U with look-ahead: wave 0 updates the next diagonal tile first and factors it while waves 1..3 update the rest
-      // Wave 0 is on the critical path (next diagonal tile, then its factorization: worth about seven tile updates); in the
-      // first block columns the other three would still be updating long after it is done, so it takes the tail of the
-      // tile list once the factor is out: n0 = (n - 21) / 4 balances 7 + n0 against (n - n0) / 3.
-      const int m = NTL - 1 - kb, ntiles = m * (m + 1) / 2;
-      const int n0 = ntiles - 1 > 21 ? (ntiles - 1 - 21) / 4 : 0, split = ntiles - n0;
-      if (wave == 0) {
-        update(kb, 0, 1, 1);
-        const long long c3 = PNOW();
-        factor(kb + 1, false);
-        const long long c4 = PNOW();
-        pu += c3 - c2, pf += c4 - c3;
-        PSTAMP(8 + kb, c4 - c3);
-        if (n0 > 0) update(kb, split, 1, ntiles);
-      } else {
-        update(kb, wave, 3, split);
-      }
-    }
-#endif
-    const long long c5 = PNOW();
-    __syncthreads();
-    const long long c6 = PNOW();
-    pp += c1 - c0, pw += (c2 - c1) + (c6 - c5);
-    PSTAMP(19 + kb, c6 - c5);
-  }
-  PSTAMP(29, pf);
-  PSTAMP(30, pp);
-  PSTAMP(31, pu);
-  PSTAMP(18, pw);
+  // ---- blocked Cholesky of the 172 x 172 system (tile_cholesky above); ComputeGaussNewtonStep: `while (mu_ < max_mu_)` — no attempt at mu >= 1
+  bool bad = tile_cholesky<NTL, KP>(Hs, invd, tid, !(mu < 1.0));
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  (void)wave, (void)lane;
   STAMP(S, 4);
   {
     double f = bad ? 1.0 : 0.0;
@@ -757,78 +744,7 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
     bad = f > 0.0;
   }
   STAMP(S, 5);
-  // ---- blocked back-substitution  L^T y = z  (11 diagonal blocks of 16), right-looking, from the last block to the
-  //      first.  The diagonal tiles are inverted first, ALL of them at once — four tiles per wave, one column per lane,
-  //      X = L_kk^-1 by forward substitution with the tile's entries as LDS broadcasts (120 fma per lane, no cross-lane
-  //      traffic) — so that a block of the solution is a 16 x 16 product  y_k = X^T z_k  (16 independent fma per lane)
-  //      instead of a chain of sixteen dependent broadcast steps; then every earlier block takes z_j -= L_kj^T y_k at
-  //      once (thread (j, c): one column of one tile).  29 k -> 9 k cycles.
-  if (tid < KP) yv[tid] = Hs[lidx(KP, tid)];  // z = the rhs row (it sits in the last diagonal tile: copied out before that tile is overwritten)
-  __syncthreads();
-  {
-    const int tsel = 4 * wave + (lane >> 4), c = lane & 15;
-    if (tsel < NTL) {
-      const int nb = tsel < NTL - 1 ? 16 : KP - 16 * (NTL - 1);
-      double *Tk = Hs + tile_id(tsel, tsel) * TSZ;
-      double x[16], dv[16], lr[16], ln[16];
-#pragma unroll
-      for (int r = 0; r < 16; r++) dv[r] = invd[16 * tsel + (r < nb ? r : 0)];
-      lr[0] = Tk[tsw(1, 0)];
-      x[0] = (0 >= c && 0 < nb) ? dv[0] : 0.0;
-#pragma unroll
-      for (int r = 1; r < 16; r++) {
-        // row r + 1 of L is requested while row r is in work (an LDS read issued inside the chain costs it a round trip)
-        if (r + 1 < 16) {
-#pragma unroll
-          for (int j = 0; j <= r; j++) ln[j] = Tk[tsw(r + 1, j)];
-        }
-        double acc = r == c ? 1.0 : 0.0, acc1 = 0.0;  // two accumulators: half the dependent chain
-#pragma unroll
-        for (int j = 0; j + 1 < r; j += 2) acc = fma(-lr[j], x[j], acc), acc1 = fma(-lr[j + 1], x[j + 1], acc1);  // x[j] = 0 above the diagonal
-        if (r & 1) acc = fma(-lr[r - 1], x[r - 1], acc);
-        x[r] = (r >= c && r < nb) ? (acc + acc1) * dv[r] : 0.0;
-        if (r + 1 < 16) {
-#pragma unroll
-          for (int j = 0; j <= r; j++) lr[j] = ln[j];
-        }
-      }
-      // the LDS operations of one wave complete in program order: every read above precedes these writes
-#pragma unroll
-      for (int r = 0; r < 16; r++) Tk[tsw(r, c)] = x[r];
-    }
-  }
-  __syncthreads();
-  auto tile_solve = [&](int blk) {  // 16 lanes of wave 0: y_blk = X^T z_blk, in place
-    const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16, c = lane & 15;
-    const double *Tk = Hs + tile_id(blk, blk) * TSZ;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r & 3] = fma(Tk[tsw(r, c)], r < nb ? yv[o + r] : 0.0, acc[r & 3]);
-    if (c < nb) yv[o + c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-  };
-  auto apply = [&](int blk, int j, int c) {  // z_j[c] -= (L_kj^T y_k)[c]
-    const int o = 16 * blk, nb = (KP - o) < 16 ? (KP - o) : 16;
-    const double *Tj = Hs + tile_id(blk, j) * TSZ;
-    double acc[4] = {yv[16 * j + c], 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-      if (r < nb) acc[r & 3] = fma(-Tj[tsw(r, c)], yv[o + r], acc[r & 3]);
-    yv[16 * j + c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-  };
-  if (wave == 0 && lane < 16) tile_solve(NTL - 1);
-  __syncthreads();
-  for (int blk = NTL - 1; blk >= 1; blk--) {
-    if (wave == 0) {  // look-ahead: the next block to be solved gets its update first
-      if (lane < 16) {
-        apply(blk, blk - 1, lane);
-        tile_solve(blk - 1);
-      }
-    } else {
-      const int j = (tid - 64) >> 4;
-      if (j < blk - 1) apply(blk, j, tid & 15);
-    }
-    __syncthreads();
-  }
+  tile_backsub<NTL, KP>(Hs, yv, invd, tid);
   STAMP(S, 6);
   {
     double f = 0.0;

@@ -35,6 +35,7 @@ constexpr ncclDataType_t ncclDouble = 8;
 #include "../../include/lfvio_debug.h"
 #include "kernels_marg.h"
 #include "kernels_solve.h"
+#include "kernels_solveb.h"
 #include "kernels_feat.h"
 #include "kernels_linw.h"
 #include "linb_plan.h"
@@ -130,6 +131,8 @@ struct SlotHostInfo {
   double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
   std::vector<int> perm;  // device order -> caller order
   bool linw_ok = false;    // the window carries a LinwPlan and its arrays (kernels_linw.h)
+  bool sb_chain = true;    // the prior carries no SpeedBias block but frame 0's: the reduced system has the block structure k_solve_block
+                           // eliminates along (kernels_solveb.h); otherwise the dense solve
   bool linb_ok = false;    // ... as a group list: a large single window (k_linb)
   int linb_ng = 0;
   bool uploaded = false;   // the slot's work-array pointers are on the device (until the next reserve())
@@ -204,6 +207,8 @@ struct lfvio_ctx {
   bool window_kernel = false;  // the loop of a window-resident batch as ONE launch (k_window).  Off: measured 120 000 solves/s against 143 000 for three launches per
                                // pass at 512 windows — the dense solve's 156 KB of LDS leave one workgroup per CU, so the sweep and the step phase lose the second
                                // resident window that hides their latency, and a third of the windows need every pass anyway.  LFVIO_WINDOW_KERNEL=1 / lfvio_debug_set_window
+  int block_solve = 0;   // 1: the reduced system is solved along its block structure (k_solve_block) where every slot of the launch has it; 0 (default:
+                         // measured slower): k_solve_dense
   int linw_mode = 1;     // 1: resident batches linearize with k_linw when every slot of the launch carries a plan; 0: never (k_lin roles + k_sum);
                          // 2: any launch of planned windows, however few (tests).  LFVIO_LINW / lfvio_debug_set_linw
   double fn_tol = 1e-6;  // function_tolerance of the windows uploaded from now on (debug: lfvio_debug_set_function_tolerance)
@@ -801,6 +806,10 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   if (pr) copy_prior(&info.in_prior, pr);
   info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   info.linw_ok = linw;
+  info.sb_chain = true;
+  if (pr)
+    for (int i = 0; i < pr->num_blocks; i++)
+      if (pr->blocks[i].kind == LFVIO_BLOCK_SPEEDBIAS && pr->blocks[i].frame != 0) info.sb_chain = false;
   info.linb_ok = linb, info.linb_ng = linb_ng;
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
@@ -948,15 +957,24 @@ void launch_linw(lfvio_ctx *c, int count, int mode_bits = MODE_SOLVE) {
   hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c), mode_bits);
 }
 
+// The reduced system of every slot of the launch has the chain structure (SlotHostInfo::sb_chain): solved block by block
+bool use_block_solve(const lfvio_ctx *c, int count) {
+  if (!c->block_solve) return false;
+  for (int s = 0; s < count; s++)
+    if (!c->info[s].sb_chain) return false;
+  return true;
+}
 // lw: the pass was linearized by k_linw — H_pp holds the visual terms of its camera part only, the solve adds the rest on load
 void launch_solve(lfvio_ctx *c, int count, bool lw = false) {
   const size_t st = c->L.total;
-  if (lw)
-    hipLaunchKernelGGL(k_solve_dense<true>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out,
-                       (long long)c->L.prior_A, (const int *)c->d_asm);
+  const long long xo = (long long)c->L.xch, io = (long long)c->L.imu_out, po = (long long)c->L.prior_A;
+  if (use_block_solve(c, count)) {
+    if (lw) hipLaunchKernelGGL(k_solve_block<true>, dim3(1, count), dim3(SOLVE_THREADS), SOLVEB_LDS, c->stream, c->d_base, st, xo, io, po);
+    else hipLaunchKernelGGL(k_solve_block<false>, dim3(1, count), dim3(SOLVE_THREADS), SOLVEB_LDS, c->stream, c->d_base, st, xo, io, po);
+  } else if (lw)
+    hipLaunchKernelGGL(k_solve_dense<true>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, xo, io, po, (const int *)c->d_asm);
   else
-    hipLaunchKernelGGL(k_solve_dense<false>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, (long long)c->L.xch, (long long)c->L.imu_out,
-                       (long long)c->L.prior_A, (const int *)nullptr);
+    hipLaunchKernelGGL(k_solve_dense<false>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, xo, io, po, (const int *)nullptr);
 }
 
 // A resident batch whose windows all carry a LinwPlan is linearized window by window (kernels_linw.h) instead of role by role.
@@ -1120,7 +1138,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipMalloc((void **)&c->d_pending, 256));
       HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
     }
-    const int lwk = use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0;
+    const int lwk = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0) + (use_block_solve(c, count) ? 1 << 30 : 0);
     if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk) {
       destroy_graph(c);
       c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk;
@@ -1219,7 +1237,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
   }
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
   if (c->use_graph) {
-    const int lwg = use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0;
+    const int lwg = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0) + (use_block_solve(c, count) ? 1 << 30 : 0);
     if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes || c->g_linw != lwg) {
       if (c->graph) (void)hipGraphExecDestroy(c->graph), c->graph = nullptr;
       hipGraph_t graph;
@@ -1433,10 +1451,13 @@ lfvio_ctx *lfvio_create(int device) {
   // kernels that need more than the default 64 KiB of LDS
   (void)hipFuncSetAttribute((const void *)k_solve_dense<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   (void)hipFuncSetAttribute((const void *)k_solve_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
+  (void)hipFuncSetAttribute((const void *)k_solve_block<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVEB_LDS);
+  (void)hipFuncSetAttribute((const void *)k_solve_block<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVEB_LDS);
   (void)hipFuncSetAttribute((const void *)k_linw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   (void)hipFuncSetAttribute((const void *)k_linb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   (void)hipFuncSetAttribute((const void *)k_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   if (const char *e = getenv("LFVIO_WINDOW_KERNEL")) c->window_kernel = e[0] == '1';
+  if (const char *e = getenv("LFVIO_BLOCK_SOLVE")) c->block_solve = e[0] != '0';
   if (const char *e = getenv("LFVIO_LINW")) c->linw_mode = std::max(0, std::min(2, atoi(e)));
   {  // static table of k_linw's phase 3: where each packed camera entry of H_pp (then each camera-side gradient entry) sits in the LDS accumulators
     std::vector<int> tab(SUM_VIS);
@@ -2065,6 +2086,7 @@ int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, dou
     launch_sum(c, count, g, MODE_SOLVE);
   }
   launch_solve(c, count, lw);
+  HIPCHK(c, hipGetLastError());  // (a launch that was refused — resources, LDS — must not pass as a result left by an earlier one)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const char *d = c->d_base + (size_t)slot * st;
   const int N = c->info[slot].N;
@@ -2088,6 +2110,18 @@ int lfvio_debug_upload_times(lfvio_ctx *c, double *out4) {
 int lfvio_debug_set_first_passes(lfvio_ctx *c, int n) {
   if (!c || n < 0) return LFVIO_ERR_ARG;
   c->fixed_passes = n;
+  return LFVIO_OK;
+}
+// 1: a launch over the resident slots [0, count) solves the reduced system block by block (k_solve_block); 0: k_solve_dense
+int lfvio_debug_solve_kernel(lfvio_ctx *c, int count) {
+  if (!c || !c->d_base || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
+  return use_block_solve(c, count) ? 1 : 0;
+}
+int lfvio_debug_set_block_solve(lfvio_ctx *c, int on) {
+  if (!c) return LFVIO_ERR_ARG;
+  if (int rc = join_inflight(c)) return rc;
+  c->block_solve = on != 0;
+  destroy_graph(c);  // the captured graphs hold the launch sequence
   return LFVIO_OK;
 }
 int lfvio_debug_set_window(lfvio_ctx *c, int on) {

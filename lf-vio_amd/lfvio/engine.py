@@ -55,6 +55,15 @@ class Engine:
         self.lib.lfvio_debug_set_window.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.lfvio_debug_set_window(self.ctx, int(on)), "set_window")
 
+    def set_block_solve(self, on):
+        """1: the reduced system solved along its block structure (k_solve_block); 0 (default): the dense 172 x 172 solve."""
+        self.lib.lfvio_debug_set_block_solve.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.lfvio_debug_set_block_solve(self.ctx, int(on)), "set_block_solve")
+
+    def solve_kernel(self, count):
+        self.lib.lfvio_debug_solve_kernel.argtypes = [C.c_void_p, C.c_int]
+        return int(self.lib.lfvio_debug_solve_kernel(self.ctx, count))
+
     def set_linw(self, mode):
         """How resident batches are linearized (include/lfvio_debug.h): 1 default, 0 never k_linw, 2 every launch of planned windows."""
         self.lib.lfvio_debug_set_linw.argtypes = [C.c_void_p, C.c_int]
