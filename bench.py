@@ -187,6 +187,90 @@ def two_stream_sweeps(device, wins512, flag, sweeps):
         g.close()
 
 
+def window100k_record(device, flag, calls=10):
+    """BASELINE configs[3]'s window on ONE GPU, unsharded: ms per optimization() and the roofline of its sweep kernel (k_linb), a few
+    seconds of wall time.  Resident, synchronous calls like the headline."""
+    from lfvio import synth
+    from lfvio.engine import Engine
+
+    w = synth.make_window(0, 100000)
+    e = Engine(device)
+    try:
+        e.batch_reserve(1, w.N, w.M)
+        e.batch_upload(0, w)
+        for _ in range(3):
+            e.batch_optimize(1, flag, sync=True)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            e.batch_optimize(1, flag, sync=True)
+        ms = (time.perf_counter() - t0) / calls * 1e3
+        sol, prior = e.batch_download(0, w.N)
+        sweep = e.sweep_kernel(1)
+        name = {0: "k_lin<7>", 1: "k_linw", 2: "k_linb"}[sweep]
+        lin_ms = e.time_kernel({0: 0, 1: 12, 2: 15}[sweep], 1, 20)
+        byts, flops = algorithmic_bytes(w.N, w.M), 2.0e3 * (w.M - w.N) + 1.6e3 * w.N
+        traffic, src = pmc_traffic("window100k", [name])
+        kern = dict(k_solve_us=e.time_kernel(3, 1, 5) * 1e3)
+        if sweep == 2:
+            kern.update(k_sumb_us=e.time_kernel(16, 1, 20) * 1e3, k_backsub_wt_us=e.time_kernel(17, 1, 20) * 1e3)
+        return dict(value=1e3 / ms, unit="solves/s", ms_per_step=ms, landmarks=int(w.N), observations=int(w.M), calls=calls,
+                    iterations_run=int(sol.c.num_iterations - 1), passes_per_step=e.last_passes(), result_valid=bool(prior.valid == 1 and np.isfinite(sol.c.final_cost)),
+                    description="10-keyframe / 100 000-landmark window (no prior), whole window on one GPU, resident; solve + gauge fix + MARGIN_OLD",
+                    roofline=dict(bound="fp64", kernel=name, achieved=flops / (lin_ms * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                                  frac=flops / (lin_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, fp64_frac=flops / (lin_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                  hbm_gbs=byts / (lin_ms * 1e-3) / 1e9, hbm_frac=byts / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, avg_launch_us=lin_ms * 1e3,
+                                  flops_per_launch=flops, algorithmic_bytes_per_launch=byts, traffic=traffic, traffic_source=src),
+                    kernels_us=kern)
+    finally:
+        e.close()
+
+
+def stream_record(device, flag, n_stream=33):
+    """The headline shape as a drop-in sees it: consecutive DISTINCT windows of one estimator stream, each uploaded, optimized and
+    downloaded (PCIe inside) — mean / p95 per step.  The chain is generated through the product path itself."""
+    from lfvio import abi, synth
+    from lfvio.engine import Engine
+
+    e = Engine(device)
+    try:
+        scene = synth.Scene(1000, n_total=11 + n_stream)
+        rng = np.random.default_rng([1000, 104729])
+        wins, prior, st = [], None, None
+        for k in range(n_stream):
+            kw = {} if k == 0 else dict(prior=prior, init_state=st)
+            w = synth.make_window(1000, 300, kf0=k, scene=scene, **kw)
+            sol, prior = e.optimize(w, flag)
+            wins.append(w)
+            st = synth.continue_state(scene, k + 1, sol.pose, sol.speed_bias, sol.ex_pose, sol.td, rng)
+        wins = wins[1:]
+        e.batch_reserve(1, max(w.N for w in wins), max(w.M for w in wins))
+        marsh = [w.c() for w in wins]
+        outb = [(abi.Solution(w.N), abi.Prior()) for w in wins]
+
+        def one(k):
+            e.batch_upload(0, wins[k], marsh[k])
+            e.batch_optimize(1, flag, sync=True)
+            e.batch_download(0, wins[k].N, out=outb[k])
+
+        for k in range(len(wins)):
+            one(k)
+        laps, hist = [], {}
+        for rep in range(3):
+            for k in range(len(wins)):
+                t = time.perf_counter()
+                one(k)
+                laps.append(time.perf_counter() - t)
+                p_ = e.last_passes()
+                hist[p_] = hist.get(p_, 0) + 1
+        l = np.array(laps) * 1e3
+        return dict(value=1e3 / float(l.mean()), unit="solves/s", mean_ms=float(l.mean()), p50_ms=float(np.median(l)), p95_ms=float(np.percentile(l, 95)),
+                    windows=len(wins), steps=len(laps), passes_histogram={str(k): v for k, v in sorted(hist.items())},
+                    description=f"{len(wins)} consecutive distinct 10-keyframe / 300-landmark windows of one estimator stream; per step: upload (91 KB), "
+                                "optimization(), download of solution and prior — PCIe inside the timed region, never `value`")
+    finally:
+        e.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -721,6 +805,17 @@ def main():
                 e2.close()
         except Exception as ex:  # noqa: BLE001  (a secondary figure: a failure here leaves the headline as it is)
             out["batch512"] = dict(error=repr(ex))
+    if world == 1 and workload == "window300" and not args.no_secondary:
+        # (c) the large single window of configs[3] on one GPU and (d) the PCIe-inclusive stream, next to batch512: secondary figures,
+        #     a failure leaves the headline as it is
+        try:
+            out["window100k"] = window100k_record(local_rank, flag)
+        except Exception as ex:  # noqa: BLE001
+            out["window100k"] = dict(error=repr(ex))
+        try:
+            out["stream"] = stream_record(local_rank, flag)
+        except Exception as ex:  # noqa: BLE001
+            out["stream"] = dict(error=repr(ex))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wins[0], flag)
     elif rank == 0:

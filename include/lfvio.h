@@ -364,6 +364,8 @@ int lfvio_group_download(lfvio_group *g, LfvioSolution *sol, LfvioPrior *prior);
 int lfvio_group_range(const lfvio_group *g, int rank, int *lm_begin, int *lm_end); /* landmark range of a rank */
 int lfvio_group_last_passes(const lfvio_group *g);      /* passes / collectives of the last lfvio_group_optimize() */
 int lfvio_group_last_collectives(const lfvio_group *g);
+int lfvio_group_payload_doubles(void);                  /* doubles per rank in the all-reduce of a pass's reduced system: the camera part
+                                                          * of H_pp and g_p, the Schur sums, 16 scalars (53 KB; the speed / bias rows do not travel) */
 /* independent resident windows split over the devices of this process (BASELINE "512 independent windows"): slot s
  * lives on local context s % lfvio_group_local(); no data-path collective */
 int lfvio_group_batch_reserve(lfvio_group *g, int batch, int max_landmarks, int max_observations);

@@ -76,6 +76,11 @@ int lfvio_debug_last_passes(lfvio_ctx *ctx);
 /* out3 = {passes, iterations} of the last synchronous call on one window and the number of speculative candidates per pass the next one
  * will prepare (3, or 4 where a pass of the previous call covered two iterations or more) */
 int lfvio_debug_speculation(lfvio_ctx *ctx, int *out3);
+/* tests: the local context `local_ctx` of the group reports a failure when it enqueues phase `phase` (0 the sweep, 1 solve + back-
+ * substitution, 2 step + candidate cost, 3 bookkeeping) of pass `pass` of the next lfvio_group_optimize(); local_ctx < 0 clears it.
+ * The call must still issue every collective of its sequence (the peers of a real group are waiting in them), end the loops of all
+ * ranks in the same pass and return the error. */
+int lfvio_debug_group_inject_failure(lfvio_group *g, int local_ctx, int pass, int phase);
 #ifdef __cplusplus
 }
 #endif

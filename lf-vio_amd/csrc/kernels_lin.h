@@ -844,6 +844,13 @@ DEV int imu_local(int c, int f) {
   return -1;
 }
 DEV int col_frame(int c) { return c < 66 ? c / 6 : (c < KC ? -10 : (c - KC) / 9); }
+// Does this rank add the pose-side factors (IMU, prior) to an entry of H_pp / g_p whose (larger) tangent index is r?
+//   Slot::pose_side 1  the pose-side rank of a landmark-sharded window (and every unsharded window): everywhere;
+//   Slot::pose_side 2  the other ranks of an lfvio_group: they evaluate the same factors — replicated, a few microseconds — and add
+//                      them OUTSIDE the camera part only (rows >= KC: speed / bias), which is then complete on every rank and
+//                      stays out of the all-reduce (54 KB instead of 151: group.inc); the camera part gets them once, on rank 0;
+//   Slot::pose_side 0  a rank of a caller that all-reduces the whole exchange buffer itself (lfvio_shard_*): nowhere.
+DEV bool pose_terms_here(const Slot *S, int r) { return !S->sharded || S->pose_side == 1 || (S->pose_side == 2 && r >= KC); }
 
 DEV bool col_active(const Slot *S, int c, int mode) {
   if (mode >= MODE_MARG) return true;
@@ -1006,7 +1013,8 @@ DEV void sum_hpp_entry(Slot *S, const SumArgs &o, int mode_bits, int e) {
   if (act_r && act_c) {
     // ---- round 2
     if (is_marg(mode)) end = marg_chunks > 0 ? endm : beg;
-    const bool use_prior = packed && prior_valid && (!sharded || pose_side) && pr >= 0 && pc >= 0;
+    const bool pterms = !sharded || pose_side == 1 || (pose_side == 2 && r >= KC);  // pose_terms_here(S, r)
+    const bool use_prior = packed && prior_valid && pterms && pr >= 0 && pc >= 0;
     double pa = 0.0;
     if (use_prior) pa = blob_at<double>(S, o.prior_A)[pr * prior_n + pc];
     if (r < KC) {
@@ -1023,7 +1031,7 @@ DEV void sum_hpp_entry(Slot *S, const SumArgs &o, int mode_bits, int e) {
       val += (s0 + s1) + (s2 + s3);
     }
     if (packed) {
-      if (f0 >= 0) {
+      if (f0 >= 0 && pterms) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
           const int f = f0 - 1 + u;
@@ -1032,14 +1040,14 @@ DEV void sum_hpp_entry(Slot *S, const SumArgs &o, int mode_bits, int e) {
       }
       if (use_prior) val += pa;  // prior: A' = J0^T J0
     } else {
-      if (f0 >= 0) {
+      if (f0 >= 0 && pterms) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
           const int f = f0 - 1 + u;
           if (f >= 0 && f < LFVIO_WINDOW_SIZE && imu_local(r, f) >= 0) val += imu_v[u];
         }
       }
-      val += pg;
+      if (pterms) val += pg;
     }
   }
   if (packed) S->Hpp[e] = val;
@@ -1058,12 +1066,14 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
     // for bit.  (Round 2 had a kernel of its own for this, k_xstage.)
     const TRFlags f0 = tr_flags(&S->tr);
     if (f0.done | (!f0.do_lin & !f0.do_schur)) {
-      if (!S->pose_side) {
+      if (S->pose_side != 1) {
+        // (a rank of an lfvio_group, pose_side 2: only the camera part travels — its speed / bias rows are its own complete copy)
+        const bool cam_only = S->pose_side == 2;
         const int e = b * 256 + tid;  // blocks: H_pp | g_p entries, then the Schur sums, then the scalars
         double *x = S->xch;
         if (b < HPP_BLOCKS) {
-          if (e < PACKED) x[XOFF_H + e] = 0.0;
-          else if (e < PACKED + KP) x[XOFF_G + (e - PACKED)] = 0.0;
+          if (e < (cam_only ? SUM_VIS_PACKED : PACKED)) x[XOFF_H + e] = 0.0;
+          else if (e >= PACKED && e < PACKED + (cam_only ? KC : KP)) x[XOFF_G + (e - PACKED)] = 0.0;
         } else if (b < HPP_BLOCKS + SCHUR_LEN / 256) {
           x[XOFF_S + (e - HPP_BLOCKS * 256)] = 0.0;
         } else if (tid < 16) {
@@ -1123,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
     __syncthreads();
     if (tid == 0) {
       double cost = S->lm_sum[0];
-      if (S->pose_side) {
+      if (S->pose_side == 1) {
         cost += S->prior_g[KP];
         for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += S->imu_out[(size_t)f * IMU_OUT + 930];
       }

@@ -1095,6 +1095,7 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
     const bool ex_off = !S->est_ex, td_off = !S->est_td;
     if ((ex_off && ((r >= off_ex() && r < off_ex() + 6) || (c >= off_ex() && c < off_ex() + 6))) || (td_off && (r == off_td() || c == off_td()))) return 0.0;
     double val = 0.0;
+    if (!pose_terms_here(S, r)) return 0.0;  // (a landmark-sharded window: the camera part gets the pose side on ONE rank)
     const int f0 = col_frame(r);
     if (f0 >= 0) {
 #pragma unroll
@@ -1106,7 +1107,7 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
         }
       }
     }
-    if (S->prior_valid && (!S->sharded || S->pose_side)) {  // (a landmark-sharded window: the pose side on ONE rank)
+    if (S->prior_valid) {
       const int pr = S->prior_inv[r], pc = S->prior_inv[c];
       if (pr >= 0 && pc >= 0) val += S->prior_A[pr * S->prior_n + pc];
     }
@@ -1150,7 +1151,8 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
     const int r = tid;
     double val = r < KC ? gv[r] : 0.0;
     const int f0 = col_frame(r);
-    if (f0 >= 0) {
+    const bool pterms = pose_terms_here(S, r);
+    if (f0 >= 0 && pterms) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int f = f0 - 1 + u;
@@ -1160,7 +1162,7 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
         }
       }
     }
-    val += S->prior_g[r];
+    if (pterms) val += S->prior_g[r];
     const bool act_r = !((!est_ex && r >= off_ex() && r < off_ex() + 6) || (!est_td && r == off_td()));
     lw_at<double>(S, A.gp)[r] = act_r ? val : 0.0;
   }
@@ -1174,7 +1176,7 @@ __global__ __launch_bounds__(LINB_SUM_THREADS) void k_sumb(char *base, size_t st
     __syncthreads();
     if (tid == 0) {
       double cost = gv[KC];
-      if (S->pose_side) {
+      if (S->pose_side == 1) {
         cost += S->prior_g[KP];
         for (int f = 0; f < LFVIO_WINDOW_SIZE; f++) cost += imu_out[(size_t)f * IMU_OUT + 930];
       }

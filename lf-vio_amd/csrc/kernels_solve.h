@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int wh
 #pragma unroll
         for (int q = 0; q < 5; q++) v[q] += t[u][q];
     }
-    if (which == 3 && S->pose_side && tid < 11) v[0] += S->pose_cost[tid];
+    if (which == 3 && S->pose_side == 1 && tid < 11) v[0] += S->pose_cost[tid];
   }
 #pragma unroll
   for (int q = 0; q < 5; q++) v[q] = wave_sum(v[q]);
@@ -1539,6 +1539,12 @@ DEV void decide_body(Slot *S) {
   const int sharded = S->sharded, max_iter = S->max_iter, nLmBlocks = S->nLmBlocks, nlm = S->N;
   __shared__ int acc_sh;
   if (t.done) return;
+  if (sharded && S->xch[XOFF_C + XS_ERR] != 0.0) {
+    // a peer of the group failed and said so in the collective behind this pass (group.inc): every rank ends the loop here, in
+    // the same pass, instead of waiting in a collective the failed rank would never enter
+    if (lane == 0) tr->done = 1, tr->error = LFVIO_ERR_DEVICE;
+    return;
+  }
   if (lane < 64) {
     const int K = decide_candidates(t);
     DecideSums sm;

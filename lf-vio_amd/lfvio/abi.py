@@ -348,7 +348,7 @@ HIP_SYMBOLS = [
     "lfvio_group_create", "lfvio_group_unique_id", "lfvio_group_create_rank", "lfvio_group_create_local", "lfvio_group_destroy",
     "lfvio_group_last_error", "lfvio_group_size", "lfvio_group_local", "lfvio_group_rank", "lfvio_group_ctx", "lfvio_group_backend",
     "lfvio_group_solve", "lfvio_group_upload", "lfvio_group_optimize", "lfvio_group_download", "lfvio_group_range",
-    "lfvio_group_last_passes", "lfvio_group_last_collectives", "lfvio_group_batch_reserve", "lfvio_group_batch_upload",
+    "lfvio_group_last_passes", "lfvio_group_last_collectives", "lfvio_group_payload_doubles", "lfvio_group_batch_reserve", "lfvio_group_batch_upload",
     "lfvio_group_batch_optimize", "lfvio_group_batch_download",
 ]
 

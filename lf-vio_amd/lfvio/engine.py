@@ -356,6 +356,11 @@ class Group:
     def optimize(self, flag):
         self._check(self.lib.lfvio_group_optimize(self.g, -1 if flag is None else int(flag)), "lfvio_group_optimize")
 
+    def inject_failure(self, local_ctx, pass_=0, phase=0):
+        """tests: local context `local_ctx` fails when it enqueues `phase` of pass `pass_` of the next optimize(); local_ctx < 0 clears"""
+        self.lib.lfvio_debug_group_inject_failure.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self._check(self.lib.lfvio_debug_group_inject_failure(self.g, int(local_ctx), int(pass_), int(phase)), "inject_failure")
+
     def download(self, want_prior=True):
         sol = abi.Solution(self._win.N)
         prior = abi.Prior() if want_prior else None

@@ -168,3 +168,49 @@ def test_group_create_fails_loudly_without_gpu():
     for kw in (dict(mask=1), dict(local_shards=2)):
         with pytest.raises(RuntimeError):
             Group(**kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad,pass_,phase", [(1, 0, 0), (2, 1, 1), (0, 2, 2), (1, 1, 3)])
+def test_a_rank_that_fails_still_issues_its_collectives_and_every_rank_ends_in_the_same_pass(oracle, bad, pass_, phase):
+    """A local failure used to return out of the pass at once (group.inc GCTX): in a group of processes the peers would wait for
+    ever in the collectives the failed rank never entered.  Now the failed context enqueues
+    nothing more, but the call issues EVERY collective of its sequence with an error word in that rank's scalars, all ranks read
+    it behind the pass's last reduction (k_decide) and end their loops together, and the first error is returned.
+    Here: three ranks on one GPU, a failure injected at one of them in each phase of a pass.  The collectives that went out are
+    exactly those of the passes up to the one in which the flag is read plus the one in flight behind it — three per pass, no
+    more, no fewer — and the group works again afterwards, bit for bit."""
+    from lfvio.engine import Group
+
+    w = synth.make_window_with_prior(4, 300, lambda x, f: oracle.optimize(x, f))[0]
+    g = Group(local_shards=3)
+    g.upload(w)
+    g.optimize(abi.MARGIN_OLD)
+    good_sol, good_prior = g.download()
+    passes_ok, coll_ok = g.last_passes(), g.last_collectives()
+    assert coll_ok == 3 * passes_ok + 1
+    g.inject_failure(bad, pass_, phase)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        g.optimize(abi.MARGIN_OLD)
+    # the flag enters the reductions of pass `pass_` (a failure in phase 3: of the next pass), is read by that pass's k_decide,
+    # and one more pass is in flight behind it on every rank
+    last = pass_ + (1 if phase == 3 else 0) + 1
+    assert g.last_passes() == last + 1
+    assert g.last_collectives() == 3 * (last + 1)  # every collective of every issued pass, none of the marginalization
+    g.inject_failure(-1)
+    g.optimize(abi.MARGIN_OLD)
+    sol, prior = g.download()
+    assert g.last_passes() == passes_ok and g.last_collectives() == coll_ok
+    assert np.array_equal(sol.pose, good_sol.pose) and np.array_equal(sol.lam, good_sol.lam) and np.array_equal(prior.J(), good_prior.J())
+    g.close()
+
+
+@pytest.mark.gpu
+def test_the_collective_carries_only_what_shards():
+    """The all-reduce of a pass is the camera part of H_pp (2 701 packed entries), the camera part of g_p (73), the Schur sums and the
+    16 scalars: 53 KB, not the 151 KB exchange buffer — the speed / bias rows are evaluated on every rank (include/lfvio.h)."""
+    from lfvio import abi as _abi
+
+    lib = _abi.load_hip_library()
+    assert lib.lfvio_group_payload_doubles() == 2701 + 73 + 15 * 256 + 16
+    assert lib.lfvio_shard_exchange_len() > 3 * lib.lfvio_group_payload_doubles() - 3 * 2701
