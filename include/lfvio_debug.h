@@ -47,6 +47,10 @@ int lfvio_debug_set_first_passes(lfvio_ctx *ctx, int n);
  * alone).  0 makes the loop run to its iteration cap or another criterion: the diagnostic of tests/tools/fuzz_parity.py, which
  * asks whether two solvers that disagree in the 6th digit of an inverse depth stopped early in a flat valley. */
 int lfvio_debug_set_function_tolerance(lfvio_ctx *ctx, double tol);
+/* Solver::Options::initial_trust_region_radius of the windows uploaded from now on (Ceres' default 1e4, which estimator.cpp:810-822
+ * leaves alone; <= 0 restores it).  A small radius takes the dogleg through its Cauchy-point and interpolation cases from the first
+ * iteration on — with the default they are only reached after a dozen rejected steps. */
+int lfvio_debug_set_initial_radius(lfvio_ctx *ctx, double r);
 /* Where the strip sweep (kernels_linw.h) replaces the role-by-role one (k_lin + k_sum): 1 (default) for a resident batch whose
  * windows all carry a plan (k_linw: one workgroup per window, no partial sums through HBM) and for a single window — or a rank's
  * share of a sharded one — of at least 40 960 landmarks (k_linb + k_sumb: one workgroup per group of strips); 0 never; 2 for every

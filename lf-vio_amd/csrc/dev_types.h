@@ -207,6 +207,7 @@ struct Slot {
   long long mail;
   TRDecision dec;
   double g[3], tr_over_row, half_row, sqrt_info;
+  double init_radius;  // Solver::Options::initial_trust_region_radius: Ceres' default 1e4 unless lfvio_debug_set_initial_radius() changed it
   double fn_tol;  // Solver::Options::function_tolerance of this window: Ceres' default 1e-6 unless lfvio_debug_set_function_tolerance() changed it
   FrameState x0;
   LfvioPreintegration imu[LFVIO_WINDOW_SIZE];

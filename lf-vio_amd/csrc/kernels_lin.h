@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     for (int k = tid; k < (int)(sizeof(FrameState) / 8); k += 256) dst[k] = src[k];
     if (tid == 0) {
       TRState *t = &S->tr;
-      t->radius = 1e4;
+      t->radius = S->init_radius;
       t->function_tolerance = S->fn_tol;
       t->mu = 1e-8;
       t->x_cost = t->cand_cost = t->model_cost_change = t->dogleg_step_norm = t->alpha = 0.0;

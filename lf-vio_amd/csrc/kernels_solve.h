@@ -1112,9 +1112,15 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
         tr->grad_gn_total = grad_gn_total;
       }
     }
+    // A rank of an lfvio_group (Slot::sharded 2) does not know the landmark part of ||gauss_newton||^2 here — it travels with the
+    // candidate's cost, in ONE all-reduce behind this kernel: the candidate of a pass with a fresh solve is the Gauss-Newton
+    // step itself (what the dogleg takes whenever that step fits the radius), and k_decide, which sees the reduced norms, either
+    // confirms it or voids the pass (decide_body); a pass without a fresh solve has the totals in the header and takes them.
+    const bool spec_gn = sharded == 2 && do_schur;
     for (int z = z_lo; z < z_hi; z++) {
       double cg, cn, sn;
       dogleg_coeffs(grad_sq_total, gn_sq_total, grad_gn_total, alpha, ldexp(radius, -z), cg, cn, sn);
+      if (spec_gn) cg = 0.0, cn = 1.0, sn = 0.0;
       if (z == 0) tr->cg = cg, tr->cn = cn, tr->dogleg_step_norm = sn;
       else tr->cgE[z - 1] = cg, tr->cnE[z - 1] = cn, tr->snE[z - 1] = sn;
       sh2[2 * z] = cg, sh2[2 * z + 1] = cn;
@@ -1440,7 +1446,8 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_step(char *base, size
 // k_backsub) or phase C (which = 3: after k_cost) into the exchange scalars, everything else zeroed so that
 // the caller can sum-all-reduce the 16-scalar tail blindly.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int which) {
+__global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int which_bits) {
+  const int which = which_bits & 7;  // bit 3: the scalars of the other phase are in the tail already (one all-reduce for both: group.inc) — nothing is zeroed
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   if (!S->sharded) return;
@@ -1475,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int wh
 #pragma unroll
     for (int q = 0; q < 5; q++) red[wv][q] = v[q];
   }
-  if (tid < 16) sc[tid] = 0.0;
+  if (tid < 16 && !(which_bits & 8)) sc[tid] = 0.0;
   __syncthreads();
   if (tid == 0) {
     double s5[5];
@@ -1544,6 +1551,25 @@ DEV void decide_body(Slot *S) {
     // the same pass, instead of waiting in a collective the failed rank would never enter
     if (lane == 0) tr->done = 1, tr->error = LFVIO_ERR_DEVICE;
     return;
+  }
+  if (sharded == 2 && t.do_schur && !t.chol_fail) {
+    // The candidate of this pass was the Gauss-Newton step, formed before its norm was known (dogleg_body).  With the reduced
+    // landmark parts in: the dogleg's own case analysis — if it says "Gauss-Newton step" (it fits the radius), the candidate IS
+    // the dogleg step and the pass is decided as always; if not, the pass is void: the totals go into the header, nothing is
+    // re-linearized or solved, and the next pass forms the interpolated step from them (the path of a rejected step).
+    const double *sc = S->xch + XOFF_C;
+    const double gn_sq = t.q[Q_GN_SQ] + sc[XS_GN2], ggn = t.q[Q_GRAD_GN] + sc[XS_GGN];
+    double cg, cn, sn;
+    dogleg_coeffs(t.grad_sq_total, gn_sq, ggn, t.alpha, t.radius, cg, cn, sn);
+    t.gn_sq_total = gn_sq, t.grad_gn_total = ggn;
+    if (lane == 0) tr->gn_sq_total = gn_sq, tr->grad_gn_total = ggn;
+    if (cg == 0.0 && cn == 1.0) {
+      t.cg = 0.0, t.cn = 1.0, t.dogleg_step_norm = sn;
+      if (lane == 0) tr->dogleg_step_norm = sn;
+    } else {
+      if (lane == 0) tr->do_lin = 0, tr->do_schur = 0;
+      return;
+    }
   }
   if (lane < 64) {
     const int K = decide_candidates(t);

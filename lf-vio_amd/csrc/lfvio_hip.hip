@@ -207,10 +207,12 @@ struct lfvio_ctx {
   bool window_kernel = false;  // the loop of a window-resident batch as ONE launch (k_window).  Off: measured 120 000 solves/s against 143 000 for three launches per
                                // pass at 512 windows — the dense solve's 156 KB of LDS leave one workgroup per CU, so the sweep and the step phase lose the second
                                // resident window that hides their latency, and a third of the windows need every pass anyway.  LFVIO_WINDOW_KERNEL=1 / lfvio_debug_set_window
+  int shard_kmax0 = -1;  // lfvio_shard_begin: the longest track among the WHOLE window's frame-0 landmarks (0: none), for the marginalization's plan
   int block_solve = 0;   // 1: the reduced system is solved along its block structure (k_solve_block) where every slot of the launch has it; 0 (default:
                          // measured slower): k_solve_dense
   int linw_mode = 1;     // 1: resident batches linearize with k_linw when every slot of the launch carries a plan; 0: never (k_lin roles + k_sum);
                          // 2: any launch of planned windows, however few (tests).  LFVIO_LINW / lfvio_debug_set_linw
+  double init_radius = 1e4;  // initial_trust_region_radius of the windows uploaded from now on (debug: lfvio_debug_set_initial_radius)
   double fn_tol = 1e-6;  // function_tolerance of the windows uploaded from now on (debug: lfvio_debug_set_function_tolerance)
   bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
   // landmark-sharded mode (multi-GPU)
@@ -325,7 +327,9 @@ inline int tangent_off(int kind, int frame) {
 // Structure of MarginalizationInfo for this window (estimator.cpp:833-1005): which blocks
 // take part, which are dropped, canonical column order (dropped first, then poses / speed-bias
 // by frame, ex pose, td) and the addr_shift of the kept blocks.
-void plan_marg(const LfvioWindow *w, const LfvioPrior *pr, int flag, int N0, int kmax0, int nChunks0, bool imu0_ok, MargPlan *mp) {
+// N0 / nChunks0: what THIS slot sweeps; any0 / kmax0: whether the WINDOW has landmarks anchored at frame 0 and their longest track —
+// the same thing unless the slot holds a rank's share of a landmark-sharded window, whose block structure is the whole window's
+void plan_marg(const LfvioWindow *w, const LfvioPrior *pr, int flag, int N0, bool any0, int kmax0, int nChunks0, bool imu0_ok, MargPlan *mp) {
   std::memset(mp, 0, sizeof *mp);
   for (int c = 0; c < KP; c++) mp->col[c] = -1;
   bool present[4][LFVIO_NUM_FRAMES] = {}, dropped[4][LFVIO_NUM_FRAMES] = {};
@@ -344,7 +348,7 @@ void plan_marg(const LfvioWindow *w, const LfvioPrior *pr, int flag, int N0, int
       touch(LFVIO_BLOCK_POSE, 0, true), touch(LFVIO_BLOCK_SPEEDBIAS, 0, true);
       touch(LFVIO_BLOCK_POSE, 1, false), touch(LFVIO_BLOCK_SPEEDBIAS, 1, false);
     }
-    if (N0 > 0) {
+    if (any0) {
       touch(LFVIO_BLOCK_POSE, 0, true);
       for (int j = 1; j < kmax0; j++) touch(LFVIO_BLOCK_POSE, j, false);
       touch(LFVIO_BLOCK_EX_POSE, 0, false);
@@ -497,6 +501,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->half_row = w->row / 2;
   S->sqrt_info = w->sqrt_info;
   S->fn_tol = c->fn_tol;
+  S->init_radius = c->init_radius;
   std::memcpy(S->x0.pose, w->para_pose, sizeof S->x0.pose);
   std::memcpy(S->x0.sb, w->para_speed_bias, sizeof S->x0.sb);
   std::memcpy(S->x0.ex, w->para_ex_pose, sizeof S->x0.ex);
@@ -775,8 +780,12 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     std::memcpy(h + L.prior_J, pr->linearized_jacobians, sizeof(double) * pr->n * pr->n);
     std::memcpy(h + L.prior_r, pr->linearized_residuals, sizeof(double) * pr->n);
   }
-  plan_marg(w, pr, LFVIO_MARGIN_OLD, N0, kmax0, S->pair_chunk0[11], true, &S->marg[0]);
-  plan_marg(w, pr, LFVIO_MARGIN_SECOND_NEW, 0, 0, 0, true, &S->marg[1]);
+  {
+    // (a rank's share of a sharded window: the other ranks' frame-0 landmarks shape the prior's blocks too — lfvio_shard_begin)
+    const bool whole = sharded && c->shard_kmax0 >= 0;
+    plan_marg(w, pr, LFVIO_MARGIN_OLD, N0, whole ? c->shard_kmax0 > 0 : N0 > 0, whole ? c->shard_kmax0 : kmax0, S->pair_chunk0[11], true, &S->marg[0]);
+  }
+  plan_marg(w, pr, LFVIO_MARGIN_SECOND_NEW, 0, false, 0, 0, true, &S->marg[1]);
   for (int f = 0; f < 2; f++)
     if (S->marg[f].valid && (S->marg[f].n > 76 || S->marg[f].m15 + S->marg[f].n > 92)) {
       // k_marg_solve keeps the dense system in LDS: sized for what the reference's own marginalization produces
@@ -2141,6 +2150,11 @@ int lfvio_debug_set_linw(lfvio_ctx *c, int mode) {
 int lfvio_debug_set_function_tolerance(lfvio_ctx *c, double tol) {
   if (!c || !(tol >= 0.0)) return LFVIO_ERR_ARG;
   c->fn_tol = tol;
+  return LFVIO_OK;
+}
+int lfvio_debug_set_initial_radius(lfvio_ctx *c, double r) {
+  if (!c) return LFVIO_ERR_ARG;
+  c->init_radius = r > 0.0 ? r : 1e4;
   return LFVIO_OK;
 }
 int lfvio_debug_last_chunks(lfvio_ctx *c) { return c ? c->stat_chunks : -1; }

@@ -64,6 +64,10 @@ class Engine:
         self.lib.lfvio_debug_solve_kernel.argtypes = [C.c_void_p, C.c_int]
         return int(self.lib.lfvio_debug_solve_kernel(self.ctx, count))
 
+    def set_initial_radius(self, r):
+        self.lib.lfvio_debug_set_initial_radius.argtypes = [C.c_void_p, C.c_double]
+        self._check(self.lib.lfvio_debug_set_initial_radius(self.ctx, float(r)), "set_initial_radius")
+
     def set_linw(self, mode):
         """How resident batches are linearized (include/lfvio_debug.h): 1 default, 0 never k_linw, 2 every launch of planned windows."""
         self.lib.lfvio_debug_set_linw.argtypes = [C.c_void_p, C.c_int]
@@ -355,6 +359,12 @@ class Group:
 
     def optimize(self, flag):
         self._check(self.lib.lfvio_group_optimize(self.g, -1 if flag is None else int(flag)), "lfvio_group_optimize")
+
+    def set_initial_radius(self, r):
+        self.lib.lfvio_debug_set_initial_radius.argtypes = [C.c_void_p, C.c_double]
+        for i in range(self.local):
+            rc = self.lib.lfvio_debug_set_initial_radius(self.ctx(i), float(r))
+            assert rc == 0, rc
 
     def inject_failure(self, local_ctx, pass_=0, phase=0):
         """tests: local context `local_ctx` fails when it enqueues `phase` of pass `pass_` of the next optimize(); local_ctx < 0 clears"""

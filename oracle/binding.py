@@ -195,6 +195,14 @@ def set_function_tolerance(tol):
     return L.oracle_set_function_tolerance(float(tol))
 
 
+def set_initial_radius(r):
+    """Diagnostic knob: Solver::Options::initial_trust_region_radius (default 1e4; <= 0 restores it)."""
+    L = lib()
+    L.oracle_set_initial_radius.argtypes = [C.c_double]
+    L.oracle_set_initial_radius.restype = C.c_double
+    return L.oracle_set_initial_radius(float(r))
+
+
 def set_marg_threads(n):
     """4: marginalize() builds A, b on four threads like the reference's ThreadsConstructA (bit-identical sums); 1: serial."""
     L = lib()

@@ -160,6 +160,10 @@ double oracle_set_function_tolerance(double tol) {  // diagnostic (tests/tools/f
   g_function_tolerance = tol >= 0.0 ? tol : 1e-6;
   return g_function_tolerance;
 }
+double oracle_set_initial_radius(double r) {  // diagnostic: <= 0 restores Ceres' default 1e4
+  g_initial_radius = r > 0.0 ? r : 1e4;
+  return g_initial_radius;
+}
 int oracle_set_marg_threads(int n) {
   g_marg_threads = n >= 4 ? 4 : 1;
   return g_marg_threads;

@@ -27,6 +27,7 @@
 namespace orc {
 
 double g_function_tolerance = 1e-6;
+double g_initial_radius = 1e4;
 
 // ---------------------------------------------------------------------------
 // Problem assembly (estimator.cpp:678-772)
@@ -265,7 +266,7 @@ namespace {
 
 struct Dogleg {
   // constants: DoglegStrategy ctor + Solver::Options defaults
-  double radius = 1e4;  // initial_trust_region_radius
+  double radius = g_initial_radius;  // initial_trust_region_radius: 1e4 (Ceres 1.12 default; estimator.cpp:810-822 leaves it alone) unless the diagnostic knob is set
   const double max_radius = 1e16;
   const double min_diagonal = 1e-6, max_diagonal = 1e32;  // min/max_lm_diagonal
   double mu = 1e-8;

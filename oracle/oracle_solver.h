@@ -68,6 +68,8 @@ int marginalize(const LfvioWindow &w, int flag, LfvioPrior *out, std::vector<dou
 void triangulate(const LfvioTriangulateIn &in, double *depth);
 void shift_depth(int n, const double *uv_i, const double *marg_R, const double *marg_P, const double *new_R, const double *new_P,
                  double init_depth, double *depth);
+extern double g_initial_radius;      // Solver::Options::initial_trust_region_radius: 1e4; diagnostic knob oracle_set_initial_radius (a small one takes the
+                                     // dogleg through its Cauchy-point and interpolation cases, which the default radius seldom reaches)
 extern double g_function_tolerance;  // Solver::Options::function_tolerance: 1e-6 (Ceres 1.12 default); diagnostic knob oracle_set_function_tolerance
 extern int g_marg_threads;  // 1 (default) or 4 = NUM_THREADS of the reference's ThreadsConstructA; same sums either way
 

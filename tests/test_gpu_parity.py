@@ -202,6 +202,24 @@ def test_kkt_residual_at_the_solution(eng, oracle, seed, n, kw):
     assert max(np.abs(lx["g"] - lo["g"]).max(), np.abs(lx["b"] - lo["b"]).max()) <= 1e-9 * scale
 
 
+@pytest.mark.parametrize("seed,n,radius", [(0, 300, 1.0), (3, 120, 0.05), (5, 64, 3.0), (7, 1000, 0.5)])
+def test_small_initial_radius_takes_the_dogleg_through_all_its_cases(eng, oracle, seed, n, radius):
+    """With Ceres' initial_trust_region_radius = 1e4 (what estimator.cpp:810-822 runs with) the Gauss-Newton step nearly always fits
+    the radius, so the Cauchy-point and interpolation cases of the traditional dogleg (dogleg_strategy.cc ComputeTraditionalDoglegStep)
+    are only reached after a dozen rejected steps.  A diagnostic knob on both sides starts the loop at a small radius: the steps are then
+    scaled gradients and interpolants from the first iteration on, and the radius grows back — same trace, same state."""
+    w = synth.make_window(seed, n)
+    try:
+        eng.set_initial_radius(radius)
+        oracle.set_initial_radius(radius)
+        sol, ref = eng.solve(w), oracle.solve(w)
+    finally:
+        eng.set_initial_radius(0)
+        oracle.set_initial_radius(0)
+    assert min(t["radius"] for t in ref.trace()) <= radius  # the loop did start there
+    check_solution(sol, ref, w)
+
+
 def test_trace_summary_worst_case_report():
     """(runs after the solve tests of this file: prints the worst relative deviation of each IterationSummary field)"""
     print("worst trace-field deviations:", {k: f"{v:.2e}" for k, v in TRACE_WORST.items()})
