@@ -57,10 +57,6 @@ int lfvio_debug_set_initial_radius(lfvio_ctx *ctx, double r);
  * launch, however few or small the windows (<= 320 landmarks: k_linw, more: k_linb; tests).  Applies to windows uploaded
  * afterwards.  Environment: LFVIO_LINW. */
 int lfvio_debug_set_linw(lfvio_ctx *ctx, int mode);
-/* 1: the trust-region loop of a window-resident batch is ONE launch (k_window: every pass of a window by the workgroup that owns
- * it); 0 (default: faster at 512 windows): three launches per pass (k_linw, k_solve_dense<true>, k_stepw).  Same results.
- * Environment: LFVIO_WINDOW_KERNEL. */
-int lfvio_debug_set_window(lfvio_ctx *ctx, int on);
 /* 1: the reduced pose system is solved along its block structure — the speed/bias chain eliminated block by block, a
  * dense 73-wide camera block left (k_solve_block, 78 KB of LDS: two windows of a batch per CU) — where every window of the launch
  * has that structure (a prior with no SpeedBias block but frame 0's: what the reference's marginalization produces); 0 (default:

@@ -571,7 +571,6 @@ constexpr int LWT_ABS = 1 << 16, LWT_EX = 1 << 17, LWT_TD = 1 << 18;
 // ---------------------------------------------------------------------------
 // k_linw: grid (1, batch) x 256, dynamic LDS = LW_LDS_BYTES
 // ---------------------------------------------------------------------------
-// (the body: k_linw's, and the linearization phase of k_window — kernels_stepw.h)
 DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;

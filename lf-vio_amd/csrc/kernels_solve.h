@@ -463,7 +463,6 @@ DEV void solve_epilogue(Slot *S, TRState *tr, const double *ls, double gn2, doub
 // parity share no column — every entry of the lower triangle of their 30 x 30 block as (index into imu_out) | (tile address << 16).
 constexpr int ASM_VIS = KC * (KC + 1) / 2, ASM_IMU_F = 30 * 31 / 2, ASM_IMU_HALF = 5 * ASM_IMU_F, ASM_LEN = ASM_VIS + 2 * ASM_IMU_HALF;
 __host__ __device__ constexpr int asm_lidx(int i, int j) { return tile_id(i >> 4, j >> 4) * TSZ + (i & 15) * TLD + (j & 15); }
-// (the body: k_solve_dense's, and the solve phase of k_window — kernels_stepw.h —, which brings its own workspace)
 template <bool ASSEMBLE>
 DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off, long long prior_A_off, const int *asm_tab) {
   TRState *tr = &S->tr;
@@ -1024,7 +1023,7 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
     double *ug = cand, *un = cand + WLD;
     for (int c = tid; c < WLD; c += nthr) ug[c] = S->uc_grad[c], un[c] = S->uc_gn[c];
     __syncthreads();
-    // (one landmark per thread with the 320 threads of k_dogleg / k_step / k_stepw; k_window's 256 take the last 64 in a second trip)
+    // (one landmark per thread with the 320 threads of k_dogleg / k_step / k_stepw)
     // (written as two guarded trips, not a loop: with one trip known the loads above stay in one batch with these)
     auto row = [&](const int l) {
       const double s = S->scale_l[l], bl = S->b[l], einv = S->einv_l[l], dgl = S->diag_l[l], grl = S->grad_l[l];

@@ -16,7 +16,7 @@ constexpr int STEPW_THREADS = DOGLEG_INLINE_THREADS;  // 320: one landmark per t
 static_assert(STEPW_THREADS == 320 && SPEC_MAX_LM == 320, "one landmark per thread");
 
 // ws: >= 5 * 8 + KP + SPEC_MAX_LM doubles of LDS.  320 threads: the visual factors on waves 0 .. 3, the IMU factors on wave 4;
-// 256 threads (k_window): the IMU factors on wave 0, the visual ones on waves 1 .. 3.
+// 256 threads (k_stepw as launched): the IMU factors on wave 0, the visual ones on waves 1 .. 3.
 constexpr int STEPW_WS = 5 * 8 + KP + 4 + SPEC_MAX_LM;
 DEV void stepw_cost(Slot *S, int cur, double cg, double cn, double *ws) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nthr = blockDim.x, nwv = nthr >> 6;
@@ -154,36 +154,4 @@ constexpr int STEPW_LAUNCH_THREADS = 256;
 __global__ __launch_bounds__(STEPW_LAUNCH_THREADS, 2) void k_stepw(char *base, size_t stride) {
   __shared__ double ws[STEPW_WS];
   stepw_body<1>(SLOT(base, stride), ws);
-}
-
-// ---------------------------------------------------------------------------
-// k_window: grid (1, batch) x 256, dynamic LDS = SOLVE_LDS — the whole trust-region loop of a window in ONE launch: up to
-// `npass` passes of [ k_linw | k_solve_dense<true> | k_stepw ] by the workgroup that owns the window, no launch boundary and no
-// other window in between.  A batch no longer waits, pass by pass, for its slowest window: a window whose step is rejected
-// goes straight on to the next radius, a finished one leaves the CU to the next window of the grid.  Same bodies, same
-// arithmetic, same results as the three launches.  What a launch boundary did implicitly is explicit here: a workgroup
-// barrier between the phases (the phases hand data over through the slot in global memory: coherent inside one CU), and the
-// scalar cache is invalidated before a linearization (it reads the pair tables through it, and the step phase of the pass
-// before has rewritten them with vector stores).
-// ---------------------------------------------------------------------------
-// (out of line: inlined into one loop the three phases share a register allocation — loop-invariant pieces of each are hoisted
-// over the others and 700 registers spill; as calls every phase is allocated as the kernel it came from)
-__device__ __noinline__ void window_lin(Slot *S, double *smem, const LinwArgs *A) { linw_body(S, smem, *A, MODE_SOLVE); }
-__device__ __noinline__ void window_solve(Slot *S, double *smem, long long xch_off, long long imu_off, long long prior_A_off, const int *asm_tab) {
-  solve_body<true>(S, smem, xch_off, imu_off, prior_A_off, asm_tab);
-}
-__device__ __noinline__ void window_step(Slot *S, double *smem) { stepw_body<1>(S, smem); }
-__global__ __launch_bounds__(LW_THREADS) void k_window(char *base, size_t stride, const LinwArgs A, long long xch_off, long long prior_A_off, const int *asm_tab, int npass) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  Slot *S = SLOT(base, stride);
-  for (int p = 0; p < npass; p++) {
-    if (tr_flags(&S->tr).done) break;  // (wave-uniform, workgroup-uniform: the header was written in front of the last barrier)
-    __builtin_amdgcn_s_dcache_inv();
-    window_lin(S, smem, &A);
-    __syncthreads();
-    window_solve(S, smem, xch_off, A.imu_out, prior_A_off, asm_tab);
-    __syncthreads();
-    window_step(S, smem);
-    __syncthreads();
-  }
 }

@@ -204,9 +204,6 @@ struct lfvio_ctx {
   int spec_count = 3;   // candidates per pass of a speculating launch: radius, radius / 2, radius / 4 (, radius / 8)
   int *d_lwt = nullptr;  // static table of k_linw's phase 3 (kernels_linw.h LWT_*)
   int *d_asm = nullptr;  // static scatter table of k_solve_dense<true> (kernels_solve.h ASM_*)
-  bool window_kernel = false;  // the loop of a window-resident batch as ONE launch (k_window).  Off: measured 120 000 solves/s against 143 000 for three launches per
-                               // pass at 512 windows — the dense solve's 156 KB of LDS leave one workgroup per CU, so the sweep and the step phase lose the second
-                               // resident window that hides their latency, and a third of the windows need every pass anyway.  LFVIO_WINDOW_KERNEL=1 / lfvio_debug_set_window
   int shard_kmax0 = -1;  // lfvio_shard_begin: the longest track among the WHOLE window's frame-0 landmarks (0: none), for the marginalization's plan
   int block_solve = 0;   // 1: the reduced system is solved along its block structure (k_solve_block) where every slot of the launch has it; 0 (default:
                          // measured slower): k_solve_dense
@@ -1018,16 +1015,6 @@ void launch_linb(lfvio_ctx *c, int count) {
   hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_GRID, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, c->L.total, linw_args(c));
 }
 
-// The whole trust-region loop of a resident batch as ONE launch (k_window, kernels_stepw.h): every condition of the
-// window-resident sweep and of k_stepw, i.e. planned windows of at most 320 landmarks, one candidate per pass.
-bool use_window(lfvio_ctx *c, int count, const Grid &g, bool speculate) {
-  return c->window_kernel && use_linw(c, count, g, MODE_SOLVE) && g.lm <= DOGLEG_INLINE_BLOCKS && !speculate && !c->no_fuse;
-}
-void launch_window(lfvio_ctx *c, int count, int npass) {
-  hipLaunchKernelGGL(k_window, dim3(1, count), dim3(LW_THREADS), SOLVE_LDS, c->stream, c->d_base, c->L.total, linw_args(c), (long long)c->L.xch,
-                     (long long)c->L.prior_A, (const int *)c->d_asm, npass);
-}
-
 // speculate: small windows evaluate the steps for radius, radius / 2, radius / 4 in every pass (dev_types.h, SPEC_EXTRA)
 // first / last: position of the pass in the sequence being issued (a graph, or a plain run of passes).  For small windows
 // the trust-region bookkeeping of a pass rides in the prologue of the NEXT pass's k_lin (MODE_DECIDE, one launch less per
@@ -1174,9 +1161,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       if (setup)
         hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
       bool gauged = false;
-      if (use_window(c, count, g, speculate)) launch_window(c, count, npass);
-      else
-        for (int it = 0; it < npass; it++) gauged = launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1, tail_flag >= 0);
+      for (int it = 0; it < npass; it++) gauged = launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1, tail_flag >= 0);
       if (tail_flag >= 0) {
         if (!gauged) {
           hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
@@ -1252,9 +1237,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       CaptureGuard guard(c->stream);
-      if (use_window(c, count, g, false)) launch_window(c, count, passes);
-      else
-        for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1);
+      for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1);
       HIPCHK(c, guard.end(&graph));
       HIPCHK(c, hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
@@ -1262,9 +1245,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     }
     HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
   } else {
-    if (use_window(c, count, g, false)) launch_window(c, count, passes);
-    else
-      for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1);
+    for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1);
   }
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
@@ -1464,8 +1445,6 @@ lfvio_ctx *lfvio_create(int device) {
   (void)hipFuncSetAttribute((const void *)k_solve_block<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVEB_LDS);
   (void)hipFuncSetAttribute((const void *)k_linw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   (void)hipFuncSetAttribute((const void *)k_linb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
-  (void)hipFuncSetAttribute((const void *)k_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
-  if (const char *e = getenv("LFVIO_WINDOW_KERNEL")) c->window_kernel = e[0] == '1';
   if (const char *e = getenv("LFVIO_BLOCK_SOLVE")) c->block_solve = e[0] != '0';
   if (const char *e = getenv("LFVIO_LINW")) c->linw_mode = std::max(0, std::min(2, atoi(e)));
   {  // static table of k_linw's phase 3: where each packed camera entry of H_pp (then each camera-side gradient entry) sits in the LDS accumulators
@@ -2131,13 +2110,6 @@ int lfvio_debug_set_block_solve(lfvio_ctx *c, int on) {
   if (int rc = join_inflight(c)) return rc;
   c->block_solve = on != 0;
   destroy_graph(c);  // the captured graphs hold the launch sequence
-  return LFVIO_OK;
-}
-int lfvio_debug_set_window(lfvio_ctx *c, int on) {
-  if (!c) return LFVIO_ERR_ARG;
-  if (int rc = join_inflight(c)) return rc;
-  c->window_kernel = on != 0;
-  destroy_graph(c);
   return LFVIO_OK;
 }
 int lfvio_debug_set_linw(lfvio_ctx *c, int mode) {

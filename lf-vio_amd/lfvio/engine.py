@@ -50,11 +50,6 @@ class Engine:
         self.lib.lfvio_debug_set_decide_merge.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_set_decide_merge(self.ctx, int(on))
 
-    def set_window(self, on):
-        """k_window (the whole loop of a window as one launch) on / off (include/lfvio_debug.h)."""
-        self.lib.lfvio_debug_set_window.argtypes = [C.c_void_p, C.c_int]
-        self._check(self.lib.lfvio_debug_set_window(self.ctx, int(on)), "set_window")
-
     def set_block_solve(self, on):
         """1: the reduced system solved along its block structure (k_solve_block); 0 (default): the dense 172 x 172 solve."""
         self.lib.lfvio_debug_set_block_solve.argtypes = [C.c_void_p, C.c_int]
