@@ -354,9 +354,19 @@ const char *lfvio_group_backend(const lfvio_group *g); /* path of the RCCL libra
 /* One process per GPU (lfvio_group_create_rank): these calls contain collectives, and a collective completes only when every
  * rank of the group has entered it.  All ranks must therefore make the same sequence of lfvio_group_* calls with the same
  * window, the same marg_flag and the same choice of sol == NULL / != NULL (sol->inv_depth may be NULL on some ranks and not
- * on others: the gather of the inverse depths runs either way).  A rank that fails locally (a refused upload, a device
- * error) returns at once and its peers wait in RCCL: the caller must treat an error from any rank as fatal for the group
- * (destroy it on every rank) — RCCL has no timeout of its own. */
+ * on others: the gather of the inverse depths runs either way).
+ * Collectives of lfvio_group_optimize(): per pass of the trust-region loop TWO sum-all-reduces — the reduced system (only what
+ * shards over landmarks: the camera part of H_pp and of g_p, the Schur sums, 16 scalars: lfvio_group_payload_doubles() = 6 630
+ * doubles, 53 KB; the speed / bias rows come from the IMU factors and the prior, which every rank evaluates for itself) and the
+ * 16 scalars behind the candidate (its cost, the model terms, the landmark parts of the Gauss-Newton step's norms) — and one more
+ * of the reduced system for the marginalization: 2 x passes + 1 (round 4: 3 x passes + 1 of the whole 151 KB buffer).
+ * A rank that fails locally inside lfvio_group_optimize() (an enqueue refused, a HIP error) does NOT leave the others waiting: it
+ * enqueues no more work but keeps issuing every collective of the sequence with an error word raised in its scalars; every rank
+ * reads that word behind the pass's last reduction, ends its loop in the same pass and returns LFVIO_ERR_DEVICE (the failed rank:
+ * its own error).  The group stays usable.  What this cannot cover: a rank whose device or RCCL communicator is gone (its
+ * collectives cannot be issued at all), and errors before the first collective that are not common to all ranks (a malformed
+ * window is refused by every rank alike; an allocation failure on one rank is not) — there the caller must still treat the
+ * error as fatal for the group on every rank: RCCL has no timeout of its own. */
 int lfvio_group_solve(lfvio_group *g, const LfvioWindow *in, int marg_flag, LfvioSolution *sol, LfvioPrior *prior);
 int lfvio_group_upload(lfvio_group *g, const LfvioWindow *in);
 int lfvio_group_optimize(lfvio_group *g, int marg_flag);

@@ -43,7 +43,7 @@ constexpr int XOFF_G = 14880;                 // PACKED rounded up to even
 constexpr int XOFF_S = XOFF_G + 176;          // KP rounded up
 constexpr int XOFF_C = XOFF_S + 15 * 256;
 constexpr int XCH_LEN = XOFF_C + 16;
-enum { XS_COST = 0, XS_G2, XS_ASV2, XS_LAM2, XS_BMAX, XS_GN2, XS_GGN, XS_CCOST, XS_MLIN, XS_MQUAD, XS_DN, XS_XN, XS_N0, XS_ERR };  // XS_ERR: a rank of an lfvio_group that failed locally raises it in every collective it still issues (group.inc)   // packed H_pp (14878), reused as dense scratch by the marginalization
+enum { XS_COST = 0, XS_G2, XS_ASV2, XS_LAM2, XS_BMAX, XS_GN2, XS_GGN, XS_CCOST, XS_MLIN, XS_MQUAD, XS_DN, XS_XN, XS_N0, XS_ERR, XS_CB2, XS_NCLAMP };  // XS_CB2 = sum c_l b_l^2, XS_NCLAMP = landmarks whose diagonal sits on Ceres' min / max_lm_diagonal clamp (kernels_solve.h k_lm_cb2);  // XS_ERR: a rank of an lfvio_group that failed locally raises it in every collective it still issues (group.inc)   // packed H_pp (14878), reused as dense scratch by the marginalization
 constexpr int LM_BLOCK = 64;     // landmarks per workgroup (one wave) in the landmark sweep
 constexpr int CHUNK_LANES = 64;
 constexpr int CHUNK_MAX = 64;    // observations per Gram chunk: one wave pass; a workgroup of k_lin takes 4 chunks
@@ -86,6 +86,9 @@ enum {
   Q_GN_SQ,     // ||gauss_newton_step_||^2, pose side
   Q_GRAD_GN,   // gradient_ . gauss_newton_step_, pose side
   Q_ZG,        // z-cross terms: sum_l G_l (w_l . G_c) is carried per landmark (d1/d2), unused slot
+  Q_LGN,       // lfvio_group: landmark part of ||gauss_newton_step_||^2 from the reduced Schur sums (solve_body) ...
+  Q_LGG,       // ... and of gradient_ . gauss_newton_step_
+  Q_LEX,       // 1: the two above were formed in this solve
   Q_COUNT = 16
 };
 
@@ -114,7 +117,7 @@ constexpr int MAIL_MAX_LM = 8192;  // landmarks a window may have for its soluti
   double q[Q_COUNT]; \
   int iteration, cur, do_lin, do_schur, done, termination, chol_fail, scaled; \
   int num_succ, num_unsucc, consec_invalid, trace_len, step_valid, skip_step, error, new_point; \
-  int spec_n, spec_pad_; \
+  int spec_n, gn_unconfirmed; /* lfvio_group: this pass's candidate is the Gauss-Newton step and k_decide has yet to check its norm (dogleg_body) */ \
   double cgE[SPEC_EXTRA], cnE[SPEC_EXTRA], snE[SPEC_EXTRA], step_sqE[SPEC_EXTRA], xn2E[SPEC_EXTRA];
 struct TRHead {
   TR_HEAD_FIELDS
@@ -127,7 +130,7 @@ struct TRState {
 // layout of the mailbox (Slot::mail), the same order as the pinned download block of the host side: the flag word, both
 // state slots (only x[cur] is written), the trust-region header with the trace, both inverse-depth buffers (only [cur])
 // Behind them the prior of the gated marginalization (an LfvioPrior, of which the header, n x n Jacobian entries and n
-// residuals are written), announced by the second flag word; word 2 carries Slot::passes_used of the call.
+// residuals are written), announced by the second flag word; words 2 and 3 carry Slot::passes_used and the iteration count of the call.
 constexpr size_t MAIL_X = 64, MAIL_TR = MAIL_X + 2 * sizeof(FrameState), MAIL_LAM = (MAIL_TR + sizeof(TRState) + 63) / 64 * 64,
                  MAIL_LAM_STRIDE = (size_t)MAIL_MAX_LM * 8, MAIL_PRIOR = MAIL_LAM + 2 * MAIL_LAM_STRIDE, MAIL_BYTES = MAIL_PRIOR + sizeof(LfvioPrior);
 

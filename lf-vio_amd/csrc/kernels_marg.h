@@ -75,7 +75,7 @@ DEV void publish_prior(Slot *S) {
   }
   for (int k = tid; k < n * n; k += nthr) dst->linearized_jacobians[k] = src->linearized_jacobians[k];
   for (int k = tid; k < n; k += nthr) dst->linearized_residuals[k] = src->linearized_residuals[k];
-  if (tid == 0) ((int *)m)[2] = S->passes_used | (S->tr.iteration << 8);
+  if (tid == 0) ((int *)m)[2] = S->passes_used, ((int *)m)[3] = S->tr.iteration;  // (two words: max_num_iterations is the caller's, either count may pass 255)
   __threadfence_system();
   __syncthreads();
   if (tid == 0) __hip_atomic_store((int *)m + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -809,11 +809,39 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
       gG = g[tid] * Gd[tid];
       gN = g[tid] * yv[tid];
     }
-    double sums[6] = {gn2, ggn, gG, gN, qgn, qnn};
+    // lfvio_group (Slot::sharded 2): the landmark parts of the two norms the dogleg needs, from the reduced Schur sums this thread
+    // has held since the start — N_c^T (sum c w w^T) N_c and (sum c b w) . N_c (k_lm_cb2 above has the identities)
+    double nsn = 0, z1n = 0;
+    if (sharded == 2) {
+      int n15 = 0;
+#pragma unroll
+      for (int t = 0; t < NTILES; t++)
+        if (tile_a(t) <= 4) {
+          const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
+          if (i < KC && j <= i) nsn = fma(sreg[n15], (i == j ? 1.0 : 2.0) * yv[i] * yv[j], nsn);
+          n15++;
+        }
+      if (er == 0) {
+#pragma unroll
+        for (int b = 0; b < 5; b++)
+          if (16 * b + ek < KC) z1n = fma(srhs[b], yv[16 * b + ek], z1n);
+      }
+    }
+    double sums[8] = {gn2, ggn, gG, gN, qgn, qnn, nsn, z1n};
     block_sum_n(sums, scratch, tid);
     gn2 = sums[0], ggn = sums[1], gG = sums[2], gN = sums[3], qgn = sums[4], qnn = sums[5];
     STAMP(S, 7);
-    if (tid == 0) solve_epilogue(S, tr, ls, gn2, ggn, gG, gN, qgn, qnn);
+    if (tid == 0) {
+      solve_epilogue(S, tr, ls, gn2, ggn, gG, gN, qgn, qnn);
+      if (sharded == 2) {
+        const double cb2 = ls[XS_CB2];
+        tr->q[Q_LGN] = (cb2 + 2.0 * sums[7] + sums[6]) / (1.0 + mu);
+        tr->q[Q_LGG] = -(cb2 + sums[7]);
+        tr->q[Q_LEX] = 1.0;
+      } else {
+        tr->q[Q_LEX] = 0.0;
+      }
+    }
   }
 }
 template <bool ASSEMBLE>
@@ -981,6 +1009,7 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
   FrameState *xc = &S->x[cur ^ 1];
   const double lm4 = sharded ? 0.0 : S->lm_sum[4];
   const double xg0 = sharded ? S->xch[XOFF_C + XS_GN2] : 0.0, xg1 = sharded ? S->xch[XOFF_C + XS_GGN] : 0.0;
+  const double xncl = sharded == 2 ? S->xch[XOFF_C + XS_NCLAMP] : 0.0;
   double xb[7] = {0, 0, 0, 0, 0, 0, 0}, gpv[6] = {0, 0, 0, 0, 0, 0};
   const int role = tid < 12 ? 0 : (tid >= 16 && tid < 16 + 99) ? 1 : tid == 120 ? 2 : 3;
   const int po = tid < 11 ? off_pose(tid) : off_ex();
@@ -1115,7 +1144,16 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
     // candidate's cost, in ONE all-reduce behind this kernel: the candidate of a pass with a fresh solve is the Gauss-Newton
     // step itself (what the dogleg takes whenever that step fits the radius), and k_decide, which sees the reduced norms, either
     // confirms it or voids the pass (decide_body); a pass without a fresh solve has the totals in the header and takes them.
-    const bool spec_gn = sharded == 2 && do_schur;
+    // ... unless the solve has already formed the landmark parts from the reduced Schur sums (k_lm_cb2: exact while no landmark
+    // of the window sits on the diagonal clamp), which is the usual case: then this IS the dogleg step and nothing is left to confirm.
+    bool spec_gn = sharded == 2 && do_schur;
+    if (spec_gn && t.q[Q_LEX] == 1.0 && xncl == 0.0) {
+      gn_sq_total = t.q[Q_GN_SQ] + t.q[Q_LGN];
+      grad_gn_total = t.q[Q_GRAD_GN] + t.q[Q_LGG];
+      if (first) tr->gn_sq_total = gn_sq_total, tr->grad_gn_total = grad_gn_total;
+      spec_gn = false;
+    }
+    if (first && sharded == 2) tr->gn_unconfirmed = spec_gn ? 1 : 0;
     for (int z = z_lo; z < z_hi; z++) {
       double cg, cn, sn;
       dogleg_coeffs(grad_sq_total, gn_sq_total, grad_gn_total, alpha, ldexp(radius, -z), cg, cn, sn);
@@ -1441,57 +1479,92 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_step(char *base, size
 }
 
 // ---------------------------------------------------------------------------
-// k_xpack: grid (1, batch) x 64 — sharded mode only: local scalar partials of phase B (which = 2: after
-// k_backsub) or phase C (which = 3: after k_cost) into the exchange scalars, everything else zeroed so that
-// the caller can sum-all-reduce the 16-scalar tail blindly.
+// k_xpack: grid (1, batch) x 256 — sharded mode only: local scalar partials into the exchange scalars.
+//   which & 7:  1  sum c_l b_l^2 and the clamp count (k_lm_cb2; lfvio_group, behind the sweep)
+//               2  phase B (after k_backsub): landmark parts of ||gauss_newton||^2 and gradient . gauss_newton
+//               3  phase C (after k_cost): the candidate's cost and model terms
+//               6  both B and C (lfvio_group: one all-reduce carries them)
+//   which & 8:  the scalars of another phase are in the tail already — nothing is zeroed; otherwise everything else is
+//               zeroed so that the caller can sum-all-reduce the 16-scalar tail blindly.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int which_bits) {
-  const int which = which_bits & 7;  // bit 3: the scalars of the other phase are in the tail already (one all-reduce for both: group.inc) — nothing is zeroed
+  const int which = which_bits & 7;
   Slot *S = SLOT(base, stride);
   const TRState *tr = &S->tr;
   if (!S->sharded) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double *sc = S->xch + XOFF_C;
-  __shared__ double red[4][5];
-  double v[5] = {0, 0, 0, 0, 0};
+  __shared__ double red[4][7];
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};
   const TRFlags fl = tr_flags(tr);
-  if (!fl.done && !fl.chol_fail) {
+  const bool want_b = which == 2 || which == 6, want_c = which == 3 || which == 6, want_a = which == 1;
+  if (!fl.done && (!fl.chol_fail || want_a)) {
     // a rank of a large window has thousands of block partials: 256 threads, the loads of four blocks in flight per thread
     const int nb = S->nLmBlocks;
-    const double *src = which == 2 ? (const double *)S->lm_part + 8 : (const double *)S->cost_part;
-    const int nv = which == 2 ? 2 : 5;
+    const double *srcb = (const double *)S->lm_part + (want_a ? 5 : 8), *srcc = (const double *)S->cost_part;
     for (int k0 = tid; k0 < nb; k0 += 4 * 256) {
-      double t[4][5];
+      double t[4][7];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int k = k0 + 256 * u;
 #pragma unroll
-        for (int q = 0; q < 5; q++) t[u][q] = (k < nb && q < nv) ? src[(size_t)k * LMS + q] : 0.0;
+        for (int q = 0; q < 2; q++) t[u][q] = (k < nb && (want_b || want_a)) ? srcb[(size_t)k * LMS + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) t[u][2 + q] = (k < nb && want_c) ? srcc[(size_t)k * LMS + q] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int q = 0; q < 5; q++) v[q] += t[u][q];
+        for (int q = 0; q < 7; q++) v[q] += t[u][q];
     }
-    if (which == 3 && S->pose_side == 1 && tid < 11) v[0] += S->pose_cost[tid];
+    if (want_c && S->pose_side == 1 && tid < 11) v[2] += S->pose_cost[tid];
   }
 #pragma unroll
-  for (int q = 0; q < 5; q++) v[q] = wave_sum(v[q]);
+  for (int q = 0; q < 7; q++) v[q] = wave_sum(v[q]);
   if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 5; q++) red[wv][q] = v[q];
+    for (int q = 0; q < 7; q++) red[wv][q] = v[q];
   }
   if (tid < 16 && !(which_bits & 8)) sc[tid] = 0.0;
   __syncthreads();
   if (tid == 0) {
-    double s5[5];
+    double s7[7];
 #pragma unroll
-    for (int q = 0; q < 5; q++) s5[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
-    if (which == 2) {
-      sc[XS_GN2] = s5[0], sc[XS_GGN] = s5[1];
-    } else {
-      sc[XS_CCOST] = s5[0], sc[XS_MLIN] = s5[1], sc[XS_MQUAD] = s5[2], sc[XS_DN] = s5[3], sc[XS_XN] = s5[4];
-    }
+    for (int q = 0; q < 7; q++) s7[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+    if (want_a) sc[XS_CB2] = s7[0], sc[XS_NCLAMP] = s7[1];
+    if (want_b) sc[XS_GN2] = s7[0], sc[XS_GGN] = s7[1];
+    if (want_c) sc[XS_CCOST] = s7[2], sc[XS_MLIN] = s7[3], sc[XS_MQUAD] = s7[4], sc[XS_DN] = s7[5], sc[XS_XN] = s7[6];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_lm_cb2: grid (nLmBlocks, batch) x 64 — lfvio_group, behind the sweep of a rank's landmarks: per block of 64 landmarks
+//   sum_l c_l b_l^2   (c_l = s_l^2 / e_l, the weight of landmark l in the Schur complement)   and
+//   the number of landmarks whose diagonal_ entry sits on Ceres' min / max_lm_diagonal clamp,
+// into slots 5 and 6 of the block's scalar partials.  With them — and the Schur sums every rank holds after the all-reduce —
+// the landmark parts of ||gauss_newton_step_||^2 and gradient_ . gauss_newton_step_ are quadratic forms in the camera part N_c of
+// the Gauss-Newton direction that EVERY rank evaluates for itself right after the solve (solve_body):
+//   y_l = s_l (b_l + w_l . N_c) / e_l,  gauss_newton_l = -d_l y_l,  d_l^2 = s_l^2 a_l,  e_l = s_l^2 a_l (1 + mu)   (no clamp)
+//   sum_l gauss_newton_l^2        = ( sum c b^2 + 2 (sum c b w) . N_c + N_c^T (sum c w w^T) N_c ) / (1 + mu)
+//   sum_l gradient_l gauss_newton_l = -( sum c b^2 + (sum c b w) . N_c )
+// so the dogleg needs no second all-reduce between the solve and the candidate.  A clamped landmark breaks the first identity:
+// the pass then falls back to the unconfirmed Gauss-Newton candidate (dogleg_body / decide_body).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lm_cb2(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  const TRFlags fl = tr_flags(&S->tr);
+  if (fl.done | !fl.do_lin) return;  // (the partials of the last linearization stand)
+  const int lane = threadIdx.x, l = blockIdx.x * LM_BLOCK + lane;
+  double cb2 = 0.0, ncl = 0.0;
+  if (l < S->N) {
+    const double s = S->scale_l[l], a = S->a[l], b = S->b[l], s2a = s * s * a;
+    cb2 = s * s * S->einv_l[l] * b * b;
+    ncl = (s2a < 1e-6 || s2a > 1e32) ? 1.0 : 0.0;
+  }
+  cb2 = wave_sum(cb2), ncl = wave_sum(ncl);
+  if (lane == 0) {
+    double *p = S->lm_part + (size_t)blockIdx.x * LMS;
+    p[5] = cb2, p[6] = ncl;
   }
 }
 
@@ -1551,8 +1624,8 @@ DEV void decide_body(Slot *S) {
     if (lane == 0) tr->done = 1, tr->error = LFVIO_ERR_DEVICE;
     return;
   }
-  if (sharded == 2 && t.do_schur && !t.chol_fail) {
-    // The candidate of this pass was the Gauss-Newton step, formed before its norm was known (dogleg_body).  With the reduced
+  if (sharded == 2 && t.do_schur && !t.chol_fail && t.gn_unconfirmed) {
+    // The candidate of this pass was the Gauss-Newton step, formed before its norm was known (dogleg_body: a landmark on the clamp).  With the reduced
     // landmark parts in: the dogleg's own case analysis — if it says "Gauss-Newton step" (it fits the radius), the candidate IS
     // the dogleg step and the pass is decided as always; if not, the pass is void: the totals go into the header, nothing is
     // re-linearized or solved, and the next pass forms the interpolated step from them (the path of a rejected step).

@@ -204,6 +204,7 @@ struct lfvio_ctx {
   int spec_count = 3;   // candidates per pass of a speculating launch: radius, radius / 2, radius / 4 (, radius / 8)
   int *d_lwt = nullptr;  // static table of k_linw's phase 3 (kernels_linw.h LWT_*)
   int *d_asm = nullptr;  // static scatter table of k_solve_dense<true> (kernels_solve.h ASM_*)
+  bool shard_group = false;  // the resident shard is driven by an lfvio_group (two collectives per pass: shard.inc phase 4)
   int shard_kmax0 = -1;  // lfvio_shard_begin: the longest track among the WHOLE window's frame-0 landmarks (0: none), for the marginalization's plan
   int block_solve = 0;   // 1: the reduced system is solved along its block structure (k_solve_block) where every slot of the launch has it; 0 (default:
                          // measured slower): k_solve_dense
@@ -1702,7 +1703,7 @@ int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
     }
     if (there) {
       c->inflight = false, c->unsynced = true;  // (what is left of the graph is a copy of two words: the next join waits for it)
-      c->last_passes = std::max(((const int *)c->h_mail)[2] & 255, 1), c->last_iters = ((const int *)c->h_mail)[2] >> 8;
+      c->last_passes = std::max(((const int *)c->h_mail)[2], 1), c->last_iters = ((const int *)c->h_mail)[3];
       if (c->inflight_first) c->predict_passes = c->last_passes;
       Fetched f{};
       f.prior = (LfvioPrior *)(c->h_mail + MAIL_PRIOR);

@@ -217,16 +217,25 @@ def test_the_collective_carries_only_what_shards():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shards,n,radius", [(3, 300, 1.0), (2, 1000, 0.5), (4, 120, 0.05)])
-def test_a_gauss_newton_step_outside_the_radius_voids_the_pass(shards, n, radius):
-    """A pass of the group carries ONE scalar all-reduce: the landmark parts of ||gauss_newton||^2 travel together with the cost of
-    the candidate, which is therefore formed as the Gauss-Newton step before its norm is known (kernels_solve.h dogleg_body); k_decide
-    then either confirms it — the dogleg's Case 1, nearly always with the default radius of 1e4 — or voids the pass and the next one
-    interpolates from the totals.  A small initial radius makes the second route the common one: the group must still follow the
-    single-context optimization() step for step, in more passes, with two collectives each."""
+@pytest.mark.parametrize("shards,n,radius,motion", [(3, 300, 1.0, "full"), (2, 1000, 0.5, "full"), (4, 120, 0.05, "full"),
+                                                     (3, 60, 0.05, "rotate"), (2, 60, 0.5, "static")])
+def test_the_dogleg_of_a_group_without_a_collective_between_solve_and_candidate(shards, n, radius, motion):
+    """A pass of the group carries TWO all-reduces: the reduced system behind the sweep, 16 scalars behind the candidate.  The
+    dogleg sits between them and needs ||gauss_newton||^2 and gradient . gauss_newton over ALL landmarks:
+    * usually every rank forms them itself, right after the solve, as quadratic forms in the camera part of the Gauss-Newton
+      direction with the reduced Schur sums as coefficients (kernels_solve.h k_lm_cb2 / solve_body) — exact while no landmark of the
+      window sits on Ceres' min_lm_diagonal clamp;
+    * a window with such landmarks (no baseline: a_l at rounding level; motion "rotate" / "static") forms the candidate as the
+      Gauss-Newton step before its norm is known, k_decide confirms it or voids the pass, and the next one interpolates.
+    A small initial radius takes both routes through the Cauchy-point and interpolation cases; the group follows the single-context
+    optimization() step for step either way, two collectives per pass."""
     from lfvio.engine import Engine, Group
 
-    w = synth.make_window(11, n)
+    w = synth.make_window(11, n, motion=motion, pose_noise=(1e-5 if motion != "full" else 0.02, np.deg2rad(0.5)))
+    if motion != "full":  # (no lever arm either: the camera's centre does not move, a_l is the 1e-5 m of position noise squared)
+        ex = w.ex_pose.copy()
+        ex[:3] = 0.0
+        w = w.copy(ex_pose=ex)
     ref = Engine(0)
     g = Group(local_shards=shards)
     try:
@@ -236,10 +245,16 @@ def test_a_gauss_newton_step_outside_the_radius_voids_the_pass(shards, n, radius
         sol, prior = g.solve(w, abi.MARGIN_OLD)
     finally:
         ref.close()
-    _compare(sol, prior, want, want_prior)
+    assert (sol.c.num_iterations, sol.c.termination) == (want.c.num_iterations, want.c.termination)
     assert [t["successful"] for t in sol.trace()] == [t["successful"] for t in want.trace()]
     assert np.allclose([t["radius"] for t in sol.trace()], [t["radius"] for t in want.trace()], rtol=1e-9)
+    assert np.allclose([t["step_norm"] for t in sol.trace()], [t["step_norm"] for t in want.trace()], rtol=1e-6)
+    assert np.abs(sol.pose - want.pose).max() < 1e-6 and np.abs(sol.speed_bias - want.speed_bias).max() < 1e-6
     assert min(t["radius"] for t in want.trace()) <= radius
     assert g.last_collectives() == 2 * g.last_passes() + 1
-    assert g.last_passes() > want.c.num_iterations  # passes that were voided (and the pass in flight behind the last one)
+    if motion == "full":
+        _compare(sol, prior, want, want_prior)
+        assert g.last_passes() <= want.c.num_iterations + 1  # a pass per step attempt and the one in flight behind the last: none voided
+    else:
+        assert g.last_passes() > want.c.num_iterations + 1   # clamped landmarks: passes whose Gauss-Newton candidate was voided
     g.close()
