@@ -356,9 +356,10 @@ const char *lfvio_group_backend(const lfvio_group *g); /* path of the RCCL libra
  * window, the same marg_flag and the same choice of sol == NULL / != NULL (sol->inv_depth may be NULL on some ranks and not
  * on others: the gather of the inverse depths runs either way).
  * Collectives of lfvio_group_optimize(): per pass of the trust-region loop TWO sum-all-reduces — the reduced system (only what
- * shards over landmarks: the camera part of H_pp and of g_p, the Schur sums, 16 scalars: lfvio_group_payload_doubles() = 6 630
- * doubles, 53 KB; the speed / bias rows come from the IMU factors and the prior, which every rank evaluates for itself) and the
- * 16 scalars behind the candidate (its cost, the model terms, the landmark parts of the Gauss-Newton step's norms) — and one more
+ * shards over landmarks: the camera part of H_pp and of g_p, the Schur sums, 16 scalars and 256 partial sums: lfvio_group_payload_doubles() = 6 886
+ * doubles, 55 KB; the speed / bias rows come from the IMU factors and the prior, which every rank evaluates for itself) and the
+ * 16 scalars behind the candidate (its cost and the model terms; the landmark parts of the Gauss-Newton step's norms, which the dogleg
+ * needs in between, every rank forms itself from the reduced Schur sums) — and one more
  * of the reduced system for the marginalization: 2 x passes + 1 (round 4: 3 x passes + 1 of the whole 151 KB buffer).
  * A rank that fails locally inside lfvio_group_optimize() (an enqueue refused, a HIP error) does NOT leave the others waiting: it
  * enqueues no more work but keeps issuing every collective of the sequence with an error word raised in its scalars; every rank
@@ -375,7 +376,7 @@ int lfvio_group_range(const lfvio_group *g, int rank, int *lm_begin, int *lm_end
 int lfvio_group_last_passes(const lfvio_group *g);      /* passes / collectives of the last lfvio_group_optimize() */
 int lfvio_group_last_collectives(const lfvio_group *g);
 int lfvio_group_payload_doubles(void);                  /* doubles per rank in the all-reduce of a pass's reduced system: the camera part
-                                                          * of H_pp and g_p, the Schur sums, 16 scalars (53 KB; the speed / bias rows do not travel) */
+                                                          * of H_pp and g_p, the Schur sums, 16 scalars, 256 partial sums (55 KB; the speed / bias rows do not travel) */
 /* independent resident windows split over the devices of this process (BASELINE "512 independent windows"): slot s
  * lives on local context s % lfvio_group_local(); no data-path collective */
 int lfvio_group_batch_reserve(lfvio_group *g, int batch, int max_landmarks, int max_observations);

@@ -43,7 +43,10 @@ constexpr int XOFF_G = 14880;                 // PACKED rounded up to even
 constexpr int XOFF_S = XOFF_G + 176;          // KP rounded up
 constexpr int XOFF_C = XOFF_S + 15 * 256;
 constexpr int XCH_LEN = XOFF_C + 16;
-enum { XS_COST = 0, XS_G2, XS_ASV2, XS_LAM2, XS_BMAX, XS_GN2, XS_GGN, XS_CCOST, XS_MLIN, XS_MQUAD, XS_DN, XS_XN, XS_N0, XS_ERR, XS_CB2, XS_NCLAMP };  // XS_CB2 = sum c_l b_l^2, XS_NCLAMP = landmarks whose diagonal sits on Ceres' min / max_lm_diagonal clamp (kernels_solve.h k_lm_cb2);  // XS_ERR: a rank of an lfvio_group that failed locally raises it in every collective it still issues (group.inc)   // packed H_pp (14878), reused as dense scratch by the marginalization
+// behind the scalars (lfvio_group only; not part of lfvio_shard_exchange_len()): XP_WGS partial sums of [sum c_l b_l^2, clamp count] — one pair
+// per workgroup of k_lm_cb2 (kernels_solve.h); they ride in the all-reduce of the reduced system and every rank adds them up in its solve
+constexpr int XP_WGS = 128, XOFF_P = XCH_LEN, XCH_ALLOC = XCH_LEN + 2 * XP_WGS;
+enum { XS_COST = 0, XS_G2, XS_ASV2, XS_LAM2, XS_BMAX, XS_GN2, XS_GGN, XS_CCOST, XS_MLIN, XS_MQUAD, XS_DN, XS_XN, XS_N0, XS_ERR };  // XS_ERR: a rank of an lfvio_group that failed locally raises it in every collective it still issues (group.inc)   // packed H_pp (14878), reused as dense scratch by the marginalization
 constexpr int LM_BLOCK = 64;     // landmarks per workgroup (one wave) in the landmark sweep
 constexpr int CHUNK_LANES = 64;
 constexpr int CHUNK_MAX = 64;    // observations per Gram chunk: one wave pass; a workgroup of k_lin takes 4 chunks

@@ -827,17 +827,19 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
           if (16 * b + ek < KC) z1n = fma(srhs[b], yv[16 * b + ek], z1n);
       }
     }
-    double sums[8] = {gn2, ggn, gG, gN, qgn, qnn, nsn, z1n};
+    double pcb = 0, pnc = 0;  // (k_lm_cb2's partials, reduced over the ranks: a pair per thread)
+    if (sharded == 2 && tid < XP_WGS) pcb = xch[XOFF_P + 2 * tid], pnc = xch[XOFF_P + 2 * tid + 1];
+    double sums[10] = {gn2, ggn, gG, gN, qgn, qnn, nsn, z1n, pcb, pnc};
     block_sum_n(sums, scratch, tid);
     gn2 = sums[0], ggn = sums[1], gG = sums[2], gN = sums[3], qgn = sums[4], qnn = sums[5];
     STAMP(S, 7);
     if (tid == 0) {
       solve_epilogue(S, tr, ls, gn2, ggn, gG, gN, qgn, qnn);
       if (sharded == 2) {
-        const double cb2 = ls[XS_CB2];
+        const double cb2 = sums[8], ncl = sums[9];
         tr->q[Q_LGN] = (cb2 + 2.0 * sums[7] + sums[6]) / (1.0 + mu);
         tr->q[Q_LGG] = -(cb2 + sums[7]);
-        tr->q[Q_LEX] = 1.0;
+        tr->q[Q_LEX] = ncl == 0.0 ? 1.0 : 0.0;  // (a landmark on the clamp: the first identity does not hold, the dogleg falls back)
       } else {
         tr->q[Q_LEX] = 0.0;
       }
@@ -1009,7 +1011,6 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
   FrameState *xc = &S->x[cur ^ 1];
   const double lm4 = sharded ? 0.0 : S->lm_sum[4];
   const double xg0 = sharded ? S->xch[XOFF_C + XS_GN2] : 0.0, xg1 = sharded ? S->xch[XOFF_C + XS_GGN] : 0.0;
-  const double xncl = sharded == 2 ? S->xch[XOFF_C + XS_NCLAMP] : 0.0;
   double xb[7] = {0, 0, 0, 0, 0, 0, 0}, gpv[6] = {0, 0, 0, 0, 0, 0};
   const int role = tid < 12 ? 0 : (tid >= 16 && tid < 16 + 99) ? 1 : tid == 120 ? 2 : 3;
   const int po = tid < 11 ? off_pose(tid) : off_ex();
@@ -1147,7 +1148,7 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
     // ... unless the solve has already formed the landmark parts from the reduced Schur sums (k_lm_cb2: exact while no landmark
     // of the window sits on the diagonal clamp), which is the usual case: then this IS the dogleg step and nothing is left to confirm.
     bool spec_gn = sharded == 2 && do_schur;
-    if (spec_gn && t.q[Q_LEX] == 1.0 && xncl == 0.0) {
+    if (spec_gn && t.q[Q_LEX] == 1.0) {
       gn_sq_total = t.q[Q_GN_SQ] + t.q[Q_LGN];
       grad_gn_total = t.q[Q_GRAD_GN] + t.q[Q_LGG];
       if (first) tr->gn_sq_total = gn_sq_total, tr->grad_gn_total = grad_gn_total;
@@ -1480,8 +1481,7 @@ __global__ __launch_bounds__(DOGLEG_INLINE_THREADS) void k_step(char *base, size
 
 // ---------------------------------------------------------------------------
 // k_xpack: grid (1, batch) x 256 — sharded mode only: local scalar partials into the exchange scalars.
-//   which & 7:  1  sum c_l b_l^2 and the clamp count (k_lm_cb2; lfvio_group, behind the sweep)
-//               2  phase B (after k_backsub): landmark parts of ||gauss_newton||^2 and gradient . gauss_newton
+//   which & 7:  2  phase B (after k_backsub): landmark parts of ||gauss_newton||^2 and gradient . gauss_newton
 //               3  phase C (after k_cost): the candidate's cost and model terms
 //               6  both B and C (lfvio_group: one all-reduce carries them)
 //   which & 8:  the scalars of another phase are in the tail already — nothing is zeroed; otherwise everything else is
@@ -1497,18 +1497,18 @@ __global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int wh
   __shared__ double red[4][7];
   double v[7] = {0, 0, 0, 0, 0, 0, 0};
   const TRFlags fl = tr_flags(tr);
-  const bool want_b = which == 2 || which == 6, want_c = which == 3 || which == 6, want_a = which == 1;
-  if (!fl.done && (!fl.chol_fail || want_a)) {
+  const bool want_b = which == 2 || which == 6, want_c = which == 3 || which == 6;
+  if (!fl.done && !fl.chol_fail) {
     // a rank of a large window has thousands of block partials: 256 threads, the loads of four blocks in flight per thread
     const int nb = S->nLmBlocks;
-    const double *srcb = (const double *)S->lm_part + (want_a ? 5 : 8), *srcc = (const double *)S->cost_part;
+    const double *srcb = (const double *)S->lm_part + 8, *srcc = (const double *)S->cost_part;
     for (int k0 = tid; k0 < nb; k0 += 4 * 256) {
       double t[4][7];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int k = k0 + 256 * u;
 #pragma unroll
-        for (int q = 0; q < 2; q++) t[u][q] = (k < nb && (want_b || want_a)) ? srcb[(size_t)k * LMS + q] : 0.0;
+        for (int q = 0; q < 2; q++) t[u][q] = (k < nb && want_b) ? srcb[(size_t)k * LMS + q] : 0.0;
 #pragma unroll
         for (int q = 0; q < 5; q++) t[u][2 + q] = (k < nb && want_c) ? srcc[(size_t)k * LMS + q] : 0.0;
       }
@@ -1531,17 +1531,16 @@ __global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int wh
     double s7[7];
 #pragma unroll
     for (int q = 0; q < 7; q++) s7[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
-    if (want_a) sc[XS_CB2] = s7[0], sc[XS_NCLAMP] = s7[1];
     if (want_b) sc[XS_GN2] = s7[0], sc[XS_GGN] = s7[1];
     if (want_c) sc[XS_CCOST] = s7[2], sc[XS_MLIN] = s7[3], sc[XS_MQUAD] = s7[4], sc[XS_DN] = s7[5], sc[XS_XN] = s7[6];
   }
 }
 
 // ---------------------------------------------------------------------------
-// k_lm_cb2: grid (nLmBlocks, batch) x 64 — lfvio_group, behind the sweep of a rank's landmarks: per block of 64 landmarks
+// k_lm_cb2: grid (XP_WGS, batch) x 256 — lfvio_group, behind the sweep of a rank's landmarks: per workgroup (a fixed stride of landmarks)
 //   sum_l c_l b_l^2   (c_l = s_l^2 / e_l, the weight of landmark l in the Schur complement)   and
 //   the number of landmarks whose diagonal_ entry sits on Ceres' min / max_lm_diagonal clamp,
-// into slots 5 and 6 of the block's scalar partials.  With them — and the Schur sums every rank holds after the all-reduce —
+// into the pair of the workgroup behind the exchange scalars (XOFF_P), which rides in the all-reduce of the reduced system.  With the sums — and the Schur sums every rank holds after the all-reduce —
 // the landmark parts of ||gauss_newton_step_||^2 and gradient_ . gauss_newton_step_ are quadratic forms in the camera part N_c of
 // the Gauss-Newton direction that EVERY rank evaluates for itself right after the solve (solve_body):
 //   y_l = s_l (b_l + w_l . N_c) / e_l,  gauss_newton_l = -d_l y_l,  d_l^2 = s_l^2 a_l,  e_l = s_l^2 a_l (1 + mu)   (no clamp)
@@ -1550,22 +1549,31 @@ __global__ __launch_bounds__(256) void k_xpack(char *base, size_t stride, int wh
 // so the dogleg needs no second all-reduce between the solve and the candidate.  A clamped landmark breaks the first identity:
 // the pass then falls back to the unconfirmed Gauss-Newton candidate (dogleg_body / decide_body).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lm_cb2(char *base, size_t stride) {
+__global__ __launch_bounds__(256) void k_lm_cb2(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
-  const TRFlags fl = tr_flags(&S->tr);
-  if (fl.done | !fl.do_lin) return;  // (the partials of the last linearization stand)
-  const int lane = threadIdx.x, l = blockIdx.x * LM_BLOCK + lane;
+  if (tr_flags(&S->tr).done) return;
+  const int tid = threadIdx.x, N = S->N;
+  const double *sl = S->scale_l, *av = S->a, *bv = S->b, *ei = S->einv_l;
   double cb2 = 0.0, ncl = 0.0;
-  if (l < S->N) {
-    const double s = S->scale_l[l], a = S->a[l], b = S->b[l], s2a = s * s * a;
-    cb2 = s * s * S->einv_l[l] * b * b;
-    ncl = (s2a < 1e-6 || s2a > 1e32) ? 1.0 : 0.0;
+  for (int l0 = blockIdx.x * 256 + tid; l0 < N; l0 += 4 * XP_WGS * 256) {  // (the loads of four landmarks in flight)
+    double s[4], b[4], a[4], e[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int l = l0 + u * XP_WGS * 256, lc = l < N ? l : l0;
+      s[u] = sl[lc], b[u] = l < N ? bv[lc] : 0.0, a[u] = av[lc], e[u] = ei[lc];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const double s2a = s[u] * s[u] * a[u];
+      cb2 = fma(s[u] * s[u] * e[u], b[u] * b[u], cb2);
+      ncl += (l0 + u * XP_WGS * 256 < N && (s2a < 1e-6 || s2a > 1e32)) ? 1.0 : 0.0;
+    }
   }
+  __shared__ double red[4][2];
   cb2 = wave_sum(cb2), ncl = wave_sum(ncl);
-  if (lane == 0) {
-    double *p = S->lm_part + (size_t)blockIdx.x * LMS;
-    p[5] = cb2, p[6] = ncl;
-  }
+  if ((tid & 63) == 0) red[tid >> 6][0] = cb2, red[tid >> 6][1] = ncl;
+  __syncthreads();
+  if (tid < 2) S->xch[XOFF_P + 2 * blockIdx.x + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 // k_cost_imu: grid ceil(10 * batch / 64) x 64 — the candidate's IMU factor costs of a resident batch, one lane per factor

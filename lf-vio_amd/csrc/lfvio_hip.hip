@@ -111,7 +111,7 @@ Layout make_layout(int maxN, int maxM) {
   L.gram_part = take((size_t)L.capChunks * NGP * 8);
   L.pairG = take((size_t)NPAIR * NGP * 8);
   L.schur_part = take((size_t)L.capSchurParts * LINB_LEN * 8);  // (k_linb's partials live there too: LINB_LEN > SCHUR_LEN doubles per group, at most a group per strip)
-  L.xch = take((size_t)XCH_LEN * 8);
+  L.xch = take((size_t)XCH_ALLOC * 8);
   L.lm_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.cost_part = take((size_t)L.capLmBlocks * LMS * 8);
   L.imu_out = take((size_t)LFVIO_WINDOW_SIZE * IMU_OUT * 8);

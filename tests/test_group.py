@@ -208,11 +208,11 @@ def test_a_rank_that_fails_still_issues_its_collectives_and_every_rank_ends_in_t
 @pytest.mark.gpu
 def test_the_collective_carries_only_what_shards():
     """The all-reduce of a pass is the camera part of H_pp (2 701 packed entries), the camera part of g_p (73), the Schur sums and the
-    16 scalars: 53 KB, not the 151 KB exchange buffer — the speed / bias rows are evaluated on every rank (include/lfvio.h)."""
+    16 scalars (and 256 partial sums behind them): 55 KB, not the 151 KB exchange buffer — the speed / bias rows are evaluated on every rank (include/lfvio.h)."""
     from lfvio import abi as _abi
 
     lib = _abi.load_hip_library()
-    assert lib.lfvio_group_payload_doubles() == 2701 + 73 + 15 * 256 + 16
+    assert lib.lfvio_group_payload_doubles() == 2701 + 73 + 15 * 256 + 16 + 256  # (+ the 128 pairs of k_lm_cb2)
     assert lib.lfvio_shard_exchange_len() > 3 * lib.lfvio_group_payload_doubles() - 3 * 2701
 
 
