@@ -99,6 +99,87 @@ def test_shards_sum_to_the_whole_window_gloo(oracle):
     assert np.abs(S_red - S_ref).max() <= 1e-12 * np.abs(S_ref).max()
 
 
+def _gloo_worker_camera_payload(rank, world, port, q):
+    """round 5: what an lfvio_group rank sends and keeps (csrc/group.inc XR_SYSTEM, kernels_lin.h pose_terms_here,
+    kernels_solve.h k_lm_cb2), restated with the oracle's linearization and a real all-reduce"""
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "lf-vio_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import binding as ob
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = synth.make_window_with_prior(3, 200, lambda x, f: ob.optimize(x, f))[0]
+    b, e = partition_landmarks(w.obs_offset, world)[rank]
+    KC = 73
+    # EVERY rank evaluates the pose-side factors (IMU, prior) with its landmark range ...
+    lin = ob.linearize(sub_window(w, b, e, pose_side=True))
+    pose = ob.linearize(sub_window(w, 0, 0, pose_side=True))  # (... which alone are this)
+    H, g = lin["H"].copy(), lin["g"].copy()
+    if rank != 0:  # ... but only rank 0 adds them to the part that travels
+        H[:KC, :KC] -= pose["H"][:KC, :KC]
+        g[:KC] -= pose["g"][:KC]
+    # Ceres' scaling and damping of the landmark blocks (Jacobi scale at this point, mu = 1e-4, no landmark on the clamp)
+    mu = 1e-4
+    a, bl, W = lin["a"], lin["b"], lin["W"]
+    s = 1.0 / (1.0 + np.sqrt(a))
+    d2 = np.clip(s * s * a, 1e-6, 1e32)
+    assert np.all(d2 == s * s * a)
+    el = s * s * a + mu * d2
+    c = s * s / el
+    schur, z1, cb2 = (W * c[:, None]).T @ W, (W * c[:, None]).T @ bl, float(np.sum(c * bl * bl))
+    payload = torch.from_numpy(np.concatenate([H[:KC, :KC].ravel(), g[:KC], schur.ravel(), z1, [cb2]]))
+    dist.all_reduce(payload)
+    p = payload.numpy()
+    Hc, gc = p[:KC * KC].reshape(KC, KC), p[KC * KC:KC * KC + KC]
+    o = KC * KC + KC
+    S_all, z_all, cb_all = p[o:o + KC * KC].reshape(KC, KC), p[o + KC * KC:o + KC * KC + KC], p[-1]
+    # the system this rank solves: the reduced camera part, its OWN speed / bias rows
+    Hfull, gfull = H.copy(), g.copy()
+    Hfull[:KC, :KC], gfull[:KC] = Hc, gc
+    # and the landmark parts of the Gauss-Newton step's norms for a camera direction N_c, from the reduced sums
+    Nc = np.random.default_rng(5).normal(size=KC) * 1e-2
+    lgn = (cb_all + 2.0 * z_all @ Nc + Nc @ S_all @ Nc) / (1.0 + mu)
+    lgg = -(cb_all + z_all @ Nc)
+    # ... against the same sums taken landmark by landmark over this rank's range, then all-reduced
+    y = s * (bl + W @ Nc) / el
+    gn = -np.sqrt(d2) * y
+    direct = torch.tensor([float(np.sum(gn * gn)), float(np.sum((s * bl / np.sqrt(d2)) * gn))], dtype=torch.float64)
+    dist.all_reduce(direct)
+    dist.barrier()
+    q.put((rank, Hfull, gfull, lgn, lgg, direct.numpy()))
+    dist.destroy_process_group()
+
+
+def test_camera_payload_and_landmark_norms_of_the_group_gloo(oracle):
+    """What an lfvio_group rank all-reduces is the camera part only; the speed / bias rows are every rank's own copy; the dogleg's
+    landmark norms come from the reduced Schur sums.  Two processes, a real (gloo) all-reduce: every rank ends
+    with the unsharded system, and the quadratic forms equal the per-landmark sums."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker_camera_payload, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = synth.make_window_with_prior(3, 200, lambda x, f: oracle.optimize(x, f))[0]
+    lin = oracle.linearize(w)
+    for rank, Hfull, gfull, lgn, lgg, direct in got:
+        assert np.abs(Hfull - lin["H"]).max() <= 1e-12 * np.abs(lin["H"]).max(), rank
+        assert np.abs(gfull - lin["g"]).max() <= 1e-12 * np.abs(lin["g"]).max(), rank
+        assert abs(lgn - direct[0]) <= 1e-9 * abs(direct[0]) and abs(lgg - direct[1]) <= 1e-9 * abs(direct[1]), (rank, lgn, lgg, direct)
+
+
 @pytest.mark.gpu
 # 20000: the two-level reductions under sharding; (8, 100000): BASELINE configs[3] at its full size on 8 emulated ranks
 @pytest.mark.parametrize("world,n", [(2, 300), (3, 300), (2, 20000), (8, 100000)])
