@@ -192,6 +192,10 @@ DEV double sum8(double v) {  // over aligned groups of eight lanes; every lane o
   v += dpp_f64<0x141>(v);  // row_half_mirror
   return v;
 }
+// Workgroup barrier for data handed over through LDS only: waits for this wave's LDS (and scalar) operations, NOT for its global
+// loads and stores — __syncthreads() drains those too, and a kernel that has just stored a dozen per-landmark scalars pays their write
+// latency (1 - 2 us) at the next barrier although nobody in the workgroup reads them.
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 DEV double wave_sum(double v) {
   v = sum8(v);
   v += dpp_f64<0x140>(v);  // row_mirror: the other half of the row of 16

@@ -203,6 +203,7 @@ struct Slot {
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
   int max_iter, prior_valid, prior_n, prior_nb;
   int tail_state, passes_used, iters_done, hdr_pad_;  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
+  int lm_half;                   // the landmark role of k_lin runs 8 lanes per track, 32 landmarks per workgroup (windows of at most SPEC_MAX_LM landmarks)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
   int dec_pending, dec_pad_;     // dec holds a decision k_solve has not moved into the header yet

@@ -215,7 +215,10 @@ DEV void load_pair_uniform(const Tab *T, int pair, PairU &u) {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int LIN_THREADS = 256;
-constexpr int LIN_LDS = LM_BLOCK * (WLD + 1) + 64 + 2 * LM_BLOCK;  // doubles: W tile of the landmark role, reduction scratch, Schur weights
+constexpr int LIN_LDS_LM = LM_BLOCK * (WLD + 1) + 64 + 2 * LM_BLOCK;  // doubles: W tile of the landmark role, reduction scratch, Schur weights
+constexpr int LIN_PRIOR_N = 76;  // a prior of up to 76 rows (the reference's own: 10 poses, one speed/bias, extrinsic, td) is staged in LDS by the prior role
+constexpr int LIN_LDS_PRIOR = LIN_PRIOR_N * LIN_PRIOR_N + 4 * KP;
+constexpr int LIN_LDS = LIN_LDS_LM > LIN_LDS_PRIOR ? LIN_LDS_LM : LIN_LDS_PRIOR;
 
 DEV double quad_sum(double v) {  // sum over the 4 lanes of a quad, same value and same order in every lane
   v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]  (DPP moves: a __shfl_xor is a ds_bpermute round trip per dword)
@@ -223,6 +226,11 @@ DEV double quad_sum(double v) {  // sum over the 4 lanes of a quad, same value a
   return v;
 }
 DEV d3 quad_sum3(d3 v) { return mk3(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z)); }
+// the lanes of one track: 4 (a quad) or 8
+template <int LPT>
+DEV double track_sum(double v) { return LPT == 8 ? sum8(v) : quad_sum(v); }
+template <int LPT>
+DEV d3 track_sum3(d3 v) { return mk3(track_sum<LPT>(v.x), track_sum<LPT>(v.y), track_sum<LPT>(v.z)); }
 
 // Schur SYRK of one landmark block from the LDS tile: part `blk` of the 15 upper 16x16 tiles of sum_l c_l w_l w_l^T
 // (cols 73/74 carry b_l and the Cauchy cross-term column) on the FP64 matrix pipe.  Wave w owns tiles w, w+4, w+8,
@@ -231,7 +239,7 @@ DEV d3 quad_sum3(d3 v) { return mk3(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z))
 // TIGHT: the form for launches whose landmark role is a latency chain (k_lin with all roles in one grid: single windows);
 // a resident batch (the landmark role as a launch of its own, two waves per SIMD) measured 0.4 % better with the plain loop.
 template <bool TIGHT>
-DEV void schur_block(int blk, int mode, int Nlim, double (*tile)[WLD + 1], const double *lcoef, const double *le, double *part) {
+DEV void schur_block(int lm0, int lmb, int mode, int Nlim, double (*tile)[WLD + 1], const double *lcoef, const double *le, double *part) {
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63, kk = lane >> 4, cc = lane & 15;
   double4_t acc[4];
@@ -246,8 +254,8 @@ DEV void schur_block(int blk, int mode, int Nlim, double (*tile)[WLD + 1], const
     ct[j] = ti < NT ? 16 * t + cc : 0, cu[j] = ti < NT ? 16 * u + cc : 0;
     scale_k[j] = mode == MODE_SOLVE && cu[j] == COL_K;  // b/D2 * e  -> z2 column
   }
-  int rows = Nlim - blk * LM_BLOCK;
-  rows = rows > LM_BLOCK ? LM_BLOCK : rows;
+  int rows = Nlim - lm0;  // (lm0: the workgroup's first landmark; lmb: how many it has at most — 64, or 32 in the 8-lanes-per-track form)
+  rows = rows > lmb ? lmb : rows;
   // No branch inside the loop: a tile skipped there (the sixteenth slot, wave 3) was two branches of the wave per tile and
   // step — 670 cycles per step, now 550 — so wave 3 runs its own loop over three tiles.  (Reading the operands of step s + 1
   // while the matrix pipe works on step s, kept from being undone with opaque copies, measured no better.)  Rows past the
@@ -301,24 +309,26 @@ struct LinView {
 
 // A solve repeated with a new mu on an unchanged linearization (do_schur without do_lin): only the Schur weights
 // change.  The block's W rows come back from HBM into the tile and the SYRK is redone.
-DEV void lin_schur_only_role(Slot *S, const LinView &lv, int blk, double *lds, double *part) {
+template <int LPT>
+DEV void lin_schur_only_role(Slot *S, const LinView &lv, int wg, double *lds, double *part) {
+  constexpr int LMB = LIN_THREADS / LPT;  // landmarks of the workgroup
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *lcoef = lds + LM_BLOCK * (WLD + 1) + 64, *le = lcoef + LM_BLOCK;
   const int tid = threadIdx.x;
   for (int e = tid; e < LM_BLOCK * (WLD + 1); e += LIN_THREADS) lds[e] = 0.0;
   __syncthreads();
-  {  // the stored rows back into the 80-wide tile: 4 lanes per landmark
-    const int lml = tid >> 2, q = tid & 3, l = blk * LM_BLOCK + lml;
+  {  // the stored rows back into the 80-wide tile: LPT lanes per landmark
+    const int lml = tid / LPT, q = tid % LPT, l = wg * LMB + lml;
     if (l < S->N) {
       const int st = S->lm_start[l], cnt = S->lm_cnt[l];
       const double *w = S->W + S->lm_woff[l];
-      for (int ci = q; ci < w_row_len(cnt); ci += 4) tile[lml][w_col(ci, st, cnt)] = w[ci];
+      for (int ci = q; ci < w_row_len(cnt); ci += LPT) tile[lml][w_col(ci, st, cnt)] = w[ci];
     }
   }
   if (tid < LM_BLOCK) {
-    const int l = blk * LM_BLOCK + tid;
+    const int l = wg * LMB + tid;
     double cf = 0.0, eb = 0.0;
-    if (l < S->N) {
+    if (tid < LMB && l < S->N) {
       const double sc = S->scale_l[l], s2a = sc * sc * S->a[l];
       const double D2 = fmin(fmax(s2a, 1e-6), 1e32);
       eb = s2a + lv.mu * D2;  // e-block + lm_diagonal^2
@@ -329,7 +339,7 @@ DEV void lin_schur_only_role(Slot *S, const LinView &lv, int blk, double *lds, d
     lcoef[tid] = cf, le[tid] = eb;
   }
   __syncthreads();
-  schur_block<false>(blk, MODE_SOLVE, S->N, tile, lcoef, le, part);
+  schur_block<false>(wg * LMB, LMB, MODE_SOLVE, S->N, tile, lcoef, le, part);
 }
 
 // Landmark role: 64 landmarks per workgroup, 4 lanes per landmark (lane q takes the observations 1+q, 5+q, 9+q of the
@@ -341,16 +351,21 @@ DEV void lin_schur_only_role(Slot *S, const LinView &lv, int blk, double *lds, d
 #else
 #define LSTAMP(k) do { } while (0)
 #endif
-template <bool TIGHT>
-DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double *lds, double *part) {
+// LPT: lanes per track.  4: 64 landmarks per workgroup (every window).  8 (round 5; windows of at most SPEC_MAX_LM landmarks,
+// Slot::lm_half): 32 landmarks per workgroup, twice the workgroups — a lane takes the observations 1 + q, 9 + q of its track
+// instead of 1 + q, 5 + q, 9 + q, and the workgroup's Schur SYRK is 8 steps instead of 16: the role is the latency chain of a single
+// window's k_lin (36 k cycles of which the observations 14 k and the SYRK 8 k), and a 300-landmark window has 246 CUs to spare.
+template <bool TIGHT, int LPT>
+DEV void lin_landmark_role(Slot *S, const LinView &lv, int wg, int mode, double *lds, double *part) {
+  constexpr int LMB = LIN_THREADS / LPT;  // landmarks of the workgroup
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
   double *red = lds + LM_BLOCK * (WLD + 1);
   double *lcoef = red + 64, *le = lcoef + LM_BLOCK;  // Schur weight c_l and e-block of the block's landmarks
-  const int tid = threadIdx.x, lml = tid >> 2, q = tid & 3;
+  const int tid = threadIdx.x, lml = tid / LPT, q = tid % LPT;
   const TRState *tr = &S->tr;
   const Tab *T = lv.tab;
   const int Nlim = is_marg(mode) ? marg_plan(S, mode)->N0 : S->N;
-  const int l = blk * LM_BLOCK + lml;
+  const int l = wg * LMB + lml;
   const bool valid = l < Nlim;
   const int est_td = S->est_td;
   const int est_ex = is_marg(mode) ? 1 : S->est_ex;  // ResidualBlockInfo::Evaluate asks for every Jacobian
@@ -371,7 +386,7 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
     ObsPair ob;
     load_obs(S, o0, ob.pi, ob.vi, ob.tdi, ob.rowi);
     const m33 ricT = ldm(T->ricT);
-    for (int o = 1 + q; o < k; o += 4) {
+    for (int o = 1 + q; o < k; o += LPT) {
       const int j = i + o, pair = i * 11 + j;
       load_obs(S, o0 + o, ob.pj, ob.vj, ob.tdj, ob.rowj);
       PairU u;
@@ -399,9 +414,9 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
     }
   }
   LSTAMP(9);
-  // the track's sums over its 4 lanes (fixed order)
-  wPi = quad_sum3(wPi), wTi = quad_sum3(wTi), wTic = quad_sum3(wTic), wTx = quad_sum3(wTx);
-  wtd = quad_sum(wtd), a = quad_sum(a), b = quad_sum(b), cost = quad_sum(cost);
+  // the track's sums over its lanes (fixed order)
+  wPi = track_sum3<LPT>(wPi), wTi = track_sum3<LPT>(wTi), wTic = track_sum3<LPT>(wTic), wTx = track_sum3<LPT>(wTx);
+  wtd = track_sum<LPT>(wtd), a = track_sum<LPT>(a), b = track_sum<LPT>(b), cost = track_sum<LPT>(cost);
   const bool lead = valid && q == 0;
   if (lead) {
     tile[lml][6 * i + 0] = wPi.x, tile[lml][6 * i + 1] = wPi.y, tile[lml][6 * i + 2] = wPi.z;
@@ -460,9 +475,11 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
     double *r = red + 8 * (tid >> 6);
     r[0] = cost, r[1] = g2, r[2] = asv2, r[3] = lam2, r[4] = bmax;
   }
-  __syncthreads();
+  lds_barrier();  // (the per-landmark scalars stored above are read by later kernels only: their write latency is not waited for)
   if (tid < 5) {
-    double *p = S->lm_part + (size_t)blk * LMS;
+    // (the scalar partials are kept per block of 64 landmarks — k_backsub's and k_cost's unit: the second half-block of the
+    // 8-lanes form writes slots 10 .. 14 of the same record, k_sum adds both)
+    double *p = S->lm_part + (size_t)(LPT == 8 ? wg >> 1 : wg) * LMS + (LPT == 8 && (wg & 1) ? 10 : 0);
     p[tid] = tid < 4 ? ((red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]))
                      : fmax(fmax(red[4], red[12]), fmax(red[20], red[28]));
   }
@@ -470,27 +487,29 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int blk, int mode, double
   // the rows leave over their non-zero span only (the block's rows are one contiguous stretch of W: offsets are prefix sums)
   if (valid) {
     double *w = S->W + woff_l;
-    for (int ci = q; ci < w_row_len(cnt_l); ci += 4) w[ci] = tile[lml][w_col(ci, i, cnt_l)];
+    for (int ci = q; ci < w_row_len(cnt_l); ci += LPT) w[ci] = tile[lml][w_col(ci, i, cnt_l)];
   }
   if (TIGHT && mode == MODE_SOLVE && S->N <= SPEC_MAX_LM) {  // (TIGHT: not in the role-by-role launches of a resident batch, whose k_dogleg keeps the compact rows)
     // small windows: the block's columns once more, transposed (Slot::Wt) — 512-byte lines, LDS stride 81: no bank conflict
     // (columns in pairs — [pair][landmark][2] — so that the reader's row is WT_PAIRS 16-byte loads: a wave has 63 loads in flight at most)
-    double2 *wt = (double2 *)(double *)S->Wt + blk * LM_BLOCK + (tid & 63);
-    constexpr int WPT = (WT_PAIRS + LIN_THREADS / 64 - 1) / (LIN_THREADS / 64);  // pairs per thread: all read from the tile, then all stored
+    constexpr int WGRP = LIN_THREADS / LMB;  // thread groups of LMB lanes: group g takes the column pairs g, g + WGRP, ...
+    const int lr = tid % LMB, wg4 = tid / LMB;
+    double2 *wt = (double2 *)(double *)S->Wt + wg * LMB + lr;
+    constexpr int WPT = (WT_PAIRS + WGRP - 1) / WGRP;  // pairs per thread: all read from the tile, then all stored
     double2 v[WPT];
 #pragma unroll
     for (int k = 0; k < WPT; k++) {
-      const int cp = (tid >> 6) + (LIN_THREADS / 64) * k, c = cp < WT_PAIRS ? 2 * cp : 0;
-      v[k] = make_double2(tile[tid & 63][c], c + 1 < KC ? tile[tid & 63][c + 1] : 0.0);
+      const int cp = wg4 + WGRP * k, c = cp < WT_PAIRS ? 2 * cp : 0;
+      v[k] = make_double2(tile[lr][c], c + 1 < KC ? tile[lr][c + 1] : 0.0);
     }
 #pragma unroll
     for (int k = 0; k < WPT; k++) {
-      const int cp = (tid >> 6) + (LIN_THREADS / 64) * k;
+      const int cp = wg4 + WGRP * k;
       if (cp < WT_PAIRS) wt[(size_t)cp * SPEC_MAX_LM] = v[k];
     }
   }
   LSTAMP(23);
-  schur_block<TIGHT>(blk, mode, Nlim, tile, lcoef, le, part);
+  schur_block<TIGHT>(wg * LMB, LMB, mode, Nlim, tile, lcoef, le, part);
   LSTAMP(20);
 }
 
@@ -662,17 +681,34 @@ DEV void lin_imu_role(Slot *S, const LinView &lv, int f, int mode, double *lds) 
   }
 }
 
+// STAGED (the workspace holds LIN_LDS_PRIOR doubles: the all-roles launch of a single window): J0 comes into LDS with one batch of
+// coalesced loads while the block differences are formed — the two products then read LDS; from global memory every term of them was
+// a load the loop had to wait for, and the prior's workgroup was the longest of the launch (12.3 us against 8.9 for an IMU factor).
+template <bool STAGED>
 DEV void lin_prior_role(Slot *S, const LinView &lv, int mode, double *lds) {
-  double *dx = lds, *r = lds + KP, *part = r + KP;  // part: [2][KP]
+  const int n = S->prior_n;
+  const bool staged = STAGED && n <= LIN_PRIOR_N;
+  double *Js = lds, *dx = lds + (STAGED ? LIN_PRIOR_N * LIN_PRIOR_N : 0), *r = dx + KP, *part = r + KP;  // part: [2][KP]
   const int tid = threadIdx.x;
   double *g = S->prior_g;
   for (int c = tid; c < KP + 4; c += LIN_THREADS) g[c] = 0.0;
   if (!S->prior_valid || (S->sharded && !S->pose_side)) return;
-  const int n = S->prior_n;
   const FrameState *x = lv.x;
-  if (tid < S->prior_nb) prior_block_dx(S, x, tid, dx);
+  const double *Jg = S->prior_J;
+  if (staged) {
+    constexpr int PER = (LIN_PRIOR_N * LIN_PRIOR_N + LIN_THREADS - 1) / LIN_THREADS;
+    double v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) v[k] = tid + LIN_THREADS * k < n * n ? Jg[tid + LIN_THREADS * k] : 0.0;
+    if (tid < S->prior_nb) prior_block_dx(S, x, tid, dx);
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+      if (tid + LIN_THREADS * k < n * n) Js[tid + LIN_THREADS * k] = v[k];
+  } else if (tid < S->prior_nb) {
+    prior_block_dx(S, x, tid, dx);
+  }
   __syncthreads();
-  const double *J = S->prior_J;
+  const double *J = staged ? Js : Jg;
   // r = r0 + J0 dx: 4 lanes per row
   for (int row = tid >> 2; row < n; row += LIN_THREADS / 4) {
     double s = 0;
@@ -784,11 +820,17 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
     // LDS was built and measured at 100 000 landmarks: k_presum + k_sum 33.5 -> 25.3 us, but the loop around the sweep — nothing
     // is carried through it — costs it 50 spilled registers and the landmark role 64 -> 97 us.)
     if (ROLES & LIN_ROLE_LM) {
-      const int nblk = is_marg(mode) ? (marg_plan(S, mode)->N0 + LM_BLOCK - 1) / LM_BLOCK : S->nLmBlocks;
+      const int half = S->lm_half, lmb = half ? LM_BLOCK / 2 : LM_BLOCK;
+      const int nblk = ((is_marg(mode) ? marg_plan(S, mode)->N0 : S->N) + lmb - 1) / lmb;
       if (b >= nblk) return;
       double *part = S->schur_part + (size_t)b * SCHUR_LEN;
-      if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL>(S, lv, b, mode, lds, part);
-      else lin_schur_only_role(S, lv, b, lds, part);
+      if (half) {  // (wave-uniform)
+        if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 8>(S, lv, b, mode, lds, part);
+        else lin_schur_only_role<8>(S, lv, b, lds, part);
+      } else {
+        if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 4>(S, lv, b, mode, lds, part);
+        else lin_schur_only_role<4>(S, lv, b, lds, part);
+      }
     }
     return;
   }
@@ -805,7 +847,7 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
       else lin_imu_role<false>(S, lv, b, mode, lds);
       return;
     }
-    lin_prior_role(S, lv, mode, lds);
+    lin_prior_role<ROLES == LIN_ROLE_ALL>(S, lv, mode, lds);
   }
 }
 
@@ -1115,12 +1157,21 @@ __global__ __launch_bounds__(256) void k_sum(char *base, size_t stride, int mode
   int blocks = pre ? 0 : S->nLmBlocks;  // pre: lm_sum comes from k_presum
   if (pre) {
   } else if (tid < 4) {
+    // (Slot::lm_half: a block's record holds two partials — the second where the block has more than 32 landmarks)
+    const int half = S->lm_half, N = S->N;
     double s = 0;
-    for (int k = 0; k < blocks; k++) s += S->lm_part[(size_t)k * LMS + tid];
+    for (int k = 0; k < blocks; k++) {
+      s += S->lm_part[(size_t)k * LMS + tid];
+      if (half && k * LM_BLOCK + LM_BLOCK / 2 < N) s += S->lm_part[(size_t)k * LMS + 10 + tid];
+    }
     S->lm_sum[tid] = s;
   } else if (tid == 4) {
+    const int half = S->lm_half, N = S->N;
     double m = 0;
-    for (int k = 0; k < blocks; k++) m = fmax(m, S->lm_part[(size_t)k * LMS + 4]);
+    for (int k = 0; k < blocks; k++) {
+      m = fmax(m, S->lm_part[(size_t)k * LMS + 4]);
+      if (half && k * LM_BLOCK + LM_BLOCK / 2 < N) m = fmax(m, S->lm_part[(size_t)k * LMS + 14]);
+    }
     S->lm_sum[4] = m;
   }
   if (S->sharded) {

@@ -515,7 +515,7 @@ DEV void linw_prior(Slot *S, const LinView &lv, double *lw) {
   const int tid = threadIdx.x;
   const int n = S->prior_n;
   if (!S->prior_valid || (S->sharded && !S->pose_side) || n > LW_PRIOR_MAXN) {
-    lin_prior_role(S, lv, MODE_SOLVE, lw);  // (zeroes prior_g when there is no prior)
+    lin_prior_role<false>(S, lv, MODE_SOLVE, lw);  // (zeroes prior_g when there is no prior)
     __syncthreads();
     return;
   }

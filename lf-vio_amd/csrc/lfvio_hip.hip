@@ -206,6 +206,7 @@ struct lfvio_ctx {
   int *d_asm = nullptr;  // static scatter table of k_solve_dense<true> (kernels_solve.h ASM_*)
   bool shard_group = false;  // the resident shard is driven by an lfvio_group (two collectives per pass: shard.inc phase 4)
   int shard_kmax0 = -1;  // lfvio_shard_begin: the longest track among the WHOLE window's frame-0 landmarks (0: none), for the marginalization's plan
+  int lm_half = 1;       // windows of at most SPEC_MAX_LM landmarks: 8 lanes per track in k_lin's landmark role (LFVIO_LM_HALF=0: the 4-lane form)
   int block_solve = 0;   // 1: the reduced system is solved along its block structure (k_solve_block) where every slot of the launch has it; 0 (default:
                          // measured slower): k_solve_dense
   int linw_mode = 1;     // 1: resident batches linearize with k_linw when every slot of the launch carries a plan; 0: never (k_lin roles + k_sum);
@@ -577,8 +578,10 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->nChunks = nChunks;
   lm_woff[N] = N == 0 ? 0 : lm_woff[N - 1] + w_row_len(lm_cnt[N - 1]);
   S->nLmBlocks = (N + LM_BLOCK - 1) / LM_BLOCK;
-  S->schur_lm = SCHUR_LM;  // one part per landmark block: k_lin forms it from its LDS tile
-  S->nSchurParts = S->nLmBlocks;
+  // one part per landmark workgroup of k_lin, which forms it from its LDS tile: 64 landmarks, or 32 in the 8-lanes-per-track form
+  S->lm_half = (N <= SPEC_MAX_LM && c->lm_half) ? 1 : 0;
+  S->schur_lm = S->lm_half ? SCHUR_LM / 2 : SCHUR_LM;
+  S->nSchurParts = S->lm_half ? (N + SCHUR_LM / 2 - 1) / (SCHUR_LM / 2) : S->nLmBlocks;
   // ---- k_linw (kernels_linw.h): strips of <= 64 landmarks of one start frame, dealt to the four waves of the window's
   //      workgroup (all strips of a start frame on one wave: it is the one writer of that frame's pair blocks), and the
   //      observations once more in the orders its lanes read them — anchors by landmark, the others pair-major.
@@ -1447,6 +1450,7 @@ lfvio_ctx *lfvio_create(int device) {
   (void)hipFuncSetAttribute((const void *)k_linw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   (void)hipFuncSetAttribute((const void *)k_linb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   if (const char *e = getenv("LFVIO_BLOCK_SOLVE")) c->block_solve = e[0] != '0';
+  if (const char *e = getenv("LFVIO_LM_HALF")) c->lm_half = e[0] != '0';
   if (const char *e = getenv("LFVIO_LINW")) c->linw_mode = std::max(0, std::min(2, atoi(e)));
   {  // static table of k_linw's phase 3: where each packed camera entry of H_pp (then each camera-side gradient entry) sits in the LDS accumulators
     std::vector<int> tab(SUM_VIS);
@@ -1983,7 +1987,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     c->err = "the resident windows are not linearized by k_linw";
     return LFVIO_ERR_ARG;
   }
-  if (which >= 15 && !lb) {
+  if (which >= 15 && which <= 17 && !lb) {
     c->err = "the resident window is not linearized by k_linb";
     return LFVIO_ERR_ARG;
   }
@@ -1997,7 +2001,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   // one full linearization so that every kernel has valid inputs
   if (lw) {
     launch_linw(c, count);
-  } else if (lb && which >= 15) {
+  } else if (lb && which >= 15 && which <= 17) {
     launch_linb(c, count);
   } else {
     launch_lin(c, count, g, MODE_SOLVE);
@@ -2011,9 +2015,9 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     switch (which) {
       case 0: launch_lin(c, count, g, MODE_SOLVE); break;
       case 2: launch_sum(c, count, g, MODE_SOLVE); break;  // k_presum + k_sum for large windows
-      case 8: case 9: case 10: {  // k_lin by role: landmark blocks | Gram chunks | IMU factors + prior
+      case 8: case 9: case 10: case 18: {  // k_lin by role: landmark blocks | Gram chunks | IMU factors + prior | IMU factors alone
         const int gram_wgs = (g.ch + 3) / 4;
-        const int gx = which == 8 ? g.lw : which == 9 ? gram_wgs : LFVIO_WINDOW_SIZE + 1;
+        const int gx = which == 8 ? g.lw : which == 9 ? gram_wgs : which == 18 ? LFVIO_WINDOW_SIZE : LFVIO_WINDOW_SIZE + 1;
         hipLaunchKernelGGL(k_lin<LIN_ROLE_ALL>, dim3(gx, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, which == 8 ? g.lw : 0,
                            which == 9 ? gram_wgs : 0);
       } break;
