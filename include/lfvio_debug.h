@@ -51,6 +51,10 @@ int lfvio_debug_set_function_tolerance(lfvio_ctx *ctx, double tol);
  * leaves alone; <= 0 restores it).  A small radius takes the dogleg through its Cauchy-point and interpolation cases from the first
  * iteration on — with the default they are only reached after a dozen rejected steps. */
 int lfvio_debug_set_initial_radius(lfvio_ctx *ctx, double r);
+/* 1 (default): the landmark role of k_lin runs eight lanes per track, 32 landmarks per workgroup, for windows of at most 320 landmarks
+ * uploaded from now on; 0: four lanes, 64 landmarks, the form larger windows take.  Same sums in a different association.
+ * Environment: LFVIO_LM_HALF. */
+int lfvio_debug_set_lm_half(lfvio_ctx *ctx, int on);
 /* Where the strip sweep (kernels_linw.h) replaces the role-by-role one (k_lin + k_sum): 1 (default) for a resident batch whose
  * windows all carry a plan (k_linw: one workgroup per window, no partial sums through HBM) and for a single window — or a rank's
  * share of a sharded one — of at least 40 960 landmarks (k_linb + k_sumb: one workgroup per group of strips); 0 never; 2 for every

@@ -2129,6 +2129,11 @@ int lfvio_debug_set_function_tolerance(lfvio_ctx *c, double tol) {
   c->fn_tol = tol;
   return LFVIO_OK;
 }
+int lfvio_debug_set_lm_half(lfvio_ctx *c, int on) {
+  if (!c) return LFVIO_ERR_ARG;
+  c->lm_half = on != 0;  // (takes effect with the next upload)
+  return LFVIO_OK;
+}
 int lfvio_debug_set_initial_radius(lfvio_ctx *c, double r) {
   if (!c) return LFVIO_ERR_ARG;
   c->init_radius = r > 0.0 ? r : 1e4;

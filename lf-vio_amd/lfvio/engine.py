@@ -59,6 +59,10 @@ class Engine:
         self.lib.lfvio_debug_solve_kernel.argtypes = [C.c_void_p, C.c_int]
         return int(self.lib.lfvio_debug_solve_kernel(self.ctx, count))
 
+    def set_lm_half(self, on):
+        self.lib.lfvio_debug_set_lm_half.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.lfvio_debug_set_lm_half(self.ctx, int(on)), "set_lm_half")
+
     def set_initial_radius(self, r):
         self.lib.lfvio_debug_set_initial_radius.argtypes = [C.c_void_p, C.c_double]
         self._check(self.lib.lfvio_debug_set_initial_radius(self.ctx, float(r)), "set_initial_radius")

@@ -220,6 +220,30 @@ def test_small_initial_radius_takes_the_dogleg_through_all_its_cases(eng, oracle
     check_solution(sol, ref, w)
 
 
+@pytest.mark.parametrize("seed,n,kw", [(0, 300, {}), (5, 64, {}), (6, 33, dict(estimate_td=0)), (9, 320, dict(tr=0.02)), (3, 7, {})])
+def test_eight_lanes_per_track_equal_four(eng, oracle, seed, n, kw):
+    """The landmark role of k_lin for windows of at most 320 landmarks: eight lanes per track and 32 landmarks per workgroup
+    (the default since round 5) against four lanes and 64 — the same per-observation arithmetic, the track's sums and the Schur
+    partials associated differently: linearization 1e-12, whole optimization() (with a prior, both flags) 1e-7 (the bar two
+    associations of the same sums get in tests/test_linw.py: the reduced system's conditioning), and the oracle's bars."""
+    w = synth.make_window_with_prior(seed, n, lambda x, f: oracle.optimize(x, f), **kw)[0]
+    out = {}
+    try:
+        for half in (0, 1):
+            eng.set_lm_half(half)
+            out[half] = (eng.linearize(w), eng.optimize(w, abi.MARGIN_OLD), eng.optimize(w, abi.MARGIN_SECOND_NEW))
+    finally:
+        eng.set_lm_half(1)
+    (l4, (s4, p4), (t4, q4)), (l8, (s8, p8), (t8, q8)) = out[0], out[1]
+    check_linearization(l8, l4, tol=1e-12)
+    for a, b in ((s8, s4), (t8, t4)):
+        assert a.c.num_iterations == b.c.num_iterations and [t["successful"] for t in a.trace()] == [t["successful"] for t in b.trace()]
+        assert np.abs(a.pose - b.pose).max() < 1e-7 and np.abs(a.speed_bias - b.speed_bias).max() < 1e-7 and rel(a.lam, b.lam) < 1e-7
+    assert p8.block_list() == p4.block_list() and rel(p8.J().T @ p8.J(), p4.J().T @ p4.J()) < 1e-7
+    assert q8.valid == q4.valid and (q8.valid != 1 or rel(q8.J().T @ q8.J(), q4.J().T @ q4.J()) < 1e-7)
+    check_solution(eng.solve(w), oracle.solve(w), w)
+
+
 def test_trace_summary_worst_case_report():
     """(runs after the solve tests of this file: prints the worst relative deviation of each IterationSummary field)"""
     print("worst trace-field deviations:", {k: f"{v:.2e}" for k, v in TRACE_WORST.items()})
