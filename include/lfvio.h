@@ -227,6 +227,21 @@ int lfvio_batch_download(lfvio_ctx *ctx, int slot, LfvioSolution *sol, LfvioPrio
  *                                lfvio_batch_optimize_finish would) and goes up with the window.  With nothing in flight it
  *                                is lfvio_batch_upload with in->prior = prior_io. */
 int lfvio_batch_upload_chained(lfvio_ctx *ctx, int slot, const LfvioWindow *in, LfvioPrior *prior_io);
+/* lfvio_batch_upload_chained_device  the same hand-over WITHOUT the host in it (round 5): while the call begun with
+ *                                lfvio_batch_optimize_begin is still marginalizing, the next window of the same estimator is
+ *                                packed, its copies are enqueued behind that marginalization, and the prior it is producing becomes
+ *                                this window's prior where it lies on the device (in->prior is ignored; the block structure is the one
+ *                                this library planned for that marginalization, the values never leave the GPU).  Nothing is waited
+ *                                for: the call returns as soon as the copies are enqueued, and the lfvio_batch_optimize_begin that
+ *                                follows goes out behind them — the device runs window after window back to back, the caller still
+ *                                gets every state as early as before (estimator.cpp:700-706: the prior is read by the NEXT
+ *                                optimization(), which is exactly where it stays).  The prior of the call that was in flight is no
+ *                                longer collectable afterwards (lfvio_batch_optimize_finish delivers the NEWEST call's prior).
+ *                                LFVIO_ERR_ARG (nothing enqueued, the call in flight untouched) when there is no call in flight on
+ *                                slot 0 or when its marginalization passes the input prior through (MARGIN_SECOND_NEW without a prior
+ *                                on the newest pose): use lfvio_batch_upload_chained then.  If that marginalization fails on the
+ *                                device, the next lfvio_batch_optimize_begin returns LFVIO_ERR_DEVICE. */
+int lfvio_batch_upload_chained_device(lfvio_ctx *ctx, int slot, const LfvioWindow *in);
 int lfvio_batch_optimize_begin(lfvio_ctx *ctx, int marg_flag, LfvioSolution *sol);
 int lfvio_batch_optimize_finish(lfvio_ctx *ctx, LfvioPrior *prior);
 int lfvio_batch_optimize_pending(const lfvio_ctx *ctx);

@@ -202,11 +202,11 @@ struct Slot {
   // ---------------- header: sizes, flags, constants
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
   int max_iter, prior_valid, prior_n, prior_nb;
-  int tail_state, passes_used, iters_done, hdr_pad_;  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
+  int tail_state, passes_used, iters_done, chain_err;  // chain_err: the prior this window was to take over on the device (k_prior_chain) was not there  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
   int lm_half;                   // the landmark role of k_lin runs 8 lanes per track, 32 landmarks per workgroup (windows of at most SPEC_MAX_LM landmarks)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
-  int dec_pending, dec_pad_;     // dec holds a decision k_solve has not moved into the header yet
+  int dec_pending, mail_seq;     // dec holds a decision k_solve has not moved into the header yet; mail_seq: what the mailbox flags are set to (the upload's sequence number, never 0)
   // Early hand-over of the solution (lfvio_batch_optimize_begin): host memory the device writes directly — 0, or the
   // mailbox [flag | x[2] | TRState | lam[0] | lam[1]] (MAIL_* below) of the context.  The gated gauge fix ends by copying
   // the state it has just re-anchored there and raising the flag, so the caller has its poses while the marginalization

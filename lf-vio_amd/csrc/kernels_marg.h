@@ -55,9 +55,12 @@ DEV void publish_solution(Slot *S) {
     double *dst = (double *)(m + MAIL_LAM + (size_t)cur * MAIL_LAM_STRIDE);
     for (int k = tid; k < N; k += nthr) dst[k] = src[k];
   }
+  if (tid == 0) ((int *)m)[4] = S->passes_used, ((int *)m)[5] = S->chain_err;  // (final: the loop is closed; k_prior_chain's verdict on the prior this window ran with)
   __threadfence_system();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store((int *)m, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (the flags carry the upload's sequence number, not 1: the marginalization of the window BEFORE may still be publishing its
+  // prior when the host is already waiting for this window's — lfvio_batch_upload_chained_device)
+  if (tid == 0) __hip_atomic_store((int *)m, S->mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // The prior the gated marginalization has just written (Slot::prior_out) into the mailbox, then the second flag.  Called by
 // every thread of k_marg_solve's workgroup at its end, behind a barrier that follows the last store to prior_out.
@@ -78,13 +81,32 @@ DEV void publish_prior(Slot *S) {
   if (tid == 0) ((int *)m)[2] = S->passes_used, ((int *)m)[3] = S->tr.iteration;  // (two words: max_num_iterations is the caller's, either count may pass 255)
   __threadfence_system();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store((int *)m + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) __hip_atomic_store((int *)m + 1, S->mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // behind a k_gauge of several workgroups (windows too large for k_decide_gauge): the same gate, then the mailbox
 __global__ __launch_bounds__(256) void k_publish(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
   if (!tail_gate(S, S->tr.done)) return;
   publish_solution(S);
+}
+// k_prior_chain: grid 1 x 256, behind the upload of the NEXT window of the same estimator into a slot whose marginalization has
+// just run (or is the kernel in front of this one on the stream): the prior that marginalization left in Slot::prior_out becomes
+// the window's input prior where it lies — values only (J0, r0, the blocks' linearization points); the block structure is the
+// host's, which planned that marginalization itself (lfvio_batch_upload_chained_device).  46 KB that neither go down nor come up
+// again, and no host in between: the upload is enqueued while the marginalization is still running.
+__global__ __launch_bounds__(256) void k_prior_chain(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  const LfvioPrior *src = &S->prior_out;
+  const int tid = threadIdx.x, n = S->prior_n, nb = S->prior_nb;
+  if (src->valid != 1 || src->n != n || src->num_blocks != nb) {
+    // no prior where one was promised (the marginalization failed or produced another structure): the window runs without one and says so
+    if (tid == 0) S->prior_valid = 0, S->chain_err = 1;
+    return;
+  }
+  double *J = S->prior_J, *r = S->prior_r;
+  for (int e = tid; e < n * n; e += 256) J[e] = src->linearized_jacobians[e];
+  for (int e = tid; e < n; e += 256) r[e] = src->linearized_residuals[e];
+  for (int e = tid; e < nb * 9; e += 256) S->prior_x0[e / 9][e % 9] = src->block_x0[e / 9][e % 9];
 }
 __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int gated) {
   Slot *S = SLOT(base, stride);

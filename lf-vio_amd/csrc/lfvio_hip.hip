@@ -141,6 +141,14 @@ struct SlotHostInfo {
                            // later call refuses instead of one described by the wrong sizes
   LfvioPrior in_prior;    // kept for the "prior passes through" case of MARGIN_SECOND_NEW
   bool has_in_prior = false;
+  bool in_prior_device = false;  // ... whose values never came to the host (lfvio_batch_upload_chained_device): in_prior holds the structure only
+  // what a marginalization of this window leaves as its prior, as planned at the upload [MARGIN_OLD, MARGIN_SECOND_NEW]: the
+  // structure of the NEXT window's input prior when that window takes it over on the device
+  struct MargOut {
+    int valid = 0, n = 0, m = 0, nb = 0;
+    int kind[LFVIO_MAX_PRIOR_BLOCKS], frame[LFVIO_MAX_PRIOR_BLOCKS], idx[LFVIO_MAX_PRIOR_BLOCKS];
+  } marg_out[2];
+  int mail_seq = 0;  // Slot::mail_seq of the resident window: what its mailbox flags are set to
   // k_sum's gather lists on the device are a function of the chunks per frame pair alone: kept from one upload of the slot
   // to the next while that table stays the same (consecutive windows of one estimator: nearly always)
   std::vector<int> list_key;  // pair_chunk0[0 .. NPAIR], pre_gram
@@ -195,6 +203,11 @@ struct lfvio_ctx {
   double up_us[4] = {0, 0, 0, 0};  // last upload: host packing | collecting the chained prior | prior + copies enqueued | final synchronization (lfvio_debug_upload_times)
   std::unique_ptr<LfvioPrior> held;
   bool has_held = false;
+  int inflight_flag = 0;        // marg_flag of the call in flight
+  bool pipelined = false;       // the window resident in slot 0 was uploaded behind a marginalization still running (lfvio_batch_upload_chained_device):
+                                // the stream holds work nobody has waited for; the next lfvio_batch_optimize_begin goes out behind it without a wait
+  int mail_seq = 0;             // sequence number of the last upload (Slot::mail_seq)
+  std::unique_ptr<LfvioPrior> chain_struct;  // the structure-only prior of a device-chained upload
   bool inflight_first = false;  // the flag came out of the first graph: {tail_state, passes_used} land in h_pending[2..3] when it ends
   bool use_graph = true;
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
@@ -231,9 +244,9 @@ namespace {
 
 void destroy_graph(lfvio_ctx *c) {
   // (a graph whose tail is still running behind an early state is not destroyed under it)
-  if (c->stream && (c->inflight || c->unsynced)) {
+  if (c->stream && (c->inflight || c->unsynced || c->pipelined)) {
     (void)hipStreamSynchronize(c->stream);
-    c->unsynced = false;
+    c->unsynced = false, c->pipelined = false;
   }
   if (c->graph) {
     (void)hipGraphExecDestroy(c->graph);
@@ -253,9 +266,13 @@ void destroy_graph(lfvio_ctx *c) {
 
 // The tail of a call whose solution went out early (lfvio_batch_optimize_begin) is still on the stream: wait for it and
 // take the bookkeeping its graph left in the pinned block.  First statement of everything that touches the slots.
-int join_inflight(lfvio_ctx *c) {
-  if (c->unsynced) {
-    c->unsynced = false;
+// pipelined_ok (lfvio_batch_optimize_begin only): a window uploaded behind a marginalization that is still running
+// (lfvio_batch_upload_chained_device) is optimized behind it too — everything is ordered by the stream, nothing is waited for.
+constexpr const char *CHAIN_ERR_TEXT = "the prior this window was to take over on the device was not there (the marginalization before it produced none): it ran without a prior";
+int join_inflight(lfvio_ctx *c, bool pipelined_ok = false) {
+  if (c->pipelined && !c->inflight && pipelined_ok) return LFVIO_OK;
+  if (c->unsynced || c->pipelined) {
+    c->unsynced = false, c->pipelined = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   if (!c->inflight) return LFVIO_OK;
@@ -268,17 +285,24 @@ int join_inflight(lfvio_ctx *c) {
       c->err = "the marginalization behind an early solution did not finish";
       return LFVIO_ERR_DEVICE;
     }
+    if (c->h_pending[5]) {
+      c->err = CHAIN_ERR_TEXT;
+      return LFVIO_ERR_DEVICE;
+    }
   }
   return LFVIO_OK;
 }
 
 // After a graph launch: the first of "the solution is in the mailbox" (true) and "everything enqueued has run" (false: the
 // window was not done within these passes and the gated gauge fix did not run, or there is no mailbox for this window).
+// (the flag is the sequence number of the resident window's upload: a window optimized behind the marginalization of the one
+// before must not take that one's late prior flag for its own)
 bool wait_early(lfvio_ctx *c) {
   int *flag = (int *)c->h_mail;
+  const int want = c->info[0].mail_seq;
   for (;;) {
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE)) return true;
-    if (hipStreamQuery(c->stream) != hipErrorNotReady) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) return true;
+    if (hipStreamQuery(c->stream) != hipErrorNotReady) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want;
   }
 }
 
@@ -442,15 +466,36 @@ constexpr int LIN_SPLIT_MIN_BATCH = 8;   // ... when they are a batch: ONE large
 // marginalization behind an early state), it is THAT call's prior: the landmark tables and gather lists of the new window —
 // nine tenths of the host work of an upload — are packed while the device finishes it, then the prior is taken from the
 // mailbox into *chain and the upload goes on with it.
-int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0, int pose_side = 1, LfvioPrior *chain = nullptr) {
-  const bool chained = chain && (c->inflight || c->has_held) && slot == 0;
+// device_chain (lfvio_batch_upload_chained_device): the prior of the call in flight STAYS on the device — nothing is waited for or
+// collected; the new window's prior has the structure the host planned for that marginalization (SlotHostInfo::marg_out) and the
+// values k_prior_chain copies out of Slot::prior_out behind these copies, which the stream puts behind the marginalization.
+int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0, int pose_side = 1, LfvioPrior *chain = nullptr, bool device_chain = false) {
+  if (device_chain) {
+    if (slot != 0 || sharded || !c->inflight || c->has_held || !c->info[0].resident) {
+      c->err = "lfvio_batch_upload_chained_device: no call in flight on slot 0 (lfvio_batch_optimize_begin) whose prior could be taken over";
+      return LFVIO_ERR_ARG;
+    }
+    const SlotHostInfo::MargOut &mo = c->info[0].marg_out[c->inflight_flag];
+    if (!mo.valid) {
+      c->err = "lfvio_batch_upload_chained_device: the marginalization in flight passes its input prior through (MARGIN_SECOND_NEW without a "
+               "prior on the newest pose) — use lfvio_batch_upload_chained";
+      return LFVIO_ERR_ARG;
+    }
+    if (!c->chain_struct) c->chain_struct.reset(new LfvioPrior);
+    LfvioPrior *sp = c->chain_struct.get();
+    std::memset(sp, 0, offsetof(LfvioPrior, linearized_jacobians));
+    sp->valid = 1, sp->n = mo.n, sp->m = mo.m, sp->num_blocks = mo.nb;
+    for (int i = 0; i < mo.nb; i++) sp->blocks[i].kind = mo.kind[i], sp->blocks[i].frame = mo.frame[i], sp->block_idx[i] = mo.idx[i];
+    chain = sp;
+  }
+  const bool chained = !device_chain && chain && (c->inflight || c->has_held) && slot == 0;
   const auto t_up0 = std::chrono::steady_clock::now();
   auto lap = [&](int k, std::chrono::steady_clock::time_point from) {
     const auto now = std::chrono::steady_clock::now();
     c->up_us[k] = std::chrono::duration<double>(now - from).count() * 1e6;
     return now;
   };
-  if (!chained)
+  if (!chained && !device_chain)
     if (int rc = join_inflight(c)) return rc;
   if (!w || w->num_landmarks < 0 || w->num_observations < 0) {
     c->err = "null window / negative sizes";
@@ -495,6 +540,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->max_iter = w->max_num_iterations;
   S->sharded = sharded, S->pose_side = pose_side;
   S->mail = (slot == 0 && !sharded && c->d_mail && w->num_landmarks <= MAIL_MAX_LM) ? (long long)(uintptr_t)c->d_mail : 0;
+  const int seq = c->mail_seq == 0x7fffffff ? 1 : c->mail_seq + 1;  // (never 0: the host clears the flags to 0)
+  S->mail_seq = seq;
   for (int k = 0; k < 3; k++) S->g[k] = w->g[k];
   S->tr_over_row = w->row > 0.0 ? w->tr / w->row : 0.0;  // only the td factor reads it (row > 0 checked above)
   S->half_row = w->row / 2;
@@ -771,15 +818,17 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     S->prior_valid = 1, S->prior_n = pr->n, S->prior_nb = pr->num_blocks;
     for (int i = 0; i < pr->num_blocks; i++) {
       S->prior_kind[i] = pr->blocks[i].kind, S->prior_frame[i] = pr->blocks[i].frame, S->prior_idx[i] = pr->block_idx[i];
-      std::memcpy(S->prior_x0[i], pr->block_x0[i], sizeof(double) * 9);
+      if (!device_chain) std::memcpy(S->prior_x0[i], pr->block_x0[i], sizeof(double) * 9);  // (device_chain: k_prior_chain fills them)
       const int to = tangent_off(pr->blocks[i].kind, pr->blocks[i].frame);
       for (int e = 0; e < local_size(pr->blocks[i].kind); e++) {
         S->prior_cmap[pr->block_idx[i] + e] = to + e;
         S->prior_inv[to + e] = pr->block_idx[i] + e;
       }
     }
-    std::memcpy(h + L.prior_J, pr->linearized_jacobians, sizeof(double) * pr->n * pr->n);
-    std::memcpy(h + L.prior_r, pr->linearized_residuals, sizeof(double) * pr->n);
+    if (!device_chain) {
+      std::memcpy(h + L.prior_J, pr->linearized_jacobians, sizeof(double) * pr->n * pr->n);
+      std::memcpy(h + L.prior_r, pr->linearized_residuals, sizeof(double) * pr->n);
+    }
   }
   {
     // (a rank's share of a sharded window: the other ranks' frame-0 landmarks shape the prior's blocks too — lfvio_shard_begin)
@@ -813,7 +862,16 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   info.perm.swap(perm);
   info.gLm = S->nLmBlocks, info.gLw = S->nSchurParts, info.gCh = nChunks, info.gSc = S->nSchurParts;
   info.has_in_prior = pr != nullptr;
-  if (pr) copy_prior(&info.in_prior, pr);
+  info.in_prior_device = pr && device_chain;
+  if (pr && device_chain) std::memcpy(&info.in_prior, pr, offsetof(LfvioPrior, linearized_jacobians));  // (structure; the values are the device's)
+  else if (pr) copy_prior(&info.in_prior, pr);
+  for (int f = 0; f < 2; f++) {
+    SlotHostInfo::MargOut &mo = info.marg_out[f];
+    const MargPlan &mp = S->marg[f];
+    mo.valid = mp.valid, mo.n = mp.n, mo.m = mp.m15 + mp.N0, mo.nb = mp.nb;
+    for (int i = 0; i < mp.nb; i++) mo.kind[i] = mp.kind[i], mo.frame[i] = mp.shifted_frame[i], mo.idx[i] = mp.idx[i];
+  }
+  info.mail_seq = c->mail_seq = seq;
   info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   info.linw_ok = linw;
   info.sb_chain = true;
@@ -825,7 +883,12 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, (lists_cached ? L.sum_off : L.sum_items + (size_t)used_items * 4) - L.in_begin, hipMemcpyHostToDevice,
                            c->stream));
-  if (pr) HIPCHK(c, hipMemcpyAsync(d + L.prior_J, h + L.prior_J, sizeof(double) * pr->n * pr->n, hipMemcpyHostToDevice, c->stream));
+  if (pr && !device_chain) HIPCHK(c, hipMemcpyAsync(d + L.prior_J, h + L.prior_J, sizeof(double) * pr->n * pr->n, hipMemcpyHostToDevice, c->stream));
+  if (device_chain) {
+    hipLaunchKernelGGL(k_prior_chain, dim3(1, 1), dim3(256), 0, c->stream, d, L.total);  // (the slot's own blob as base)
+    // the call that was in flight is now only work on the stream in front of this window's: nothing of it is left to collect
+    c->inflight = false, c->pipelined = true;
+  }
   if (linw) HIPCHK(c, hipMemcpyAsync(d + L.linw_begin, h + L.linw_begin, L.pm_pair + (size_t)std::max(M - N, 0) - L.linw_begin, hipMemcpyHostToDevice, c->stream));
   if (linb) HIPCHK(c, hipMemcpyAsync(d + L.linb_lm0, h + L.linb_lm0, L.linw_end - L.linb_lm0, hipMemcpyHostToDevice, c->stream));
   info.list_items = used_items;  // (only now: an upload refused half-way leaves the key without lists on the device)
@@ -1124,7 +1187,7 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated 
 // (the marginalization) is still running then and c->inflight says so.
 int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fused_flag = -1, bool *tail_done = nullptr,
                   double max_seconds = -1.0, bool early = false) {
-  if (int rc = join_inflight(c)) return rc;
+  if (int rc = join_inflight(c, early)) return rc;
   const Grid g = grid_for(c, count);
   const int passes = std::max(max_iter, 0) + 4;
   if (adaptive && c->use_graph) {
@@ -1175,7 +1238,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       }
       if (tail_flag >= 0 && count == 1) {
         // one window: its {tail_state, passes_used} pair is the answer — copied as it is, no k_pending launch
-        HIPCHK(c, hipMemcpyAsync(c->h_pending + 2, c->d_base + offsetof(Slot, tail_state), 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_pending + 2, c->d_base + offsetof(Slot, tail_state), 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));  // (.. chain_err)
       } else {
         hipLaunchKernelGGL(k_pending, dim3(1), dim3(64), 0, c->stream, c->d_base, c->L.total, count, c->d_pending, tail_flag >= 0 ? 1 : 0);
         HIPCHK(c, hipMemcpyAsync(c->h_pending, c->d_pending, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1204,6 +1267,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       const bool watch = early && done_passes == 0 && fuse && c->publish;
       if (watch) __atomic_store_n((int *)c->h_mail + 1, 0, __ATOMIC_RELAXED), __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
       HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk[sv], c->stream));
+      if (c->pipelined && done_passes == 0) c->up_us[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch).count() * 1e6;  // (debug: lfvio_debug_upload_times)
       if (watch && wait_early(c)) {  // the window was done inside the first graph: its tail follows in the same graph
         c->inflight = true, c->inflight_first = true;
         if (tail_done) *tail_done = true;
@@ -1217,6 +1281,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       }
       done_passes += first ? first_passes : SOLVE_CHUNK;
       if (first && fuse && count == 1) c->h_pending[0] = c->h_pending[2] == 2 ? 0 : 1, c->h_pending[1] = c->h_pending[3], c->last_iters = c->h_pending[4];
+      if (first && fuse && count == 1 && c->h_pending[5]) {
+        c->err = CHAIN_ERR_TEXT;
+        return LFVIO_ERR_DEVICE;
+      }
       if (c->h_pending[0] == 0) {
         if (tail_done && fuse && first) *tail_done = true;
         break;
@@ -1256,7 +1324,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
 }
 
 int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated) {
-  if (int rc = join_inflight(c)) return rc;
+  if (int rc = join_inflight(c, gated)) return rc;  // (gated: part of a graph of lfvio_batch_optimize*, which has joined — or may go out behind a pipelined upload)
   const Grid g = grid_for(c, count);
   const int mode = (MODE_MARG + flag) | (gated ? MODE_GATED : 0);
   if (standalone)
@@ -1386,13 +1454,30 @@ void unpack_prior(lfvio_ctx *c, int slot, const Fetched &f, bool pass, LfvioPrio
   if (pass) {
     if (info.has_in_prior) copy_prior(out, &info.in_prior);
     else out->valid = 0;
-    return;
+    return;  // (a prior whose values stayed on the device: fetch_device_prior below, by the callers that can synchronize)
   }
   const LfvioPrior *hp = f.prior;
   const int n = hp->n;
   std::memcpy(out, hp, offsetof(LfvioPrior, linearized_jacobians));
   std::memcpy(out->linearized_jacobians, hp->linearized_jacobians, sizeof(double) * n * n);
   std::memcpy(out->linearized_residuals, hp->linearized_residuals, sizeof(double) * n);
+}
+
+// The input prior of a window that took it over on the device (lfvio_batch_upload_chained_device) and whose own marginalization
+// passes it through: its values have never been on the host — they are read out of the slot now (a synchronization and three
+// small copies, in a case the reference meets once per MARGIN_SECOND_NEW without a prior on the newest pose).
+int fetch_device_prior(lfvio_ctx *c, int slot, LfvioPrior *out) {
+  SlotHostInfo &info = c->info[slot];
+  if (!info.in_prior_device) return LFVIO_OK;
+  const char *d = c->d_base + (size_t)slot * c->L.total;
+  LfvioPrior *p = &info.in_prior;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(p->linearized_jacobians, d + c->L.prior_J, sizeof(double) * p->n * p->n, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(p->linearized_residuals, d + c->L.prior_r, sizeof(double) * p->n, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(p->block_x0, d + offsetof(Slot, prior_x0), sizeof(double) * 9 * p->num_blocks, hipMemcpyDeviceToHost));
+  info.in_prior_device = false;
+  if (out) copy_prior(out, p);
+  return LFVIO_OK;
 }
 
 int download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior *prior) {
@@ -1403,6 +1488,7 @@ int download(lfvio_ctx *c, int slot, LfvioSolution *sol, LfvioPrior *prior) {
   if (sol && (rc = check_solution(c, slot, f))) return rc;
   if (prior && (rc = check_prior(c, slot, f, &pass))) return rc;
   if (sol) unpack_solution(c, slot, f, sol);
+  if (prior && pass && (rc = fetch_device_prior(c, slot, nullptr))) return rc;
   if (prior) unpack_prior(c, slot, f, pass, prior);
   return LFVIO_OK;
 }
@@ -1573,6 +1659,16 @@ int lfvio_batch_upload(lfvio_ctx *c, int slot, const LfvioWindow *in) {
   return upload_window(c, slot, in);
 }
 
+int lfvio_batch_upload_chained_device(lfvio_ctx *c, int slot, const LfvioWindow *in) {
+  if (!c || !in || slot < 0 || slot >= c->batch) return LFVIO_ERR_ARG;
+  if (in->num_landmarks > c->L.maxN || in->num_observations > c->L.maxM) {
+    c->err = "window larger than the reserved capacity";
+    return LFVIO_ERR_ARG;
+  }
+  (void)hipSetDevice(c->device);
+  return upload_window(c, slot, in, 0, 1, nullptr, true);
+}
+
 int lfvio_batch_upload_chained(lfvio_ctx *c, int slot, const LfvioWindow *in, LfvioPrior *prior_io) {
   if (!c || !in || !prior_io || slot < 0 || slot >= c->batch) return LFVIO_ERR_ARG;
   if (in->num_landmarks > c->L.maxN || in->num_observations > c->L.maxM) {
@@ -1590,8 +1686,9 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
     return LFVIO_ERR_ARG;
   }
   (void)hipSetDevice(c->device);
-  if (int rc = join_inflight(c)) return rc;
+  if (int rc = join_inflight(c, early && count == 1)) return rc;
   c->has_held = false;  // (a prior nobody collected before the next optimization is dropped, like one left in the slot)
+  c->inflight_flag = marg_flag;
   c->publish = early && adaptive && count == 1 && c->h_mail && c->info[0].resident && c->info[0].N <= MAIL_MAX_LM;
   struct PublishOff {
     lfvio_ctx *c;
@@ -1679,6 +1776,14 @@ int lfvio_batch_optimize_begin(lfvio_ctx *c, int marg_flag, LfvioSolution *sol) 
   if (!c->inflight) return download(c, 0, sol, nullptr);  // (synchronizes)
   Fetched f;
   char *m = c->h_mail;
+  // the loop is closed: its pass and iteration counts size the next call's first graph (a caller that pipelines — the next window
+  // uploaded behind this call's marginalization — never joins this graph)
+  c->last_passes = std::max(((const int *)m)[4], 1), c->last_iters = ((const TRState *)(m + MAIL_TR))->iteration;
+  if (c->inflight_first) c->predict_passes = c->last_passes;
+  if (((const int *)m)[5]) {
+    c->err = CHAIN_ERR_TEXT;
+    return LFVIO_ERR_DEVICE;
+  }
   f.xs = (const FrameState *)(m + MAIL_X), f.tr = (const TRState *)(m + MAIL_TR);
   f.lam[0] = (const double *)(m + MAIL_LAM), f.lam[1] = (const double *)(m + MAIL_LAM + MAIL_LAM_STRIDE), f.prior = nullptr;
   if ((rc = check_solution(c, 0, f))) return rc;
@@ -1697,11 +1802,12 @@ int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
   if (c->inflight && prior) {
     // the marginalization ends by pushing its prior into the mailbox (publish_prior): wait for that word, not for the stream
     int *flag = (int *)c->h_mail + 1;
+    const int want = c->info[0].mail_seq;
     bool there = false;
     for (;;) {
-      if ((there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0)) break;
+      if ((there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want)) break;
       if (hipStreamQuery(c->stream) != hipErrorNotReady) {
-        there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) != 0;
+        there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want;
         break;
       }
     }
@@ -1713,6 +1819,8 @@ int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
       f.prior = (LfvioPrior *)(c->h_mail + MAIL_PRIOR);
       bool pass = false;
       if (int rc = check_prior(c, 0, f, &pass)) return rc;
+      if (pass)
+        if (int rc = fetch_device_prior(c, 0, nullptr)) return rc;
       unpack_prior(c, 0, f, pass, prior);
       return LFVIO_OK;
     }

@@ -280,6 +280,7 @@ void lfvio_host_set_fused(void *h, int on) { E(h)->fused = on != 0; }
 void lfvio_host_set_device_mask(unsigned mask) { config().device_mask = mask ? mask : 1u; }
 void lfvio_host_set_local_shards(int n) { config().local_shards = n; }
 void lfvio_host_set_split_call(int on) { config().split_call = on != 0; }
+void lfvio_host_set_device_chain(int on) { config().device_chain = on != 0; }
 // waits for the marginalization a split optimization() left running and adopts its prior (what the next pack() would do)
 int lfvio_host_collect_prior(void *h) { return E(h)->collectPrior() ? 0 : E(h)->status; }
 void lfvio_host_get_timers(void *h, double *out6, int reset) {

@@ -651,9 +651,17 @@ void WindowEstimator::optimization() {
     if (status == LFVIO_OK && chain) {
       // `prior` is an output here first (the prior of the call in flight), then the window's input
       w.prior = nullptr;
-      status = lfvio_batch_upload_chained(gpu, 0, &w, &prior);
-      prior_pending_ = lfvio_batch_optimize_pending(gpu) != 0;  // (an upload refused before it got to the prior leaves it where it was)
-      if (!prior_pending_) has_prior = prior.valid != 0;
+      // first choice: the prior stays on the device and nothing is waited for.  Refused with LFVIO_ERR_ARG — and the call in flight
+      // untouched — when that marginalization passes its input prior through or the window is malformed: the host-side hand-over
+      // then decides (it reports a malformed window itself).
+      status = config().device_chain ? lfvio_batch_upload_chained_device(gpu, 0, &w) : LFVIO_ERR_ARG;
+      if (status == LFVIO_OK) {
+        prior_pending_ = false, has_prior = true;  // (`prior` itself is stale until something collects the next one)
+      } else {
+        status = lfvio_batch_upload_chained(gpu, 0, &w, &prior);
+        prior_pending_ = lfvio_batch_optimize_pending(gpu) != 0;  // (an upload refused before it got to the prior leaves it where it was)
+        if (!prior_pending_) has_prior = prior.valid != 0;
+      }
       if (status == LFVIO_OK) {
         second_new = marg_flag == LFVIO_MARGIN_SECOND_NEW && has_prior;
         marginalize = marg_flag == LFVIO_MARGIN_OLD || second_new;

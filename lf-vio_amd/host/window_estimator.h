@@ -52,6 +52,10 @@ struct Config {
   // finish in the background (lfvio_batch_optimize_begin / _finish): the pose is published ~0.2 ms earlier, the prior is
   // collected when the next window is packed.  false: the call returns when the prior is on the host as well.
   bool split_call = true;
+  // ... and the next window takes that prior over ON THE DEVICE (lfvio_batch_upload_chained_device): the upload goes out behind the
+  // marginalization without waiting for it, the prior never crosses PCIe.  The host's copy (`prior`) is then only refreshed when
+  // something asks for it (collectPrior()).  false: the upload collects the prior and sends it back up (lfvio_batch_upload_chained).
+  bool device_chain = true;
 };
 Config &config();
 

@@ -341,7 +341,7 @@ HIP_SYMBOLS = [
     "lfvio_create", "lfvio_destroy", "lfvio_last_error", "lfvio_version", "lfvio_solve", "lfvio_marginalize",
     "lfvio_batch_reserve", "lfvio_batch_upload", "lfvio_batch_optimize", "lfvio_batch_optimize_async",
     "lfvio_batch_sync", "lfvio_batch_download", "lfvio_stream",
-    "lfvio_batch_optimize_begin", "lfvio_batch_optimize_finish", "lfvio_batch_optimize_pending", "lfvio_batch_upload_chained",
+    "lfvio_batch_optimize_begin", "lfvio_batch_optimize_finish", "lfvio_batch_optimize_pending", "lfvio_batch_upload_chained", "lfvio_batch_upload_chained_device",
     "lfvio_shard_begin", "lfvio_shard_exchange_len", "lfvio_shard_scalar_offset", "lfvio_shard_exchange_ptr", "lfvio_shard_linearize",
     "lfvio_shard_solve", "lfvio_shard_candidate", "lfvio_shard_decide", "lfvio_shard_marg_linearize", "lfvio_shard_marg_finish",
     "lfvio_shard_finish", "lfvio_shard_restart", "lfvio_shard_enqueue", "lfvio_shard_poll", "lfvio_triangulate", "lfvio_shift_depth", "lfvio_preintegrate",
@@ -388,6 +388,7 @@ def load_hip_library(path=None):
     lib.lfvio_batch_optimize_finish.argtypes = [C.c_void_p, C.POINTER(Prior)]
     lib.lfvio_batch_optimize_pending.argtypes = [C.c_void_p]
     lib.lfvio_batch_upload_chained.argtypes = [C.c_void_p, C.c_int, C.POINTER(WindowC), C.POINTER(Prior)]
+    lib.lfvio_batch_upload_chained_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(WindowC)]
     lib.lfvio_stream.restype = C.c_void_p
     lib.lfvio_stream.argtypes = [C.c_void_p]
     lib.lfvio_shard_begin.argtypes = [C.c_void_p, C.POINTER(WindowC), C.c_int, C.c_int, C.c_int]

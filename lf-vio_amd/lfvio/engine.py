@@ -147,6 +147,12 @@ class Engine:
         self._check(self.lib.lfvio_batch_upload_chained(self.ctx, slot, C.byref(marshalled if marshalled is not None else win.c()), C.byref(prior)),
                     "batch_upload_chained")
 
+    def batch_upload_chained_device(self, slot, win, marshalled=None):
+        """The next window of the same estimator, its prior taken over ON THE DEVICE from the call still in flight (no wait, no
+        copy of the prior in either direction); win.prior is ignored."""
+        self._check(self.lib.lfvio_batch_upload_chained_device(self.ctx, slot, C.byref(marshalled if marshalled is not None else win.c())),
+                    "batch_upload_chained_device")
+
     def batch_optimize(self, count, flag, sync=True):
         fn = self.lib.lfvio_batch_optimize if sync else self.lib.lfvio_batch_optimize_async
         self._check(fn(self.ctx, count, flag), "batch_optimize")

@@ -4,6 +4,7 @@
 // product stack (host mirror + liblfvio_hip.so) writes for a recording with the one this stack writes.  Nothing under
 // lf-vio_amd/ loads this library; the product fails without liblfvio_hip.so.
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -112,6 +113,18 @@ int lfvio_batch_upload_chained(lfvio_ctx *c, int slot, const LfvioWindow *in, Lf
   }
   LfvioWindow w = *in;
   w.prior = prior_io->valid ? prior_io : nullptr;
+  return lfvio_batch_upload(c, slot, &w);
+}
+// ... and the form in which the prior never reaches the caller (the product keeps it on the device): here simply the prior of
+// the call "in flight", handed from one slot copy to the next
+int lfvio_batch_upload_chained_device(lfvio_ctx *c, int slot, const LfvioWindow *in) {
+  if (!c || !in || slot != 0 || c->slots.empty() || !c->pending) return LFVIO_ERR_ARG;
+  std::unique_ptr<LfvioPrior> p(new LfvioPrior);
+  p->valid = 0;
+  int rc = lfvio_batch_optimize_finish(c, p.get());
+  if (rc != LFVIO_OK) return rc;
+  LfvioWindow w = *in;
+  w.prior = p->valid ? p.get() : nullptr;
   return lfvio_batch_upload(c, slot, &w);
 }
 // the split form: the oracle has nothing to overlap — begin does everything, finish hands the prior over

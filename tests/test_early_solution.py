@@ -235,6 +235,97 @@ def test_chained_upload_refused_leaves_the_prior_collectable():
     same_prior(eng.optimize_finish(), ref[0][2])
 
 
+def test_device_chained_upload_follows_the_stream():
+    """upload_chained_device(k + 1) while the marginalization of window k is in flight: the prior never leaves the device, nothing is
+    waited for — and every window of the chain still gets, bit for bit, the solution of the plain upload / optimize / download sequence
+    that generated the chain (same values in the same arrays: only the road they took differs); the last call's prior is collectable."""
+    ref = stream_windows(Engine(0), 8)
+    eng = Engine(0)
+    eng.batch_reserve(1, 400, 3000)
+    for k, (w, rsol, rprior) in enumerate(ref):
+        if k == 0:
+            eng.batch_upload(0, w)
+        else:
+            assert eng.optimize_pending()
+            eng.batch_upload_chained_device(0, w.copy(prior=None))
+            assert not eng.optimize_pending()  # (the call that was in flight is only work on the stream now)
+        same_solution(eng.optimize_begin(abi.MARGIN_OLD, w.N), rsol)
+    same_prior(eng.optimize_finish(), ref[-1][2])
+    # ... and the context goes on through every other road: host-chained, plain, whole
+    carried = abi.Prior()
+    eng.batch_upload(0, ref[3][0])
+    eng.optimize_begin(abi.MARGIN_OLD, ref[3][0].N)
+    eng.batch_upload_chained_device(0, ref[4][0].copy(prior=None))
+    same_solution(eng.optimize_begin(abi.MARGIN_OLD, ref[4][0].N), ref[4][1])
+    eng.batch_upload_chained(0, ref[5][0].copy(prior=None), carried)  # collects window 4's prior, which ran on a device-chained one
+    same_prior(carried, ref[4][2])
+    same_solution(eng.optimize_begin(abi.MARGIN_OLD, ref[5][0].N), ref[5][1])
+    eng.batch_upload_chained_device(0, ref[6][0].copy(prior=None))
+    sol6 = eng.optimize_begin(abi.MARGIN_OLD, ref[6][0].N)
+    _, prior6 = eng.batch_download(0, ref[6][0].N)  # joins the tail, then the usual download
+    same_solution(sol6, ref[6][1])
+    same_prior(prior6, ref[6][2])
+
+
+def test_device_chained_upload_needs_a_prior_in_flight():
+    ref = stream_windows(Engine(0), 2)
+    eng = Engine(0)
+    eng.batch_reserve(1, 400, 3000)
+    w0, w1 = ref[0][0], ref[1][0]
+    with pytest.raises(RuntimeError):  # nothing uploaded, nothing in flight
+        eng.batch_upload_chained_device(0, w1.copy(prior=None))
+    eng.batch_upload(0, w0)
+    eng.batch_optimize(1, abi.MARGIN_OLD)  # a whole call: its prior is in the slot, but no call is in flight
+    with pytest.raises(RuntimeError):
+        eng.batch_upload_chained_device(0, w1.copy(prior=None))
+    # MARGIN_SECOND_NEW of a window without a prior marginalizes nothing: there is no prior to take over
+    eng.batch_upload(0, w0)
+    eng.optimize_begin(abi.MARGIN_SECOND_NEW, w0.N)
+    with pytest.raises(RuntimeError):
+        eng.batch_upload_chained_device(0, w1.copy(prior=None))
+    assert eng.optimize_pending()  # (refused: the call in flight is untouched)
+    assert eng.optimize_finish().valid == 0
+    # a refused window (every track leaves it) leaves the prior of the call in flight collectable
+    eng.batch_upload(0, w0)
+    eng.optimize_begin(abi.MARGIN_OLD, w0.N)
+    bad = w1.copy(prior=None, start_frame=np.full(w1.N, 10, dtype=np.int32))
+    with pytest.raises(RuntimeError):
+        eng.batch_upload_chained_device(0, bad)
+    same_prior(eng.optimize_finish(), ref[0][2])
+    # and the road is open afterwards
+    eng.batch_upload(0, w0)
+    eng.optimize_begin(abi.MARGIN_OLD, w0.N)
+    eng.batch_upload_chained_device(0, w1.copy(prior=None))
+    same_solution(eng.optimize_begin(abi.MARGIN_OLD, w1.N), ref[1][1])
+    same_prior(eng.optimize_finish(), ref[1][2])
+
+
+def test_device_chained_prior_that_passes_through_is_fetched():
+    """A window that took its prior over on the device and whose own MARGIN_SECOND_NEW marginalizes nothing (the prior does not touch
+    the newest pose) hands that prior back: its values have never been on the host and are read out of the slot."""
+    found = None
+    for seed in range(40, 80):  # a chain whose first prior lacks Pose[9]: few landmarks, short tracks
+        e0 = Engine(0)
+        ref = stream_windows(e0, 1, n_lm=2, seed=seed)
+        p0 = ref[0][2]
+        if p0.valid == 1 and (abi.BLOCK_POSE, 9) not in [(b[0], b[1]) for b in p0.block_list()]:
+            found = ref
+            break
+    if found is None:
+        pytest.skip("no short-track chain among the seeds tried")
+    (w0, _, p0), (w1, _, _) = found
+    r_sol, r_prior = whole(Engine(0), w1, abi.MARGIN_SECOND_NEW)  # w1 carries p0 (the chain's generator put it there)
+    eng = Engine(0)
+    eng.batch_reserve(1, 400, 3000)
+    eng.batch_upload(0, w0)
+    eng.optimize_begin(abi.MARGIN_OLD, w0.N)
+    eng.batch_upload_chained_device(0, w1.copy(prior=None))
+    same_solution(eng.optimize_begin(abi.MARGIN_SECOND_NEW, w1.N), r_sol)
+    got = eng.optimize_finish()
+    same_prior(got, r_prior)
+    same_prior(got, p0)
+
+
 def test_context_torn_down_or_reconfigured_with_the_tail_in_flight():
     """lfvio_destroy and the calls that drop the captured graphs (here lfvio_debug_force_eig) wait for a marginalization
     still running behind an early state instead of pulling its graph from under it."""
