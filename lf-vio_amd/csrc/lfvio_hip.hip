@@ -182,7 +182,9 @@ struct lfvio_ctx {
   hipGraphExec_t chunk[2] = {}, tail[2][3] = {};  // chunk[speculation variant]
   hipGraphExec_t first[2][2][4][13] = {};  // [speculation variant: 0 three candidates (or none), 1 four][publish][0: solve only, 1 + flag: with the gated tail][passes in the first graph]
   int fixed_passes = 0;             // debug (LFVIO_FIRST_PASSES / lfvio_debug_set_first_passes): > 0 sizes every first graph with this many passes
-  int predict_passes = 4;           // passes the previous synchronous call needed; tail[flag]: force-done + gated gauge fix + marginalization
+  int recent_passes[4] = {0, 0, 0, 0}, recent_head = 0;  // passes of the last four synchronous calls (predict())
+  bool predicted_early = false;     // lfvio_batch_optimize_begin has fed this call's pass count to predict() already (the join / finish that follows must not again)
+  int predict_passes = 4;           // passes the first graph of the next call carries: the most any of the last four calls needed (predict()); tail[flag]: force-done + gated gauge fix + marginalization
   double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
   int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0, k_linw = 0;
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
@@ -268,6 +270,17 @@ void destroy_graph(lfvio_ctx *c) {
 // take the bookkeeping its graph left in the pinned block.  First statement of everything that touches the slots.
 // pipelined_ok (lfvio_batch_optimize_begin only): a window uploaded behind a marginalization that is still running
 // (lfvio_batch_upload_chained_device) is optimized behind it too — everything is ordered by the stream, nothing is waited for.
+// The first graph of the next call is sized from the calls before it.  A pass the window does not need returns at once (~15 us of
+// launches for the four kernels); a pass it needs and the graph does not carry is a round trip to the host and another graph
+// launch (~60 us).  A resident window re-solved again and again needs the same number every time; the windows of a stream vary by
+// one or two passes from frame to frame (4 .. 8 on the synthetic stream): the most any of the last four calls needed covers nearly
+// all of them (measured on the stream: 0.881 ms per window with the last call's count, 0.862 with a fixed 8).
+void predict(lfvio_ctx *c) {
+  c->recent_passes[c->recent_head++ & 3] = c->last_passes;
+  int m = 1;
+  for (int k = 0; k < 4; k++) m = std::max(m, c->recent_passes[k]);
+  c->predict_passes = m;
+}
 constexpr const char *CHAIN_ERR_TEXT = "the prior this window was to take over on the device was not there (the marginalization before it produced none): it ran without a prior";
 int join_inflight(lfvio_ctx *c, bool pipelined_ok = false) {
   if (c->pipelined && !c->inflight && pipelined_ok) return LFVIO_OK;
@@ -280,7 +293,8 @@ int join_inflight(lfvio_ctx *c, bool pipelined_ok = false) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->inflight_first) {
     c->last_passes = std::max(c->h_pending[3], 1), c->last_iters = c->h_pending[4];
-    c->predict_passes = c->last_passes;
+    if (!c->predicted_early) predict(c);
+    c->predicted_early = false;
     if (c->h_pending[2] != 2) {
       c->err = "the marginalization behind an early solution did not finish";
       return LFVIO_ERR_DEVICE;
@@ -1297,7 +1311,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       }
     }
     c->last_passes = std::max(c->h_pending[1], 1);  // passes the slowest window has used
-    c->predict_passes = c->last_passes;
+    predict(c);
     HIPCHK(c, hipGetLastError());
     return LFVIO_OK;
   }
@@ -1779,7 +1793,7 @@ int lfvio_batch_optimize_begin(lfvio_ctx *c, int marg_flag, LfvioSolution *sol) 
   // the loop is closed: its pass and iteration counts size the next call's first graph (a caller that pipelines — the next window
   // uploaded behind this call's marginalization — never joins this graph)
   c->last_passes = std::max(((const int *)m)[4], 1), c->last_iters = ((const TRState *)(m + MAIL_TR))->iteration;
-  if (c->inflight_first) c->predict_passes = c->last_passes;
+  if (c->inflight_first) predict(c), c->predicted_early = true;
   if (((const int *)m)[5]) {
     c->err = CHAIN_ERR_TEXT;
     return LFVIO_ERR_DEVICE;
@@ -1814,7 +1828,8 @@ int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
     if (there) {
       c->inflight = false, c->unsynced = true;  // (what is left of the graph is a copy of two words: the next join waits for it)
       c->last_passes = std::max(((const int *)c->h_mail)[2], 1), c->last_iters = ((const int *)c->h_mail)[3];
-      if (c->inflight_first) c->predict_passes = c->last_passes;
+      if (c->inflight_first && !c->predicted_early) predict(c);
+      c->predicted_early = false;
       Fetched f{};
       f.prior = (LfvioPrior *)(c->h_mail + MAIL_PRIOR);
       bool pass = false;

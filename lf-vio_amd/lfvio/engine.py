@@ -147,6 +147,11 @@ class Engine:
         self._check(self.lib.lfvio_batch_upload_chained(self.ctx, slot, C.byref(marshalled if marshalled is not None else win.c()), C.byref(prior)),
                     "batch_upload_chained")
 
+    def set_first_passes(self, n):
+        """Debug: > 0 sizes every first graph of the synchronous calls with this many passes (0: from the recent calls again)."""
+        self.lib.lfvio_debug_set_first_passes.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.lfvio_debug_set_first_passes(self.ctx, n), "set_first_passes")
+
     def batch_upload_chained_device(self, slot, win, marshalled=None):
         """The next window of the same estimator, its prior taken over ON THE DEVICE from the call still in flight (no wait, no
         copy of the prior in either direction); win.prior is ignored."""

@@ -371,16 +371,20 @@ def test_windows_that_need_more_than_one_chunk_of_passes(eng, oracle):
         return k
 
     check(quick)
-    assert check(quick) == 1  # sized from the call before: one graph, marginalization included
+    assert check(quick) == 1  # sized from the calls before: one graph, marginalization included
+    eng.set_first_passes(4)   # (as a context that has only ever seen the quick window sizes it: the fixture's has seen others)
     assert check(slow) >= 2   # the first graph was too short: continuation chunks, then the gated tail
-    assert check(slow) == 1   # ... and the next call knows
+    eng.set_first_passes(0)
+    assert check(slow) == 1   # ... and the next call knows (the most any of the last four calls needed)
     assert check(quick) == 1  # a first graph that is too long costs dead passes, not launches
     wins = [quick, slow]
     # the two windows in one batch: the first chunk finishes one of them, the other goes on
     eng.batch_reserve(2, 120, max(w.M for w in wins))
     for s, w in enumerate(wins):
         eng.batch_upload(s, w)
+    eng.set_first_passes(4)
     eng.batch_optimize(2, abi.MARGIN_OLD)
+    eng.set_first_passes(0)
     assert eng.last_chunks() >= 2
     for s, w in enumerate(wins):
         sol, prior = eng.batch_download(s, w.N)
