@@ -326,6 +326,60 @@ def test_device_chained_prior_that_passes_through_is_fetched():
     same_prior(got, p0)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_call_sequences_keep_the_chain(seed):
+    """The three ways a window can reach the device (plain upload with its prior, the host-side hand-over, the hand-over on the device)
+    and the two ways it can be optimized (split, whole), drawn at random along one chain, with collections, joins and a growing
+    reservation thrown in between: every window still gets the bits of the plain sequence that generated the chain."""
+    ref = stream_windows(Engine(0), 10, n_lm=150)
+    rng = np.random.default_rng(seed)
+    eng = Engine(0)
+    eng.batch_reserve(1, 200, 1500)
+    carried = abi.Prior()
+    pending = False  # a begin() whose prior nobody has collected yet
+    for k, (w, rsol, rprior) in enumerate(ref):
+        bare = w.copy(prior=None)
+        assert eng.optimize_pending() == pending
+        road = rng.choice(["plain", "host", "device"]) if (k and pending) else "plain"
+        if road == "plain":
+            if pending and rng.random() < 0.5:
+                same_prior(eng.optimize_finish(), ref[k - 1][2])
+            eng.batch_upload(0, w)  # (joins whatever is in flight; the window carries its prior)
+        elif road == "host":
+            eng.batch_upload_chained(0, bare, carried)
+            same_prior(carried, ref[k - 1][2])
+        else:
+            eng.batch_upload_chained_device(0, bare)
+        pending = False
+        if rng.random() < 0.25:
+            eng.batch_reserve(1, 200 + 40 * k, 1500 + 300 * k)  # (may re-allocate: the resident window has to survive or be re-sent)
+            eng.batch_upload(0, w)
+        if rng.random() < 0.7:
+            sol = eng.optimize_begin(abi.MARGIN_OLD, w.N)
+            pending = eng.optimize_pending()
+            same_solution(sol, rsol)
+            what = rng.choice(["nothing", "finish", "download", "sync"])
+            if what == "finish":
+                same_prior(eng.optimize_finish(), rprior)
+                pending = False
+            elif what == "download":
+                sol2, prior2 = eng.batch_download(0, w.N)
+                same_solution(sol2, rsol)
+                same_prior(prior2, rprior)
+                pending = False
+            elif what == "sync":
+                eng.batch_sync()
+                pending = False
+                same_prior(eng.batch_download(0, w.N)[1], rprior)
+        else:
+            eng.batch_optimize(1, abi.MARGIN_OLD)
+            sol, prior = eng.batch_download(0, w.N)
+            same_solution(sol, rsol)
+            same_prior(prior, rprior)
+    if pending:
+        same_prior(eng.optimize_finish(), ref[-1][2])
+
+
 def test_context_torn_down_or_reconfigured_with_the_tail_in_flight():
     """lfvio_destroy and the calls that drop the captured graphs (here lfvio_debug_force_eig) wait for a marginalization
     still running behind an early state instead of pulling its graph from under it."""
