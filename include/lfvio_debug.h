@@ -39,9 +39,10 @@ int lfvio_debug_set_decide_merge(lfvio_ctx *ctx, int on);
 int lfvio_debug_force_eig(lfvio_ctx *ctx, int on);
 /* graph launches the last synchronous solve loop needed (1: every window was done within the first chunk of passes,
    and gauge fix + marginalization ran in the same graph) */
-/* microseconds of the last upload: host packing | collecting a chained prior | prior + copies enqueued | final synchronization */
+/* microseconds of the last upload: host packing | collecting a chained prior (after lfvio_batch_upload_chained_device: the graph launch of the
+   lfvio_batch_optimize_begin that followed, which goes out behind work still running) | prior + copies enqueued | final synchronization */
 int lfvio_debug_upload_times(lfvio_ctx *ctx, double *out4);
-/* n > 0: every first graph of the synchronous entry points carries n passes instead of the number the previous call needed; 0: adaptive */
+/* n > 0: every first graph of the synchronous entry points carries n passes instead of the most any of the last four calls needed; 0: adaptive */
 int lfvio_debug_set_first_passes(lfvio_ctx *ctx, int n);
 /* Solver::Options::function_tolerance of the windows uploaded from now on (Ceres' default 1e-6; estimator.cpp:810-822 leaves it
  * alone).  0 makes the loop run to its iteration cap or another criterion: the diagnostic of tests/tools/fuzz_parity.py, which
