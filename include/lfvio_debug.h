@@ -56,6 +56,10 @@ int lfvio_debug_set_initial_radius(lfvio_ctx *ctx, double r);
  * uploaded from now on; 0: four lanes, 64 landmarks, the form larger windows take.  Same sums in a different association.
  * Environment: LFVIO_LM_HALF. */
 int lfvio_debug_set_lm_half(lfvio_ctx *ctx, int on);
+/* The next lfvio_batch_upload_chained_device promises the device a prior of one row more than the marginalization in flight will leave:
+ * k_prior_chain refuses it, the window runs without a prior, and the lfvio_batch_optimize_begin that follows returns LFVIO_ERR_DEVICE —
+ * the path a failed marginalization takes, for tests. */
+int lfvio_debug_break_next_chain(lfvio_ctx *ctx);
 /* Where the strip sweep (kernels_linw.h) replaces the role-by-role one (k_lin + k_sum): 1 (default) for a resident batch whose
  * windows all carry a plan (k_linw: one workgroup per window, no partial sums through HBM) and for a single window — or a rank's
  * share of a sharded one — of at least 40 960 landmarks (k_linb + k_sumb: one workgroup per group of strips); 0 never; 2 for every

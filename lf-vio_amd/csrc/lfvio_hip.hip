@@ -210,6 +210,8 @@ struct lfvio_ctx {
                                 // the stream holds work nobody has waited for; the next lfvio_batch_optimize_begin goes out behind it without a wait
   int mail_seq = 0;             // sequence number of the last upload (Slot::mail_seq)
   std::unique_ptr<LfvioPrior> chain_struct;  // the structure-only prior of a device-chained upload
+  bool chain_err_told = false;     // the call in flight ran without the prior it was promised and its begin() has said so
+  bool debug_break_chain = false;  // lfvio_debug_break_next_chain: the next device-chained upload promises a prior of another size than the device will find
   bool inflight_first = false;  // the flag came out of the first graph: {tail_state, passes_used} land in h_pending[2..3] when it ends
   bool use_graph = true;
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
@@ -299,7 +301,9 @@ int join_inflight(lfvio_ctx *c, bool pipelined_ok = false) {
       c->err = "the marginalization behind an early solution did not finish";
       return LFVIO_ERR_DEVICE;
     }
-    if (c->h_pending[5]) {
+    const bool told = c->chain_err_told;  // (lfvio_batch_optimize_begin has reported it with the state: once is enough)
+    c->chain_err_told = false;
+    if (c->h_pending[5] && !told) {
       c->err = CHAIN_ERR_TEXT;
       return LFVIO_ERR_DEVICE;
     }
@@ -499,6 +503,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     LfvioPrior *sp = c->chain_struct.get();
     std::memset(sp, 0, offsetof(LfvioPrior, linearized_jacobians));
     sp->valid = 1, sp->n = mo.n, sp->m = mo.m, sp->num_blocks = mo.nb;
+    if (c->debug_break_chain) sp->n = mo.n + 1, c->debug_break_chain = false;  // (k_prior_chain finds a prior of mo.n rows: the failure path, end to end)
     for (int i = 0; i < mo.nb; i++) sp->blocks[i].kind = mo.kind[i], sp->blocks[i].frame = mo.frame[i], sp->block_idx[i] = mo.idx[i];
     chain = sp;
   }
@@ -1796,6 +1801,7 @@ int lfvio_batch_optimize_begin(lfvio_ctx *c, int marg_flag, LfvioSolution *sol) 
   if (c->inflight_first) predict(c), c->predicted_early = true;
   if (((const int *)m)[5]) {
     c->err = CHAIN_ERR_TEXT;
+    c->chain_err_told = true;
     return LFVIO_ERR_DEVICE;
   }
   f.xs = (const FrameState *)(m + MAIL_X), f.tr = (const TRState *)(m + MAIL_TR);
@@ -2250,6 +2256,11 @@ int lfvio_debug_set_linw(lfvio_ctx *c, int mode) {
 int lfvio_debug_set_function_tolerance(lfvio_ctx *c, double tol) {
   if (!c || !(tol >= 0.0)) return LFVIO_ERR_ARG;
   c->fn_tol = tol;
+  return LFVIO_OK;
+}
+int lfvio_debug_break_next_chain(lfvio_ctx *c) {
+  if (!c) return LFVIO_ERR_ARG;
+  c->debug_break_chain = true;
   return LFVIO_OK;
 }
 int lfvio_debug_set_lm_half(lfvio_ctx *c, int on) {

@@ -59,6 +59,10 @@ class Engine:
         self.lib.lfvio_debug_solve_kernel.argtypes = [C.c_void_p, C.c_int]
         return int(self.lib.lfvio_debug_solve_kernel(self.ctx, count))
 
+    def break_next_chain(self):
+        self.lib.lfvio_debug_break_next_chain.argtypes = [C.c_void_p]
+        self._check(self.lib.lfvio_debug_break_next_chain(self.ctx), "break_next_chain")
+
     def set_lm_half(self, on):
         self.lib.lfvio_debug_set_lm_half.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.lfvio_debug_set_lm_half(self.ctx, int(on)), "set_lm_half")

@@ -300,6 +300,31 @@ def test_device_chained_upload_needs_a_prior_in_flight():
     same_prior(eng.optimize_finish(), ref[1][2])
 
 
+def test_device_chained_prior_that_is_not_there_is_an_error_not_a_silent_solve():
+    """The marginalization in flight does not leave the prior the next window was promised (here: a promise of the wrong size; in the field:
+    a marginalization that failed on the device): the window must not pass for solved — the begin() behind the upload reports it, whether
+    the state came early or not, and the context goes on with the next plain upload."""
+    ref = stream_windows(Engine(0), 3)
+    eng = Engine(0)
+    eng.batch_reserve(1, 400, 3000)
+    for early in (True, False):
+        eng.batch_upload(0, ref[0][0])
+        eng.optimize_begin(abi.MARGIN_OLD, ref[0][0].N)
+        eng.break_next_chain()
+        eng.batch_upload_chained_device(0, ref[1][0].copy(prior=None))
+        if not early:
+            eng.set_first_passes(2)  # too short a first graph: the call goes the synchronous way (continuation chunks, tail graph)
+        with pytest.raises(RuntimeError, match="was not there"):
+            eng.optimize_begin(abi.MARGIN_OLD, ref[1][0].N)
+        eng.set_first_passes(0)
+        # the road is open again, device-chained included
+        eng.batch_upload(0, ref[1][0])
+        same_solution(eng.optimize_begin(abi.MARGIN_OLD, ref[1][0].N), ref[1][1])
+        eng.batch_upload_chained_device(0, ref[2][0].copy(prior=None))
+        same_solution(eng.optimize_begin(abi.MARGIN_OLD, ref[2][0].N), ref[2][1])
+        same_prior(eng.optimize_finish(), ref[2][2])
+
+
 def test_device_chained_prior_that_passes_through_is_fetched():
     """A window that took its prior over on the device and whose own MARGIN_SECOND_NEW marginalizes nothing (the prior does not touch
     the newest pose) hands that prior back: its values have never been on the host and are read out of the slot."""
