@@ -672,7 +672,7 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
   STAMP(S, 2);
   // ---- reduced system, in place:  S = S_p (H_pp - Schur) S_p + mu D^2  and the rhs row; the Cauchy-point quadratic
   //      form G^T H G is accumulated from the same entries on the way.
-  double qgg_part = 0;
+  double qgg_part = 0, grhs_part = 0;  // grhs: G . (g - z1) over the active columns = gamma^T rhs of the scaled system (the forms below)
   {
     int n15 = 0;
     // per-thread slices of the vectors: row index 16 a + er, column index 16 b + ek
@@ -704,6 +704,7 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
           double r = g[j];
           if (j < KC) r -= srhs[b < 5 ? b : 0];  // z1
           v = sj[b] * r;
+          grhs_part = fma(Gj[b], r, grhs_part);
         }
       }
       Hs[t * TSZ + esw] = v;
@@ -743,6 +744,7 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
     bad = f > 0.0;
   }
   STAMP(S, 5);
+  const double zt = tid < KP ? Hs[lidx(KP, tid)] : 0.0;  // z = L^-1 rhs (the rhs row of the factor): y^T rhs = |z|^2, for N^T H N below
   tile_backsub<NTL, KP>(Hs, yv, invd, tid);
   STAMP(S, 6);
   {
@@ -775,32 +777,12 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
   if (tid >= KC && tid < WLD) S->uc_grad[tid] = S->uc_gn[tid] = 0.0;
   __syncthreads();
   {
-    // G^T H N and N^T H N from the entries of H_pp this thread has held in registers since the start
-    double qgn = 0, qnn = 0;
-    {
-      double Gi[NTL], Ni[NTL], Gj[NTL], Nj[NTL];
-#pragma unroll
-      for (int a = 0; a < NTL; a++) {
-        const int i = 16 * a + er, j = 16 * a + ek;
-        Gi[a] = i < KP ? Gd[i] : 0.0, Ni[a] = i < KP ? yv[i] : 0.0;
-        Gj[a] = j < KP ? Gd[j] : 0.0, Nj[a] = j < KP ? yv[j] : 0.0;
-      }
-#pragma unroll
-      for (int t = 0; t < NTILES; t++) {
-        const int a = tile_a(t), b = tile_b(t);
-        const int i = 16 * a + er, j = 16 * b + ek;
-        if (i < KP && j <= i) {
-          const double h = hreg[t];
-          if (i == j) {
-            qgn = fma(h, Gi[a] * Nj[b], qgn);
-            qnn = fma(h, Ni[a] * Nj[b], qnn);
-          } else {
-            qgn = fma(h, Gi[a] * Nj[b] + Ni[a] * Gj[b], qgn);
-            qnn = fma(h, 2.0 * Ni[a] * Nj[b], qnn);
-          }
-        }
-      }
-    }
+    // G^T H N and N^T H N WITHOUT another pass over H_pp (round 5; it was a second walk over this thread's 66 tile entries).  With the
+    // scaled system  S = s (H - C) s + mu D^2  (C: the landmarks' Schur sums, camera block), S y = rhs, N = -s y, G = s gamma:
+    //   N^T H N = y^T rhs - mu |D y|^2 + N_c^T C N_c = |z|^2 - mu |gauss_newton|^2 + N_c^T C N_c         (z = L^-1 rhs: L^T y = z)
+    //   G^T H N = -gamma^T rhs - mu gradient_ . gauss_newton + G_c^T C N_c                                (gamma^T rhs = G . (g - z1))
+    // — sums over 172 entries and over the 15 camera tiles of C, every term of them already here.  No cancellation: |z|^2 and the C form
+    // are non-negative and the mu terms are 1e-4 of them or less.
     double gn2 = 0, ggn = 0, gG = 0, gN = 0;
     if (tid < KP) {
       const double gn = hv[tid];
@@ -809,18 +791,23 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
       gG = g[tid] * Gd[tid];
       gN = g[tid] * yv[tid];
     }
-    // lfvio_group (Slot::sharded 2): the landmark parts of the two norms the dogleg needs, from the reduced Schur sums this thread
-    // has held since the start — N_c^T (sum c w w^T) N_c and (sum c b w) . N_c (k_lm_cb2 above has the identities)
-    double nsn = 0, z1n = 0;
-    if (sharded == 2) {
+    // N_c^T C N_c and G_c^T C N_c from the reduced Schur sums this thread has held since the start (the first is also the landmark
+    // part of |gauss_newton|^2 an lfvio_group rank forms for itself: k_lm_cb2 above has the identities, with (sum c b w) . N_c)
+    double nsn = 0, gcn = 0, z1n = 0;
+    {
       int n15 = 0;
 #pragma unroll
       for (int t = 0; t < NTILES; t++)
         if (tile_a(t) <= 4) {
           const int i = 16 * tile_a(t) + er, j = 16 * tile_b(t) + ek;
-          if (i < KC && j <= i) nsn = fma(sreg[n15], (i == j ? 1.0 : 2.0) * yv[i] * yv[j], nsn);
+          if (i < KC && j <= i) {
+            nsn = fma(sreg[n15], (i == j ? 1.0 : 2.0) * yv[i] * yv[j], nsn);
+            gcn = fma(sreg[n15], i == j ? Gd[i] * yv[j] : Gd[i] * yv[j] + yv[i] * Gd[j], gcn);
+          }
           n15++;
         }
+    }
+    if (sharded == 2) {
       if (er == 0) {
 #pragma unroll
         for (int b = 0; b < 5; b++)
@@ -829,9 +816,10 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
     }
     double pcb = 0, pnc = 0;  // (k_lm_cb2's partials, reduced over the ranks: a pair per thread)
     if (sharded == 2 && tid < XP_WGS) pcb = xch[XOFF_P + 2 * tid], pnc = xch[XOFF_P + 2 * tid + 1];
-    double sums[10] = {gn2, ggn, gG, gN, qgn, qnn, nsn, z1n, pcb, pnc};
+    double sums[11] = {gn2, ggn, gG, gN, zt * zt, grhs_part, nsn, z1n, pcb, pnc, gcn};
     block_sum_n(sums, scratch, tid);
-    gn2 = sums[0], ggn = sums[1], gG = sums[2], gN = sums[3], qgn = sums[4], qnn = sums[5];
+    gn2 = sums[0], ggn = sums[1], gG = sums[2], gN = sums[3];
+    const double qnn = sums[4] - mu * gn2 + sums[6], qgn = -sums[5] - mu * ggn + sums[10];
     STAMP(S, 7);
     if (tid == 0) {
       solve_epilogue(S, tr, ls, gn2, ggn, gG, gN, qgn, qnn);
