@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--batch-secondary", action="store_true",
                     help="also time 512 resident windows per GPU (no collective) and add it to the line as 'batch512_weak' "
                          "(on by default next to the sharded workload on more than one GPU)")
+    ap.add_argument("--lib", default=None, help="A/B runs: another build of the product library (default: lf-vio_amd/liblfvio_hip.so)")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line.  Libraries below (RCCL prints a version banner through C stdio when a communicator is
@@ -374,7 +375,7 @@ def main():
     from lfvio import abi, synth
     from lfvio.engine import Engine
 
-    eng = Engine(local_rank)
+    eng = Engine(local_rank, args.lib)
     flag = abi.MARGIN_OLD
 
     def hip_optimize(w, f):  # warm-up MARGIN_OLD step of the window sequence: the product path itself

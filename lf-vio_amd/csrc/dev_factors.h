@@ -22,7 +22,14 @@ struct ObsPair {
 struct PairU {  // pair-uniform inputs
   m33 M2, T, ric, ricT;
   d3 c, tic;
+  // Non-null for a pair whose frame j or extrinsic quaternion is off the unit sphere (dev_types.h, struct Tab): T and c above are
+  // the residual chain's then, and the Jacobians fetch what they need beyond M2 from the table themselves (a start point's
+  // newest frame — the lanes that go there are few, and nothing of it is live on the way everybody else takes)
+  const double *offc;  // the pair's Jacobian-flavour c, Tab::c[tab_cj(pair)]
+  const double *offr;  // ricF, Tab::T[0]
 };
+DEV int pair_is_off(unsigned offm, int j) { return (offm & ((1u << j) | (1u << TAB_EX_BIT))) != 0; }
+DEV unsigned tab_offmask(const Tab *T) { return (unsigned)uniform_cptr(&T->c[0][0])[0]; }  // (written by an earlier kernel: a scalar load)
 
 struct Basis {
   d3 red[2];   // reduce rows (corrected)
@@ -69,6 +76,8 @@ DEV double visual_cost(const ObsPair &ob, double lam, double td, int est_td, dou
 
 // residual + basis Jacobian columns, robust-corrected (ceres Corrector with rho'' <= 0:
 // everything scaled by sqrt(rho'), marginalization_factor.cpp:49-53).
+// OFFS = false: compiled without the off-sphere flavour (u.offc is not looked at) — the caller has seen a zero mask.
+template <bool OFFS = true>
 DEV void visual_basis(const ObsPair &ob, double lam, double td, int est_td, double tr_over_row, double half_row,
                       double sqrt_info, const PairU &u, Basis &B) {
   d3 pi = ob.pi, pj = ob.pj;
@@ -81,6 +90,13 @@ DEV void visual_basis(const ObsPair &ob, double lam, double td, int est_td, doub
   d3 Xbi = mul(u.ric, Xci) + u.tic;      // pts_imu_i              (:57)
   d3 Xcj = mul(u.T, Xci) + u.c;          // pts_camera_j           (:58-60 folded)
   d3 Xbj = mul(u.ric, Xcj) + u.tic;      // pts_imu_j
+  // The Jacobians write the skew argument of :131 with transposes where the chain above went through Quaternion::inverse() —
+  // the same unless a quaternion of the pair is off the unit sphere:  (M2 ric) Xci + c = M2 (Xbi - tic) + c  needs no second T.
+  d3 XcjJ = Xcj;
+  if (OFFS && u.offc) {
+    Xbj = mul(ldm(u.offr), Xcj) + u.tic;  // the chain's pts_imu_j (:59): ricF undoes R(qic^-1) exactly
+    XcjJ = mul(u.M2, Xbi - u.tic) + ld3(u.offc);
+  }
   const double inv_n = rsqrt(dot(Xcj, Xcj));
   d3 nh = inv_n * Xcj;
   d3 pjn = rsqrt(dot(pj, pj)) * pj;
@@ -113,10 +129,11 @@ DEV void visual_basis(const ObsPair &ob, double lam, double td, int est_td, doub
   d3 rr0 = vmul(red0, u.ricT), rr1 = vmul(red1, u.ricT);
   B.jtj[0] = cross(rr0, Xbj);  // reduce ric^T skew(pts_imu_j)                     (:116-120)
   B.jtj[1] = cross(rr1, Xbj);
-  d3 rt0 = vmul(red0, u.T), rt1 = vmul(red1, u.T);
+  // reduce ric^T Rj^T Ri ric (:126,:137,:143) = (reduce M2) ric: the Jacobians' flavour whatever T holds
+  d3 rt0 = vmul(rm0, u.ric), rt1 = vmul(rm1, u.ric);
   // -T skew(Xci) + skew(T Xci) + skew(c)  ==  -T skew(Xci) + skew(Xcj)             (:126-131)
-  B.jtx[0] = cross(red0, Xcj) - cross(rt0, Xci);
-  B.jtx[1] = cross(red1, Xcj) - cross(rt1, Xci);
+  B.jtx[0] = cross(red0, XcjJ) - cross(rt0, Xci);
+  B.jtx[1] = cross(red1, XcjJ) - cross(rt1, Xci);
   const double il2 = inv_lam * inv_lam;
   B.jl[0] = -dot(rt0, pi) * il2;  // :137
   B.jl[1] = -dot(rt1, pi) * il2;
@@ -129,25 +146,47 @@ DEV void visual_basis(const ObsPair &ob, double lam, double td, int est_td, doub
 }
 
 // Block-cooperative construction of the per-frame / per-pair table for one state.
-// Call with >= 128 threads; contains __syncthreads().
 // Per-frame and per-pair quantities of one linearization point.  poses: 12 x 7 doubles in LDS (pose[0..10], ex_pose);
-// lds: >= 256 doubles of scratch.  The intermediate results travel through LDS (a global write -> barrier -> read by
+// lds: >= TAB_SCRATCH doubles of scratch.  The intermediate results travel through LDS (a global write -> barrier -> read by
 // another thread is a full memory round trip each time, and there are two of them), the table itself is written once.
 // Needs >= 121 threads; every thread of the workgroup has to come here (barriers inside).
-DEV void build_tab(const double *poses, Tab *t, int tid, double *lds) {
+// A quaternion off the unit sphere (struct Tab, dev_types.h) gets its back-rotation R(q^-1) beside R^T; the pairs it touches
+// take T and c from it and keep the transposed flavour of c for their Jacobians.
+constexpr int TAB_SCRATCH = 376;
+DEV bool q_off_sphere(q4 q) { return fabs((q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z) - 1.0) > TAB_OFF_SPHERE; }
+// Returns the table's off-sphere mask (every thread).
+DEV unsigned build_tab(const double *poses, Tab *t, int tid, double *lds) {
   double *R = lds, *P = lds + 99, *ric = lds + 132, *ricT = lds + 141, *tic = lds + 150, *M1 = lds + 153;  // .. 252
+  double *RI = lds + 252, *ricI = lds + 351;  // R(q^-1) of the frames / the extrinsic whose quaternion is off the sphere
+  unsigned *offm = (unsigned *)(lds + 360);   // their mask
+  bool off = false;
   if (tid < 11) {
     const double *p = poses + 7 * tid;
-    const m33 r = q2R(q_from_pose(p));
+    const q4 q = q_from_pose(p);
+    const m33 r = q2R(q);
     stm(R + 9 * tid, r), stm(t->R[tid], r);
+    off = q_off_sphere(q);
+    if (off) stm(RI + 9 * tid, q2R(qinv(q)));
 #pragma unroll
     for (int k = 0; k < 3; k++) P[3 * tid + k] = p[k], t->P[tid][k] = p[k];
   } else if (tid == 11) {
     const double *p = poses + 77;
-    const m33 r = q2R(q_from_pose(p)), rT = tr(r);
+    const q4 q = q_from_pose(p);
+    const m33 r = q2R(q), rT = tr(r);
     stm(ric, r), stm(ricT, rT), stm(t->ric, r), stm(t->ricT, rT);
+    off = q_off_sphere(q);
+    m33 rF = r;  // ricF
+    if (off) {
+      const m33 rI = q2R(qinv(q));
+      stm(ricI, rI), rF = inv33(rI);
+    }
+    stm(t->T[0], rF);
 #pragma unroll
     for (int k = 0; k < 3; k++) tic[k] = p[k], t->tic[k] = p[k];
+  }
+  if (tid < 64) {  // (the twelve quaternions sit in wave 0)
+    const unsigned m = (unsigned)__ballot(off) & 0xfffu;
+    if (tid == 0) *offm = m, t->c[0][0] = (double)m;
   }
   __syncthreads();
   if (tid < 11) {
@@ -161,15 +200,27 @@ DEV void build_tab(const double *poses, Tab *t, int tid, double *lds) {
       const m33 Ri = ldm(R + 9 * i), rc = ldm(ric);
       const m33 M2 = mm(ldm(M1 + 9 * j), Ri);
       stm(t->M2[tid], M2);
-      stm(t->T[tid], mm(M2, rc));
       const d3 tc = ld3(tic);
       const d3 v = mul(Ri, tc) + ld3(P + 3 * i) - ld3(P + 3 * j);
       const m33 RjT = tr(ldm(R + 9 * j));
       const d3 cc = mul(ldm(ricT), mul(RjT, v) - tc);
-      t->c[tid][0] = cc.x, t->c[tid][1] = cc.y, t->c[tid][2] = cc.z;
+      const unsigned om = *offm;
+      if (pair_is_off(om, j)) {
+        // the residual chain of this pair through Quaternion::inverse() (projection_td_factor.cpp:59-60)
+        const m33 RjI = (om >> j) & 1 ? ldm(RI + 9 * j) : RjT, rcI = (om >> TAB_EX_BIT) & 1 ? ldm(ricI) : ldm(ricT);
+        stm(t->T[tid], mm(mm(rcI, RjI), mm(Ri, rc)));
+        const d3 cr = mul(rcI, mul(RjI, v) - tc);
+        t->c[tid][0] = cr.x, t->c[tid][1] = cr.y, t->c[tid][2] = cr.z;
+        const int tj = tab_cj(tid);
+        t->c[tj][0] = cc.x, t->c[tj][1] = cc.y, t->c[tj][2] = cc.z;
+      } else {
+        stm(t->T[tid], mm(M2, rc));
+        t->c[tid][0] = cc.x, t->c[tid][1] = cc.y, t->c[tid][2] = cc.z;
+      }
     }
   }
   __syncthreads();
+  return *offm;
 }
 
 // ---------------------------------------------------------------------------

@@ -57,6 +57,18 @@ DEV void stm(double *p, const m33 &m) {
 #pragma unroll
   for (int i = 0; i < 9; i++) p[i] = m.a[i];
 }
+// inverse by the adjugate (a near-orthogonal matrix: build_tab's ricF)
+DEV m33 inv33(const m33 &m) {
+  const double *a = m.a;
+  m33 r;
+  r.a[0] = a[4] * a[8] - a[5] * a[7], r.a[1] = a[2] * a[7] - a[1] * a[8], r.a[2] = a[1] * a[5] - a[2] * a[4];
+  r.a[3] = a[5] * a[6] - a[3] * a[8], r.a[4] = a[0] * a[8] - a[2] * a[6], r.a[5] = a[2] * a[3] - a[0] * a[5];
+  r.a[6] = a[3] * a[7] - a[4] * a[6], r.a[7] = a[1] * a[6] - a[0] * a[7], r.a[8] = a[0] * a[4] - a[1] * a[3];
+  const double id = 1.0 / (a[0] * r.a[0] + a[1] * r.a[3] + a[2] * r.a[6]);
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.a[i] *= id;
+  return r;
+}
 DEV m33 skewm(d3 q) {
   m33 r;
   r.a[0] = 0, r.a[1] = -q.z, r.a[2] = q.y;
@@ -153,6 +165,15 @@ DEV void pose_plus(const double *x, const double *d, double *o) {
   o[0] = x[0] + d[0], o[1] = x[1] + d[1], o[2] = x[2] + d[2];
   q4 r = qnormalized(qmul(q_from_pose(x), deltaQ(ld3(d + 3))));
   o[3] = r.x, o[4] = r.y, o[5] = r.z, o[6] = r.w;
+}
+
+// A wave-uniform, read-only address: loads through it go through the scalar cache into SGPRs (s_load: no slot of the vector
+// memory counter, no VGPR).  The address is built from scalars so that the compiler need not prove uniformity.
+typedef const __attribute__((address_space(4))) double cdouble;
+DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+DEV cdouble *uniform_cptr(const void *p) {
+  const unsigned long long a = (unsigned long long)p;
+  return (cdouble *)(((unsigned long long)(unsigned)rfl((int)(a >> 32)) << 32) | (unsigned)rfl((int)a));
 }
 
 // wave64 butterfly sum

@@ -69,14 +69,31 @@ struct FrameState {
 };
 
 // Quantities that are uniform per frame / per frame pair at one linearization point.
+//
+// Two flavours of the back-rotation.  The reference rotates back with Eigen's Quaternion::inverse() = conjugate / |q|^2 in the
+// RESIDUAL chain (`Qj.inverse() * (pts_w - Pj)`, `qic.inverse() * (pts_imu_j - tic)`: projection_td_factor.cpp:59-60,
+// projection_factor.cpp:38-39) and with the transposed rotation matrices in the JACOBIANS (:101-146).  For a unit quaternion the two
+// are one matrix; the start point of a call can hold a quaternion off the unit sphere (the newest frame is IMU-propagated with
+// unnormalised delta quaternions, estimator.cpp:107-116; an extrinsic rotation typed into a config file), and there
+// R(q^-1) = (1 - s^2) I + s^2 R^T, s = 1 / |q|, is not R^T.  `T` and `c` are the residual chain's: for a pair (i, j) whose frame j
+// or extrinsic quaternion is off the sphere (bit j / bit 11 of the mask below) they are formed from R(q^-1), for every other pair
+// from the transposes as the Jacobian tables are — the same arithmetic as before the distinction existed.  What the Jacobians of
+// an off-sphere pair need beyond M1 / M2 lives in entries of the pair tables that no pair uses (only i < j is a pair):
+//   c[j * 11 + i]   the Jacobian flavour of c for the pair (i, j):  ric^T (Rj^T (Ri tic + Pi - Pj) - tic)   (:131)
+//   T[0]            ricF = R(qic^-1)^-1: pts_imu_j of the residual chain from pts_camera_j (= ric for a unit qic)
+//   c[0][0]         the mask, as a double (0.0: every quaternion of this point is on the sphere — the only word a kernel reads then)
 struct Tab {
   double R[11][9], P[11][3];
   double ric[9], ricT[9], tic[3];
   double M1[11][9];     // ric^T Rj^T
   double M2[NPAIR][9];  // ric^T Rj^T Ri
-  double T[NPAIR][9];   // ric^T Rj^T Ri ric
-  double c[NPAIR][3];   // ric^T (Rj^T (Ri tic + Pi - Pj) - tic)
+  double T[NPAIR][9];   // residual chain: X_cj = T X_ci + c;  ric^T Rj^T Ri ric on the sphere
+  double c[NPAIR][3];   // ric^T (Rj^T (Ri tic + Pi - Pj) - tic) on the sphere
 };
+constexpr int TAB_EX_BIT = 11;                      // mask bit of the extrinsic quaternion
+constexpr double TAB_OFF_SPHERE = 1e-14;            // | |q|^2 - 1 | above this is "off": a normalised quaternion is within 1e-15, and a
+                                                    // defect e moves the linearization by <= ~500 e (depth / baseline), bar 1e-10
+__host__ __device__ inline int tab_cj(int pair) { return (pair % 11) * 11 + pair / 11; }  // where the pair's Jacobian-flavour c lives
 
 // indices into TRState::q (pose-side scalars produced by k_solve / k_dogleg)
 enum {
@@ -203,6 +220,7 @@ struct Slot {
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
   int max_iter, prior_valid, prior_n, prior_nb;
   int tail_state, passes_used, iters_done, chain_err;  // chain_err: the prior this window was to take over on the device (k_prior_chain) was not there  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
+  int x0_off;                    // Tab mask of the start point's table (k_setup): k_lin picks its instantiation from this word and num_succ without a dependent fetch
   int lm_half;                   // the landmark role of k_lin runs 8 lanes per track, 32 landmarks per workgroup (windows of at most SPEC_MAX_LM landmarks)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG

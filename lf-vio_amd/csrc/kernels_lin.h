@@ -65,11 +65,12 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
       S->dec_pending = 0;
       if (mode >= MODE_MARG) t->mu = 0.0;
     }
-    __shared__ double bt[84 + 256];
+    __shared__ double bt[84 + TAB_SCRATCH];
     if (tid < 77) bt[tid] = (&S->x0.pose[0][0])[tid];
     else if (tid < 84) bt[tid] = S->x0.ex[tid - 77];
     __syncthreads();
-    build_tab(bt, &S->tab[0], tid, bt + 84);
+    const unsigned offm = build_tab(bt, &S->tab[0], tid, bt + 84);
+    if (tid == 0) S->x0_off = (int)offm;
   } else if (blockIdx.x <= LFVIO_WINDOW_SIZE) {
     // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64), hoisted out of the iteration loop:
     // the reference recomputes it in every Evaluate().  One factor per workgroup: Gauss-Jordan with
@@ -210,6 +211,12 @@ DEV void load_pair_uniform(const Tab *T, int pair, PairU &u) {
   u.ricT = ldm(T->ricT);
   u.c = ld3(T->c[pair]);
   u.tic = ld3(T->tic);
+  u.offc = u.offr = nullptr;
+}
+// the same for a table with a quaternion off the unit sphere (offm = tab_offmask(T) != 0, read once per workgroup)
+DEV void load_pair_uniform(const Tab *T, int pair, unsigned offm, PairU &u) {
+  load_pair_uniform(T, pair, u);
+  if (offm && pair_is_off(offm, pair % 11)) u.offc = T->c[tab_cj(pair)], u.offr = T->T[0];
 }
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -355,7 +362,9 @@ DEV void lin_schur_only_role(Slot *S, const LinView &lv, int wg, double *lds, do
 // Slot::lm_half): 32 landmarks per workgroup, twice the workgroups — a lane takes the observations 1 + q, 9 + q of its track
 // instead of 1 + q, 5 + q, 9 + q, and the workgroup's Schur SYRK is 8 steps instead of 16: the role is the latency chain of a single
 // window's k_lin (36 k cycles of which the observations 14 k and the SYRK 8 k), and a 300-landmark window has 246 CUs to spare.
-template <bool TIGHT, int LPT>
+// OFFS: the linearization point holds a quaternion off the unit sphere (struct Tab) — a call's start point at most; every other
+// sweep runs the instantiation without that flavour.
+template <bool TIGHT, int LPT, bool OFFS>
 DEV void lin_landmark_role(Slot *S, const LinView &lv, int wg, int mode, double *lds, double *part) {
   constexpr int LMB = LIN_THREADS / LPT;  // landmarks of the workgroup
   double(*tile)[WLD + 1] = (double(*)[WLD + 1]) lds;
@@ -386,13 +395,15 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int wg, int mode, double 
     ObsPair ob;
     load_obs(S, o0, ob.pi, ob.vi, ob.tdi, ob.rowi);
     const m33 ricT = ldm(T->ricT);
+    const unsigned offm = OFFS ? tab_offmask(T) : 0u;
     for (int o = 1 + q; o < k; o += LPT) {
       const int j = i + o, pair = i * 11 + j;
       load_obs(S, o0 + o, ob.pj, ob.vj, ob.tdj, ob.rowj);
       PairU u;
-      load_pair_uniform(T, pair, u);
+      if (OFFS) load_pair_uniform(T, pair, offm, u);
+      else load_pair_uniform(T, pair, u);
       Basis B;
-      visual_basis(ob, lam, td, est_td, S->tr_over_row, S->half_row, S->sqrt_info, u, B);
+      visual_basis<OFFS>(ob, lam, td, est_td, S->tr_over_row, S->half_row, S->sqrt_info, u, B);
       const double jl0 = B.jl[0], jl1 = B.jl[1];
       d3 eR = jl0 * B.red[0] + jl1 * B.red[1];
       const m33 M1 = ldm(T->M1[j]);
@@ -520,6 +531,7 @@ DEV void lin_landmark_role(Slot *S, const LinView &lv, int wg, int mode, double 
 // column col to both operands: D += C^T C).  The accumulator is 4 doubles per lane instead of 105 and no cross-lane
 // reduction of the Gram entries is left.  LDS operations of one wave execute in program order, so between the phases
 // only the compiler has to be kept from moving them (wavefront-scope fences).
+template <bool OFFS>
 DEV void lin_gram_role(Slot *S, const LinView &lv, int wg, int mode, double *lds) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int chunk = 4 * wg + wv;
@@ -537,7 +549,8 @@ DEV void lin_gram_role(Slot *S, const LinView &lv, int wg, int mode, double *lds
   const int est_td = S->est_td;
   const double td = lv.x->td;
   PairU u;
-  load_pair_uniform(T, pair, u);
+  if (OFFS) load_pair_uniform(T, pair, tab_offmask(T), u);
+  else load_pair_uniform(T, pair, u);
   // E: basis(14) -> factor columns(20) = [Pi th_i Pj th_j tic th_ic td r]
   for (int e = lane; e < 14 * 20; e += 64) E[0][e] = 0.0;
   for (int e = lane; e < 32 * 17; e += 64) stage[0][e] = 0.0;  // columns 14, 15 stay zero
@@ -553,7 +566,7 @@ DEV void lin_gram_role(Slot *S, const LinView &lv, int wg, int mode, double *lds
     load_obs(S, oi, ob.pi, ob.vi, ob.tdi, ob.rowi);
     load_obs(S, oj, ob.pj, ob.vj, ob.tdj, ob.rowj);
     Basis B;
-    visual_basis(ob, lam, td, est_td, S->tr_over_row, S->half_row, S->sqrt_info, u, B);
+    visual_basis<OFFS>(ob, lam, td, est_td, S->tr_over_row, S->half_row, S->sqrt_info, u, B);
     c0[0] = B.red[0].x, c0[1] = B.red[0].y, c0[2] = B.red[0].z;
     c1[0] = B.red[1].x, c1[1] = B.red[1].y, c1[2] = B.red[1].z;
     c0[3] = B.jti[0].x, c0[4] = B.jti[0].y, c0[5] = B.jti[0].z;
@@ -774,6 +787,12 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
   const TRFlags fl = tr_flags(tr);
   int do_lin = fl.do_lin, do_schur = fl.do_schur, cur = fl.cur, acc_z = 0;
   double mu = tr->mu;
+  // Which instantiation of the visual roles this sweep takes: a table with a quaternion off the unit sphere (struct Tab) is the
+  // start point's — no step accepted yet — or any table of a window whose EXTRINSIC quaternion came in off the sphere (a fixed
+  // extrinsic stays as it is).  From two header words fetched with the flags: reading the table's own mask first would put a
+  // dependent fetch (~0.6 us, measured) in front of every sweep.  Too often "yes" costs time only: the instantiation reads the mask.
+  const unsigned x0_off = (unsigned)S->x0_off;
+  int num_succ = tr->num_succ;
   if (mode_bits & MODE_GATED) {
     if (!tail_gate(S, fl.done)) return;
   } else {
@@ -799,6 +818,7 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
       // (wave-uniform: kept on the scalar side, the view's pointers included)
       do_lin = __builtin_amdgcn_readfirstlane(dsh.do_lin), do_schur = __builtin_amdgcn_readfirstlane(dsh.do_schur);
       cur = __builtin_amdgcn_readfirstlane(dsh.cur), acc_z = __builtin_amdgcn_readfirstlane(dsh.acc_z), done = __builtin_amdgcn_readfirstlane(dsh.done);
+      num_succ = __builtin_amdgcn_readfirstlane(dsh.num_succ);
       mu = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dsh.mu)), __builtin_amdgcn_readfirstlane(__double2loint(dsh.mu)));
       if (acc_z > 0 && blockIdx.x == gridDim.x - 1 && !(mode_bits & MODE_NOCOUNT)) copy_accepted(S, acc_z, cur, S->N, threadIdx.x, LIN_THREADS);
     }
@@ -812,6 +832,8 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
   lv.tab = acc_z > 0 ? &S->tabE[acc_z > 0 ? acc_z - 1 : 0] : &S->tab[cur];
   lv.lam = acc_z > 0 ? (const double *)S->lamE[acc_z > 0 ? acc_z - 1 : 0] : (const double *)S->lam[cur];
   lv.mu = mu;
+  // a quaternion of this point off the unit sphere: the visual roles take the instantiation with the reference's two back-rotations
+  const bool offs = x0_off != 0u && (num_succ == 0 || ((x0_off >> TAB_EX_BIT) & 1u));
   __shared__ __attribute__((aligned(16))) double lds[(ROLES & (LIN_ROLE_LM | LIN_ROLE_GRAM)) ? LIN_LDS : LIN_LDS_POSE];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLw, gCh); each slot uses its own counts
   int b = blockIdx.x;
@@ -825,10 +847,12 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
       if (b >= nblk) return;
       double *part = S->schur_part + (size_t)b * SCHUR_LEN;
       if (half) {  // (wave-uniform)
-        if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 8>(S, lv, b, mode, lds, part);
+        if (do_lin && offs) lin_landmark_role<ROLES == LIN_ROLE_ALL, 8, true>(S, lv, b, mode, lds, part);
+        else if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 8, false>(S, lv, b, mode, lds, part);
         else lin_schur_only_role<8>(S, lv, b, lds, part);
       } else {
-        if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 4>(S, lv, b, mode, lds, part);
+        if (do_lin && offs) lin_landmark_role<ROLES == LIN_ROLE_ALL, 4, true>(S, lv, b, mode, lds, part);
+        else if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 4, false>(S, lv, b, mode, lds, part);
         else lin_schur_only_role<4>(S, lv, b, lds, part);
       }
     }
@@ -837,7 +861,10 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
   if (!do_lin) return;
   b -= gLw;
   if (b < gCh) {  // gCh workgroups of 4 chunks
-    if (ROLES & LIN_ROLE_GRAM) lin_gram_role(S, lv, b, mode, lds);
+    if (ROLES & LIN_ROLE_GRAM) {
+      if (offs) lin_gram_role<true>(S, lv, b, mode, lds);
+      else lin_gram_role<false>(S, lv, b, mode, lds);
+    }
     return;
   }
   b -= gCh;

@@ -36,7 +36,6 @@
 #define WACC(k, t0) do { } while (0)
 #define WNOW() 0ll
 #endif
-typedef const __attribute__((address_space(4))) double cdouble;  // uniform addresses: loads through the scalar cache
 
 constexpr int LW_THREADS = 256;
 constexpr int LW_STAGE = 32 * 17;                  // 32 basis rows x (16 + 1 pad)
@@ -65,7 +64,6 @@ DEV m33 ldm_s(cdouble *p) {
   return r;
 }
 DEV d3 ld3_s(cdouble *p) { return d3{p[0], p[1], p[2]}; }
-DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // basis row (0 .. 13) that local column p (0 .. 19: Pi th_i Pj th_j tic th_ic td r) of the factor block starts at: the three
 // translation blocks are [M1 | -M1 | M3]^T times the `red` rows 0 .. 2, every other column is one basis row
@@ -130,10 +128,10 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
   const int est_td = S->est_td, est_ex = marg ? 1 : S->est_ex;  // (ResidualBlockInfo::Evaluate asks for every Jacobian)
   const double td = lv.x->td, tr_over_row = S->tr_over_row, half_row = S->half_row, sqrt_info = S->sqrt_info;
   // (the address built from scalars: the tables of this linearization point are read-only here and wave-uniform)
-  const unsigned long long ta = (unsigned long long)(const void *)lv.tab;
-  cdouble *TT = (cdouble *)(((unsigned long long)(unsigned)rfl((int)(ta >> 32)) << 32) | (unsigned)rfl((int)ta));
+  cdouble *TT = uniform_cptr(lv.tab);
   constexpr int O_M1 = offsetof(Tab, M1) / 8, O_M2 = offsetof(Tab, M2) / 8, O_T = offsetof(Tab, T) / 8, O_C = offsetof(Tab, c) / 8;
   constexpr int O_RIC = offsetof(Tab, ric) / 8, O_RICT = offsetof(Tab, ricT) / 8, O_TIC = offsetof(Tab, tic) / 8;
+  const unsigned offm = (unsigned)TT[O_C];  // quaternions of this point off the unit sphere (struct Tab): 0 but at a call's start point
   // What this lane does with the step's basis Gram Q (its accumulator registers hold Q[kq + 4 r][ii]).  The basis rows are
   // [jP th_i th_j th_ic td r] with jP = M1^T red, so every column of the factor block but `tic` is a basis row (Pj = -jP):
   //   prim[r]   where Q[kq + 4 r][ii] itself goes (upper triangle, < 14);
@@ -231,6 +229,8 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
       PairU u;
       u.M2 = ldm_s(TT + O_M2 + pair * 9), u.T = ldm_s(TT + O_T + pair * 9), u.ric = ldm_s(TT + O_RIC), u.ricT = ldm_s(TT + O_RICT);
       u.c = ld3_s(TT + O_C + pair * 3), u.tic = ld3_s(TT + O_TIC);
+      u.offc = u.offr = nullptr;
+      if (offm && pair_is_off(offm, j)) u.offc = (const double *)TT + O_C + tab_cj(pair) * 3, u.offr = (const double *)TT + O_T;  // (wave-uniform)
       const m33 M1 = ldm_s(TT + O_M1 + j * 9);
       m33 M3 = u.M2;
 #pragma unroll

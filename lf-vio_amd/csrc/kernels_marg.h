@@ -164,7 +164,7 @@ DEV void gauge_poses(Slot *S, int gated, bool publish) {
     qn = R2q(q2R(q_from_pose(x->ex)));  // ric = Quaterniond(para_Ex_Pose).toRotationMatrix(); Quaterniond{ric}
   }
   __syncthreads();
-  __shared__ double bt[84 + 256];  // the re-anchored poses for build_tab, and its scratch
+  __shared__ double bt[84 + TAB_SCRATCH];  // the re-anchored poses for build_tab, and its scratch
   if (tid < 11) {
     const double pn[7] = {Psi.x, Psi.y, Psi.z, qn.x, qn.y, qn.z, qn.w};
 #pragma unroll

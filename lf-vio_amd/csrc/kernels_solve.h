@@ -1033,7 +1033,7 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
   GSTAMP(8);
   __shared__ double sh[2 * DOGLEG_INLINE_BLOCKS];
   __shared__ double delta[KP];
-  __shared__ double cand[84 + 256];  // candidate poses (pose[0..10], ex) for build_tab, and its scratch
+  __shared__ double cand[84 + TAB_SCRATCH];  // candidate poses (pose[0..10], ex) for build_tab, and its scratch
   if (do_schur && inline_backsub) {
     // k_backsub, one landmark per thread:  y_l = (s_l b_l - s_l w_l . (S_c y_c)) / e_l,  gauss_newton_l = -diagonal_l y_l,
     // and the two dot products w_l . G_c, w_l . N_c every dogleg interpolant needs
