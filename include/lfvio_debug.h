@@ -85,6 +85,11 @@ int lfvio_debug_last_passes(lfvio_ctx *ctx);
 /* out3 = {passes, iterations} of the last synchronous call on one window and the number of speculative candidates per pass the next one
  * will prepare (3, or 4 where a pass of the previous call covered two iterations or more) */
 int lfvio_debug_speculation(lfvio_ctx *ctx, int *out3);
+/* The marginalization run ahead of the loop's end (csrc/kernels_spec.h).  on = 0: the windows uploaded from now on end with the serial
+ * tail (gauge fix, frame-0 sweep, k_marg_solve behind the last pass); 1 (default): a one-window context of at most 320 landmarks starts
+ * the marginalization of every newly accepted state on a second stream.  Either way the prior is the same bits.
+ * out2 (may be NULL) = {calls that started workers, priors a worker delivered} since the context was created. */
+int lfvio_debug_marg_ahead(lfvio_ctx *ctx, int on, long long *out2);
 /* tests: the local context `local_ctx` of the group reports a failure when it enqueues phase `phase` (0 the sweep, 1 solve + back-
  * substitution, 2 step + candidate cost, 3 bookkeeping) of pass `pass` of the next lfvio_group_optimize(); local_ctx < 0 clears it.
  * The call must still issue every collective of its sequence (the peers of a real group are waiting in them), end the loops of all

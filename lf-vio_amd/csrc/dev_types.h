@@ -124,6 +124,9 @@ enum {
 #endif
 constexpr int SPEC_EXTRA = LFVIO_SPEC_EXTRA, SPEC_MAX_LM = 320;
 constexpr int WT_PAIRS = (KC + 1) / 2;
+constexpr int SPEC_OWN = 72;  // accepted steps of a call + 1 (max_num_iterations is capped at LFVIO_MAX_TRACE = 64)
+enum { SPEC_FREE = 0, SPEC_SIDE = 1, SPEC_MAIN = 2, SPEC_COMMIT = 3, SPEC_ABANDON = 4 };
+enum { FIN_OPEN = 0, FIN_CLOSING = 1, FIN_MAIN = 2, FIN_SIDE = 3 };  // low bits of SpecCtl::fin; the final count of accepted steps sits above them (<< 2)
 constexpr int MAIL_MAX_LM = 8192;  // landmarks a window may have for its solution to travel through the mailbox (Slot::mail)
 #define TR_HEAD_FIELDS \
   double radius, mu, x_cost, x_norm, cand_cost, model_cost_change, dogleg_step_norm, alpha; \
@@ -224,6 +227,8 @@ struct Slot {
   int lm_half;                   // the landmark role of k_lin runs 8 lanes per track, 32 landmarks per workgroup (windows of at most SPEC_MAX_LM landmarks)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
+  int spec_on, spec_pad_;        // 1: this is slot 0 of a context that keeps a shadow slot behind its last one — the marginalization may be run ahead
+                                 // of the loop's end on a second stream (kernels_spec.h); set by the upload
   int dec_pending, mail_seq;     // dec holds a decision k_solve has not moved into the header yet; mail_seq: what the mailbox flags are set to (the upload's sequence number, never 0)
   // Early hand-over of the solution (lfvio_batch_optimize_begin): host memory the device writes directly — 0, or the
   // mailbox [flag | x[2] | TRState | lam[0] | lam[1]] (MAIL_* below) of the context.  The gated gauge fix ends by copying
@@ -289,6 +294,21 @@ struct Slot {
   GP<double> eig_aux;               // eigenvalues[96] | sorted b'[96] | (int) diagonal-sort permutation[96]
   double scale_p[KP], diag_p[KP], grad_p[KP], gn_p[KP], step_p[KP];
   double uc_grad[WLD], uc_gn[WLD];  // camera-side Cauchy / Gauss-Newton directions (unscaled), zero-padded to WLD
+  // The marginalization run ahead of the loop's end (kernels_spec.h).  `spec`: the words the loop (stream 0) and the workers on
+  // the second stream meet at, in the slot being solved; `shadow`: a worker's own record, in the shadow slot it computes in.
+  struct SpecCtl {
+    int ep;          // call counter of this slot (k_setup), the tag in the upper halves of `word` and `fin`
+    int word;        // ep << 16 | accepted steps << 1 | cur: the newest accepted state that is complete in x[cur] / lam[cur] (k_sum); 0: none yet
+    int fin;         // ep << 16 | state: 0 loop open, 1 closing (the gauge fix is about to rewrite x[cur] in place), FIN_* the marginalization's owner
+    int ticket;      // the caller's ticket of this call (mailbox word 6, read by k_setup): the worker that delivers the prior echoes it into word 7
+    int own[SPEC_OWN];  // per accepted-step count: who forms the prior of that state (SPEC_FREE / _SIDE / _MAIN / _COMMIT / _ABANDON)
+  } spec;
+  struct SpecShadow {
+    int hdr_ep;      // the header of the window was copied for this call
+    int word;        // what the worker of this round took (0: nothing: its kernels return)
+    int last_word;   // the state the last round worked on (finished, or given up for a newer one)
+    int ticket;      // SpecCtl::ticket of the call the round works for
+  } shadow;
   long long dbg[32];
   double jtrace[32];             // second half of lfvio_debug_read_clocks' record (bring-up instrumentation)
   // marginalization outputs

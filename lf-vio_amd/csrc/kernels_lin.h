@@ -6,6 +6,7 @@
 //   k_sum     : deterministic fixed-order reduction of the per-workgroup partials
 #pragma once
 #include "dev_factors.h"
+#include "kernels_spec.h"
 #include "tr_decide.h"
 #include <type_traits>
 
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     __syncthreads();
     const unsigned offm = build_tab(bt, &S->tab[0], tid, bt + 84);
     if (tid == 0) S->x0_off = (int)offm;
+    if (tid == 0 && S->spec_on) spec_arm(S);
   } else if (blockIdx.x <= LFVIO_WINDOW_SIZE) {
     // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64), hoisted out of the iteration loop:
     // the reference recomputes it in every Evaluate().  One factor per workgroup: Gauss-Jordan with
@@ -820,8 +822,15 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
       cur = __builtin_amdgcn_readfirstlane(dsh.cur), acc_z = __builtin_amdgcn_readfirstlane(dsh.acc_z), done = __builtin_amdgcn_readfirstlane(dsh.done);
       num_succ = __builtin_amdgcn_readfirstlane(dsh.num_succ);
       mu = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dsh.mu)), __builtin_amdgcn_readfirstlane(__double2loint(dsh.mu)));
-      if (acc_z > 0 && blockIdx.x == gridDim.x - 1 && !(mode_bits & MODE_NOCOUNT)) copy_accepted(S, acc_z, cur, S->N, threadIdx.x, LIN_THREADS);
-    }
+      if (acc_z > 0 && blockIdx.x == gridDim.x - 1 && !(mode_bits & MODE_NOCOUNT)) {
+        copy_accepted(S, acc_z, cur, S->N, threadIdx.x, LIN_THREADS);
+        if (S->spec_on) {  // the accepted state is complete in x[cur] / lam[cur] once this copy is: a worker may take it (kernels_spec.h)
+          __threadfence();
+          __syncthreads();
+          if (threadIdx.x == 0) spec_publish(S, num_succ, cur);
+        }
+      } else if (acc_z == 0 && owner && threadIdx.x == 0 && S->spec_on) spec_publish(S, num_succ, cur);  // (candidate 0 was written where it lies by the pass before)
+    } else if (owner && threadIdx.x == 0 && mode == MODE_SOLVE && S->spec_on) spec_publish(S, num_succ, cur);  // (the header's own state: the first pass of a graph)
     // a pass that starts with the loop still open is a pass this slot needs (the synchronous drivers size the first
     // graph of the next call from this count)
     if (mode == MODE_SOLVE && owner && !done && threadIdx.x == 0) S->passes_used++;

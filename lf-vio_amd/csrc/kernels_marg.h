@@ -86,7 +86,7 @@ DEV void publish_prior(Slot *S) {
 // behind a k_gauge of several workgroups (windows too large for k_decide_gauge): the same gate, then the mailbox
 __global__ __launch_bounds__(256) void k_publish(char *base, size_t stride) {
   Slot *S = SLOT(base, stride);
-  if (!tail_gate(S, S->tr.done)) return;
+  if (!(S->tr.done && (S->tail_state == 0 || S->tail_state == 3))) return;  // (3: the prior of this state is a worker's — kernels_spec.h; the state is the loop's)
   publish_solution(S);
 }
 // k_prior_chain: grid 1 x 256, behind the upload of the NEXT window of the same estimator into a slot whose marginalization has
@@ -98,7 +98,20 @@ __global__ __launch_bounds__(256) void k_prior_chain(char *base, size_t stride) 
   Slot *S = SLOT(base, stride);
   const LfvioPrior *src = &S->prior_out;
   const int tid = threadIdx.x, n = S->prior_n, nb = S->prior_nb;
-  if (src->valid != 1 || src->n != n || src->num_blocks != nb) {
+  // the marginalization in front of this window was a worker's on the second stream (kernels_spec.h): it ends by moving the prior
+  // here and setting tail_state to 2 — bounded wait (a worker the loop has committed holds a finished prior)
+  __shared__ int late;
+  if (tid == 0) {
+    late = 0;
+    const long long t0 = wall_clock64();
+    while (spec_ld(&S->tail_state) == 3)
+      if (wall_clock64() - t0 > 10 * SPEC_WAIT_TICKS) {
+        late = 1;
+        break;
+      }
+  }
+  __syncthreads();
+  if (late || src->valid != 1 || src->n != n || src->num_blocks != nb) {
     // no prior where one was promised (the marginalization failed or produced another structure): the window runs without one and says so
     if (tid == 0) S->prior_valid = 0, S->chain_err = 1;
     return;
@@ -116,6 +129,8 @@ __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int ga
     return;
   }
   gauge_poses(S, gated, false);
+  // (the kernel in front of this one — k_decide, k_force_done — has raised FIN_CLOSING: several workgroups rewrite the state here)
+  if (gated && S->spec_on && threadIdx.x == 0) spec_settle(S);
 }
 // k_decide_gauge: grid (1, batch) x 128 — behind the last pass of a graph of few small windows: k_decide and, for the slots
 // that are done then, the gated k_gauge in ONE launch (one workgroup per slot: nobody else reads the header it rewrites).
@@ -124,8 +139,14 @@ __global__ __launch_bounds__(128) void k_decide_gauge(char *base, size_t stride,
   decide_body(S);
   __syncthreads();  // (the header and the accepted candidate, written by wave 0, are read by all from here on)
   if (!tail_gate(S, S->tr.done)) return;
+  const int spec = S->spec_on;
+  if (spec) {  // a worker that has not claimed this state by now never will (kernels_spec.h): x[cur] is rewritten in place below
+    if (threadIdx.x == 0) spec_closing(S);
+    __syncthreads();
+  }
   for (int l0 = 0; l0 < S->N; l0 += 128) gauge_landmarks(S, l0);
   gauge_poses(S, 1, publish != 0);  // publish: this call hands its state over early (lfvio_batch_optimize_begin)
+  if (spec && threadIdx.x == 0) spec_settle(S);  // (behind the state's way out: the prior's owner is the marginalization's business)
 }
 DEV void gauge_poses(Slot *S, int gated, bool publish) {
   TRState *ts = &S->tr;
@@ -185,6 +206,107 @@ DEV void gauge_poses(Slot *S, int gated, bool publish) {
     ts->chol_fail = 0;
   }
   build_tab(bt, &S->tab[ts->cur], tid, bt + 84);
+}
+
+// k_spec_wait: grid 1 x 64 on stream 0, in front of an upload that goes out behind a call still in flight
+// (lfvio_batch_upload_chained_device): the worker that owns that call's prior reads slot 0's input arrays until it has delivered.
+__global__ __launch_bounds__(64) void k_spec_wait(char *base) {
+  Slot *S = (Slot *)base;
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64();
+  while (spec_ld(&S->tail_state) == 3 && wall_clock64() - t0 < 10 * SPEC_WAIT_TICKS) __builtin_amdgcn_s_sleep(8);
+}
+// k_spec_begin: grid 1 x 128 on a worker's stream — first launch of a round (kernels_spec.h).  base: the worker's SHADOW slot; back: its
+// distance from the slot being solved.  Waits for an accepted state newer than the last one it looked at, copies it, claims
+// its prior (the other worker may be faster: then it goes back to waiting) and re-anchors the copy like the gated gauge fix
+// re-anchors the original (the same gauge_poses on the same numbers).
+// Leaves tr.done = 0 in the shadow when there is nothing to do: the round's three gated launches return.
+__global__ __launch_bounds__(128) void k_spec_begin(char *base, size_t back) {
+  Slot *S = (Slot *)base;
+  Slot *S0 = (Slot *)(base - back);
+  const int tid = threadIdx.x;
+  __shared__ int sh_word, sh_go;
+  const long long t0 = wall_clock64();
+  for (;;) {
+    if (tid == 0) {
+      int go = 0, w = 0;
+      const int last = S->shadow.last_word;
+      for (;;) {
+        const int f = spec_ld(&S0->spec.fin);
+        w = spec_ld(&S0->spec.word);
+        if (w != 0) {
+          const int st = spec_ep(f) == spec_ep(w) ? spec_fin_state(f) : FIN_OPEN;
+          if (st != FIN_OPEN) break;  // the loop is closing or closed: whatever was not claimed is its own
+          if (w != last) {
+            go = 1;
+            break;
+          }
+        }
+        if (wall_clock64() - t0 > SPEC_WAIT_TICKS) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      sh_word = w, sh_go = go;
+    }
+    __syncthreads();
+    // (onto the scalar side explicitly: with the LDS word in a vector register the compiler of ROCm 7.2 selected `go ? w : 0`
+    // by s_cselect on a condition code no scalar compare had set)
+    int go = __builtin_amdgcn_readfirstlane(sh_go);
+    const int w = __builtin_amdgcn_readfirstlane(sh_word);
+    if (!go) {
+      if (tid == 0) S->shadow.word = 0, S->tr.done = 0;
+      return;
+    }
+    const int ep = spec_ep(w), a = spec_acc(w), cur = w & 1;
+    if (S->shadow.hdr_ep != ep) {
+      // first round of this call: the window's header (sizes, plans, x0, IMU factors, prior structure) and the IMU information
+      // roots; the input pointers of the copy are moved back by the distance so that they lead into slot 0's arrays
+      const long long *src = (const long long *)S0;
+      long long *dst = (long long *)S;
+      constexpr int W0 = (int)(offsetof(Slot, lm_start) / 8), W1 = (int)(offsetof(Slot, x) / 8);
+      static_assert(offsetof(Slot, lm_start) % 8 == 0 && offsetof(Slot, x) % 8 == 0, "header words");
+      for (int k = tid; k < W1; k += 128) dst[k] = src[k] - (k >= W0 ? (long long)back : 0ll);
+      const double *is = &S0->imu_sqrt[0][0];
+      double *id = &S->imu_sqrt[0][0];
+      for (int k = tid; k < LFVIO_WINDOW_SIZE * 225; k += 128) id[k] = is[k];
+    }
+    __syncthreads();
+    {
+      const double *xs = (const double *)&S0->x[cur];
+      double *xd = (double *)&S->x[0];
+      for (int k = tid; k < (int)(sizeof(FrameState) / 8); k += 128) xd[k] = xs[k];
+      const double *ls = S0->lam[cur];
+      double *ld = S->lam[0];
+      const int N = S0->N;
+      for (int k = tid; k < N; k += 128) ld[k] = ls[k];
+      const long long *ts = (const long long *)&S0->tr;
+      long long *td = (long long *)&S->tr;
+      for (int k = tid; k < (int)(sizeof(TRHead) / 8); k += 128) td[k] = ts[k];
+    }
+    __syncthreads();  // (every load of the copy has returned)
+    if (tid == 0) {
+      // still the newest state, and the loop has not begun to close (its gauge fix rewrites x[cur] in place behind FIN_CLOSING)
+      const int f = spec_ld(&S0->spec.fin), w2 = spec_ld(&S0->spec.word);
+      const bool open = spec_ep(f) != ep || spec_fin_state(f) == FIN_OPEN;
+      sh_go = (w2 == w && open && spec_cas(&S0->spec.own[a], SPEC_FREE, SPEC_SIDE) == SPEC_FREE) ? 1 : 0;
+      S->shadow.hdr_ep = ep;
+      S->shadow.last_word = w;  // (claimed, or somebody else's: not to be looked at again)
+    }
+    __syncthreads();
+    go = __builtin_amdgcn_readfirstlane(sh_go);
+    if (!go) {
+      __syncthreads();  // (sh_go is rewritten at the top)
+      continue;         // the other worker has it, or it is no longer the newest: wait for the next one
+    }
+    if (tid == 0) {
+      S->shadow.word = w, S->shadow.ticket = S0->spec.ticket;
+      S->spec_on = 0, S->dec_pending = 0, S->tail_state = 0, S->chain_err = 0;
+      S->tr.cur = 0, S->tr.done = 1;
+    }
+    __syncthreads();
+    break;
+  }
+  for (int l0 = 0; l0 < S->N; l0 += 128) gauge_landmarks(S, l0);
+  gauge_poses(S, 1, false);
 }
 
 // Inverse of a symmetric positive-definite m x m (m <= 15) matrix by ONE wave, everything in registers: lane i holds
@@ -581,7 +703,11 @@ DEV void bt_dispatch(const double *RV, const double *tau, int k, int n, int l8, 
 DEV double guard_pivot(double q, double pivmin) { return copysign(fmax(fabs(q), pivmin), q); }
 // A: n x n, row stride LDN, full symmetric (destroyed; receives Z, component i of vector m at [i * LDN + m]); b: n;
 // RV: >= n * 76, DM: >= n * LDN, vec: >= 7 * 96, nn2: >= 2 * 96 doubles of LDS.  Writes out->linearized_jacobians / _residuals.
-DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, double *DM, double *vec, double *scr, double *nn2, double *Tglob, LfvioPrior *out, double eps, long long *dbg) {
+// sp (a worker's launch, kernels_spec.h): thread MARG_THREADS - 1 — idle in phases 1 to 3 — polls whether the state this prior belongs
+// to has been overtaken; returns true (nothing written) when it has.
+DEV bool eig_tridiag(double *A, const double *b, int n, int tid, double *RV, double *DM, double *vec, double *scr, double *nn2, double *Tglob, LfvioPrior *out, double eps, long long *dbg,
+                     SpecPoll *sp = nullptr) {
+  const bool poller = sp && tid == MARG_THREADS - 1;
 #define ESTAMP(k) do { if (tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
   ESTAMP(26);
   const int wave = tid >> 6, lane = tid & 63;
@@ -616,6 +742,10 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
   for (int k = 0; k + 2 < n; k++) {
     const int P = (k + 1) >> 4;
     double vj[5];
+    if (poller) {  // (six columns between the loads and their use: the poller's wave must not reach a barrier waiting for them)
+      if ((k & 7) == 0) spec_poll_issue(*sp);
+      else if ((k & 7) == 6) spec_poll_take(*sp);
+    }
 #ifdef LFVIO_TRI_PROFILE
 #define TSTAMP(j) do { if (tid == 0 && k == LFVIO_TRI_PROFILE) dbg[16 + j] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
@@ -646,6 +776,7 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
     TSTAMP(3);
     __syncthreads();
     TSTAMP(4);
+    if (sp && (k & 7) == 6 && *sp->flag) return true;  // (uniform: written in front of this step's first barrier)
   }
   if (tri) {
 #pragma unroll
@@ -654,6 +785,7 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
       for (int q = 0; q < 5; q++)
         if (r0 + 16 * i == n - 1 && c0 + 16 * q == n - 1) dd[n - 1] = ar[i][q];
   }
+  if (poller) spec_poll_issue(*sp);
   __syncthreads();
   ESTAMP(27);
   // ---- 2. eigenvalues
@@ -721,8 +853,10 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
         lo = nlo, hi = nhi;
       }
     if (tid < 256 && m < n && l8 == 0) lam[m] = 0.5 * (lo + hi);
+    if (poller) spec_poll_take(*sp), spec_poll_issue(*sp);
     __syncthreads();
     ESTAMP(28);
+    if (sp && *sp->flag) return true;
     // ---- 3. eigenvectors of T: thread me (set 0) runs the stationary recurrence (top down) into A, thread 128 + me (set 1)
     //         the progressive one (bottom up) into DM; each set then looks for the twist in its half of the rows and
     //         multiplies out on its side of it.  Every loop has a uniform trip count (rows on the wrong side of the twist are
@@ -786,8 +920,10 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
         ((int *)ee2)[set * 96 + mec] = kt;  // (pp | nrm: 192 doubles, free by now)
       }
     }
+    if (poller) spec_poll_take(*sp);
     __syncthreads();
     ESTAMP(17);
+    if (sp && *sp->flag) return true;
     if (work) {
       const double g0 = pp[mec], g1 = pp[96 + mec];
       const int kt = g1 < g0 ? ((int *)ee2)[96 + mec] : ((int *)ee2)[mec];  // the first minimum, as one scan would find it
@@ -873,6 +1009,59 @@ DEV void eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
       if (l8 == 0) out->linearized_residuals[m] = keep ? rb / sq : 0.0;
     }
   }
+  return false;
+}
+
+// End of a worker's k_marg_solve (kernels_spec.h): the prior of the state `my_word` lies finished in the shadow slot S.  Wait for
+// the loop of S0 to close (or for a newer accepted state); if this state is the final one the loop has committed the prior to us:
+// it moves into S0->prior_out, tail_state 3 -> 2, the caller's ticket is echoed (and the mailbox filled when the call hands its
+// results over early).  Every thread of the workgroup comes here, behind a barrier that follows the last store to S->prior_out.
+DEV void spec_deliver(Slot *S, Slot *S0, int my_word, bool publish) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  __shared__ int give;
+  if (tid == 0) {
+    const int ep = spec_ep(my_word), a = spec_acc(my_word);
+    long long t0 = wall_clock64();
+    int g = 0;
+    for (;;) {
+      const int f = spec_ld(&S0->spec.fin), w = spec_ld(&S0->spec.word);
+      if (spec_ep(w) != ep) break;  // (the slot has gone on to another call: cannot happen to a committed worker)
+      const int st = spec_ep(f) == ep ? spec_fin_state(f) : FIN_OPEN;
+      if (st >= FIN_MAIN) {
+        g = st == FIN_SIDE && spec_fin_acc(f) == a;
+        break;
+      }
+      if (w != my_word) break;  // a newer accepted state: the next round's
+      if (wall_clock64() - t0 > SPEC_WAIT_TICKS) {
+        if (spec_cas(&S0->spec.own[a], SPEC_SIDE, SPEC_ABANDON) == SPEC_SIDE) break;
+        t0 = wall_clock64();  // the loop has committed this prior: its FIN_SIDE is on the way
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    give = g;
+  }
+  __syncthreads();
+  if (!give) return;
+  const LfvioPrior *src = &S->prior_out;
+  LfvioPrior *dst = &S0->prior_out;
+  const int n = src->valid == 1 ? src->n : 0;
+  {
+    const long long *a = (const long long *)src;
+    long long *b = (long long *)dst;
+    for (int k = tid; k < (int)(offsetof(LfvioPrior, linearized_jacobians) / 8); k += nthr) b[k] = a[k];
+  }
+  for (int k = tid; k < n * n; k += nthr) dst->linearized_jacobians[k] = src->linearized_jacobians[k];
+  for (int k = tid; k < n; k += nthr) dst->linearized_residuals[k] = src->linearized_residuals[k];
+  // ONE fence for both readers — the next kernel of stream 0 that looks at tail_state (device) and the host behind the echo
+  // (system): every thread's stores are out before anybody raises a flag
+  __threadfence_system();
+  __syncthreads();
+  if (publish) publish_prior(S0);  // (ends behind a system-scope fence and a barrier)
+  char *m = (char *)S0->mail;
+  if (tid == 0) {
+    __hip_atomic_store(&S0->tail_state, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m) __hip_atomic_store((int *)m + 7, S->shadow.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // grid (1, batch) x 256, dynamic LDS = MARG_LDS
@@ -880,15 +1069,29 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int flag = flag_bits & 255, force_eig = (flag_bits >> 8) & 1, gated = (flag_bits >> 9) & 1;  // bit 8: debug, see lfvio_debug_force_eig; bit 9: MODE_GATED
   const int publish = (flag_bits >> 10) & 1;  // bit 10: the prior goes into the caller's mailbox as well (lfvio_batch_optimize_begin)
-  Slot *S = SLOT(base, stride);
+  // bit 11: a worker's launch on the second stream (kernels_spec.h) — base is the shadow slot, `stride` its distance from the slot
+  // being solved; the prior is handed over at the end if the state it belongs to turns out to be the final one
+  const bool worker = (flag_bits >> 11) & 1;
+  Slot *S = worker ? (Slot *)base : SLOT(base, stride);
+  Slot *S0 = worker ? (Slot *)(base - stride) : S;
+  __shared__ int spec_flag;
+  SpecPoll sp{S0, worker ? S->shadow.word : 0, &spec_flag, 0, 0};
+  if (threadIdx.x == 0) spec_flag = 0;
+  const bool poller = worker && threadIdx.x == MARG_THREADS - 1;
   TRState *tr = &S->tr;
   const MargPlan *mp = &S->marg[flag];
   const int tid = threadIdx.x;
   LfvioPrior *out = &S->prior_out;
   if (gated && !tail_gate(S, tr->done)) return;
+  if (worker && sp.my_word == 0) return;
   if (!mp->valid) {
     // MARGIN_SECOND_NEW with no prior touching Pose[WINDOW_SIZE-1]: the prior is left as it is
     if (tid == 0) out->valid = -1;  // host copies the input prior through
+    if (worker) {
+      __syncthreads();
+      spec_deliver(S, S0, sp.my_word, publish != 0);
+      return;
+    }
     if (gated && tid == 0) S->iters_done = tr->iteration, S->tail_state = 2;
     if (gated && publish) {
       __syncthreads();
@@ -896,6 +1099,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     }
     return;
   }
+  if (poller) spec_poll_issue(sp);
   STAMP(S, 10);
   // ---- the dense system over the present blocks, D = m15 + n, straight from the packed pose-side Hessian: entry
   // (a, b) of A is H(r, c) of the tangent columns the plan maps there, minus the frame-0 landmarks' Schur sums
@@ -936,8 +1140,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     if (sub && c < KC) v -= Sc[schur_index(c, COL_B)];
     bv[a] = v;
   }
+  if (poller) spec_poll_take(sp), spec_poll_issue(sp);
   __syncthreads();
   STAMP(S, 11);
+  if (worker && spec_flag) return;  // (overtaken: the next round takes the newer state)
   // ---- A_mm pseudo-inverse by eigen-decomposition (marginalization_factor.cpp:267-272)
   for (int e = tid; e < m15 * m15; e += MARG_THREADS) {
     const int r = e / m15, c = e % m15;
@@ -1012,12 +1218,14 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   double *Aout = Ag + 92 * 92 + 96;
   for (int e = tid; e < n * n; e += MARG_THREADS) Aout[e] = Ar[(e / n) * LDN + e % n];
   for (int r = tid; r < n; r += MARG_THREADS) Aout[n * n + r] = br[r];
+  if (poller) spec_poll_take(sp);
   __syncthreads();
+  if (worker && spec_flag) return;
   // ---- second eigen-decomposition -> J0 = sqrt(S) V^T, r0 = sqrt(1/S) V^T b'  (:283-291)
   // The matrix is strongly graded (eigenvalues 1e-6 .. 1e6): cyclic Jacobi converges markedly faster when the
   // diagonal is sorted in decreasing order first (de Rijk), which is a permutation similarity.
   STAMP(S, 13);
-  eig_tridiag(Ar, br, n, tid, RV, DMs, vec8, scr, (double *)cs, S->eig_aux, out, 1e-8, S->dbg);
+  if (eig_tridiag(Ar, br, n, tid, RV, DMs, vec8, scr, (double *)cs, S->eig_aux, out, 1e-8, S->dbg, worker ? &sp : nullptr)) return;
   if (tid == 0) S->dbg[24] = sw1;
   STAMP(S, 14);
   // ---- getParameterBlocks + addr_shift
@@ -1040,7 +1248,12 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     out->m = m15 + (S->sharded ? (int)(S->xch[XOFF_C + XS_N0] + 0.5) : mp->N0);
     out->n = n;
     out->num_blocks = mp->nb;
-    if (gated) S->iters_done = tr->iteration, S->tail_state = 2;
+    if (gated && !worker) S->iters_done = tr->iteration, S->tail_state = 2;
+  }
+  if (worker) {
+    __syncthreads();
+    spec_deliver(S, S0, sp.my_word, publish != 0);
+    return;
   }
   if (gated && publish) {
     __syncthreads();

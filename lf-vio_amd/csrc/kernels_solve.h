@@ -1658,4 +1658,9 @@ DEV void decide_body(Slot *S) {
   const int az = acc_sh & 255;
   if (az > 0 && lane < 64) copy_accepted(S, az, acc_sh >> 8, nlm, lane, 64);
 }
-__global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) { decide_body(SLOT(base, stride)); }
+__global__ __launch_bounds__(64) void k_decide(char *base, size_t stride) {
+  Slot *S = SLOT(base, stride);
+  decide_body(S);
+  // the loop is closed and the gated gauge fix is the next kernel: no worker may claim this state from here on (kernels_spec.h)
+  if (S->spec_on && threadIdx.x == 0 && S->tr.done && S->tail_state == 0) spec_closing(S);
+}

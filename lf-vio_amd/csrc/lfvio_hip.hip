@@ -125,6 +125,7 @@ Layout make_layout(int maxN, int maxM) {
 size_t down_bytes(int maxN) { return sizeof(FrameState) * 2 + sizeof(TRState) + 2 * ((size_t)maxN * 8 + 128) + sizeof(LfvioPrior) + 4096; }
 
 struct SlotHostInfo {
+  bool spec_on = false;  // Slot::spec_on of the resident window
   int N = 0, M = 0, gLm = 0, gLw = 0, gCh = 0, gSc = 0;  // gLm: landmark blocks of 64; gLw: landmark workgroups of k_lin
   int marg_n = 0;            // the largest prior (tangent rows) a marginalization of this window can produce
   int max_iter = 0;          // LfvioWindow::max_num_iterations of the uploaded window
@@ -195,6 +196,19 @@ struct lfvio_ctx {
   // (triangulate / shift_depth / preintegrate) have their own stream and scratch and do not wait for the tail.
   char *h_mail = nullptr, *d_mail = nullptr;
   hipStream_t fstream = nullptr;
+  // The marginalization run ahead of the loop's end (kernels_spec.h): a SHADOW slot behind the last one (contexts of one small
+  // window), workers on a stream of their own (lowest priority: a third pool of hardware queues), one graph of SIDE_ROUNDS rounds
+  // per marginalization flag and hand-over variant.  mail[6]: the ticket of the call in flight, echoed into mail[7] by the worker
+  // that delivers its prior.
+  static constexpr int WORKERS = 2;  // two, so that the newest accepted state never waits for the round of an older one to notice it is stale
+  hipStream_t sstream[WORKERS] = {};
+  bool shadow = false;          // the blob has batch + WORKERS slots, the last ones the shadows of slot 0
+  bool marg_ahead = true;       // debug (lfvio_debug_configure): off = every call ends with the serial tail
+  hipGraphExec_t side[WORKERS][2][2] = {};  // [worker][marg_flag][publish]
+  int side_ticket = 0;          // last ticket handed out
+  bool side_launched = false;   // workers were started for the call in flight (or just finished)
+  bool side_known = false;      // ... and h_pending[2] holds its tail_state (the first graph carried the tail)
+  long long stat_ahead_calls = 0, stat_ahead_hits = 0;  // calls with workers | priors a worker delivered
   bool inflight = false;
   bool unsynced = false;        // finish() took the prior from the mailbox and left the last microseconds of the graph to the next join
   // a prior collected on the caller's behalf because the slots had to be re-allocated while its call was in flight
@@ -256,6 +270,12 @@ void destroy_graph(lfvio_ctx *c) {
     (void)hipGraphExecDestroy(c->graph);
     c->graph = nullptr;
   }
+  for (auto &st : c->sstream)
+    if (st) (void)hipStreamSynchronize(st);  // (rounds that found nothing to do may still be draining)
+  for (auto &wk : c->side)
+    for (auto &row : wk)
+      for (auto &t : row)
+        if (t) (void)hipGraphExecDestroy(t), t = nullptr;
   for (auto &t : c->chunk)
     if (t) (void)hipGraphExecDestroy(t), t = nullptr;
   for (auto &row : c->tail)
@@ -283,21 +303,47 @@ void predict(lfvio_ctx *c) {
   for (int k = 0; k < 4; k++) m = std::max(m, c->recent_passes[k]);
   c->predict_passes = m;
 }
+// The call whose loop has just ended on stream 0 left its prior to a worker on the second stream (tail_state 3, kernels_spec.h): wait
+// for the worker's echo of the call's ticket — it follows the prior's arrival in slot 0 (and in the mailbox) behind a system-scope
+// fence.  Stream 0 is idle when this is called.
+int wait_side(lfvio_ctx *c) {
+  if (!c->side_launched) return LFVIO_OK;
+  c->side_launched = false;
+  int ts = 0;
+  if (c->side_known) ts = c->h_pending[2];
+  else HIPCHK(c, hipMemcpy(&ts, c->d_base + offsetof(Slot, tail_state), sizeof ts, hipMemcpyDeviceToHost));  // (a tail graph of its own: rare)
+  const int *echo = (const int *)c->h_mail + 7;
+  if (ts == 3) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (__atomic_load_n(echo, __ATOMIC_ACQUIRE) != c->side_ticket) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+        c->err = "the marginalization handed to a worker stream did not arrive";
+        return LFVIO_ERR_DEVICE;
+      }
+    }
+  }
+  if (__atomic_load_n(echo, __ATOMIC_ACQUIRE) == c->side_ticket) c->stat_ahead_hits++;
+  return LFVIO_OK;
+}
 constexpr const char *CHAIN_ERR_TEXT = "the prior this window was to take over on the device was not there (the marginalization before it produced none): it ran without a prior";
 int join_inflight(lfvio_ctx *c, bool pipelined_ok = false) {
   if (c->pipelined && !c->inflight && pipelined_ok) return LFVIO_OK;
   if (c->unsynced || c->pipelined) {
     c->unsynced = false, c->pipelined = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->inflight)
+      if (int rc = wait_side(c)) return rc;
   }
   if (!c->inflight) return LFVIO_OK;
   c->inflight = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  const bool handed = c->side_launched && c->side_known && c->h_pending[2] == 3;  // the prior was a worker's (kernels_spec.h)
+  if (int rc = wait_side(c)) return rc;
   if (c->inflight_first) {
     c->last_passes = std::max(c->h_pending[3], 1), c->last_iters = c->h_pending[4];
     if (!c->predicted_early) predict(c);
     c->predicted_early = false;
-    if (c->h_pending[2] != 2) {
+    if (c->h_pending[2] != 2 && !handed) {
       c->err = "the marginalization behind an early solution did not finish";
       return LFVIO_ERR_DEVICE;
     }
@@ -324,6 +370,7 @@ bool wait_early(lfvio_ctx *c) {
   }
 }
 
+constexpr int SHADOW_MAX_LM = 1024;  // capacity (with reserve()'s headroom) up to which a one-window context carries a shadow slot
 int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
   if (c->d_base && batch <= c->batch && maxN <= c->L.maxN && maxM <= c->L.maxM) return LFVIO_OK;  // (the usual case: nothing to wait for)
   if (c->inflight) {  // the slot that holds the prior of the call in flight is about to be freed: collect it first
@@ -343,8 +390,11 @@ int reserve(lfvio_ctx *c, int batch, int maxN, int maxM) {
   c->stage_busy = false;  // (hipFree above waited for the device)
   // grow with headroom so a slowly growing window does not re-allocate every frame
   Layout L = make_layout(maxN + maxN / 4 + 64, maxM + maxM / 4 + 256);
-  HIPCHK(c, hipMalloc((void **)&c->d_base, L.total * (size_t)batch));
-  HIPCHK(c, hipMemsetAsync(c->d_base, 0, L.total * (size_t)batch, c->stream));
+  // one small window: a shadow slot behind it for the marginalization run ahead (kernels_spec.h)
+  c->shadow = batch == 1 && L.maxN <= SHADOW_MAX_LM && c->sstream[0] && c->sstream[lfvio_ctx::WORKERS - 1] && c->d_mail;
+  const size_t slots = (size_t)batch + (c->shadow ? lfvio_ctx::WORKERS : 0);
+  HIPCHK(c, hipMalloc((void **)&c->d_base, L.total * slots));
+  HIPCHK(c, hipMemsetAsync(c->d_base, 0, L.total * slots, c->stream));
   HIPCHK(c, hipHostMalloc((void **)&c->h_stage, L.linw_end, hipHostMallocDefault));
   c->h_down_bytes = down_bytes(L.maxN);
   HIPCHK(c, hipHostMalloc((void **)&c->h_down, c->h_down_bytes, hipHostMallocDefault));
@@ -559,6 +609,9 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   S->max_iter = w->max_num_iterations;
   S->sharded = sharded, S->pose_side = pose_side;
   S->mail = (slot == 0 && !sharded && c->d_mail && w->num_landmarks <= MAIL_MAX_LM) ? (long long)(uintptr_t)c->d_mail : 0;
+  // (the loop's side of kernels_spec.h costs a store per pass and a compare-and-swap at its end; whether workers are started is
+  // decided per call, enqueue_solve)
+  S->spec_on = (slot == 0 && c->shadow && c->marg_ahead && !sharded && S->mail && N <= SPEC_MAX_LM) ? 1 : 0;
   const int seq = c->mail_seq == 0x7fffffff ? 1 : c->mail_seq + 1;  // (never 0: the host clears the flags to 0)
   S->mail_seq = seq;
   for (int k = 0; k < 3; k++) S->g[k] = w->g[k];
@@ -891,6 +944,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     for (int i = 0; i < mp.nb; i++) mo.kind[i] = mp.kind[i], mo.frame[i] = mp.shifted_frame[i], mo.idx[i] = mp.idx[i];
   }
   info.mail_seq = c->mail_seq = seq;
+  info.spec_on = S->spec_on != 0;
   info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   info.linw_ok = linw;
   info.sb_chain = true;
@@ -898,6 +952,8 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     for (int i = 0; i < pr->num_blocks; i++)
       if (pr->blocks[i].kind == LFVIO_BLOCK_SPEEDBIAS && pr->blocks[i].frame != 0) info.sb_chain = false;
   info.linb_ok = linb, info.linb_ng = linb_ng;
+  // (an upload behind a call in flight whose prior a worker on the second stream may own: it reads this slot's inputs until it delivers)
+  if (slot == 0 && c->side_launched) hipLaunchKernelGGL(k_spec_wait, dim3(1), dim3(64), 0, c->stream, d);
   // header prefix + input arrays (two copies: the work-pointer part of the header is written once below)
   HIPCHK(c, hipMemcpyAsync(d, h, offsetof(Slot, x), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d + L.in_begin, h + L.in_begin, (lists_cached ? L.sum_off : L.sum_items + (size_t)used_items * 4) - L.in_begin, hipMemcpyHostToDevice,
@@ -938,6 +994,23 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
     PUTP(Hpp);
     PUTP(mscr); PUTP(eig_aux);
 #undef PUTP
+    if (c->shadow && slot == 0) {
+      // a shadow slot's work arrays are its own, laid out like every slot's (the members are self-relative: the same bytes) —
+      // but J0^T J0 of the input prior, which k_setup forms once per call, is read from slot 0
+      GP<double> prior_A[lfvio_ctx::WORKERS];
+      for (int wk = 0; wk < lfvio_ctx::WORKERS; wk++) {
+        char *ds = c->d_base + (size_t)(c->batch + wk) * L.total;
+#define PUTS(field) HIPCHK(c, hipMemcpyAsync(ds + offsetof(Slot, field), &W.field, sizeof W.field, hipMemcpyHostToDevice, c->stream))
+        PUTS(lam); PUTS(lamE); PUTS(cost_partE);
+        PUTS(a); PUTS(b); PUTS(W); PUTS(Wt); PUTS(scale_l); PUTS(grad_l); PUTS(gn_l); PUTS(diag_l); PUTS(einv_l); PUTS(d1); PUTS(d2);
+        PUTS(gram_part); PUTS(pairG); PUTS(schur_part); PUTS(schur_sum); PUTS(xch); PUTS(gp); PUTS(lm_part); PUTS(cost_part); PUTS(imu_out); PUTS(imu_raw);
+        PUTS(Hpp);
+        PUTS(mscr); PUTS(eig_aux);
+#undef PUTS
+        prior_A[wk].off = W.prior_A.off - (long long)((size_t)(c->batch + wk) * L.total);
+        HIPCHK(c, hipMemcpyAsync(ds + offsetof(Slot, prior_A), &prior_A[wk], sizeof prior_A[wk], hipMemcpyHostToDevice, c->stream));
+      }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));  // W is on the stack
     info.uploaded = true;
   }
@@ -1184,6 +1257,7 @@ __global__ void k_force_done(char *base, size_t stride, int count) {
   if (s < count) {
     Slot *S = (Slot *)(base + (size_t)s * stride);
     if (!S->tr.done) S->tr.done = 1;
+    if (S->spec_on && S->tail_state == 0) spec_closing(S);  // (the gated gauge fix follows: kernels_spec.h)
   }
 }
 
@@ -1194,6 +1268,7 @@ __global__ void k_force_done(char *base, size_t stride, int count) {
 //     of unfinished slots in between.  A pass costs its ~30 us of launches and first loads whether or not the loop is
 //     already done, and with the speculative candidates of small windows nine iterations are four passes, not twelve.
 constexpr int SOLVE_CHUNK = 2, MAX_FIRST_PASSES = 12;  // continuation chunk; longest first graph
+constexpr int SIDE_ROUNDS = 4;  // rounds of the workers' graph (kernels_spec.h): accepted states a call can have a prior started for
 int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated = false);
 // fused_flag >= 0 (adaptive only): gauge fix + marginalization ride in the graph of the first chunk, gated per slot on
 // `done` — the common case (every window done within the first chunk) is ONE graph launch and one synchronization; *tail_done
@@ -1279,16 +1354,55 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       const int rc = capture(&c->chunk[sv], false, SOLVE_CHUNK, -1);
       if (rc) return rc;
     }
+    // Workers for the marginalization run ahead (kernels_spec.h): one small window on the merged launch sequence (its loop ends in
+    // k_decide_gauge), with a shadow slot and a mailbox.  SIDE_ROUNDS rounds of [k_spec_begin, k_lin, k_sum, k_marg_solve] on the shadow
+    // slot, captured once per marginalization flag and hand-over variant; a round that finds nothing to do is four launches that return.
+    const bool ahead = fuse && count == 1 && c->info[0].spec_on && c->shadow && c->marg_ahead && !c->no_merge && !c->no_fuse && !c->shard_active &&
+                       g.lm <= DOGLEG_INLINE_BLOCKS && !use_linw(c, count, g, MODE_SOLVE) && !use_linb(c, count, g, MODE_SOLVE);
+    for (int wk = 0; ahead && wk < lfvio_ctx::WORKERS; wk++) {
+      hipGraphExec_t *side_graph = &c->side[wk][fused_flag][c->publish ? 1 : 0];
+      if (*side_graph) continue;
+      hipStream_t ss = c->sstream[wk];
+      hipGraph_t graph;
+      HIPCHK(c, hipStreamBeginCapture(ss, hipStreamCaptureModeThreadLocal));
+      CaptureGuard guard(ss);
+      const size_t back = (size_t)(c->batch + wk) * c->L.total;
+      char *sh = c->d_base + back;
+      const int mode = (MODE_MARG + fused_flag) | MODE_GATED, gram_wgs = (g.ch + 3) / 4;
+      const int pre = (g.ch_raw > PRE_CHUNK_LIMIT || g.sc > 4 * PRE_GROUP) ? 1 : 0, groups = (g.sc + PRE_GROUP - 1) / PRE_GROUP;
+      const Layout &L = c->L;
+      // (the gather lists are inputs: the shadow's copies of those members lead back into slot 0, and so do these offsets)
+      const SumArgs sa{(long long)L.sum_off - (long long)back, (long long)L.sum_end_marg - (long long)back, (long long)L.sum_items - (long long)back,
+                       (long long)L.gram_part, (long long)L.pairG, (long long)L.imu_out, (long long)L.prior_A - (long long)back};
+      for (int r = 0; r < SIDE_ROUNDS; r++) {
+        hipLaunchKernelGGL(k_spec_begin, dim3(1), dim3(128), 0, ss, sh, back);
+        hipLaunchKernelGGL(k_lin<LIN_ROLE_ALL>, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, ss, sh, back, mode, g.lw, gram_wgs);
+        if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + (SCHUR_LEN / 256) * groups + 1, 1), dim3(256), 0, ss, sh, back, mode, groups);
+        hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, 1), dim3(256), 0, ss, sh, back, mode, pre, sa);
+        hipLaunchKernelGGL(k_marg_solve, dim3(1, 1), dim3(MARG_THREADS), MARG_LDS, ss, sh, back,
+                           fused_flag | (c->force_eig ? 256 : 0) | 512 | (c->publish ? 1024 : 0) | 2048);
+      }
+      HIPCHK(c, guard.end(&graph));
+      HIPCHK(c, hipGraphInstantiate(side_graph, graph, nullptr, nullptr, 0));
+      HIPCHK(c, hipGraphDestroy(graph));
+    }
+    c->side_launched = false, c->side_known = false;
     c->stat_chunks = 0;
     for (int done_passes = 0; done_passes < passes;) {
       c->stat_chunks++;
       const auto t_launch = std::chrono::steady_clock::now();
       const bool watch = early && done_passes == 0 && fuse && c->publish;
       if (watch) __atomic_store_n((int *)c->h_mail + 1, 0, __ATOMIC_RELAXED), __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
+      if (ahead && done_passes == 0) ((volatile int *)c->h_mail)[6] = c->side_ticket = (c->side_ticket == 0x7fffffff ? 1 : c->side_ticket + 1);
       HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk[sv], c->stream));
+      if (ahead && done_passes == 0) {  // (behind the loop's graph: on a shared hardware queue the workers would otherwise wait in front of it)
+        for (int wk = 0; wk < lfvio_ctx::WORKERS; wk++) HIPCHK(c, hipGraphLaunch(c->side[wk][fused_flag][c->publish ? 1 : 0], c->sstream[wk]));
+        c->side_launched = true, c->stat_ahead_calls++;
+      }
       if (c->pipelined && done_passes == 0) c->up_us[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch).count() * 1e6;  // (debug: lfvio_debug_upload_times)
       if (watch && wait_early(c)) {  // the window was done inside the first graph: its tail follows in the same graph
         c->inflight = true, c->inflight_first = true;
+        c->side_known = c->side_launched;
         if (tail_done) *tail_done = true;
         return LFVIO_OK;
       }
@@ -1299,7 +1413,8 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
         c->pass_seconds = 0.75 * c->pass_seconds + 0.25 * dt;
       }
       done_passes += first ? first_passes : SOLVE_CHUNK;
-      if (first && fuse && count == 1) c->h_pending[0] = c->h_pending[2] == 2 ? 0 : 1, c->h_pending[1] = c->h_pending[3], c->last_iters = c->h_pending[4];
+      if (first && fuse && count == 1) c->h_pending[0] = c->h_pending[2] >= 2 ? 0 : 1, c->h_pending[1] = c->h_pending[3], c->last_iters = c->h_pending[4];  // (3: the prior is a worker's)
+      if (first && fuse && count == 1 && c->h_pending[0] == 0) c->side_known = c->side_launched;
       if (first && fuse && count == 1 && c->h_pending[5]) {
         c->err = CHAIN_ERR_TEXT;
         return LFVIO_ERR_DEVICE;
@@ -1318,6 +1433,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     c->last_passes = std::max(c->h_pending[1], 1);  // passes the slowest window has used
     predict(c);
     HIPCHK(c, hipGetLastError());
+    // (a call that ended inside its first graph: the prior may be on its way from a worker; one that continues with a tail graph
+    // is waited for by the join in front of whatever comes next)
+    if (tail_done && *tail_done)
+      if (int rc = wait_side(c)) return rc;
     return LFVIO_OK;
   }
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
@@ -1538,6 +1657,9 @@ lfvio_ctx *lfvio_create(int device) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (hipStreamCreateWithPriority(&c->fstream, hipStreamNonBlocking, greatest) != hipSuccess) c->fstream = nullptr;  // (falls back to `stream`)
+    // ... and the workers of the marginalization run ahead (kernels_spec.h) from the third pool; without three levels there are none
+    for (int wk = 0; wk < lfvio_ctx::WORKERS; wk++)
+      if (least == greatest || hipStreamCreateWithPriority(&c->sstream[wk], hipStreamNonBlocking, least) != hipSuccess) c->sstream[wk] = nullptr;
   }
   // the mailbox: fine-grained host memory mapped into the device's address space.  Without it begin() simply waits for the end.
   if (hipHostMalloc((void **)&c->h_mail, MAIL_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
@@ -1635,6 +1757,8 @@ void lfvio_destroy(lfvio_ctx *c) {
   if (c->stage_event) (void)hipEventDestroy(c->stage_event);
   if (c->h_mail) (void)hipHostFree(c->h_mail);
   if (c->fstream) (void)hipStreamDestroy(c->fstream);
+  for (auto &st : c->sstream)
+    if (st) (void)hipStreamDestroy(st);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1766,7 +1890,7 @@ int lfvio_batch_sync(lfvio_ctx *c) {
   if (!c) return LFVIO_ERR_ARG;
   if (int rc = join_inflight(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return LFVIO_OK;
+  return wait_side(c);
 }
 
 int lfvio_batch_optimize(lfvio_ctx *c, int count, int marg_flag) {
@@ -1826,8 +1950,8 @@ int lfvio_batch_optimize_finish(lfvio_ctx *c, LfvioPrior *prior) {
     bool there = false;
     for (;;) {
       if ((there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want)) break;
-      if (hipStreamQuery(c->stream) != hipErrorNotReady) {
-        there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want;
+      if (hipStreamQuery(c->stream) != hipErrorNotReady && !(c->side_launched && (hipStreamQuery(c->sstream[0]) == hipErrorNotReady || hipStreamQuery(c->sstream[1]) == hipErrorNotReady))) {
+        there = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want;  // (a worker of kernels_spec.h may still be delivering when stream 0 is idle)
         break;
       }
     }
@@ -2278,6 +2402,13 @@ int lfvio_debug_last_passes(lfvio_ctx *c) { return c ? c->last_passes : -1; }
 int lfvio_debug_speculation(lfvio_ctx *c, int *out3) {
   if (!c || !out3) return LFVIO_ERR_ARG;
   out3[0] = c->last_passes, out3[1] = c->last_iters, out3[2] = c->spec_count;
+  return LFVIO_OK;
+}
+
+int lfvio_debug_marg_ahead(lfvio_ctx *c, int on, long long *out2) {
+  if (!c) return LFVIO_ERR_ARG;
+  if (on >= 0) c->marg_ahead = on != 0;  // (a flag of the upload: Slot::spec_on)
+  if (out2) out2[0] = c->stat_ahead_calls, out2[1] = c->stat_ahead_hits;
   return LFVIO_OK;
 }
 

@@ -50,6 +50,14 @@ class Engine:
         self.lib.lfvio_debug_set_decide_merge.argtypes = [C.c_void_p, C.c_int]
         self.lib.lfvio_debug_set_decide_merge(self.ctx, int(on))
 
+    def marg_ahead(self, on=-1):
+        """on = 0 / 1: the windows uploaded from now on end with the serial tail / may have their marginalization started on a second
+        stream as soon as a state is accepted (csrc/kernels_spec.h; -1: leave).  Returns (calls with workers, priors a worker delivered)."""
+        out = (C.c_longlong * 2)()
+        self.lib.lfvio_debug_marg_ahead.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
+        self._check(self.lib.lfvio_debug_marg_ahead(self.ctx, int(on), out), "marg_ahead")
+        return int(out[0]), int(out[1])
+
     def set_block_solve(self, on):
         """1: the reduced system solved along its block structure (k_solve_block); 0 (default): the dense 172 x 172 solve."""
         self.lib.lfvio_debug_set_block_solve.argtypes = [C.c_void_p, C.c_int]
