@@ -129,8 +129,9 @@ DEV void visual_basis(const ObsPair &ob, double lam, double td, int est_td, doub
   d3 rr0 = vmul(red0, u.ricT), rr1 = vmul(red1, u.ricT);
   B.jtj[0] = cross(rr0, Xbj);  // reduce ric^T skew(pts_imu_j)                     (:116-120)
   B.jtj[1] = cross(rr1, Xbj);
-  // reduce ric^T Rj^T Ri ric (:126,:137,:143) = (reduce M2) ric: the Jacobians' flavour whatever T holds
-  d3 rt0 = vmul(rm0, u.ric), rt1 = vmul(rm1, u.ric);
+  // reduce ric^T Rj^T Ri ric (:126,:137,:143): T is that product unless the pair is off the sphere — then (reduce M2) ric
+  d3 rt0 = vmul(red0, u.T), rt1 = vmul(red1, u.T);
+  if (OFFS && u.offc) rt0 = vmul(rm0, u.ric), rt1 = vmul(rm1, u.ric);
   // -T skew(Xci) + skew(T Xci) + skew(c)  ==  -T skew(Xci) + skew(Xcj)             (:126-131)
   B.jtx[0] = cross(red0, XcjJ) - cross(rt0, Xci);
   B.jtx[1] = cross(red1, XcjJ) - cross(rt1, Xci);
@@ -153,9 +154,19 @@ DEV void visual_basis(const ObsPair &ob, double lam, double td, int est_td, doub
 // A quaternion off the unit sphere (struct Tab, dev_types.h) gets its back-rotation R(q^-1) beside R^T; the pairs it touches
 // take T and c from it and keep the transposed flavour of c for their Jacobians.
 constexpr int TAB_SCRATCH = 376;
+// (out of line: the few lanes that ever come here must not cost every kernel that builds a table their registers — k_setup of a
+// resident batch runs five workgroups per CU)
+__device__ __attribute__((noinline)) void off_sphere_back_rotation(double qw, double qx, double qy, double qz, double *RI, double *RF) {
+  const m33 rI = q2R(qinv(q4{qw, qx, qy, qz}));
+  stm(RI, rI);
+  if (RF) stm(RF, inv33(rI));
+}
 DEV bool q_off_sphere(q4 q) { return fabs((q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z) - 1.0) > TAB_OFF_SPHERE; }
+// DETECT = false (the candidates of a pass: every pose has just left PoseLocalParameterization::Plus, which normalizes; an extrinsic
+// that is not estimated stays what it was): nothing is tested, the extrinsic is off the sphere iff ex_off says so (Slot::ex_fixed_off).
 // Returns the table's off-sphere mask (every thread).
-DEV unsigned build_tab(const double *poses, Tab *t, int tid, double *lds) {
+template <bool DETECT = true>
+DEV unsigned build_tab(const double *poses, Tab *t, int tid, double *lds, int ex_off = 0) {
   double *R = lds, *P = lds + 99, *ric = lds + 132, *ricT = lds + 141, *tic = lds + 150, *M1 = lds + 153;  // .. 252
   double *RI = lds + 252, *ricI = lds + 351;  // R(q^-1) of the frames / the extrinsic whose quaternion is off the sphere
   unsigned *offm = (unsigned *)(lds + 360);   // their mask
@@ -165,8 +176,8 @@ DEV unsigned build_tab(const double *poses, Tab *t, int tid, double *lds) {
     const q4 q = q_from_pose(p);
     const m33 r = q2R(q);
     stm(R + 9 * tid, r), stm(t->R[tid], r);
-    off = q_off_sphere(q);
-    if (off) stm(RI + 9 * tid, q2R(qinv(q)));
+    off = DETECT && q_off_sphere(q);
+    if (off) off_sphere_back_rotation(q.w, q.x, q.y, q.z, RI + 9 * tid, nullptr);
 #pragma unroll
     for (int k = 0; k < 3; k++) P[3 * tid + k] = p[k], t->P[tid][k] = p[k];
   } else if (tid == 11) {
@@ -174,19 +185,20 @@ DEV unsigned build_tab(const double *poses, Tab *t, int tid, double *lds) {
     const q4 q = q_from_pose(p);
     const m33 r = q2R(q), rT = tr(r);
     stm(ric, r), stm(ricT, rT), stm(t->ric, r), stm(t->ricT, rT);
-    off = q_off_sphere(q);
-    m33 rF = r;  // ricF
-    if (off) {
-      const m33 rI = q2R(qinv(q));
-      stm(ricI, rI), rF = inv33(rI);
-    }
-    stm(t->T[0], rF);
+    off = DETECT ? q_off_sphere(q) : ex_off != 0;
+    if (off) off_sphere_back_rotation(q.w, q.x, q.y, q.z, ricI, t->T[0]);  // ricF
+    else stm(t->T[0], r);
 #pragma unroll
     for (int k = 0; k < 3; k++) tic[k] = p[k], t->tic[k] = p[k];
   }
-  if (tid < 64) {  // (the twelve quaternions sit in wave 0)
-    const unsigned m = (unsigned)__ballot(off) & 0xfffu;
-    if (tid == 0) *offm = m, t->c[0][0] = (double)m;
+  if (DETECT) {
+    if (tid < 64) {  // (the twelve quaternions sit in wave 0)
+      const unsigned m = (unsigned)__ballot(off) & 0xfffu;
+      if (tid == 0) *offm = m, t->c[0][0] = (double)m;
+    }
+  } else if (tid == 0) {
+    const unsigned m = ex_off ? 1u << TAB_EX_BIT : 0u;
+    *offm = m, t->c[0][0] = (double)m;
   }
   __syncthreads();
   if (tid < 11) {

@@ -223,7 +223,7 @@ struct Slot {
   int N, M, NV, nLmBlocks, nChunks, nSchurParts, est_ex, est_td;
   int max_iter, prior_valid, prior_n, prior_nb;
   int tail_state, passes_used, iters_done, chain_err;  // chain_err: the prior this window was to take over on the device (k_prior_chain) was not there  // passes_used: passes of the loop that began with this slot still open (k_lin)  // gated gauge fix + marginalization of this call: 0 not run, 2 finished (kernels_lin.h, MODE_GATED)
-  int x0_off;                    // Tab mask of the start point's table (k_setup): k_lin picks its instantiation from this word and num_succ without a dependent fetch
+  int ex_fixed_off;              // the extrinsic quaternion is off the unit sphere and not estimated (k_setup): every table of the call carries its bit (struct Tab)
   int lm_half;                   // the landmark role of k_lin runs 8 lanes per track, 32 landmarks per workgroup (windows of at most SPEC_MAX_LM landmarks)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG

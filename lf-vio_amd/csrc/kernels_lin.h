@@ -33,7 +33,7 @@ DEV int gidx20(int p, int q) { return p * 20 - (p * (p - 1)) / 2 + (q - p); }  /
 // ---------------------------------------------------------------------------
 constexpr int SETUP_PRIOR_WGS = 16;
 constexpr int SETUP_WGS = 1 + LFVIO_WINDOW_SIZE + SETUP_PRIOR_WGS;
-__global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mode, int zero_wt) {
+__global__ __launch_bounds__(256, 5) void k_setup(char *base, size_t stride, int mode, int zero_wt) {  // (five waves per SIMD: what the workgroups of a resident batch ran at before build_tab learnt the off-sphere flavour)
   Slot *S = SLOT(base, stride);
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_setup(char *base, size_t stride, int mo
     else if (tid < 84) bt[tid] = S->x0.ex[tid - 77];
     __syncthreads();
     const unsigned offm = build_tab(bt, &S->tab[0], tid, bt + 84);
-    if (tid == 0) S->x0_off = (int)offm;
+    if (tid == 0) S->ex_fixed_off = ((offm >> TAB_EX_BIT) & 1u) && !S->est_ex;  // (the candidates' tables inherit it: build_tab<false>)
     if (tid == 0 && S->spec_on) spec_arm(S);
   } else if (blockIdx.x <= LFVIO_WINDOW_SIZE) {
     // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64), hoisted out of the iteration loop:
@@ -364,8 +364,7 @@ DEV void lin_schur_only_role(Slot *S, const LinView &lv, int wg, double *lds, do
 // Slot::lm_half): 32 landmarks per workgroup, twice the workgroups — a lane takes the observations 1 + q, 9 + q of its track
 // instead of 1 + q, 5 + q, 9 + q, and the workgroup's Schur SYRK is 8 steps instead of 16: the role is the latency chain of a single
 // window's k_lin (36 k cycles of which the observations 14 k and the SYRK 8 k), and a 300-landmark window has 246 CUs to spare.
-// OFFS: the linearization point holds a quaternion off the unit sphere (struct Tab) — a call's start point at most; every other
-// sweep runs the instantiation without that flavour.
+// OFFS: see k_lin.
 template <bool TIGHT, int LPT, bool OFFS>
 DEV void lin_landmark_role(Slot *S, const LinView &lv, int wg, int mode, double *lds, double *part) {
   constexpr int LMB = LIN_THREADS / LPT;  // landmarks of the workgroup
@@ -780,7 +779,11 @@ __global__ __launch_bounds__(64) void k_imu_raw(char *base, size_t stride, int c
 constexpr int LIN_ROLE_LM = 1, LIN_ROLE_GRAM = 2, LIN_ROLE_POSE = 4, LIN_ROLE_ALL = 7;
 constexpr int LIN_ROLE_POSE_RAW = 8;  // the pose-side roles with the IMU factors evaluated beforehand by k_imu_raw
 constexpr int LIN_LDS_POSE = 1024;     // doubles: what the IMU (947) and the prior (688) roles carve out of the workspace
-template <int ROLES>
+// OFFS: the instantiation whose visual roles know the reference's two back-rotations of a quaternion off the unit sphere (struct Tab,
+// dev_types.h; it reads the table's mask and serves every table).  The host launches it where the point may hold such a quaternion —
+// the first pass of a call whose uploaded state has one, every pass of a window whose FIXED extrinsic has one (SlotHostInfo::offs_*)
+// — and the instantiation without that flavour everywhere else.
+template <int ROLES, bool OFFS = true>
 __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES == LIN_ROLE_POSE_RAW ? 6 : 2)) void k_lin(char *base, size_t stride, int mode_bits, int gLw, int gCh) {
   Slot *S = SLOT(base, stride);
   TRState *tr = &S->tr;
@@ -789,11 +792,6 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
   const TRFlags fl = tr_flags(tr);
   int do_lin = fl.do_lin, do_schur = fl.do_schur, cur = fl.cur, acc_z = 0;
   double mu = tr->mu;
-  // Which instantiation of the visual roles this sweep takes: a table with a quaternion off the unit sphere (struct Tab) is the
-  // start point's — no step accepted yet — or any table of a window whose EXTRINSIC quaternion came in off the sphere (a fixed
-  // extrinsic stays as it is).  From two header words fetched with the flags: reading the table's own mask first would put a
-  // dependent fetch (~0.6 us, measured) in front of every sweep.  Too often "yes" costs time only: the instantiation reads the mask.
-  const unsigned x0_off = (unsigned)S->x0_off;
   int num_succ = tr->num_succ;
   if (mode_bits & MODE_GATED) {
     if (!tail_gate(S, fl.done)) return;
@@ -841,8 +839,6 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
   lv.tab = acc_z > 0 ? &S->tabE[acc_z > 0 ? acc_z - 1 : 0] : &S->tab[cur];
   lv.lam = acc_z > 0 ? (const double *)S->lamE[acc_z > 0 ? acc_z - 1 : 0] : (const double *)S->lam[cur];
   lv.mu = mu;
-  // a quaternion of this point off the unit sphere: the visual roles take the instantiation with the reference's two back-rotations
-  const bool offs = x0_off != 0u && (num_succ == 0 || ((x0_off >> TAB_EX_BIT) & 1u));
   __shared__ __attribute__((aligned(16))) double lds[(ROLES & (LIN_ROLE_LM | LIN_ROLE_GRAM)) ? LIN_LDS : LIN_LDS_POSE];  // one workspace, aliased per role
   // the grid is sized for the largest resident window (gLw, gCh); each slot uses its own counts
   int b = blockIdx.x;
@@ -856,12 +852,10 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
       if (b >= nblk) return;
       double *part = S->schur_part + (size_t)b * SCHUR_LEN;
       if (half) {  // (wave-uniform)
-        if (do_lin && offs) lin_landmark_role<ROLES == LIN_ROLE_ALL, 8, true>(S, lv, b, mode, lds, part);
-        else if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 8, false>(S, lv, b, mode, lds, part);
+        if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 8, OFFS>(S, lv, b, mode, lds, part);
         else lin_schur_only_role<8>(S, lv, b, lds, part);
       } else {
-        if (do_lin && offs) lin_landmark_role<ROLES == LIN_ROLE_ALL, 4, true>(S, lv, b, mode, lds, part);
-        else if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 4, false>(S, lv, b, mode, lds, part);
+        if (do_lin) lin_landmark_role<ROLES == LIN_ROLE_ALL, 4, OFFS>(S, lv, b, mode, lds, part);
         else lin_schur_only_role<4>(S, lv, b, lds, part);
       }
     }
@@ -870,10 +864,7 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
   if (!do_lin) return;
   b -= gLw;
   if (b < gCh) {  // gCh workgroups of 4 chunks
-    if (ROLES & LIN_ROLE_GRAM) {
-      if (offs) lin_gram_role<true>(S, lv, b, mode, lds);
-      else lin_gram_role<false>(S, lv, b, mode, lds);
-    }
+    if (ROLES & LIN_ROLE_GRAM) lin_gram_role<OFFS>(S, lv, b, mode, lds);
     return;
   }
   b -= gCh;

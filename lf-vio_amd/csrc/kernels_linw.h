@@ -115,7 +115,8 @@ DEV double lw_sel3(int q, double x0, double x1, double x2) { return q == 0 ? x0 
 // apart and every entry of a strip's span is WRITTEN (nothing zero-fills a large window's Wt), the pose-pose blocks are private.
 // o1 / ostep (BIG): the wave takes the steps o1, o1 + ostep, ... of its strip — ostep waves share a strip whose tracks are long
 // (the steps of a strip are a serial chain; a workgroup with one or two strips splits them) and the landmark's sums meet in LDS.
-template <bool BIG>
+// OFFS: see k_lin (kernels_lin.h)
+template <bool BIG, bool OFFS>
 DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int scaled, int mode, double *lw, double part[5], int t0, int t1, int d_lm0,
                      int d_nsk, int o1 = 1, int ostep = 1) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -131,7 +132,7 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
   cdouble *TT = uniform_cptr(lv.tab);
   constexpr int O_M1 = offsetof(Tab, M1) / 8, O_M2 = offsetof(Tab, M2) / 8, O_T = offsetof(Tab, T) / 8, O_C = offsetof(Tab, c) / 8;
   constexpr int O_RIC = offsetof(Tab, ric) / 8, O_RICT = offsetof(Tab, ricT) / 8, O_TIC = offsetof(Tab, tic) / 8;
-  const unsigned offm = (unsigned)TT[O_C];  // quaternions of this point off the unit sphere (struct Tab): 0 but at a call's start point
+  const unsigned offm = OFFS ? (unsigned)TT[O_C] : 0u;  // quaternions of this point off the unit sphere (struct Tab)
   // What this lane does with the step's basis Gram Q (its accumulator registers hold Q[kq + 4 r][ii]).  The basis rows are
   // [jP th_i th_j th_ic td r] with jP = M1^T red, so every column of the factor block but `tic` is a basis row (Pj = -jP):
   //   prim[r]   where Q[kq + 4 r][ii] itself goes (upper triangle, < 14);
@@ -230,7 +231,7 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
       u.M2 = ldm_s(TT + O_M2 + pair * 9), u.T = ldm_s(TT + O_T + pair * 9), u.ric = ldm_s(TT + O_RIC), u.ricT = ldm_s(TT + O_RICT);
       u.c = ld3_s(TT + O_C + pair * 3), u.tic = ld3_s(TT + O_TIC);
       u.offc = u.offr = nullptr;
-      if (offm && pair_is_off(offm, j)) u.offc = (const double *)TT + O_C + tab_cj(pair) * 3, u.offr = (const double *)TT + O_T;  // (wave-uniform)
+      if (OFFS && offm && pair_is_off(offm, j)) u.offc = (const double *)TT + O_C + tab_cj(pair) * 3, u.offr = (const double *)TT + O_T;  // (wave-uniform)
       const m33 M1 = ldm_s(TT + O_M1 + j * 9);
       m33 M3 = u.M2;
 #pragma unroll
@@ -239,7 +240,7 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
       // with a zero information factor: every basis entry, the residual and log(1 + s) are exact zeros — nothing to mask
       // in the sums or in the SYRK operand.
       Basis B;
-      visual_basis(ob, lam, td, est_td, tr_over_row, half_row, act ? sqrt_info : 0.0, u, B);
+      visual_basis<OFFS>(ob, lam, td, est_td, tr_over_row, half_row, act ? sqrt_info : 0.0, u, B);
       {
         const double jl0 = B.jl[0], jl1 = B.jl[1];
         const d3 eR = jl0 * B.red[0] + jl1 * B.red[1];
@@ -571,6 +572,7 @@ constexpr int LWT_ABS = 1 << 16, LWT_EX = 1 << 17, LWT_TD = 1 << 18;
 // ---------------------------------------------------------------------------
 // k_linw: grid (1, batch) x 256, dynamic LDS = LW_LDS_BYTES
 // ---------------------------------------------------------------------------
+template <bool OFFS>
 DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -610,8 +612,8 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
     {
       const LinwPlan *P = &S->linw;
       const int tl = lane < LINW_MAX_STRIPS ? lane : 0;
-      linw_strips<false>(S, lv, A, fl.cur, fl.scaled, mode, lw, part, rfl(P->wave_first[wv]), rfl(P->wave_first[wv + 1]), P->lm0[tl],
-                         P->nlm[tl] | (P->start[tl] << 8) | (P->kmax[tl] << 16));
+      linw_strips<false, OFFS>(S, lv, A, fl.cur, fl.scaled, mode, lw, part, rfl(P->wave_first[wv]), rfl(P->wave_first[wv + 1]), P->lm0[tl],
+                               P->nlm[tl] | (P->start[tl] << 8) | (P->kmax[tl] << 16));
     }
     WSTAMP(10);
     if (lane == 0) {
@@ -809,9 +811,10 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
   }
   WSTAMP(14);
 }
+template <bool OFFS = true>  // (see k_lin, kernels_lin.h)
 __global__ __launch_bounds__(LW_THREADS, 2) void k_linw(char *base, size_t stride, const LinwArgs A, int mode_bits) {
   extern __shared__ __attribute__((aligned(16))) double lw[];
-  linw_body(SLOT(base, stride), lw, A, mode_bits);
+  linw_body<OFFS>(SLOT(base, stride), lw, A, mode_bits);
 }
 
 // ---------------------------------------------------------------------------
@@ -867,6 +870,7 @@ __global__ __launch_bounds__(256) void k_linb_gather(char *base, size_t stride) 
 #else
 #define BSTAMP(k) do { } while (0)
 #endif
+template <bool OFFS>
 DEV void linb_body(Slot *S, double *lw, const LinwArgs &A) {
   TRState *tr = &S->tr;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -907,7 +911,7 @@ DEV void linb_body(Slot *S, double *lw, const LinwArgs &A) {
     __syncthreads();
     BSTAMP(9);
     double part[5];
-    linw_strips<true>(S, lv, A, fl.cur, fl.scaled, MODE_SOLVE, lw, part, 0, nmine, lm0w, nw | (s << 8) | (kmaxw << 16), 1 + wv % split, split);
+    linw_strips<true, OFFS>(S, lv, A, fl.cur, fl.scaled, MODE_SOLVE, lw, part, 0, nmine, lm0w, nw | (s << 8) | (kmaxw << 16), 1 + wv % split, split);
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 5; k++) lw[LB_RED0 + 8 * wv + k] = part[k];
@@ -1038,9 +1042,10 @@ DEV void linb_body(Slot *S, double *lw, const LinwArgs &A) {
   }
   BSTAMP(13);
 }
+template <bool OFFS = true>
 __global__ __launch_bounds__(LW_THREADS, 2) void k_linb(char *base, size_t stride, const LinwArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lw[];
-  linb_body(SLOT(base, stride), lw, A);
+  linb_body<OFFS>(SLOT(base, stride), lw, A);
 }
 
 // ---------------------------------------------------------------------------

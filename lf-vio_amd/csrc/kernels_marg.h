@@ -705,9 +705,11 @@ DEV double guard_pivot(double q, double pivmin) { return copysign(fmax(fabs(q), 
 // RV: >= n * 76, DM: >= n * LDN, vec: >= 7 * 96, nn2: >= 2 * 96 doubles of LDS.  Writes out->linearized_jacobians / _residuals.
 // sp (a worker's launch, kernels_spec.h): thread MARG_THREADS - 1 — idle in phases 1 to 3 — polls whether the state this prior belongs
 // to has been overtaken; returns true (nothing written) when it has.
+template <bool SPEC>
 DEV bool eig_tridiag(double *A, const double *b, int n, int tid, double *RV, double *DM, double *vec, double *scr, double *nn2, double *Tglob, LfvioPrior *out, double eps, long long *dbg,
-                     SpecPoll *sp = nullptr) {
-  const bool poller = sp && tid == MARG_THREADS - 1;
+                     SpecPoll *sp_) {
+  SpecPoll *const sp = SPEC ? sp_ : nullptr;  // (the plain instantiation carries none of it)
+  const bool poller = SPEC && tid == MARG_THREADS - 1;
 #define ESTAMP(k) do { if (tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
   ESTAMP(26);
   const int wave = tid >> 6, lane = tid & 63;
@@ -1065,13 +1067,15 @@ DEV void spec_deliver(Slot *S, Slot *S0, int my_word, bool publish) {
 }
 
 // grid (1, batch) x 256, dynamic LDS = MARG_LDS
+// WORKER: the instantiation a worker of kernels_spec.h launches (polling, hand-over); the plain one is compiled without any of it.
+template <bool WORKER>
 __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t stride, int flag_bits) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int flag = flag_bits & 255, force_eig = (flag_bits >> 8) & 1, gated = (flag_bits >> 9) & 1;  // bit 8: debug, see lfvio_debug_force_eig; bit 9: MODE_GATED
   const int publish = (flag_bits >> 10) & 1;  // bit 10: the prior goes into the caller's mailbox as well (lfvio_batch_optimize_begin)
-  // bit 11: a worker's launch on the second stream (kernels_spec.h) — base is the shadow slot, `stride` its distance from the slot
+  // WORKER: a worker's launch on the second stream (kernels_spec.h) — base is the shadow slot, `stride` its distance from the slot
   // being solved; the prior is handed over at the end if the state it belongs to turns out to be the final one
-  const bool worker = (flag_bits >> 11) & 1;
+  constexpr bool worker = WORKER;
   Slot *S = worker ? (Slot *)base : SLOT(base, stride);
   Slot *S0 = worker ? (Slot *)(base - stride) : S;
   __shared__ int spec_flag;
@@ -1225,7 +1229,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
   // The matrix is strongly graded (eigenvalues 1e-6 .. 1e6): cyclic Jacobi converges markedly faster when the
   // diagonal is sorted in decreasing order first (de Rijk), which is a permutation similarity.
   STAMP(S, 13);
-  if (eig_tridiag(Ar, br, n, tid, RV, DMs, vec8, scr, (double *)cs, S->eig_aux, out, 1e-8, S->dbg, worker ? &sp : nullptr)) return;
+  if (eig_tridiag<WORKER>(Ar, br, n, tid, RV, DMs, vec8, scr, (double *)cs, S->eig_aux, out, 1e-8, S->dbg, &sp)) return;
   if (tid == 0) S->dbg[24] = sw1;
   STAMP(S, 14);
   // ---- getParameterBlocks + addr_shift

@@ -993,7 +993,7 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
   // round trip (1 - 1.5 us) of its own, so everything that is read — the header, this thread's piece of the state, of the
   // gradient and of the step vectors, the landmark partials, the landmark rows — is requested here in one batch, before the first use.
   const TRHead t = *reinterpret_cast<const TRHead *>(tr);
-  const int sharded = S->sharded, nLmBlocks = S->nLmBlocks, est_ex = S->est_ex, est_td = S->est_td;
+  const int sharded = S->sharded, nLmBlocks = S->nLmBlocks, est_ex = S->est_ex, est_td = S->est_td, ex_off = S->ex_fixed_off;
   const int cur = t.cur, do_schur = t.do_schur;
   const FrameState *x = &S->x[cur];
   FrameState *xc = &S->x[cur ^ 1];
@@ -1242,7 +1242,7 @@ DEV bool dogleg_body(Slot *S, int z_lo, int z_hi, bool first, int spec, double *
       else tr->step_sqE[z - 1] = sdn, tr->xn2E[z - 1] = sxn;
     }
     GSTAMP(19);
-    build_tab(cand, z == 0 ? &S->tab[cur ^ 1] : &S->tabE[z - 1], tid, cand + 84);  // ends on a barrier: delta / sh / cand are free again
+    build_tab<false>(cand, z == 0 ? &S->tab[cur ^ 1] : &S->tabE[z - 1], tid, cand + 84, ex_off);  // ends on a barrier: delta / sh / cand are free again
     GSTAMP(3);
   }
   return true;

@@ -126,6 +126,10 @@ size_t down_bytes(int maxN) { return sizeof(FrameState) * 2 + sizeof(TRState) + 
 
 struct SlotHostInfo {
   bool spec_on = false;  // Slot::spec_on of the resident window
+  // The uploaded state holds a quaternion off the unit sphere (struct Tab, dev_types.h: |q|^2 further than TAB_OFF_SPHERE from 1): the
+  // sweep that linearizes at that state — the first pass of a call — and, where the off-sphere quaternion is an extrinsic that is not
+  // estimated, every sweep of the window run the instantiations that know the reference's two back-rotations
+  bool offs_first = false, offs_all = false;
   int N = 0, M = 0, gLm = 0, gLw = 0, gCh = 0, gSc = 0;  // gLm: landmark blocks of 64; gLw: landmark workgroups of k_lin
   int marg_n = 0;            // the largest prior (tangent rows) a marginalization of this window can produce
   int max_iter = 0;          // LfvioWindow::max_num_iterations of the uploaded window
@@ -175,7 +179,7 @@ struct lfvio_ctx {
   std::vector<int> perm_build;  // upload_window builds the next permutation here and swaps it in at its commit point
   // cached graph of the solve loop
   hipGraphExec_t graph = nullptr;
-  int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0, g_linw = 0;
+  int g_batch = 0, g_lm = 0, g_ch = 0, g_sc = 0, g_iters = 0, g_linw = 0, g_offs = 0;
   // cached graph of one chunk of passes (synchronous entry points: the loop is launched chunk by chunk)
   // [publish]: the variants whose gated gauge fix / marginalization also push state and prior into the caller's mailbox
   // (lfvio_batch_optimize_begin) — a kernel argument, so the plain call pays nothing for the split one
@@ -187,7 +191,7 @@ struct lfvio_ctx {
   bool predicted_early = false;     // lfvio_batch_optimize_begin has fed this call's pass count to predict() already (the join / finish that follows must not again)
   int predict_passes = 4;           // passes the first graph of the next call carries: the most any of the last four calls needed (predict()); tail[flag]: force-done + gated gauge fix + marginalization
   double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
-  int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0, k_linw = 0;
+  int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0, k_linw = 0, k_offs = 0;  // (k_offs: slots_offs of the captured launches)
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   // lfvio_batch_optimize_begin / _finish: the solution of slot 0 arrives in host memory the gated gauge fix writes directly
   // (Slot::mail, dev_types.h MAIL_*) while the marginalization of the same graph is still running; `inflight` from the moment
@@ -945,6 +949,15 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   }
   info.mail_seq = c->mail_seq = seq;
   info.spec_on = S->spec_on != 0;
+  {
+    // (a little below the device's own threshold: a "yes" too many costs a few percent of one sweep, a "no" too many would put a
+    // table with the residual chain's flavour in front of a kernel that does not look for it)
+    auto off = [](const double *q) { return std::fabs((q[3] * q[3] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) - 1.0) > 0.5 * TAB_OFF_SPHERE; };
+    bool any = false;
+    for (int f = 0; f < LFVIO_NUM_FRAMES; f++) any = any || off(w->para_pose[f] + 3);
+    const bool ex = off(w->para_ex_pose + 3);
+    info.offs_first = any || ex, info.offs_all = ex && !w->estimate_extrinsic;
+  }
   info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   info.linw_ok = linw;
   info.sb_chain = true;
@@ -1072,7 +1085,9 @@ bool lin_split(int count, const Grid &g) {
   return count >= LIN_SPLIT_MIN_BATCH && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) > LIN_SPLIT_WGS;
 }
 
-void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
+// offs: the visual roles in the instantiation that knows the off-sphere flavour (k_lin, kernels_lin.h); the default is the one that is
+// always right, the loop's launches say what they need (slots_offs)
+void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode, bool offs = true) {
   const int gram_wgs = (g.ch + 3) / 4;  // one chunk per wave
   const size_t st = c->L.total;
   if (lin_split(count, g)) {
@@ -1080,15 +1095,27 @@ void launch_lin(lfvio_ctx *c, int count, const Grid &g, int mode) {
     // landmark role 115 us + Gram role 175 us + IMU / prior roles 104 us on their own, 679 us as ONE grid — workgroups of four
     // different code paths side by side on every CU (the sweep is ~30 KB of straight-line code per role) do not share an
     // instruction cache well; two more launches cost 9 us.
-    hipLaunchKernelGGL(k_lin<LIN_ROLE_LM>, dim3(g.lw, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, 0);
-    hipLaunchKernelGGL(k_lin<LIN_ROLE_GRAM>, dim3(gram_wgs, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, gram_wgs);
+    if (offs) {
+      hipLaunchKernelGGL((k_lin<LIN_ROLE_LM, true>), dim3(g.lw, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, 0);
+      hipLaunchKernelGGL((k_lin<LIN_ROLE_GRAM, true>), dim3(gram_wgs, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, gram_wgs);
+    } else {
+      hipLaunchKernelGGL((k_lin<LIN_ROLE_LM, false>), dim3(g.lw, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, 0);
+      hipLaunchKernelGGL((k_lin<LIN_ROLE_GRAM, false>), dim3(gram_wgs, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, gram_wgs);
+    }
     const bool raw = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & (MODE_GATED | MODE_DECIDE));
     if (raw) hipLaunchKernelGGL(k_imu_raw, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
-    if (raw) hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE_RAW>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
-    else hipLaunchKernelGGL(k_lin<LIN_ROLE_POSE>, dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
+    if (raw) hipLaunchKernelGGL((k_lin<LIN_ROLE_POSE_RAW, false>), dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
+    else hipLaunchKernelGGL((k_lin<LIN_ROLE_POSE, false>), dim3(LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode | MODE_NOCOUNT, 0, 0);
     return;
   }
-  hipLaunchKernelGGL(k_lin<LIN_ROLE_ALL>, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, gram_wgs);
+  if (offs) hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, true>), dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, gram_wgs);
+  else hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, false>), dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, mode, g.lw, gram_wgs);
+}
+// what the sweeps of slots [0, count) need: bit 0 the sweep at the uploaded state, bit 1 every sweep
+int slots_offs(const lfvio_ctx *c, int count) {
+  int r = 0;
+  for (int k = 0; k < count; k++) r |= (c->info[k].offs_first ? 1 : 0) | (c->info[k].offs_all ? 2 : 0);
+  return r;
 }
 
 // fixed-order reduction of the partials; two levels once a single k_sum thread would have to walk hundreds of them
@@ -1118,8 +1145,9 @@ LinwArgs linw_args(const lfvio_ctx *c) {
   a.asm_tab = c->d_lwt;
   return a;
 }
-void launch_linw(lfvio_ctx *c, int count, int mode_bits = MODE_SOLVE) {
-  hipLaunchKernelGGL(k_linw, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c), mode_bits);
+void launch_linw(lfvio_ctx *c, int count, int mode_bits = MODE_SOLVE, bool offs = true) {
+  if (offs) hipLaunchKernelGGL(k_linw<true>, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c), mode_bits);
+  else hipLaunchKernelGGL(k_linw<false>, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c), mode_bits);
 }
 
 // The reduced system of every slot of the launch has the chain structure (SlotHostInfo::sb_chain): solved block by block
@@ -1169,8 +1197,9 @@ int linb_grid(const lfvio_ctx *c, int count) {
   for (int s = 0; s < count; s++) ng = std::max(ng, c->info[s].linb_ng);
   return (ng + 1 + 63) / 64 * 64;
 }
-void launch_linb(lfvio_ctx *c, int count) {
-  hipLaunchKernelGGL(k_linb, dim3(linb_grid(c, count), count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
+void launch_linb(lfvio_ctx *c, int count, bool offs = true) {
+  if (offs) hipLaunchKernelGGL(k_linb<true>, dim3(linb_grid(c, count), count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
+  else hipLaunchKernelGGL(k_linb<false>, dim3(linb_grid(c, count), count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c));
   hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_GRID, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, c->L.total, linw_args(c));
 }
 
@@ -1179,7 +1208,8 @@ void launch_linb(lfvio_ctx *c, int count) {
 // the trust-region bookkeeping of a pass rides in the prologue of the NEXT pass's k_lin (MODE_DECIDE, one launch less per
 // pass); k_decide itself is only launched behind the last pass, so that the header is final where the sequence ends.
 // gauge: the gated gauge fix follows this (last) pass — returns true if it went out with the bookkeeping (k_decide_gauge)
-bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool speculate = false, bool first = true, bool last = true, bool gauge = false) {
+// offs: see launch_lin
+bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool speculate = false, bool first = true, bool last = true, bool gauge = false, bool offs = true) {
   const size_t st = c->L.total;
   const bool solve = (mode & (MODE_GATED - 1)) == MODE_SOLVE && !(mode & MODE_GATED);
   // (latency of few windows only: in a resident batch every workgroup of k_lin repeating the decision costs more of the
@@ -1188,11 +1218,11 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   const bool merge = solve && !lw && g.lm <= DOGLEG_INLINE_BLOCKS && !c->no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
   if (lw) {
     // the window-resident sweep: one workgroup per window — pose-side factors, visual sweep, Schur; it counts the pass
-    launch_linw(c, count, mode);
+    launch_linw(c, count, mode, offs);
   } else if (lb) {
-    launch_linb(c, count);
+    launch_linb(c, count, offs);
   } else {
-    launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0));
+    launch_lin(c, count, g, mode | (merge && !first ? MODE_DECIDE : 0), offs);
     launch_sum(c, count, g, mode);
   }
   if ((mode & (MODE_GATED - 1)) == MODE_SOLVE) {
@@ -1296,9 +1326,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
     }
     const int lwk = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0) + (use_block_solve(c, count) ? 1 << 30 : 0);
-    if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk) {
+    const int offs = slots_offs(c, count);
+    if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk || c->k_offs != offs) {
       destroy_graph(c);
-      c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk;
+      c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk, c->k_offs = offs;
     }
     if (tail_done) *tail_done = false;
     const bool fuse = fused_flag >= 0 && fused_flag < 2;
@@ -1322,7 +1353,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       if (setup)
         hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
       bool gauged = false;
-      for (int it = 0; it < npass; it++) gauged = launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1, tail_flag >= 0);
+      // (the sweep behind k_setup linearizes at the uploaded state: the only point of a call that can hold a quaternion off the unit sphere,
+      // a fixed extrinsic aside — slots_offs)
+      for (int it = 0; it < npass; it++)
+        gauged = launch_iteration(c, count, g, MODE_SOLVE, speculate, it == 0, it == npass - 1, tail_flag >= 0, (offs & 2) || (setup && it == 0 && (offs & 1)));
       if (tail_flag >= 0) {
         if (!gauged) {
           hipLaunchKernelGGL(k_gauge, dim3(1 + (g.lm + 1) / 2, count), dim3(128), 0, c->stream, c->d_base, c->L.total, 1);
@@ -1376,11 +1410,13 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
                        (long long)L.gram_part, (long long)L.pairG, (long long)L.imu_out, (long long)L.prior_A - (long long)back};
       for (int r = 0; r < SIDE_ROUNDS; r++) {
         hipLaunchKernelGGL(k_spec_begin, dim3(1), dim3(128), 0, ss, sh, back);
-        hipLaunchKernelGGL(k_lin<LIN_ROLE_ALL>, dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, ss, sh, back, mode, g.lw, gram_wgs);
+        // (a re-anchored state: on the sphere but for a fixed extrinsic)
+        if (offs & 2) hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, true>), dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, ss, sh, back, mode, g.lw, gram_wgs);
+        else hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, false>), dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, ss, sh, back, mode, g.lw, gram_wgs);
         if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + (SCHUR_LEN / 256) * groups + 1, 1), dim3(256), 0, ss, sh, back, mode, groups);
         hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, 1), dim3(256), 0, ss, sh, back, mode, pre, sa);
-        hipLaunchKernelGGL(k_marg_solve, dim3(1, 1), dim3(MARG_THREADS), MARG_LDS, ss, sh, back,
-                           fused_flag | (c->force_eig ? 256 : 0) | 512 | (c->publish ? 1024 : 0) | 2048);
+        hipLaunchKernelGGL(k_marg_solve<true>, dim3(1, 1), dim3(MARG_THREADS), MARG_LDS, ss, sh, back,
+                           fused_flag | (c->force_eig ? 256 : 0) | 512 | (c->publish ? 1024 : 0));
       }
       HIPCHK(c, guard.end(&graph));
       HIPCHK(c, hipGraphInstantiate(side_graph, graph, nullptr, nullptr, 0));
@@ -1440,22 +1476,23 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     return LFVIO_OK;
   }
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
+  const int offs_s = slots_offs(c, count);  // (the pass behind k_setup sweeps at the uploaded state: launch_lin)
   if (c->use_graph) {
     const int lwg = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0) + (use_block_solve(c, count) ? 1 << 30 : 0);
-    if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes || c->g_linw != lwg) {
+    if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes || c->g_linw != lwg || c->g_offs != offs_s) {
       if (c->graph) (void)hipGraphExecDestroy(c->graph), c->graph = nullptr;
       hipGraph_t graph;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       CaptureGuard guard(c->stream);
-      for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1);
+      for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1, false, (offs_s & 2) || (it == 0 && (offs_s & 1)));
       HIPCHK(c, guard.end(&graph));
       HIPCHK(c, hipGraphInstantiate(&c->graph, graph, nullptr, nullptr, 0));
       HIPCHK(c, hipGraphDestroy(graph));
-      c->g_batch = count, c->g_lm = g.lm, c->g_ch = g.ch, c->g_sc = g.sc, c->g_iters = passes, c->g_linw = lwg;
+      c->g_batch = count, c->g_lm = g.lm, c->g_ch = g.ch, c->g_sc = g.sc, c->g_iters = passes, c->g_linw = lwg, c->g_offs = offs_s;
     }
     HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
   } else {
-    for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1);
+    for (int it = 0; it < passes; it++) launch_iteration(c, count, g, MODE_SOLVE, false, it == 0, it == passes - 1, false, (offs_s & 2) || (it == 0 && (offs_s & 1)));
   }
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
@@ -1467,8 +1504,9 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated)
   const int mode = (MODE_MARG + flag) | (gated ? MODE_GATED : 0);
   if (standalone)
     hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode, use_linw(c, count, g, mode) ? 1 : 0);
-  launch_iteration(c, count, g, mode);
-  hipLaunchKernelGGL(k_marg_solve, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total,
+  // (standalone: the sweep is at the uploaded state; gated: at the re-anchored solution, on the sphere but for a fixed extrinsic)
+  launch_iteration(c, count, g, mode, false, true, true, false, standalone ? slots_offs(c, count) != 0 : (slots_offs(c, count) & 2) != 0);
+  hipLaunchKernelGGL(k_marg_solve<false>, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total,
                      flag | (c->force_eig ? 256 : 0) | (gated ? 512 : 0) | (gated && c->publish ? 1024 : 0));
   HIPCHK(c, hipGetLastError());
   return LFVIO_OK;
@@ -1674,8 +1712,10 @@ lfvio_ctx *lfvio_create(int device) {
   (void)hipFuncSetAttribute((const void *)k_solve_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   (void)hipFuncSetAttribute((const void *)k_solve_block<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVEB_LDS);
   (void)hipFuncSetAttribute((const void *)k_solve_block<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVEB_LDS);
-  (void)hipFuncSetAttribute((const void *)k_linw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
-  (void)hipFuncSetAttribute((const void *)k_linb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void *)k_linw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void *)k_linw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void *)k_linb<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void *)k_linb<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   if (const char *e = getenv("LFVIO_BLOCK_SOLVE")) c->block_solve = e[0] != '0';
   if (const char *e = getenv("LFVIO_LM_HALF")) c->lm_half = e[0] != '0';
   if (const char *e = getenv("LFVIO_LINW")) c->linw_mode = std::max(0, std::min(2, atoi(e)));
@@ -1731,7 +1771,8 @@ lfvio_ctx *lfvio_create(int device) {
   if (const char *e = getenv("LFVIO_SPEC_COUNT"))
     if (e[0]) c->spec_count = std::max(1, std::min(1 + SPEC_EXTRA, atoi(e))), c->fixed_spec = true;
   if (const char *e = getenv("LFVIO_FIRST_PASSES")) c->fixed_passes = std::max(0, atoi(e));
-  (void)hipFuncSetAttribute((const void *)k_marg_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
+  (void)hipFuncSetAttribute((const void *)k_marg_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
+  (void)hipFuncSetAttribute((const void *)k_marg_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
   const char *env = getenv("LFVIO_NO_GRAPH");
   if (env && env[0] == '1') c->use_graph = false;
   return c;
@@ -2233,6 +2274,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   const Grid g = grid_for(c, count);
   const size_t st = c->L.total;
   const bool lw = use_linw(c, count, g, MODE_SOLVE);
+  const bool offs = (slots_offs(c, count) & 2) != 0;  // the instantiation the passes behind the first one run (launch_lin)
   // (a rank of a sharded window sweeps its share group by group under the same condition: shard.inc)
   const bool lb = !lw && (c->shard_active ? (c->linw_mode != 0 && count == 1 && c->info[0].linb_ok) : use_linb(c, count, g, MODE_SOLVE));
   // which kernel the launch would take is settled before anything is created or enqueued
@@ -2253,11 +2295,11 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
   // one full linearization so that every kernel has valid inputs
   if (lw) {
-    launch_linw(c, count);
+    launch_linw(c, count, MODE_SOLVE, offs);
   } else if (lb && which >= 15 && which <= 17) {
-    launch_linb(c, count);
+    launch_linb(c, count, offs);
   } else {
-    launch_lin(c, count, g, MODE_SOLVE);
+    launch_lin(c, count, g, MODE_SOLVE, offs);
     launch_sum(c, count, g, MODE_SOLVE);
   }
   if (which == 14) launch_solve(c, count, lw);
@@ -2266,24 +2308,24 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
   HIPCHK(c, hipEventRecord(e0, c->stream));
   for (int r = 0; r < reps; r++) {
     switch (which) {
-      case 0: launch_lin(c, count, g, MODE_SOLVE); break;
+      case 0: launch_lin(c, count, g, MODE_SOLVE, offs); break;
       case 2: launch_sum(c, count, g, MODE_SOLVE); break;  // k_presum + k_sum for large windows
       case 8: case 9: case 10: case 18: {  // k_lin by role: landmark blocks | Gram chunks | IMU factors + prior | IMU factors alone
         const int gram_wgs = (g.ch + 3) / 4;
         const int gx = which == 8 ? g.lw : which == 9 ? gram_wgs : which == 18 ? LFVIO_WINDOW_SIZE : LFVIO_WINDOW_SIZE + 1;
-        hipLaunchKernelGGL(k_lin<LIN_ROLE_ALL>, dim3(gx, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, which == 8 ? g.lw : 0,
+        hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, false>), dim3(gx, count), dim3(LIN_THREADS), 0, c->stream, c->d_base, st, MODE_SOLVE, which == 8 ? g.lw : 0,
                            which == 9 ? gram_wgs : 0);
       } break;
       case 4: case 5: case 6: case 7: {  // k_setup by role: state + table | + IMU sqrt_info | + prior J0^T J0 | + inverse depths
         const int gx = which == 4 ? 1 : which == 5 ? 1 + LFVIO_WINDOW_SIZE : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
         hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
       } break;
-      case 11: case 12: launch_linw(c, count); break;  // the window-resident sweep of a batch (k_linw: pose-side factors, visual sweep, Schur)
+      case 11: case 12: launch_linw(c, count, MODE_SOLVE, offs); break;  // the window-resident sweep of a batch (k_linw: pose-side factors, visual sweep, Schur)
       case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;
       case 14: hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_LAUNCH_THREADS), 0, c->stream, c->d_base, st); break;  // (not idempotent: a few reps only)
       // a large single window, group by group: 15 the strip sweep (k_linb), 16 the sum of its partials (k_sumb), 17 the landmark
       // back-substitution from the transposed rows (k_backsub_wt)
-      case 15: hipLaunchKernelGGL(k_linb, dim3(linb_grid(c, count), count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, linw_args(c)); break;
+      case 15: hipLaunchKernelGGL(k_linb<false>, dim3(linb_grid(c, count), count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, st, linw_args(c)); break;
       case 16: hipLaunchKernelGGL(k_sumb, dim3(LINB_SUM_GRID, count), dim3(LINB_SUM_THREADS), 0, c->stream, c->d_base, st, linw_args(c)); break;
       case 17: hipLaunchKernelGGL(k_backsub_wt, dim3(g.lm, count), dim3(64), 0, c->stream, c->d_base, st, c->L.capLmBlocks * LM_BLOCK); break;
       default: launch_solve(c, count); break;
