@@ -225,13 +225,15 @@ def window100k_record(device, flag, calls=10):
         e.close()
 
 
-def stream_record(device, flag, n_stream=33):
+def stream_record(device, flag, n_stream=33, ahead=True):
     """The headline shape as a drop-in sees it: consecutive DISTINCT windows of one estimator stream, each uploaded, optimized and
     downloaded (PCIe inside) — mean / p95 per step.  The chain is generated through the product path itself."""
     from lfvio import abi, synth
     from lfvio.engine import Engine
 
     e = Engine(device)
+    if not ahead:
+        e.marg_ahead(0)  # (A/B: every call ends with the serial tail)
     try:
         scene = synth.Scene(1000, n_total=11 + n_stream)
         rng = np.random.default_rng([1000, 104729])
@@ -475,6 +477,7 @@ def main():
         step(k)
     eng.batch_sync()
     passes_hist.clear()
+    ahead0 = eng.marg_ahead() if not sharded else (0, 0)
     barrier()
     laps = []
     t0 = time.perf_counter()
@@ -494,6 +497,13 @@ def main():
         elapsed = float(t.item())
     solves = args.steps * (1 if sharded else world * batch)
     value = solves / elapsed
+    if not sharded:
+        # the marginalization run ahead of the loop's end (csrc/kernels_spec.h): calls of the timed region that started workers, and how
+        # many of them had their prior delivered by a worker (the rest ended with the serial tail: their last pass accepted a step)
+        a1 = eng.marg_ahead()
+        if a1[0] > ahead0[0]:
+            extra_cfg["marg_ahead"] = dict(calls=a1[0] - ahead0[0], priors_from_a_worker=a1[1] - ahead0[1],
+                                           hit_fraction=(a1[1] - ahead0[1]) / (a1[0] - ahead0[0]))
 
     # ---- sanity of the timed work
     if sharded:

@@ -104,11 +104,14 @@ __global__ __launch_bounds__(256) void k_prior_chain(char *base, size_t stride) 
   if (tid == 0) {
     late = 0;
     const long long t0 = wall_clock64();
-    while (spec_ld(&S->tail_state) == 3)
+    while (spec_peek(&S->tail_state) == 3) {
       if (wall_clock64() - t0 > 10 * SPEC_WAIT_TICKS) {
         late = 1;
         break;
       }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    spec_acquire();
   }
   __syncthreads();
   if (late || src->valid != 1 || src->n != n || src->num_blocks != nb) {
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(64) void k_spec_wait(char *base) {
   Slot *S = (Slot *)base;
   if (threadIdx.x != 0) return;
   const long long t0 = wall_clock64();
-  while (spec_ld(&S->tail_state) == 3 && wall_clock64() - t0 < 10 * SPEC_WAIT_TICKS) __builtin_amdgcn_s_sleep(8);
+  while (spec_peek(&S->tail_state) == 3 && wall_clock64() - t0 < 10 * SPEC_WAIT_TICKS) __builtin_amdgcn_s_sleep(8);
 }
 // k_spec_begin: grid 1 x 128 on a worker's stream — first launch of a round (kernels_spec.h).  base: the worker's SHADOW slot; back: its
 // distance from the slot being solved.  Waits for an accepted state newer than the last one it looked at, copies it, claims
@@ -232,8 +235,8 @@ __global__ __launch_bounds__(128) void k_spec_begin(char *base, size_t back) {
       int go = 0, w = 0;
       const int last = S->shadow.last_word;
       for (;;) {
-        const int f = spec_ld(&S0->spec.fin);
-        w = spec_ld(&S0->spec.word);
+        const int f = spec_peek(&S0->spec.fin);  // (fin first, then word: k_setup withdraws the word before it re-opens fin)
+        w = spec_peek(&S0->spec.word);
         if (w != 0) {
           const int st = spec_ep(f) == spec_ep(w) ? spec_fin_state(f) : FIN_OPEN;
           if (st != FIN_OPEN) break;  // the loop is closing or closed: whatever was not claimed is its own
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(128) void k_spec_begin(char *base, size_t back) {
         if (wall_clock64() - t0 > SPEC_WAIT_TICKS) break;
         __builtin_amdgcn_s_sleep(8);
       }
+      spec_acquire();  // (what the word announces — x[cur], lam[cur] — is read behind this)
       sh_word = w, sh_go = go;
     }
     __syncthreads();
@@ -1026,7 +1030,7 @@ DEV void spec_deliver(Slot *S, Slot *S0, int my_word, bool publish) {
     long long t0 = wall_clock64();
     int g = 0;
     for (;;) {
-      const int f = spec_ld(&S0->spec.fin), w = spec_ld(&S0->spec.word);
+      const int f = spec_peek(&S0->spec.fin), w = spec_peek(&S0->spec.word);
       if (spec_ep(w) != ep) break;  // (the slot has gone on to another call: cannot happen to a committed worker)
       const int st = spec_ep(f) == ep ? spec_fin_state(f) : FIN_OPEN;
       if (st >= FIN_MAIN) {

@@ -33,6 +33,10 @@
 constexpr long long SPEC_WAIT_TICKS = 300000;  // 3 ms of the 100 MHz wall clock: the longest a worker waits for the loop
 
 DEV int spec_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+// for the waiting loops: a device-scope load that invalidates nothing (an acquire per turn of a loop empties the non-local lines of the
+// L2 the spinning wave shares with an eighth of the chip, turn after turn); spec_acquire() once when the wait is over
+DEV int spec_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void spec_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 DEV void spec_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 DEV int spec_cas(int *p, int expect, int v) {
   __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -57,7 +61,8 @@ DEV void spec_arm(Slot *S) {
 // when it is the header's or candidate 0 (written where it lies by the pass before), behind the copy when it was a speculative
 // candidate (copy_accepted, the last workgroup).  The pass's own k_step — the first kernel to overwrite x[cur ^ 1] — comes later.
 DEV void spec_publish(Slot *S, int num_succ, int cur) {
-  if (num_succ < SPEC_OWN) spec_st(&S->spec.word, S->spec.ep << 16 | num_succ << 1 | cur);
+  // (ticket 0: the host started no workers for this call; whatever rounds are still around from the call before must find nothing)
+  if (num_succ < SPEC_OWN && S->spec.ticket != 0) spec_st(&S->spec.word, S->spec.ep << 16 | num_succ << 1 | cur);
 }
 // the gated gauge fix, one thread, BEFORE the first in-place store (the caller puts a workgroup barrier behind it)
 DEV void spec_closing(Slot *S) {

@@ -264,7 +264,9 @@ struct lfvio_ctx {
 
 namespace {
 
-void destroy_graph(lfvio_ctx *c) {
+// keep_side: the workers' graphs (kernels_spec.h) stay — they are captured for the slot's CAPACITY, not for the resident window's launch
+// dimensions, and a stream of windows changes those every few frames
+void destroy_graph(lfvio_ctx *c, bool keep_side = false) {
   // (a graph whose tail is still running behind an early state is not destroyed under it)
   if (c->stream && (c->inflight || c->unsynced || c->pipelined)) {
     (void)hipStreamSynchronize(c->stream);
@@ -274,12 +276,14 @@ void destroy_graph(lfvio_ctx *c) {
     (void)hipGraphExecDestroy(c->graph);
     c->graph = nullptr;
   }
-  for (auto &st : c->sstream)
-    if (st) (void)hipStreamSynchronize(st);  // (rounds that found nothing to do may still be draining)
-  for (auto &wk : c->side)
-    for (auto &row : wk)
-      for (auto &t : row)
-        if (t) (void)hipGraphExecDestroy(t), t = nullptr;
+  if (!keep_side) {
+    for (auto &st : c->sstream)
+      if (st) (void)hipStreamSynchronize(st);  // (rounds that found nothing to do may still be draining)
+    for (auto &wk : c->side)
+      for (auto &row : wk)
+        for (auto &t : row)
+          if (t) (void)hipGraphExecDestroy(t), t = nullptr;
+  }
   for (auto &t : c->chunk)
     if (t) (void)hipGraphExecDestroy(t), t = nullptr;
   for (auto &row : c->tail)
@@ -327,6 +331,7 @@ int wait_side(lfvio_ctx *c) {
     }
   }
   if (__atomic_load_n(echo, __ATOMIC_ACQUIRE) == c->side_ticket) c->stat_ahead_hits++;
+  ((volatile int *)c->h_mail)[6] = 0;  // (whatever runs k_setup on this slot next without workers of its own — a standalone marginalization, a debug sweep — publishes nothing)
   return LFVIO_OK;
 }
 constexpr const char *CHAIN_ERR_TEXT = "the prior this window was to take over on the device was not there (the marginalization before it produced none): it ran without a prior";
@@ -1328,7 +1333,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     const int lwk = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0) + (use_block_solve(c, count) ? 1 << 30 : 0);
     const int offs = slots_offs(c, count);
     if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk || c->k_offs != offs) {
-      destroy_graph(c);
+      destroy_graph(c, c->k_batch == count && ((c->k_offs ^ offs) & 2) == 0);  // (the workers' graphs: per context, but for the fixed-extrinsic bit)
       c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk, c->k_offs = offs;
     }
     if (tail_done) *tail_done = false;
@@ -1391,8 +1396,11 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     // Workers for the marginalization run ahead (kernels_spec.h): one small window on the merged launch sequence (its loop ends in
     // k_decide_gauge), with a shadow slot and a mailbox.  SIDE_ROUNDS rounds of [k_spec_begin, k_lin, k_sum, k_marg_solve] on the shadow
     // slot, captured once per marginalization flag and hand-over variant; a round that finds nothing to do is four launches that return.
-    const bool ahead = fuse && count == 1 && c->info[0].spec_on && c->shadow && c->marg_ahead && !c->no_merge && !c->no_fuse && !c->shard_active &&
-                       g.lm <= DOGLEG_INLINE_BLOCKS && !use_linw(c, count, g, MODE_SOLVE) && !use_linb(c, count, g, MODE_SOLVE);
+    // (not behind a device-chained upload: there the marginalization already runs beside the host's packing of the next window, and the next
+    // window's upload would have to wait for a worker instead of following the stream)
+    const bool ahead = fuse && count == 1 && c->info[0].spec_on && c->shadow && c->marg_ahead && !c->no_merge && !c->no_fuse && !c->shard_active && !c->pipelined &&
+                       g.lm <= DOGLEG_INLINE_BLOCKS && g.ch_raw <= PRE_CHUNK_LIMIT && g.sc <= 4 * PRE_GROUP && !use_linw(c, count, g, MODE_SOLVE) &&
+                       !use_linb(c, count, g, MODE_SOLVE);
     for (int wk = 0; ahead && wk < lfvio_ctx::WORKERS; wk++) {
       hipGraphExec_t *side_graph = &c->side[wk][fused_flag][c->publish ? 1 : 0];
       if (*side_graph) continue;
@@ -1402,17 +1410,19 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       CaptureGuard guard(ss);
       const size_t back = (size_t)(c->batch + wk) * c->L.total;
       char *sh = c->d_base + back;
-      const int mode = (MODE_MARG + fused_flag) | MODE_GATED, gram_wgs = (g.ch + 3) / 4;
-      const int pre = (g.ch_raw > PRE_CHUNK_LIMIT || g.sc > 4 * PRE_GROUP) ? 1 : 0, groups = (g.sc + PRE_GROUP - 1) / PRE_GROUP;
+      // launch dimensions for the largest window the merged sequence takes (spare workgroups test their index against the slot's own
+      // counts and return): one capture serves every window of the context
       const Layout &L = c->L;
+      const int mode = (MODE_MARG + fused_flag) | MODE_GATED, gram_wgs = (L.capChunks + 3) / 4, lw_cap = 2 * DOGLEG_INLINE_BLOCKS;
+      const int pre = 0, groups = 1;  // (k_presum is for windows of thousands of landmarks)
       // (the gather lists are inputs: the shadow's copies of those members lead back into slot 0, and so do these offsets)
       const SumArgs sa{(long long)L.sum_off - (long long)back, (long long)L.sum_end_marg - (long long)back, (long long)L.sum_items - (long long)back,
                        (long long)L.gram_part, (long long)L.pairG, (long long)L.imu_out, (long long)L.prior_A - (long long)back};
       for (int r = 0; r < SIDE_ROUNDS; r++) {
         hipLaunchKernelGGL(k_spec_begin, dim3(1), dim3(128), 0, ss, sh, back);
         // (a re-anchored state: on the sphere but for a fixed extrinsic)
-        if (offs & 2) hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, true>), dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, ss, sh, back, mode, g.lw, gram_wgs);
-        else hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, false>), dim3(g.lw + gram_wgs + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, ss, sh, back, mode, g.lw, gram_wgs);
+        if (offs & 2) hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, true>), dim3(lw_cap + gram_wgs + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, ss, sh, back, mode, lw_cap, gram_wgs);
+        else hipLaunchKernelGGL((k_lin<LIN_ROLE_ALL, false>), dim3(lw_cap + gram_wgs + LFVIO_WINDOW_SIZE + 1, 1), dim3(LIN_THREADS), 0, ss, sh, back, mode, lw_cap, gram_wgs);
         if (pre) hipLaunchKernelGGL(k_presum, dim3(NPAIR + (SCHUR_LEN / 256) * groups + 1, 1), dim3(256), 0, ss, sh, back, mode, groups);
         hipLaunchKernelGGL(k_sum, dim3(HPP_BLOCKS + SCHUR_LEN / 256 + 1, 1), dim3(256), 0, ss, sh, back, mode, pre, sa);
         hipLaunchKernelGGL(k_marg_solve<true>, dim3(1, 1), dim3(MARG_THREADS), MARG_LDS, ss, sh, back,
@@ -1429,7 +1439,8 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       const auto t_launch = std::chrono::steady_clock::now();
       const bool watch = early && done_passes == 0 && fuse && c->publish;
       if (watch) __atomic_store_n((int *)c->h_mail + 1, 0, __ATOMIC_RELAXED), __atomic_store_n((int *)c->h_mail, 0, __ATOMIC_RELEASE);
-      if (ahead && done_passes == 0) ((volatile int *)c->h_mail)[6] = c->side_ticket = (c->side_ticket == 0x7fffffff ? 1 : c->side_ticket + 1);
+      // (ticket 0: a call without workers — rounds left over from an earlier call must not take its states: spec_publish)
+      if (done_passes == 0 && c->h_mail && count == 1) ((volatile int *)c->h_mail)[6] = ahead ? (c->side_ticket = (c->side_ticket == 0x7fffffff ? 1 : c->side_ticket + 1)) : 0;
       HIPCHK(c, hipGraphLaunch(done_passes == 0 ? first_graph : c->chunk[sv], c->stream));
       if (ahead && done_passes == 0) {  // (behind the loop's graph: on a shared hardware queue the workers would otherwise wait in front of it)
         for (int wk = 0; wk < lfvio_ctx::WORKERS; wk++) HIPCHK(c, hipGraphLaunch(c->side[wk][fused_flag][c->publish ? 1 : 0], c->sstream[wk]));

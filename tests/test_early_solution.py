@@ -17,6 +17,15 @@ from lfvio.engine import Engine
 pytestmark = pytest.mark.gpu
 
 
+def serial():
+    """A context whose calls end with the SERIAL tail (gauge fix, frame-0 sweep, k_marg_solve behind the last pass): the reference of
+    every route below.  The contexts under test run with the default — the marginalization started ahead of the loop's end on a
+    second stream for windows of at most 320 landmarks (csrc/kernels_spec.h) — and must give the same bits."""
+    e = Engine(0)
+    e.marg_ahead(0)
+    return e
+
+
 def whole(eng, w, flag):
     eng.batch_reserve(1, w.N, w.M)
     eng.batch_upload(0, w)
@@ -60,7 +69,7 @@ def test_split_call_is_the_whole_call(oracle, seed, n, flag):
         w, _ = synth.make_window_with_prior(seed, n, lambda w_, f: oracle.optimize(w_, f))
     else:
         w = synth.make_window(seed, n)
-    ref_sol, ref_prior = whole(Engine(0), w, flag)
+    ref_sol, ref_prior = whole(serial(), w, flag)
     eng = Engine(0)
     for rep in range(3):  # (the first call captures its graphs; the later ones replay them)
         sol, prior, pending = split(eng, w, flag)
@@ -93,7 +102,7 @@ def test_window_that_needs_more_passes_than_predicted():
             w = cand
             break
     assert w is not None, "no synthetic window of this family needs six passes"
-    ref_sol, ref_prior = whole(Engine(0), w, abi.MARGIN_OLD)
+    ref_sol, ref_prior = whole(serial(), w, abi.MARGIN_OLD)
     eng = Engine(0)
     sol, prior, _ = split(eng, w, abi.MARGIN_OLD)
     same_solution(sol, ref_sol)
@@ -109,7 +118,7 @@ def test_feature_steps_run_beside_the_tail(oracle):
     """lfvio_shift_depth between begin() and finish(): right result, and it has not waited for (joined) the tail."""
     w = synth.make_window(0, 300)
     eng = Engine(0)
-    ref_sol, ref_prior = whole(Engine(0), w, abi.MARGIN_OLD)
+    ref_sol, ref_prior = whole(serial(), w, abi.MARGIN_OLD)
     rng = np.random.default_rng(5)
     uv = rng.normal(size=(200, 3))
     uv /= np.linalg.norm(uv, axis=1)[:, None]
@@ -134,7 +143,7 @@ def test_any_other_entry_point_joins_the_tail():
     """An upload (or a download) issued while the tail is in flight waits for it: nothing is lost but the overlap."""
     w = synth.make_window(0, 300)
     w2 = synth.make_window(1, 300)
-    ref_sol, ref_prior = whole(Engine(0), w, abi.MARGIN_OLD)
+    ref_sol, ref_prior = whole(serial(), w, abi.MARGIN_OLD)
     eng = Engine(0)
     eng.batch_reserve(1, 400, 3000)
     eng.batch_upload(0, w)
@@ -149,7 +158,7 @@ def test_any_other_entry_point_joins_the_tail():
     assert not eng.optimize_pending()
     sol2 = eng.optimize_begin(abi.MARGIN_OLD, w2.N)
     prior2 = eng.optimize_finish()
-    r2s, r2p = whole(Engine(0), w2, abi.MARGIN_OLD)
+    r2s, r2p = whole(serial(), w2, abi.MARGIN_OLD)
     same_solution(sol2, r2s)
     same_prior(prior2, r2p)
 
@@ -171,7 +180,7 @@ def stream_windows(eng, n_windows, n_lm=200, seed=21):
 def test_chained_upload_follows_the_stream():
     """upload_chained(k + 1) while the marginalization of window k is in flight: every window of the chain gets, bit for
     bit, the solution and the prior of the plain upload / optimize / download sequence that generated the chain."""
-    ref = stream_windows(Engine(0), 8)
+    ref = stream_windows(serial(), 8)
     eng = Engine(0)
     eng.batch_reserve(1, 400, 3000)
     carried = abi.Prior()  # the caller's one prior buffer, in and out
@@ -189,7 +198,7 @@ def test_chained_upload_follows_the_stream():
 
 
 def test_chained_upload_with_nothing_in_flight_is_a_plain_upload():
-    ref = stream_windows(Engine(0), 2)
+    ref = stream_windows(serial(), 2)
     eng = Engine(0)
     eng.batch_reserve(1, 400, 3000)
     w, rsol, rprior = ref[1]
@@ -207,7 +216,7 @@ def test_chained_upload_with_nothing_in_flight_is_a_plain_upload():
 def test_chained_upload_across_a_reallocation():
     """The next window does not fit the reservation: reserve() re-allocates the slots while the marginalization is in flight —
     the prior is collected first and still reaches the chained upload."""
-    ref = stream_windows(Engine(0), 2)
+    ref = stream_windows(serial(), 2)
     eng = Engine(0)
     w0, w1 = ref[0][0], ref[1][0]
     eng.batch_reserve(1, w0.N, w0.M)
@@ -222,7 +231,7 @@ def test_chained_upload_across_a_reallocation():
 
 
 def test_chained_upload_refused_leaves_the_prior_collectable():
-    ref = stream_windows(Engine(0), 1)
+    ref = stream_windows(serial(), 1)
     eng = Engine(0)
     w0 = ref[0][0]
     eng.batch_reserve(1, 400, 3000)
@@ -239,7 +248,7 @@ def test_device_chained_upload_follows_the_stream():
     """upload_chained_device(k + 1) while the marginalization of window k is in flight: the prior never leaves the device, nothing is
     waited for — and every window of the chain still gets, bit for bit, the solution of the plain upload / optimize / download sequence
     that generated the chain (same values in the same arrays: only the road they took differs); the last call's prior is collectable."""
-    ref = stream_windows(Engine(0), 8)
+    ref = stream_windows(serial(), 8)
     eng = Engine(0)
     eng.batch_reserve(1, 400, 3000)
     for k, (w, rsol, rprior) in enumerate(ref):
@@ -268,7 +277,7 @@ def test_device_chained_upload_follows_the_stream():
 
 
 def test_device_chained_upload_needs_a_prior_in_flight():
-    ref = stream_windows(Engine(0), 2)
+    ref = stream_windows(serial(), 2)
     eng = Engine(0)
     eng.batch_reserve(1, 400, 3000)
     w0, w1 = ref[0][0], ref[1][0]
@@ -304,7 +313,7 @@ def test_device_chained_prior_that_is_not_there_is_an_error_not_a_silent_solve()
     """The marginalization in flight does not leave the prior the next window was promised (here: a promise of the wrong size; in the field:
     a marginalization that failed on the device): the window must not pass for solved — the begin() behind the upload reports it, whether
     the state came early or not, and the context goes on with the next plain upload."""
-    ref = stream_windows(Engine(0), 3)
+    ref = stream_windows(serial(), 3)
     eng = Engine(0)
     eng.batch_reserve(1, 400, 3000)
     for early in (True, False):
@@ -339,7 +348,7 @@ def test_device_chained_prior_that_passes_through_is_fetched():
     if found is None:
         pytest.skip("no short-track chain among the seeds tried")
     (w0, _, p0), (w1, _, _) = found
-    r_sol, r_prior = whole(Engine(0), w1, abi.MARGIN_SECOND_NEW)  # w1 carries p0 (the chain's generator put it there)
+    r_sol, r_prior = whole(serial(), w1, abi.MARGIN_SECOND_NEW)  # w1 carries p0 (the chain's generator put it there)
     eng = Engine(0)
     eng.batch_reserve(1, 400, 3000)
     eng.batch_upload(0, w0)
@@ -356,7 +365,7 @@ def test_random_call_sequences_keep_the_chain(seed):
     """The three ways a window can reach the device (plain upload with its prior, the host-side hand-over, the hand-over on the device)
     and the two ways it can be optimized (split, whole), drawn at random along one chain, with collections, joins and a growing
     reservation thrown in between: every window still gets the bits of the plain sequence that generated the chain."""
-    ref = stream_windows(Engine(0), 10, n_lm=150)
+    ref = stream_windows(serial(), 10, n_lm=150)
     rng = np.random.default_rng(seed)
     eng = Engine(0)
     eng.batch_reserve(1, 200, 1500)
@@ -409,7 +418,7 @@ def test_context_torn_down_or_reconfigured_with_the_tail_in_flight():
     """lfvio_destroy and the calls that drop the captured graphs (here lfvio_debug_force_eig) wait for a marginalization
     still running behind an early state instead of pulling its graph from under it."""
     w = synth.make_window(0, 300)
-    ref_sol, ref_prior = whole(Engine(0), w, abi.MARGIN_OLD)
+    ref_sol, ref_prior = whole(serial(), w, abi.MARGIN_OLD)
     eng = Engine(0)
     eng.batch_reserve(1, w.N, w.M)
     eng.batch_upload(0, w)
