@@ -240,7 +240,11 @@ int lfvio_batch_upload_chained(lfvio_ctx *ctx, int slot, const LfvioWindow *in, 
  *                                LFVIO_ERR_ARG (nothing enqueued, the call in flight untouched) when there is no call in flight on
  *                                slot 0 or when its marginalization passes the input prior through (MARGIN_SECOND_NEW without a prior
  *                                on the newest pose): use lfvio_batch_upload_chained then.  If that marginalization fails on the
- *                                device, the next lfvio_batch_optimize_begin returns LFVIO_ERR_DEVICE. */
+ *                                device — or leaves a prior of another block structure than the one promised — the window runs
+ *                                without a prior and the next lfvio_batch_optimize_begin / lfvio_batch_optimize(ctx, 1, flag)
+ *                                returns LFVIO_ERR_DEVICE.  Those two are the calls that may follow this upload: any other way
+ *                                of optimizing the slot (lfvio_batch_optimize_async, a count above one) is refused with
+ *                                LFVIO_ERR_ARG — the verdict on the prior travels with the graph of one window's synchronous call. */
 int lfvio_batch_upload_chained_device(lfvio_ctx *ctx, int slot, const LfvioWindow *in);
 int lfvio_batch_optimize_begin(lfvio_ctx *ctx, int marg_flag, LfvioSolution *sol);
 int lfvio_batch_optimize_finish(lfvio_ctx *ctx, LfvioPrior *prior);

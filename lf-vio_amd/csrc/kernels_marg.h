@@ -114,7 +114,13 @@ __global__ __launch_bounds__(256) void k_prior_chain(char *base, size_t stride) 
     spec_acquire();
   }
   __syncthreads();
-  if (late || src->valid != 1 || src->n != n || src->num_blocks != nb) {
+  // the block structure the host promised (its own plan of that marginalization) against what the marginalization wrote: same blocks in
+  // the same order at the same columns, not just as many of them
+  bool same = !late && src->valid == 1 && src->n == n && src->num_blocks == nb;
+  if (same)
+    for (int i = 0; i < nb; i++)
+      same = same && src->blocks[i].kind == S->prior_kind[i] && src->blocks[i].frame == S->prior_frame[i] && src->block_idx[i] == S->prior_idx[i];
+  if (!same) {
     // no prior where one was promised (the marginalization failed or produced another structure): the window runs without one and says so
     if (tid == 0) S->prior_valid = 0, S->chain_err = 1;
     return;

@@ -71,7 +71,9 @@ Layout make_layout(int maxN, int maxM) {
   L.maxM = maxM;
   L.capLmBlocks = std::max(1, (maxN + LM_BLOCK - 1) / LM_BLOCK);
   L.capChunks = 64 + maxM / CHUNK_MAX;
-  L.capSchurParts = L.capLmBlocks + 1;
+  // (one part per landmark workgroup of k_lin: 64 landmarks each, or 32 for windows of at most SPEC_MAX_LM landmarks — Slot::lm_half)
+  L.capSchurParts = std::max(L.capLmBlocks + 1, 2 * ((std::min(maxN, SPEC_MAX_LM) + LM_BLOCK - 1) / LM_BLOCK));
+  static_assert(LINB_LEN >= SCHUR_LEN, "the Schur partials of k_lin share the array of k_linb's group partials, which are the larger");
   size_t o = align_up(sizeof(Slot), 256);
   auto take = [&](size_t bytes) {
     size_t r = o;
@@ -1901,6 +1903,11 @@ static int batch_optimize_impl(lfvio_ctx *c, int count, int marg_flag, bool adap
     max_iter = std::max(max_iter, c->info[s].max_iter);
     const double t = c->info[s].max_seconds;
     if (t > 0.0 && (max_seconds <= 0.0 || t < max_seconds)) max_seconds = t;
+  }
+  if (c->info[0].in_prior_device && (count != 1 || !adaptive || !c->use_graph)) {
+    // (k_prior_chain's verdict on the prior travels with the graph of ONE window's synchronous call: include/lfvio.h)
+    c->err = "a window uploaded with lfvio_batch_upload_chained_device is optimized by lfvio_batch_optimize_begin or lfvio_batch_optimize(ctx, 1, flag)";
+    return LFVIO_ERR_ARG;
   }
   const bool fuse = adaptive && c->use_graph;
   bool tail_done = false;

@@ -602,7 +602,8 @@ void WindowEstimator::pack(LfvioWindow *w) {
   w->prior = has_prior ? &prior : nullptr;
 }
 
-// estimator.cpp:676-1009 over the C-ABI.  On any error the state is left as the caller had it and `status` says why (the
+// estimator.cpp:676-1009 over the C-ABI.  On any error the state is left as the caller had it — but for a prior that was lost on the
+// device with the failed call, see below — and `status` says why (the
 // reference has no error channel at all).
 void WindowEstimator::optimization() {
   status = LFVIO_OK;
@@ -656,7 +657,9 @@ void WindowEstimator::optimization() {
       // then decides (it reports a malformed window itself).
       status = config().device_chain ? lfvio_batch_upload_chained_device(gpu, 0, &w) : LFVIO_ERR_ARG;
       if (status == LFVIO_OK) {
-        prior_pending_ = false, has_prior = true;  // (`prior` itself is stale until something collects the next one)
+        // the window's prior is on the device only; the host's copy `prior` is the one of two windows back from here on, until the
+        // next marginalization is collected
+        prior_pending_ = false, has_prior = true, prior_on_device_ = true;
       } else {
         status = lfvio_batch_upload_chained(gpu, 0, &w, &prior);
         prior_pending_ = lfvio_batch_optimize_pending(gpu) != 0;  // (an upload refused before it got to the prior leaves it where it was)
@@ -674,10 +677,17 @@ void WindowEstimator::optimization() {
       // collected by the first thing that needs it (collectPrior(): the next pack()).
       status = lfvio_batch_optimize_begin(gpu, marg_flag, &summary);
       summary.inv_depth = nullptr;
-      if (status != LFVIO_OK) return;
+      if (status != LFVIO_OK) {
+        // A window that took its prior over on the device and did not get through (the prior was not there, a device error): that
+        // prior is gone with the call, and the host's copy is two windows old — its frames have been shifted twice since.  The
+        // estimator goes on WITHOUT a prior rather than with that one.
+        if (prior_on_device_) has_prior = false, prior.valid = 0, prior_on_device_ = false;
+        return;
+      }
       take_state();
       if (marginalize) prior_pending_ = true;
       else (void)lfvio_batch_optimize_finish(gpu, nullptr);
+      if (marginalize) prior_on_device_ = false;  // (what is collected next is this call's own prior)
       return;
     }
     if (status == LFVIO_OK) status = lfvio_batch_optimize(gpu, 1, marg_flag);

@@ -215,6 +215,7 @@ class WindowEstimator {
   LfvioPrior next_;  // the prior being downloaded (240 KB: a member, not a stack object; only header + n x n + n are copied)
   bool chain_upload_ = false;   // pack() on behalf of an optimization() whose upload collects the pending prior itself
   bool prior_pending_ = false;  // the marginalization of the last optimization() has not been collected yet (collectPrior)
+  bool prior_on_device_ = false;  // the resident window took its prior over on the device (lfvio_batch_upload_chained_device): `prior` is stale
   bool device();
   bool applyBootstrap();
   FrameRing ring_;

@@ -206,6 +206,37 @@ def test_a_rank_that_fails_still_issues_its_collectives_and_every_rank_ends_in_t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shards,bad,phase", [(1, 0, 0), (1, 0, 4), (3, 1, 0), (3, 2, 4)])
+def test_a_rank_that_fails_in_the_pass_behind_the_terminating_one_leaves_with_its_peers(oracle, shards, bad, phase):
+    """the loop keeps one pass in flight behind the decision it reads, so the pass after the terminating one is
+    always issued — as a no-op.  A rank that fails while enqueueing THAT pass used to skip its own decision records (with one process
+    per GPU: all it has), never learnt that the pass before had terminated, and went on issuing the collectives of one or two more
+    passes — while its peers, who had read the decision, were already in the marginalization's all-reduce: the hang the error word
+    exists to prevent.  Now it keeps reading the decisions it enqueued before it failed, leaves the loop where its peers leave it,
+    enters the marginalization's collective with the error word raised and returns its error behind it: no pass more than the good run
+    issues (one local rank is the case the fix is for; three show the peers' side)."""
+    from lfvio.engine import Group
+
+    w = synth.make_window_with_prior(4, 300, lambda x, f: oracle.optimize(x, f))[0]
+    g = Group(local_shards=shards)
+    g.upload(w)
+    g.optimize(abi.MARGIN_OLD)
+    good_sol, good_prior = g.download()
+    passes_ok, coll_ok = g.last_passes(), g.last_collectives()
+    g.inject_failure(bad, passes_ok - 1, phase)  # (passes are counted from 0: the no-op pass in flight behind the terminating one)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        g.optimize(abi.MARGIN_OLD)
+    assert g.last_passes() == passes_ok          # not one pass beyond the peers'
+    assert g.last_collectives() == coll_ok       # ... and the marginalization's collective entered with them
+    g.inject_failure(-1)
+    g.optimize(abi.MARGIN_OLD)
+    sol, prior = g.download()
+    assert g.last_passes() == passes_ok and g.last_collectives() == coll_ok
+    assert np.array_equal(sol.pose, good_sol.pose) and np.array_equal(sol.lam, good_sol.lam) and np.array_equal(prior.J(), good_prior.J())
+    g.close()
+
+
+@pytest.mark.gpu
 def test_the_collective_carries_only_what_shards():
     """The all-reduce of a pass is the camera part of H_pp (2 701 packed entries), the camera part of g_p (73), the Schur sums and the
     16 scalars (and 256 partial sums behind them): 55 KB, not the 151 KB exchange buffer — the speed / bias rows are evaluated on every rank (include/lfvio.h)."""
