@@ -378,6 +378,7 @@ def main():
     from lfvio.engine import Engine
 
     eng = Engine(local_rank, args.lib)
+    eng.configure("env")  # (measurement scripts pass switches as LFVIO_DEBUG="key=value,...": include/lfvio_debug.h; unset: nothing)
     flag = abi.MARGIN_OLD
 
     def hip_optimize(w, f):  # warm-up MARGIN_OLD step of the window sequence: the product path itself
@@ -613,10 +614,7 @@ def main():
             bare_c = [w.c() for w in bare]
             carried = abi.Prior()
             sols = [abi.Solution(w.N) for w in wins]
-            import ctypes as _C
-            _dp = _C.POINTER(_C.c_double)
-            eng.lib.lfvio_debug_upload_times.argtypes = [_C.c_void_p, _dp]
-            up_now, up_seg = np.zeros(4), None
+            up_seg = None
 
             def chained_step(k):
                 i = k % len(wins)
@@ -626,8 +624,7 @@ def main():
                 else:
                     eng.batch_upload_chained(0, bare[i], carried, bare_c[i])
                 if up_seg is not None and i:
-                    eng.lib.lfvio_debug_upload_times(eng.ctx, up_now.ctypes.data_as(_dp))
-                    up_seg.append(up_now.copy())
+                    up_seg.append(eng.query("upload_times", 4))
                 t_ = time.perf_counter()
                 eng.optimize_begin(flag, wins[i].N, sols[i])
                 return time.perf_counter() - t_

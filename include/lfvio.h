@@ -146,7 +146,7 @@ typedef struct LfvioWindow {
 typedef struct LfvioIterationSummary { /* ceres::IterationSummary subset */
   double cost;
   double cost_change;
-  double gradient_max_norm; /* -1 in the entry of a successful iteration that ended the loop (iteration cap, wall-clock cap): Ceres
+  double gradient_max_norm; /* NaN in the entry of a successful iteration that ended the loop (iteration cap, wall-clock cap): Ceres
                              * evaluates the gradient at the accepted point before it tests the cap, the device's next
                              * linearization never happens; the reference reads no summary field.  lfvio_debug_linearize() at the
                              * solution gives it (tests/test_gpu_parity.py::test_kkt_residual_at_the_solution). */

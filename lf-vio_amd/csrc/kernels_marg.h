@@ -1064,13 +1064,14 @@ DEV void spec_deliver(Slot *S, Slot *S0, int my_word, bool publish) {
   }
   for (int k = tid; k < n * n; k += nthr) dst->linearized_jacobians[k] = src->linearized_jacobians[k];
   for (int k = tid; k < n; k += nthr) dst->linearized_residuals[k] = src->linearized_residuals[k];
-  // ONE fence for both readers — the next kernel of stream 0 that looks at tail_state (device) and the host behind the echo
-  // (system): every thread's stores are out before anybody raises a flag
-  __threadfence_system();
+  // ONE release for both readers — the next kernel of stream 0 that looks at tail_state (device) and the host behind the echo
+  // (system) — by ONE thread, behind a barrier that has waited for every thread's stores: 768 write-backs of the same cache, one after
+  // the other, were a tenth of this kernel
   __syncthreads();
   if (publish) publish_prior(S0);  // (ends behind a system-scope fence and a barrier)
   char *m = (char *)S0->mail;
   if (tid == 0) {
+    __threadfence_system();
     __hip_atomic_store(&S0->tail_state, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (m) __hip_atomic_store((int *)m + 7, S->shadow.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }

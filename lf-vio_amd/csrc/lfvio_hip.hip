@@ -35,7 +35,6 @@ constexpr ncclDataType_t ncclDouble = 8;
 #include "../../include/lfvio_debug.h"
 #include "kernels_marg.h"
 #include "kernels_solve.h"
-#include "kernels_solveb.h"
 #include "kernels_feat.h"
 #include "kernels_linw.h"
 #include "linb_plan.h"
@@ -138,8 +137,6 @@ struct SlotHostInfo {
   double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
   std::vector<int> perm;  // device order -> caller order
   bool linw_ok = false;    // the window carries a LinwPlan and its arrays (kernels_linw.h)
-  bool sb_chain = true;    // the prior carries no SpeedBias block but frame 0's: the reduced system has the block structure k_solve_block
-                           // eliminates along (kernels_solveb.h); otherwise the dense solve
   bool linb_ok = false;    // ... as a group list: a large single window (k_linb)
   int linb_ng = 0;
   bool uploaded = false;   // the slot's work-array pointers are on the device (until the next reserve())
@@ -188,7 +185,7 @@ struct lfvio_ctx {
   bool publish = false;
   hipGraphExec_t chunk[2] = {}, tail[2][3] = {};  // chunk[speculation variant]
   hipGraphExec_t first[2][2][4][13] = {};  // [speculation variant: 0 three candidates (or none), 1 four][publish][0: solve only, 1 + flag: with the gated tail][passes in the first graph]
-  int fixed_passes = 0;             // debug (LFVIO_FIRST_PASSES / lfvio_debug_set_first_passes): > 0 sizes every first graph with this many passes
+  int fixed_passes = 0;             // debug (lfvio_debug_configure "first_passes"): > 0 sizes every first graph with this many passes
   int recent_passes[4] = {0, 0, 0, 0}, recent_head = 0;  // passes of the last four synchronous calls (predict())
   bool predicted_early = false;     // lfvio_batch_optimize_begin has fed this call's pass count to predict() already (the join / finish that follows must not again)
   int predict_passes = 4;           // passes the first graph of the next call carries: the most any of the last four calls needed (predict()); tail[flag]: force-done + gated gauge fix + marginalization
@@ -237,24 +234,20 @@ struct lfvio_ctx {
   int stat_chunks = 0;  // graph launches of the last synchronous solve loop (debug)
   int last_passes = 0;  // passes of the trust-region loop the last synchronous call used (slowest slot)
   int last_iters = 0;   // ... and, for one window, the iterations they covered: a window whose steps are mostly rejected gets more speculative candidates per pass
-  bool fixed_spec = false;  // LFVIO_SPEC_COUNT: a fixed number of candidates (measurements)
+  bool fixed_spec = false;  // lfvio_debug_configure "spec_count": a fixed number of candidates (measurements)
   int spec_count = 3;   // candidates per pass of a speculating launch: radius, radius / 2, radius / 4 (, radius / 8)
   int *d_lwt = nullptr;  // static table of k_linw's phase 3 (kernels_linw.h LWT_*)
   int *d_asm = nullptr;  // static scatter table of k_solve_dense<true> (kernels_solve.h ASM_*)
   bool shard_group = false;  // the resident shard is driven by an lfvio_group (two collectives per pass: shard.inc phase 4)
   int shard_kmax0 = -1;  // lfvio_shard_begin: the longest track among the WHOLE window's frame-0 landmarks (0: none), for the marginalization's plan
-  int lm_half = 1;       // windows of at most SPEC_MAX_LM landmarks: 8 lanes per track in k_lin's landmark role (LFVIO_LM_HALF=0: the 4-lane form)
-  int block_solve = 0;   // 1: the reduced system is solved along its block structure (k_solve_block) where every slot of the launch has it; 0 (default:
-                         // measured slower): k_solve_dense
+  int lm_half = 1;       // windows of at most SPEC_MAX_LM landmarks: 8 lanes per track in k_lin's landmark role (lfvio_debug_configure "lm_half" 0: the 4-lane form)
   int linw_mode = 1;     // 1: resident batches linearize with k_linw when every slot of the launch carries a plan; 0: never (k_lin roles + k_sum);
-                         // 2: any launch of planned windows, however few (tests).  LFVIO_LINW / lfvio_debug_set_linw
-  double init_radius = 1e4;  // initial_trust_region_radius of the windows uploaded from now on (debug: lfvio_debug_set_initial_radius)
-  double fn_tol = 1e-6;  // function_tolerance of the windows uploaded from now on (debug: lfvio_debug_set_function_tolerance)
+                         // 2: any launch of planned windows, however few (tests).  lfvio_debug_configure "linw"
+  double init_radius = 1e4;  // initial_trust_region_radius of the windows uploaded from now on (lfvio_debug_configure "initial_radius")
+  double fn_tol = 1e-6;  // function_tolerance of the windows uploaded from now on (lfvio_debug_configure "function_tolerance")
   bool force_eig = false;  // debug: k_marg_solve takes the eigen-decomposition path for the dropped block even when the Cholesky path applies
   // landmark-sharded mode (multi-GPU)
   bool shard_active = false;
-  bool no_merge = false;  // debug: the trust-region bookkeeping always as its own launch (lfvio_debug_set_decide_merge)
-  bool no_fuse = false;   // debug: k_dogleg and k_cost always as two launches (lfvio_debug_set_decide_merge(ctx, 0 or 2))
   int shard_begin = 0, shard_end = 0, shard_state = 0;
   std::vector<int> sh_start, sh_off;
   // stream-ordered sharded driver: ring of pinned flag records, one per enqueued decision (shard.inc)
@@ -967,10 +960,6 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   }
   info.marg_n = std::max(S->marg[0].valid ? S->marg[0].n : 0, S->marg[1].valid ? S->marg[1].n : 0);
   info.linw_ok = linw;
-  info.sb_chain = true;
-  if (pr)
-    for (int i = 0; i < pr->num_blocks; i++)
-      if (pr->blocks[i].kind == LFVIO_BLOCK_SPEEDBIAS && pr->blocks[i].frame != 0) info.sb_chain = false;
   info.linb_ok = linb, info.linb_ng = linb_ng;
   // (an upload behind a call in flight whose prior a worker on the second stream may own: it reads this slot's inputs until it delivers)
   if (slot == 0 && c->side_launched) hipLaunchKernelGGL(k_spec_wait, dim3(1), dim3(64), 0, c->stream, d);
@@ -1157,21 +1146,11 @@ void launch_linw(lfvio_ctx *c, int count, int mode_bits = MODE_SOLVE, bool offs 
   else hipLaunchKernelGGL(k_linw<false>, dim3(1, count), dim3(LW_THREADS), LW_LDS_BYTES, c->stream, c->d_base, c->L.total, linw_args(c), mode_bits);
 }
 
-// The reduced system of every slot of the launch has the chain structure (SlotHostInfo::sb_chain): solved block by block
-bool use_block_solve(const lfvio_ctx *c, int count) {
-  if (!c->block_solve) return false;
-  for (int s = 0; s < count; s++)
-    if (!c->info[s].sb_chain) return false;
-  return true;
-}
 // lw: the pass was linearized by k_linw — H_pp holds the visual terms of its camera part only, the solve adds the rest on load
 void launch_solve(lfvio_ctx *c, int count, bool lw = false) {
   const size_t st = c->L.total;
   const long long xo = (long long)c->L.xch, io = (long long)c->L.imu_out, po = (long long)c->L.prior_A;
-  if (use_block_solve(c, count)) {
-    if (lw) hipLaunchKernelGGL(k_solve_block<true>, dim3(1, count), dim3(SOLVE_THREADS), SOLVEB_LDS, c->stream, c->d_base, st, xo, io, po);
-    else hipLaunchKernelGGL(k_solve_block<false>, dim3(1, count), dim3(SOLVE_THREADS), SOLVEB_LDS, c->stream, c->d_base, st, xo, io, po);
-  } else if (lw)
+  if (lw)
     hipLaunchKernelGGL(k_solve_dense<true>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, xo, io, po, (const int *)c->d_asm);
   else
     hipLaunchKernelGGL(k_solve_dense<false>, dim3(1, count), dim3(SOLVE_THREADS), SOLVE_LDS, c->stream, c->d_base, st, xo, io, po, (const int *)nullptr);
@@ -1222,7 +1201,7 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
   // (latency of few windows only: in a resident batch every workgroup of k_lin repeating the decision costs more of the
   // GPU than the launch it saves)
   const bool lw = use_linw(c, count, g, mode), lb = !lw && use_linb(c, count, g, mode);
-  const bool merge = solve && !lw && g.lm <= DOGLEG_INLINE_BLOCKS && !c->no_merge && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
+  const bool merge = solve && !lw && g.lm <= DOGLEG_INLINE_BLOCKS && (size_t)count * (g.lw + (g.ch + 3) / 4 + LFVIO_WINDOW_SIZE + 1) <= LIN_SPLIT_WGS;
   if (lw) {
     // the window-resident sweep: one workgroup per window — pose-side factors, visual sweep, Schur; it counts the pass
     launch_linw(c, count, mode, offs);
@@ -1240,9 +1219,9 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
     const int nb = g.lm + LFVIO_WINDOW_SIZE + 1;
     // few small windows: the step and the cost of its candidates in one launch (k_step)
     const bool split = lin_split(count, g) || lw;
-    const bool fuse = inl && !split && !c->no_fuse && !c->shard_active && (size_t)count * nb <= 2048;
+    const bool fuse = inl && !split && !c->shard_active && (size_t)count * nb <= 2048;
     // a resident batch on the window-resident path: step, candidate cost and bookkeeping as ONE launch, one workgroup per window
-    const bool stepw = lw && inl && spec == 1 && !c->no_fuse;
+    const bool stepw = lw && inl && spec == 1;
     if (stepw) {
       hipLaunchKernelGGL(k_stepw, dim3(1, count), dim3(STEPW_LAUNCH_THREADS), 0, c->stream, c->d_base, st);
       return false;
@@ -1264,7 +1243,7 @@ bool launch_iteration(lfvio_ctx *c, int count, const Grid &g, int mode, bool spe
       hipLaunchKernelGGL(k_cost_imu, dim3((count * LFVIO_WINDOW_SIZE + 63) / 64), dim3(64), 0, c->stream, c->d_base, st, count);
     } else
       hipLaunchKernelGGL(k_cost<1>, dim3(spec * nb, count), dim3(64), 0, c->stream, c->d_base, st, g.lm, spec);
-    if (merge && last && gauge && !c->no_fuse) {
+    if (merge && last && gauge) {
       hipLaunchKernelGGL(k_decide_gauge, dim3(1, count), dim3(128), 0, c->stream, c->d_base, st, c->publish ? 1 : 0);
       return true;
     }
@@ -1332,7 +1311,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipMalloc((void **)&c->d_pending, 256));
       HIPCHK(c, hipHostMalloc((void **)&c->h_pending, 256, hipHostMallocDefault));
     }
-    const int lwk = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0) + (use_block_solve(c, count) ? 1 << 30 : 0);
+    const int lwk = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0);
     const int offs = slots_offs(c, count);
     if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk || c->k_offs != offs) {
       destroy_graph(c, c->k_batch == count && ((c->k_offs ^ offs) & 2) == 0);  // (the workers' graphs: per context, but for the fixed-extrinsic bit)
@@ -1400,7 +1379,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     // slot, captured once per marginalization flag and hand-over variant; a round that finds nothing to do is four launches that return.
     // (not behind a device-chained upload: there the marginalization already runs beside the host's packing of the next window, and the next
     // window's upload would have to wait for a worker instead of following the stream)
-    const bool ahead = fuse && count == 1 && c->info[0].spec_on && c->shadow && c->marg_ahead && !c->no_merge && !c->no_fuse && !c->shard_active && !c->pipelined &&
+    const bool ahead = fuse && count == 1 && c->info[0].spec_on && c->shadow && c->marg_ahead  && !c->shard_active && !c->pipelined &&
                        g.lm <= DOGLEG_INLINE_BLOCKS && g.ch_raw <= PRE_CHUNK_LIMIT && g.sc <= 4 * PRE_GROUP && !use_linw(c, count, g, MODE_SOLVE) &&
                        !use_linb(c, count, g, MODE_SOLVE);
     for (int wk = 0; ahead && wk < lfvio_ctx::WORKERS; wk++) {
@@ -1491,7 +1470,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
   hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
   const int offs_s = slots_offs(c, count);  // (the pass behind k_setup sweeps at the uploaded state: launch_lin)
   if (c->use_graph) {
-    const int lwg = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0) + (use_block_solve(c, count) ? 1 << 30 : 0);
+    const int lwg = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0);
     if (!c->graph || c->g_batch != count || c->g_lm != g.lm || c->g_ch != g.ch || c->g_sc != g.sc || c->g_iters != passes || c->g_linw != lwg || c->g_offs != offs_s) {
       if (c->graph) (void)hipGraphExecDestroy(c->graph), c->graph = nullptr;
       hipGraph_t graph;
@@ -1723,15 +1702,10 @@ lfvio_ctx *lfvio_create(int device) {
   // kernels that need more than the default 64 KiB of LDS
   (void)hipFuncSetAttribute((const void *)k_solve_dense<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
   (void)hipFuncSetAttribute((const void *)k_solve_dense<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE_LDS);
-  (void)hipFuncSetAttribute((const void *)k_solve_block<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVEB_LDS);
-  (void)hipFuncSetAttribute((const void *)k_solve_block<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVEB_LDS);
   (void)hipFuncSetAttribute((const void *)k_linw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   (void)hipFuncSetAttribute((const void *)k_linw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   (void)hipFuncSetAttribute((const void *)k_linb<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
   (void)hipFuncSetAttribute((const void *)k_linb<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LW_LDS_BYTES);
-  if (const char *e = getenv("LFVIO_BLOCK_SOLVE")) c->block_solve = e[0] != '0';
-  if (const char *e = getenv("LFVIO_LM_HALF")) c->lm_half = e[0] != '0';
-  if (const char *e = getenv("LFVIO_LINW")) c->linw_mode = std::max(0, std::min(2, atoi(e)));
   {  // static table of k_linw's phase 3: where each packed camera entry of H_pp (then each camera-side gradient entry) sits in the LDS accumulators
     std::vector<int> tab(SUM_VIS);
     for (int e = 0; e < SUM_VIS; e++) {
@@ -1781,13 +1755,8 @@ lfvio_ctx *lfvio_create(int device) {
       return nullptr;
     }
   }
-  if (const char *e = getenv("LFVIO_SPEC_COUNT"))
-    if (e[0]) c->spec_count = std::max(1, std::min(1 + SPEC_EXTRA, atoi(e))), c->fixed_spec = true;
-  if (const char *e = getenv("LFVIO_FIRST_PASSES")) c->fixed_passes = std::max(0, atoi(e));
   (void)hipFuncSetAttribute((const void *)k_marg_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
   (void)hipFuncSetAttribute((const void *)k_marg_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MARG_LDS);
-  const char *env = getenv("LFVIO_NO_GRAPH");
-  if (env && env[0] == '1') c->use_graph = false;
   return c;
 }
 
@@ -2223,7 +2192,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
   if (rc) return rc;
   if ((rc = upload_window(c, 0, in))) return rc;
   const Grid g = grid_for(c, 1);
-  const bool lw = use_linw(c, 1, g, MODE_SOLVE);  // (lfvio_debug_set_linw(ctx, 2): the window-resident sweep, for one window)
+  const bool lw = use_linw(c, 1, g, MODE_SOLVE);  // (lfvio_debug_configure "linw" 2: the window-resident sweep, for one window)
   const bool lb = !lw && use_linb(c, 1, g, MODE_SOLVE);
   char *d = c->d_base;
   const size_t o_tr = offsetof(Slot, tr);
@@ -2360,7 +2329,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
 }
 
 // Which kernel linearizes a launch over the resident slots [0, count): 0 k_lin (+ k_sum), 1 k_linw, 2 k_linb (+ k_sumb).
-int lfvio_debug_sweep_kernel(lfvio_ctx *c, int count) {
+static int sweep_kernel_of(lfvio_ctx *c, int count) {
   if (!c || !c->d_base || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
   const Grid g = grid_for(c, count);
   if (use_linw(c, count, g, MODE_SOLVE)) return 1;
@@ -2369,7 +2338,7 @@ int lfvio_debug_sweep_kernel(lfvio_ctx *c, int count) {
 }
 
 // One linearization + dense solve of the resident slots [0, count) from their uploaded state, by whichever path the launch
-// takes (k_linw or k_lin roles + k_sum: lfvio_debug_set_linw), then what the pass left in slot `slot`:
+// takes (k_linw or k_lin roles + k_sum: lfvio_debug_configure "linw"), then what the pass left in slot `slot`:
 // gp[172], schur[15 * 256] (tile layout), lm_sum[5], a[N], b[N], gn_p[172] (pose-side Gauss-Newton step), q[16] (the quadratic
 // forms of the dogleg model), x_cost.  tests/test_linw.py holds the two paths against each other with it.
 int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, double *schur, double *lm_sum, double *a, double *b, double *gn_p, double *q,
@@ -2408,89 +2377,74 @@ int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, dou
   return lw ? 1 : lb ? 2 : 0;
 }
 
-int lfvio_debug_upload_times(lfvio_ctx *c, double *out4) {
-  if (!c || !out4) return LFVIO_ERR_ARG;
-  for (int k = 0; k < 4; k++) out4[k] = c->up_us[k];
-  return LFVIO_OK;
-}
-int lfvio_debug_set_first_passes(lfvio_ctx *c, int n) {
-  if (!c || n < 0) return LFVIO_ERR_ARG;
-  c->fixed_passes = n;
-  return LFVIO_OK;
-}
-// 1: a launch over the resident slots [0, count) solves the reduced system block by block (k_solve_block); 0: k_solve_dense
-int lfvio_debug_solve_kernel(lfvio_ctx *c, int count) {
-  if (!c || !c->d_base || count <= 0 || count > c->batch) return LFVIO_ERR_ARG;
-  return use_block_solve(c, count) ? 1 : 0;
-}
-int lfvio_debug_set_block_solve(lfvio_ctx *c, int on) {
-  if (!c) return LFVIO_ERR_ARG;
-  if (int rc = join_inflight(c)) return rc;
-  c->block_solve = on != 0;
-  destroy_graph(c);  // the captured graphs hold the launch sequence
-  return LFVIO_OK;
-}
-int lfvio_debug_set_linw(lfvio_ctx *c, int mode) {
-  if (!c || mode < 0 || mode > 2) return LFVIO_ERR_ARG;
-  if (int rc = join_inflight(c)) return rc;
-  c->linw_mode = mode;  // (takes effect with the next upload: the plan and its arrays are built there)
-  destroy_graph(c);
-  return LFVIO_OK;
-}
-int lfvio_debug_set_function_tolerance(lfvio_ctx *c, double tol) {
-  if (!c || !(tol >= 0.0)) return LFVIO_ERR_ARG;
-  c->fn_tol = tol;
-  return LFVIO_OK;
-}
-int lfvio_debug_break_next_chain(lfvio_ctx *c) {
-  if (!c) return LFVIO_ERR_ARG;
-  c->debug_break_chain = true;
-  return LFVIO_OK;
-}
-int lfvio_debug_set_lm_half(lfvio_ctx *c, int on) {
-  if (!c) return LFVIO_ERR_ARG;
-  c->lm_half = on != 0;  // (takes effect with the next upload)
-  return LFVIO_OK;
-}
-int lfvio_debug_set_initial_radius(lfvio_ctx *c, double r) {
-  if (!c) return LFVIO_ERR_ARG;
-  c->init_radius = r > 0.0 ? r : 1e4;
-  return LFVIO_OK;
-}
-int lfvio_debug_last_chunks(lfvio_ctx *c) { return c ? c->stat_chunks : -1; }
-int lfvio_debug_last_passes(lfvio_ctx *c) { return c ? c->last_passes : -1; }
-int lfvio_debug_speculation(lfvio_ctx *c, int *out3) {
-  if (!c || !out3) return LFVIO_ERR_ARG;
-  out3[0] = c->last_passes, out3[1] = c->last_iters, out3[2] = c->spec_count;
+// Every switch of the debug interface in one call (include/lfvio_debug.h).  The product entry points read no environment: a tool
+// that wants LFVIO_DEBUG="key=value,key=value" honoured asks for it with the key "env".
+int lfvio_debug_configure(lfvio_ctx *c, const char *key, double value) {
+  if (!c || !key) return LFVIO_ERR_ARG;
+  const std::string k = key;
+  const int iv = (int)value;
+  if (k == "env") {
+    const char *e = getenv("LFVIO_DEBUG");
+    if (!e) return LFVIO_OK;
+    std::string all = e;
+    for (size_t p = 0; p < all.size();) {
+      const size_t q = std::min(all.find(',', p), all.size()), eq = all.find('=', p);
+      if (eq != std::string::npos && eq < q) {
+        const int rc = lfvio_debug_configure(c, all.substr(p, eq - p).c_str(), atof(all.substr(eq + 1, q - eq - 1).c_str()));
+        if (rc) return rc;
+      }
+      p = q + 1;
+    }
+    return LFVIO_OK;
+  }
+  // (switches that change what the captured graphs hold or what an upload builds: the call in flight is joined, the graphs go)
+  const bool structural = k == "graph" || k == "linw" || k == "force_eig";
+  if (structural) {
+    if (int rc = join_inflight(c)) return rc;
+  }
+  if (k == "graph") c->use_graph = iv != 0;
+  else if (k == "first_passes") {
+    if (iv < 0) return LFVIO_ERR_ARG;
+    c->fixed_passes = iv;
+  } else if (k == "spec_count") c->fixed_spec = iv > 0, c->spec_count = iv > 0 ? std::max(1, std::min(1 + SPEC_EXTRA, iv)) : 3;
+  else if (k == "function_tolerance") {
+    if (!(value >= 0.0)) return LFVIO_ERR_ARG;
+    c->fn_tol = value;
+  } else if (k == "initial_radius") c->init_radius = value > 0.0 ? value : 1e4;
+  else if (k == "linw") {
+    if (iv < 0 || iv > 2) return LFVIO_ERR_ARG;
+    c->linw_mode = iv;  // (takes effect with the next upload: the plan and its arrays are built there)
+  } else if (k == "lm_half") c->lm_half = iv != 0;  // (with the next upload)
+  else if (k == "force_eig") c->force_eig = iv != 0;  // (a kernel argument of the captured launches)
+  else if (k == "marg_ahead") c->marg_ahead = iv != 0;  // (a flag of the upload: Slot::spec_on)
+  else if (k == "break_next_chain") c->debug_break_chain = iv != 0;
+  else {
+    c->err = "lfvio_debug_configure: unknown key '" + k + "'";
+    return LFVIO_ERR_ARG;
+  }
+  if (structural) destroy_graph(c);
   return LFVIO_OK;
 }
 
-int lfvio_debug_marg_ahead(lfvio_ctx *c, int on, long long *out2) {
-  if (!c) return LFVIO_ERR_ARG;
-  if (on >= 0) c->marg_ahead = on != 0;  // (a flag of the upload: Slot::spec_on)
-  if (out2) out2[0] = c->stat_ahead_calls, out2[1] = c->stat_ahead_hits;
-  return LFVIO_OK;
-}
-
-int lfvio_debug_force_eig(lfvio_ctx *c, int on) {
-  if (!c) return LFVIO_ERR_ARG;
-  c->force_eig = on != 0;
-  destroy_graph(c);  // the flag is a kernel argument of the captured launches
-  return LFVIO_OK;
-}
-
-int lfvio_debug_set_graph(lfvio_ctx *c, int on) {
-  if (!c) return LFVIO_ERR_ARG;
-  c->use_graph = on != 0;
-  return LFVIO_OK;
-}
-
-int lfvio_debug_set_decide_merge(lfvio_ctx *c, int on) {
-  if (!c) return LFVIO_ERR_ARG;
-  destroy_graph(c);  // the captured graphs hold the launch sequence
-  c->no_merge = on == 0;
-  c->no_fuse = on == 0 || on == 2;
-  return LFVIO_OK;
+int lfvio_debug_query(lfvio_ctx *c, const char *key, double *out, int n) {
+  if (!c || !key || !out || n <= 0) return LFVIO_ERR_ARG;
+  const std::string k = key;
+  auto put = [&](std::initializer_list<double> v) {
+    int i = 0;
+    for (double x : v)
+      if (i < n) out[i++] = x;
+    return LFVIO_OK;
+  };
+  if (k == "last_call") return put({(double)c->last_passes, (double)c->last_iters, (double)c->stat_chunks, (double)c->spec_count});
+  if (k == "marg_ahead") return put({(double)c->stat_ahead_calls, (double)c->stat_ahead_hits});
+  if (k == "upload_times") return put({c->up_us[0], c->up_us[1], c->up_us[2], c->up_us[3]});
+  if (k == "sweep_kernel") {  // out[0] in: the number of resident slots the launch would cover
+    const int r = sweep_kernel_of(c, (int)out[0]);
+    if (r < 0) return r;
+    return put({(double)r});
+  }
+  c->err = "lfvio_debug_query: unknown key '" + k + "'";
+  return LFVIO_ERR_ARG;
 }
 
 // ---- landmark-sharded API: declared in lfvio.h, implemented in shard.inc

@@ -142,9 +142,9 @@ DEV int decide_walk(TRHead &t, const DecideSums &sm, int K, int sharded, int max
             it.cost = candidate_cost;  // replaced by the re-evaluated x_cost when the trace is read
             // Ceres evaluates the gradient at the accepted point before it looks at the iteration cap (HandleSuccessfulStep ->
             // EvaluateGradientAndJacobian); here that is the next pass's linearization, and k_dogleg writes its max-norm into
-            // this entry.  A loop that ends with this step never linearizes there: the entry keeps -1 = not evaluated
-            // (include/lfvio.h).
-            it.gradient_max_norm = -1.0;
+            // this entry.  A loop that ends with this step never linearizes there: the entry keeps NaN = not evaluated
+            // (include/lfvio.h): a consumer that takes a minimum or a maximum over the trace cannot mistake it for a norm.
+            it.gradient_max_norm = __builtin_nan("");
             if (it.relative_decrease < 0.25) t.radius *= 0.5;
             if (it.relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * snz);
             t.mu = fmax(1e-8, 2.0 * t.mu / 10.0);

@@ -17,10 +17,8 @@ class Engine:
         self.lib = abi.load_hip_library(lib_path)
         self.lib.lfvio_debug_linearize.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), _dp, _dp, _dp, _dp, _dp, _dp]
         self.lib.lfvio_debug_marg_system.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
-        self.lib.lfvio_debug_set_graph.argtypes = [C.c_void_p, C.c_int]
-        self.lib.lfvio_debug_force_eig.argtypes = [C.c_void_p, C.c_int]
-        self.lib.lfvio_debug_last_chunks.argtypes = [C.c_void_p]
-        self.lib.lfvio_debug_last_passes.argtypes = [C.c_void_p]
+        self.lib.lfvio_debug_configure.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        self.lib.lfvio_debug_query.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
         self.lib.lfvio_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
         self.ctx = self.lib.lfvio_create(device)
         if not self.ctx:
@@ -41,48 +39,39 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"{what} failed rc={rc}: {self.lib.lfvio_last_error(self.ctx).decode()}")
 
-    def set_graph(self, on):
-        self.lib.lfvio_debug_set_graph(self.ctx, int(on))
+    # ---- the debug interface (include/lfvio_debug.h): every switch is a key of lfvio_debug_configure, every counter one of lfvio_debug_query
+    def configure(self, key, value=1.0):
+        self._check(self.lib.lfvio_debug_configure(self.ctx, key.encode(), float(value)), f"lfvio_debug_configure({key})")
 
-    def set_decide_merge(self, on):
-        """0: k_decide, k_dogleg, k_cost each as a launch of its own; 2: the bookkeeping in the prologue of the next k_lin;
-        1 / True (default): that, and k_dogleg + k_cost as one launch (k_step) — see include/lfvio_debug.h."""
-        self.lib.lfvio_debug_set_decide_merge.argtypes = [C.c_void_p, C.c_int]
-        self.lib.lfvio_debug_set_decide_merge(self.ctx, int(on))
+    def query(self, key, n, first=0.0):
+        out = np.zeros(max(n, 1))
+        out[0] = first
+        self._check(self.lib.lfvio_debug_query(self.ctx, key.encode(), _p(out), n), f"lfvio_debug_query({key})")
+        return out
+
+    def set_graph(self, on):
+        self.configure("graph", int(on))
 
     def marg_ahead(self, on=-1):
-        """on = 0 / 1: the windows uploaded from now on end with the serial tail / may have their marginalization started on a second
-        stream as soon as a state is accepted (csrc/kernels_spec.h; -1: leave).  Returns (calls with workers, priors a worker delivered)."""
-        out = (C.c_longlong * 2)()
-        self.lib.lfvio_debug_marg_ahead.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
-        self._check(self.lib.lfvio_debug_marg_ahead(self.ctx, int(on), out), "marg_ahead")
-        return int(out[0]), int(out[1])
-
-    def set_block_solve(self, on):
-        """1: the reduced system solved along its block structure (k_solve_block); 0 (default): the dense 172 x 172 solve."""
-        self.lib.lfvio_debug_set_block_solve.argtypes = [C.c_void_p, C.c_int]
-        self._check(self.lib.lfvio_debug_set_block_solve(self.ctx, int(on)), "set_block_solve")
-
-    def solve_kernel(self, count):
-        self.lib.lfvio_debug_solve_kernel.argtypes = [C.c_void_p, C.c_int]
-        return int(self.lib.lfvio_debug_solve_kernel(self.ctx, count))
+        """on = 0 / 1: the windows uploaded from now on end with the serial tail / may have their marginalization started on worker
+        streams as soon as a state is accepted (csrc/kernels_spec.h; -1: leave).  Returns (calls with workers, priors a worker delivered)."""
+        if on >= 0:
+            self.configure("marg_ahead", int(on))
+        q = self.query("marg_ahead", 2)
+        return int(q[0]), int(q[1])
 
     def break_next_chain(self):
-        self.lib.lfvio_debug_break_next_chain.argtypes = [C.c_void_p]
-        self._check(self.lib.lfvio_debug_break_next_chain(self.ctx), "break_next_chain")
+        self.configure("break_next_chain", 1)
 
     def set_lm_half(self, on):
-        self.lib.lfvio_debug_set_lm_half.argtypes = [C.c_void_p, C.c_int]
-        self._check(self.lib.lfvio_debug_set_lm_half(self.ctx, int(on)), "set_lm_half")
+        self.configure("lm_half", int(on))
 
     def set_initial_radius(self, r):
-        self.lib.lfvio_debug_set_initial_radius.argtypes = [C.c_void_p, C.c_double]
-        self._check(self.lib.lfvio_debug_set_initial_radius(self.ctx, float(r)), "set_initial_radius")
+        self.configure("initial_radius", float(r))
 
     def set_linw(self, mode):
         """How resident batches are linearized (include/lfvio_debug.h): 1 default, 0 never k_linw, 2 every launch of planned windows."""
-        self.lib.lfvio_debug_set_linw.argtypes = [C.c_void_p, C.c_int]
-        self._check(self.lib.lfvio_debug_set_linw(self.ctx, int(mode)), "set_linw")
+        self.configure("linw", int(mode))
 
     def resident_pass(self, count, slot, n_landmarks):
         """One linearization + dense solve of the resident slots; what it left in `slot` (lfvio_debug_resident_pass)."""
@@ -97,18 +86,17 @@ class Engine:
         return out
 
     def set_function_tolerance(self, tol):
-        """Diagnostic: function_tolerance of the windows uploaded from now on (1e-6 = Ceres' default; 0 = run to the cap)."""
-        self.lib.lfvio_debug_set_function_tolerance.argtypes = [C.c_void_p, C.c_double]
-        self._check(self.lib.lfvio_debug_set_function_tolerance(self.ctx, float(tol)), "set_function_tolerance")
+        """Solver::Options::function_tolerance of the windows uploaded from now on (Ceres' default 1e-6)."""
+        self.configure("function_tolerance", float(tol))
 
     def last_chunks(self):
-        return int(self.lib.lfvio_debug_last_chunks(self.ctx))
+        return int(self.query("last_call", 4)[2])
 
     def last_passes(self):
-        return int(self.lib.lfvio_debug_last_passes(self.ctx))
+        return int(self.query("last_call", 4)[0])
 
     def force_eig(self, on):
-        self.lib.lfvio_debug_force_eig(self.ctx, int(on))
+        self.configure("force_eig", int(on))
 
     def solve(self, win):
         sol = abi.Solution(win.N)
@@ -161,8 +149,7 @@ class Engine:
 
     def set_first_passes(self, n):
         """Debug: > 0 sizes every first graph of the synchronous calls with this many passes (0: from the recent calls again)."""
-        self.lib.lfvio_debug_set_first_passes.argtypes = [C.c_void_p, C.c_int]
-        self._check(self.lib.lfvio_debug_set_first_passes(self.ctx, n), "set_first_passes")
+        self.configure("first_passes", int(n))
 
     def batch_upload_chained_device(self, slot, win, marshalled=None):
         """The next window of the same estimator, its prior taken over ON THE DEVICE from the call still in flight (no wait, no
@@ -248,12 +235,8 @@ class Engine:
         return float(ms[0])
 
     def sweep_kernel(self, count):
-        """which kernel linearizes a launch over slots [0, count): 0 k_lin, 1 k_linw, 2 k_linb"""
-        self.lib.lfvio_debug_sweep_kernel.argtypes = [C.c_void_p, C.c_int]
-        rc = self.lib.lfvio_debug_sweep_kernel(self.ctx, count)
-        if rc < 0:
-            self._check(rc, "sweep_kernel")
-        return rc
+        """Which kernel linearizes a launch over the resident slots [0, count): 0 k_lin (+ k_sum), 1 k_linw, 2 k_linb (+ k_sumb)."""
+        return int(self.query("sweep_kernel", 1, float(count))[0])
 
     # ---- landmark-sharded API (multi-GPU)
     def shard_begin(self, win, lm_begin, lm_end, add_pose_side):
@@ -382,11 +365,15 @@ class Group:
     def optimize(self, flag):
         self._check(self.lib.lfvio_group_optimize(self.g, -1 if flag is None else int(flag)), "lfvio_group_optimize")
 
-    def set_initial_radius(self, r):
-        self.lib.lfvio_debug_set_initial_radius.argtypes = [C.c_void_p, C.c_double]
+    def configure(self, key, value=1.0):
+        """lfvio_debug_configure on every local context of the group."""
+        self.lib.lfvio_debug_configure.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         for i in range(self.local):
-            rc = self.lib.lfvio_debug_set_initial_radius(self.ctx(i), float(r))
+            rc = self.lib.lfvio_debug_configure(self.ctx(i), key.encode(), float(value))
             assert rc == 0, rc
+
+    def set_initial_radius(self, r):
+        self.configure("initial_radius", r)
 
     def inject_failure(self, local_ctx, pass_=0, phase=0):
         """tests: local context `local_ctx` fails when it enqueues `phase` of pass `pass_` of the next optimize(); local_ctx < 0 clears"""
@@ -428,11 +415,12 @@ class Group:
         return float(ms[0])
 
     def sweep_kernel(self, count, i=0):
-        self.lib.lfvio_debug_sweep_kernel.argtypes = [C.c_void_p, C.c_int]
-        rc = self.lib.lfvio_debug_sweep_kernel(self.ctx(i), count)
+        self.lib.lfvio_debug_query.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
+        out = np.array([float(count)])
+        rc = self.lib.lfvio_debug_query(self.ctx(i), b"sweep_kernel", _p(out), 1)
         if rc < 0:
             raise RuntimeError(f"sweep_kernel failed rc={rc}")
-        return rc
+        return int(out[0])
 
     # independent windows split over the local devices
     def batch_reserve(self, batch, max_landmarks, max_observations):

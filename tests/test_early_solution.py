@@ -98,7 +98,7 @@ def test_window_that_needs_more_passes_than_predicted():
     for seed in range(40):
         cand = synth.make_window(seed, 200)
         whole(probe, cand, abi.MARGIN_OLD)
-        if probe.lib.lfvio_debug_last_passes(probe.ctx) >= 6:
+        if probe.last_passes() >= 6:
             w = cand
             break
     assert w is not None, "no synthetic window of this family needs six passes"
@@ -107,11 +107,11 @@ def test_window_that_needs_more_passes_than_predicted():
     sol, prior, _ = split(eng, w, abi.MARGIN_OLD)
     same_solution(sol, ref_sol)
     same_prior(prior, ref_prior)
-    passes = eng.lib.lfvio_debug_last_passes(eng.ctx)
+    passes = eng.last_passes()
     sol2, prior2, _ = split(eng, w, abi.MARGIN_OLD)  # now predicted right: the early route
     same_solution(sol2, ref_sol)
     same_prior(prior2, ref_prior)
-    assert eng.lib.lfvio_debug_last_passes(eng.ctx) == passes
+    assert eng.last_passes() == passes
 
 
 def test_feature_steps_run_beside_the_tail(oracle):
@@ -415,7 +415,7 @@ def test_random_call_sequences_keep_the_chain(seed):
 
 
 def test_context_torn_down_or_reconfigured_with_the_tail_in_flight():
-    """lfvio_destroy and the calls that drop the captured graphs (here lfvio_debug_force_eig) wait for a marginalization
+    """lfvio_destroy and the calls that drop the captured graphs (here lfvio_debug_configure "force_eig") wait for a marginalization
     still running behind an early state instead of pulling its graph from under it."""
     w = synth.make_window(0, 300)
     ref_sol, ref_prior = whole(serial(), w, abi.MARGIN_OLD)

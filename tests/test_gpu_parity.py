@@ -119,7 +119,7 @@ def check_trace_summaries(tr, rt):
     for k, (a, b) in enumerate(zip(tr, rt)):
         assert a["valid"] == b["valid"], k
         fields = ("gradient_max_norm", "step_norm")
-        if a["gradient_max_norm"] == -1.0:
+        if np.isnan(a["gradient_max_norm"]):
             # include/lfvio.h: the gradient at the point of a successful step that ENDED the loop is not evaluated on the
             # device (it would take one more linearization; test_kkt_residual_at_the_solution compares it through the debug
             # linearization instead) — legal in the last entry of the trace only
@@ -301,31 +301,6 @@ def test_graph_and_direct_launch_agree(eng):
     c = eng.solve(w)
     assert np.array_equal(a.pose, b.pose) and np.array_equal(b.pose, c.pose)  # deterministic, bit for bit
     assert np.array_equal(a.lam, b.lam)
-
-
-@pytest.mark.parametrize("n,kw", [(300, {}), (120, dict(tr=0.3)), (33, dict(estimate_td=0)), (300, dict(max_num_iterations=3))])
-def test_bookkeeping_in_the_prologue_of_k_lin_equals_k_decide(eng, n, kw):
-    """For small windows the trust-region bookkeeping of a pass rides in the prologue of the next pass's k_lin (every
-    workgroup repeats it, workgroup 0 parks the outcome, k_solve commits it); k_decide after every pass is the same
-    arithmetic as its own launch.  Solution, iteration trace and prior must agree bit for bit — with a prior (accepted
-    speculative candidates, rejected steps) and without, through graphs of several chunks (tr = 0.3: a pass per step)."""
-    w = synth.make_window_with_prior(5, n, lambda x, f: eng.optimize(x, f), **kw)[0] if n == 300 else synth.make_window(5, n, **kw)
-    out = []
-    # 0: k_decide, k_dogleg and k_cost as launches of their own; 2: bookkeeping in the prologue of k_lin; 1 (the default): that,
-    # and the dogleg step and the cost of its candidates as one launch (k_step: every workgroup of the cost evaluation forms
-    # the step itself)
-    for merge in (0, 2, 1, 1):
-        eng.set_decide_merge(merge)
-        sol, prior = eng.optimize(w, abi.MARGIN_OLD)
-        out.append((sol, prior))
-    eng.set_decide_merge(1)
-    a, b, c, d = out
-    for x, y in ((a, b), (b, c), (c, d)):
-        assert np.array_equal(x[0].pose, y[0].pose) and np.array_equal(x[0].speed_bias, y[0].speed_bias) and np.array_equal(x[0].lam, y[0].lam)
-        assert x[0].c.num_iterations == y[0].c.num_iterations and x[0].c.final_cost == y[0].c.final_cost
-        assert [t["cost"] for t in x[0].trace()] == [t["cost"] for t in y[0].trace()]
-        assert [t["radius"] for t in x[0].trace()] == [t["radius"] for t in y[0].trace()]
-        assert np.array_equal(x[1].J(), y[1].J()) and np.array_equal(x[1].r(), y[1].r())
 
 
 def test_gather_lists_kept_on_the_device_follow_the_pair_table(eng):

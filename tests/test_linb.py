@@ -6,7 +6,7 @@ Tolerances as in test_linw.py: the two device paths run the same per-observation
   * linearization outputs (g_p, Schur sums, a, b, landmark scalars, cost)      1e-10 relative to the array's largest entry
   * the dense solve behind them                                               1e-6
   * whole calls: identical iteration counts and terminations, states 1e-6, the oracle's bars of test_gpu_parity.
-Default mode takes the path from 40 960 landmarks on (where it is faster); lfvio_debug_set_linw(2) from 321 on (how the small cases here reach it).
+Default mode takes the path from 40 960 landmarks on (where it is faster); lfvio_debug_configure "linw" 2 from 321 on (how the small cases here reach it).
 """
 import numpy as np
 import pytest
@@ -122,7 +122,7 @@ def test_mu_retry_redoes_only_the_schur_phase(eng, n, mu):
 
 @pytest.mark.parametrize("shards,n,force", [(1, 100000, False), (2, 100000, False), (3, 3000, True), (1, 700, True)])
 def test_ranks_of_a_sharded_window_sweep_their_share_group_by_group(oracle, shards, n, force):
-    """lfvio_group: a rank whose share of the window carries a group list (>= 40 960 landmarks of its own; LFVIO_LINW=2: > 320)
+    """lfvio_group: a rank whose share of the window carries a group list (>= 40 960 landmarks of its own; lfvio_debug_configure "linw" 2: > 320)
     linearizes it with k_linb + k_sumb — the sums land in the exchange buffer like k_sum's — and back-substitutes from the
     transposed rows.  Against the unsharded optimization() role by role."""
     import os
@@ -135,12 +135,9 @@ def test_ranks_of_a_sharded_window_sweep_their_share_group_by_group(oracle, shar
     w = synth.make_window_with_prior(4, n, warm)[0]
     want, want_prior = ref.optimize(w, abi.MARGIN_OLD)
     ref.close()
+    g = Group(local_shards=shards)
     if force:
-        os.environ["LFVIO_LINW"] = "2"
-    try:
-        g = Group(local_shards=shards)
-    finally:
-        os.environ.pop("LFVIO_LINW", None)
+        g.configure("linw", 2)
     sol, prior = g.solve(w, abi.MARGIN_OLD)
     _compare(sol, prior, want, want_prior)
     assert sol.c.num_iterations == want.c.num_iterations

@@ -2,7 +2,7 @@
 
 A one-window context of at most 320 landmarks starts gauge fix + frame-0 sweep + k_marg_solve of every newly accepted state on worker
 streams, in a shadow slot; the loop's end settles who owns the prior of the final state.  Whoever forms it runs the same kernels on
-the same numbers: state, trace and prior must be the SAME BITS as with the serial tail (lfvio_debug_marg_ahead(ctx, 0)) — on the plain
+the same numbers: state, trace and prior must be the SAME BITS as with the serial tail (lfvio_debug_configure(ctx, "marg_ahead", 0)) — on the plain
 call, the split call, a chain of windows handed over on the device, both marginalization flags, windows whose last pass accepts a step
 (the loop owns the prior), windows without an accepted step, and under calls that interrupt each other.
 """

@@ -1,6 +1,6 @@
 """The cases of the randomized sweep (tests/tools/fuzz_parity.py, profiles/r03/fuzz.md) whose inverse depths were outside
 the 1e-6 bar, taken to ground: each is run (a) as the sweep ran it and (b) with BOTH solvers forced to
-converge — function_tolerance = 0 (lfvio_debug_set_function_tolerance / oracle_set_function_tolerance) and 50 iterations.
+converge — function_tolerance = 0 (lfvio_debug_configure "function_tolerance" / oracle_set_function_tolerance) and 50 iterations.
 If the two answers then agree to 1e-6 the early stop in a flat valley was the cause; if not, it is a bug.
 
   python tests/tools/fuzz_outliers.py [case indices ...]     (GPU box; default: the 6 + 2 of profiles/r03/fuzz.md)

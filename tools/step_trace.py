@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: kernel-trace of the window300 bench under a given LFVIO_SPEC_COUNT (argv[1], '' = adaptive); per kernel the
+"""GPU box: kernel-trace of the window300 bench under a given LFVIO_DEBUG=spec_count=N (argv[1], '' = adaptive); per kernel the
 distribution of launch durations (us)."""
 import csv, glob, os, subprocess, sys
 from collections import defaultdict
@@ -8,7 +8,7 @@ os.environ["TMPDIR"] = "/tmp"
 for spec in sys.argv[1:] or [""]:
     env = dict(os.environ)
     if spec:
-        env["LFVIO_SPEC_COUNT"] = spec
+        env["LFVIO_DEBUG"] = "spec_count=" + spec  # (bench.py applies it: lfvio_debug_configure "env")
     d = f"/tmp/st_{spec or 'a'}"
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                         "--no-cpu-baseline", "--no-secondary", "--steps", "100", "--warmup", "10"], cwd="/tmp", env=env, text=True, capture_output=True)
