@@ -225,6 +225,93 @@ def window100k_record(device, flag, calls=10):
         e.close()
 
 
+REPLAY_IMAGES, REPLAY_CPU_IMAGES = 600, 300
+
+
+def _replay_setup(h):
+    import ctypes as _C
+
+    from lfvio import synth
+
+    p = np.array([synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W, synth.G_NORM, 0.0, 960.0, -1.0, synth.TD0])
+    h.L.lfvio_host_set_params(p.ctypes.data_as(_C.POINTER(_C.c_double)), 1, 1, 8)  # estimate_extrinsic, estimate_td, NUM_ITERATIONS (mindvision.yaml)
+    h.clear_state()
+    h.set_min_parallax(10.0)  # keyframe_parallax of the shipped configs, pixels
+
+
+def replay_record(out_dir):
+    """BASELINE configs[2] as far as this box allows (the PALVIO ID01 bag is an external download, README.md:31-34): a PALVIO-SHAPED synthetic
+    recording — camera 15 Hz, IMU 200 Hz (README.md:76,193), every corner through the OCam polynomial of README.md:85-118 with a pixel of
+    noise, td and extrinsic estimated — replayed end to end through the C++ host side over the HIP stack (the loop of estimator_node.cpp:
+    206-342: IMU interpolation at image time, processIMU / processImage with keyframe policy, triangulation, optimization(), failure
+    detection, slideWindow), trajectory written like pubOdometry does (visualization.cpp:173-179), ATE against the recording's truth."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import ate
+    from lfvio import trace
+    from lfvio.host import HostEstimator
+
+    tp, jp = os.path.join(out_dir, "palvio_shaped.lfvt"), os.path.join(out_dir, "palvio_shaped_hip.txt")
+    trace.make_stream(tp, seed=7, n_frames=REPLAY_IMAGES, frame_dt=1.0 / 15.0, camera="ocam")
+    h = HostEstimator()
+    _replay_setup(h)
+    h.L.lfvio_host_set_split_call(1)
+    # (a short prefix first: graphs are captured, the context sized)
+    h.replay(tp, "", 40)
+    _replay_setup(h)
+    h.timers()  # (reset)
+    t0 = time.perf_counter()
+    rc, st, ms = h.replay_timed(tp, jp)
+    wall = time.perf_counter() - t0
+    tm = h.timers()
+    if rc != 0 or st["poses"] < 3:
+        return dict(error=f"replay rc {rc}", stats=st)
+    a = ate.ate(jp, tp)
+    solved = ms[-st["poses"]:] if st["poses"] <= len(ms) else ms
+    rec = dict(images=st["images"], solves=st["poses"], keyframes=st["keyframes"], non_keyframes=st["non_keyframes"], failures=st["failures"],
+               solves_per_s=st["poses"] / wall, wall_s=wall, ms_per_image_p50=float(np.median(solved)), ms_per_image_p95=float(np.percentile(solved, 95)),
+               optimization_ms_mean=float(tm["optimization"] / max(tm["calls"], 1) * 1e3) if "optimization" in tm else None,
+               iterations_per_solve=st["iterations"] / max(st["poses"], 1),
+               ate_rmse_m=a["rmse"], ate_max_m=a["max"], ate_poses=a["n"],
+               description=f"PALVIO-shaped synthetic recording ({REPLAY_IMAGES} images at 15 Hz, 200 Hz IMU, OCam camera model, one pixel of noise, td and extrinsic "
+                           "estimated) through WindowEstimator::replay over liblfvio_hip.so, split call; per image: its IMU samples + processImage(); "
+                           "ATE = RMSE of the position after a rigid alignment (tools/ate.py); the PALVIO ID01 bag itself is not on this box")
+    # ATE over the prefix the CPU stack replays too (cpu_baseline leg)
+    jp2 = os.path.join(out_dir, "palvio_shaped_hip_prefix.txt")
+    _replay_setup(h)
+    rc2, st2 = h.replay(tp, jp2, REPLAY_CPU_IMAGES)
+    if rc2 == 0 and st2["poses"] >= 3:
+        rec["ate_prefix_rmse_m"] = ate.ate(jp2, tp)["rmse"]
+    h.close()
+    return rec
+
+
+def replay_cpu_record(out_dir, hip_rec):
+    """The same recording's first REPLAY_CPU_IMAGES images through the SAME host sources linked against the CPU oracle (oracle/liblfvio_host_oracle.so —
+    test infrastructure, here as the checker of the trajectory): ATE ratio against the north_star's bar of 1 %."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import ate
+    from lfvio.host import HostEstimator
+
+    tp, jp = os.path.join(out_dir, "palvio_shaped.lfvt"), os.path.join(out_dir, "palvio_shaped_oracle.txt")
+    root = os.path.dirname(os.path.abspath(__file__))
+    h = HostEstimator(os.path.join(root, "oracle", "liblfvio_host_oracle.so"))
+    _replay_setup(h)
+    h.L.lfvio_host_set_split_call(0)
+    t0 = time.perf_counter()
+    rc, st = h.replay(tp, jp, REPLAY_CPU_IMAGES)
+    wall = time.perf_counter() - t0
+    h.close()
+    if rc != 0 or st["poses"] < 3:
+        return dict(error=f"oracle replay rc {rc}")
+    a = ate.ate(jp, tp)
+    rec = dict(images=st["images"], solves=st["poses"], solves_per_s=st["poses"] / wall, ate_rmse_m=a["rmse"], cores=1,
+               description=f"first {REPLAY_CPU_IMAGES} images of the same recording through the same host sources over the CPU oracle (single thread)")
+    if hip_rec and "ate_prefix_rmse_m" in hip_rec:
+        rec["ate_ratio_hip_over_cpu"] = hip_rec["ate_prefix_rmse_m"] / a["rmse"]
+        rec["ate_within_1_percent"] = bool(abs(rec["ate_ratio_hip_over_cpu"] - 1.0) <= 0.01)
+    return rec
+
+
 def stream_record(device, flag, n_stream=33, ahead=True):
     """The headline shape as a drop-in sees it: consecutive DISTINCT windows of one estimator stream, each uploaded, optimized and
     downloaded (PCIe inside) — mean / p95 per step.  The chain is generated through the product path itself."""
@@ -884,8 +971,20 @@ def main():
             out["stream"] = stream_record(local_rank, flag)
         except Exception as ex:  # noqa: BLE001
             out["stream"] = dict(error=repr(ex))
+        try:  # (e) BASELINE configs[2] on a PALVIO-shaped synthetic recording: end-to-end replay, solves/s, ms per image, ATE
+            import tempfile
+
+            replay_dir = tempfile.mkdtemp(prefix="lfvio_replay_")
+            out["replay"] = replay_record(replay_dir)
+        except Exception as ex:  # noqa: BLE001
+            out["replay"] = dict(error=repr(ex))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wins[0], flag)
+        if isinstance(out.get("replay"), dict) and "error" not in out["replay"]:
+            try:  # the trajectory's checker: the same recording over the CPU oracle, outside every timed region
+                out["cpu_baseline"]["replay"] = replay_cpu_record(replay_dir, out["replay"])
+            except Exception as ex:  # noqa: BLE001
+                out["cpu_baseline"]["replay"] = dict(error=repr(ex))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -211,6 +211,20 @@ int lfvio_host_replay(void *h, const char *trace_path, const char *traj_path, in
   return rc;
 }
 
+// the same with the wall-clock milliseconds of every image handed over (ms[cap]); *n_ms = how many were written
+int lfvio_host_replay_timed(void *h, const char *trace_path, const char *traj_path, int max_images, int *stats, double *ms, int cap, int *n_ms) {
+  Trace trace;
+  if (!trace.load(trace_path)) return -3;
+  ReplayStats st;
+  std::vector<double> t;
+  int rc = replay(*E(h), trace, traj_path, max_images, &st, &t);
+  if (stats) std::memcpy(stats, &st, sizeof st);
+  const int n = std::min((int)t.size(), cap);
+  if (ms) std::memcpy(ms, t.data(), sizeof(double) * n);
+  if (n_ms) *n_ms = n;
+  return rc;
+}
+
 // the decode of one feature record, for the wire-format test: fills ids[n] (ascending), pts[n][8]; returns n
 int lfvio_host_decode_features(const char *trace_path, int image_index, int cap, int *ids, double *pts, double *stamp) {
   Trace trace;

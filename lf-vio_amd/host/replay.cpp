@@ -1,5 +1,6 @@
 // replay.cpp — see replay.h.  Reference lines are relative to /root/reference/vins_estimator/src.
 #include "replay.h"
+#include <chrono>
 
 #include <algorithm>
 #include <cstdio>
@@ -96,7 +97,7 @@ void decodeFeatures(const TraceImage &msg, DecodedImage *out) {  // estimator_no
   }
 }
 
-int replay(WindowEstimator &est, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats) {
+int replay(WindowEstimator &est, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats, std::vector<double> *image_ms) {
   ReplayStats st;
   std::memset(&st, 0, sizeof st);
   FILE *traj = nullptr;
@@ -155,6 +156,7 @@ int replay(WindowEstimator &est, const Trace &trace, const char *traj_path, int 
       st.thrown++;
       continue;
     }
+    const auto t_image = std::chrono::steady_clock::now();
     const size_t first = front;
     while (imu[front].t < img_t) front++;
     // samples [first, front]: the first one after the image is used (interpolated) and stays queued for the next image (:127)
@@ -178,6 +180,7 @@ int replay(WindowEstimator &est, const Trace &trace, const char *traj_path, int 
     const bool was_running = est.phase == WindowEstimator::NON_LINEAR;
     est.status = LFVIO_OK;
     est.pushImage(msg.t, (int)img.ids.size(), img.ids.data(), img.pts.data());
+    if (image_ms) image_ms->push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_image).count() * 1e3);
     st.images++;
     if (est.status != LFVIO_OK) {
       st.last_status = est.status;

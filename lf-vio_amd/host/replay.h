@@ -72,6 +72,8 @@ void decodeFeatures(const TraceImage &msg, DecodedImage *out);
 // getMeasurements() + process() of estimator_node.cpp (:96-134, :206-342) over a loaded trace, single-threaded;
 // after every image in NON_LINEAR state one line of the trajectory file as pubOdometry() writes it
 // (utility/visualization.cpp:173-179).  Returns 0 or a negative error; `stats` may be null.
-int replay(WindowEstimator &estimator, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats);
+// image_ms (optional): wall-clock milliseconds of every image the loop handed over — its IMU samples and processImage(), i.e. what
+// process() spends per measurement (estimator_node.cpp:206-342) — in arrival order
+int replay(WindowEstimator &estimator, const Trace &trace, const char *traj_path, int max_images, ReplayStats *stats, std::vector<double> *image_ms = nullptr);
 
 }  // namespace lfvio

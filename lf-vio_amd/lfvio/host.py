@@ -189,6 +189,14 @@ class HostEstimator:
                                       o.ctypes.data_as(C.POINTER(C.c_int)))
         return rc, dict(zip(self.STATS, (int(x) for x in o)))
 
+    def replay_timed(self, trace_path, traj_path="", max_images=0, cap=65536):
+        """replay() with the wall-clock milliseconds the loop spent on every image it handed over -> (rc, stats, ms[n])."""
+        o, ms, n = np.zeros(10, dtype=np.int32), np.zeros(cap), C.c_int(0)
+        self.L.lfvio_host_replay_timed.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), _dp, C.c_int, C.POINTER(C.c_int)]
+        rc = self.L.lfvio_host_replay_timed(self.h, str(trace_path).encode(), str(traj_path).encode(), int(max_images),
+                                            o.ctypes.data_as(C.POINTER(C.c_int)), _p(ms), cap, C.byref(n))
+        return rc, dict(zip(self.STATS, (int(x) for x in o))), ms[:n.value].copy()
+
     def decode_features(self, trace_path, image_index, cap=4096):
         ids, pts, st = np.zeros(cap, dtype=np.int32), np.zeros((cap, 8)), np.zeros(1)
         n = self.L.lfvio_host_decode_features(str(trace_path).encode(), image_index, cap, ids.ctypes.data_as(C.POINTER(C.c_int)), _p(pts), _p(st))

@@ -91,8 +91,13 @@ def read_trace(path):
 
 
 def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset=0.0023, pixel_noise=1.0, boot_noise=(0.02, 0.5),
-                restart_at=None, spike_at=None, spike=2.0e4):
+                restart_at=None, spike_at=None, spike=2.0e4, frame_dt=None, camera="sphere"):
     """Write a synthetic recording of `n_frames` images at 10 Hz with 200 Hz IMU and return what was written.
+
+    frame_dt: seconds between images (default synth.KF_DT = 0.1; PALVIO's camera runs at 15 Hz: 1 / 15 — README.md:76,193).
+    camera = "ocam": every bearing goes through the reference's camera model like a tracked corner does — projected to a pixel by
+    the inverse polynomial, disturbed by `pixel_noise` pixels, lifted back by the polynomial (ScaramuzzaCamera.cc:623-674 with the
+    intrinsics of README.md:85-118; synth.ocam_*), u / v are that pixel; "sphere": noise of pixel_noise / 160 rad on the sphere.
 
     A static cloud of `n_points` points in a 2-12 m shell is seen through the 40-120 deg annulus; a point is tracked over
     a random span of frames and comes back under a new id afterwards, at most `max_cnt` features per image (longest
@@ -105,7 +110,8 @@ def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset
     window far enough for failureDetection() to reboot the estimator while it processes that image.  Either way the
     estimator refills its window with the next ten images and a STAMPED bootstrap record — what the node's dump hook
     writes when initialStructure() succeeds again — follows for the eleventh."""
-    scene = synth.Scene(seed, n_total=n_frames + 2)
+    fdt = synth.KF_DT if frame_dt is None else float(frame_dt)
+    scene = synth.Scene(seed, n_total=n_frames + 2 if frame_dt is None else int(np.ceil(n_frames * fdt / synth.KF_DT)) + 3)
     rng = np.random.default_rng([seed, 104729])
     traj = scene.traj
     # world points and their visibility spans
@@ -143,7 +149,7 @@ def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset
     def boot_record(first, stamp=None):
         Ps, Rs, Vs = [], [], []
         for j in range(first, first + abi.NUM_FRAMES):
-            tj = synth.KF_DT * j + cam_offset
+            tj = fdt * j + cam_offset
             Pj, Rj = cam_pose(tj)
             Ps.append(Pj + rng.normal(0, boot_noise[0], 3))
             Rs.append(Rj @ synth.exp_so3(rng.normal(0, np.deg2rad(boot_noise[1]), 3)))
@@ -156,12 +162,18 @@ def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset
 
     t_imu = traj.t
     k_imu = 0
-    first_seen = {}
+    # the spans as arrays (one row per track): a frame's candidates are the tracks alive in it whose point is inside the annulus,
+    # longest-seen first (the tracker's mask), ties by id
+    sp_f0 = np.array([f0 for s_ in spans for (f0, f1, fid) in s_], dtype=np.int64)
+    sp_f1 = np.array([f1 for s_ in spans for (f0, f1, fid) in s_], dtype=np.int64)
+    sp_id = np.array([fid for s_ in spans for (f0, f1, fid) in s_], dtype=np.int64)
+    sp_pt = np.array([p for p, s_ in enumerate(spans) for _ in s_], dtype=np.int64)
+    seen_at = np.full(next_id, -1, dtype=np.int64)
     for k in range(n_frames):
-        t_img = synth.KF_DT * k + cam_offset
+        t_img = fdt * k + cam_offset
         # IMU messages up to and including the first one after the image (arrival order)
         if restart_at is not None and k == restart_at:
-            w.restart(synth.KF_DT * k)
+            w.restart(fdt * k)
         while k_imu < len(t_imu) and t_imu[k_imu] <= t_img + synth.IMU_DT:
             acc = scene.acc_m[k_imu]
             if spike_at is not None and k == spike_at and abs(t_imu[k_imu] - (t_img - 4 * synth.IMU_DT)) < 0.5 * synth.IMU_DT:
@@ -169,27 +181,31 @@ def make_stream(path, seed=0, n_frames=40, n_points=600, max_cnt=150, cam_offset
             w.imu(t_imu[k_imu], acc, scene.gyr_m[k_imu])
             k_imu += 1
         b = bearings(t_img)
-        b_prev = bearings(t_img - synth.KF_DT) if t_img - synth.KF_DT >= 0 else b
+        b_prev = bearings(t_img - fdt) if t_img - fdt >= 0 else b
         ang = np.degrees(np.arccos(np.clip(b[:, 2], -1, 1)))
-        cand = []
-        for p in range(n_points):
-            if not (40.0 <= ang[p] <= 120.0):
-                continue
-            for (f0, f1, fid) in spans[p]:
-                if f0 <= k <= f1:
-                    cand.append((first_seen.setdefault(fid, k), fid, p))
-        cand.sort()
-        cand = cand[:max_cnt]
-        ids = np.array([c[1] for c in cand], dtype=np.int64)
-        pts = np.array([c[2] for c in cand], dtype=np.int64)
+        vis = (ang >= 40.0) & (ang <= 120.0)
+        alive = np.nonzero((sp_f0 <= k) & (k <= sp_f1) & vis[sp_pt])[0]
+        fresh = alive[seen_at[sp_id[alive]] < 0]
+        seen_at[sp_id[fresh]] = k
+        order = np.lexsort((sp_pt[alive], sp_id[alive], seen_at[sp_id[alive]]))[:max_cnt]
+        alive = alive[order]
+        ids, pts = sp_id[alive].copy(), sp_pt[alive].copy()
         bb = b[pts]
-        noise = rng.normal(0, pixel_noise / 160.0, size=bb.shape)
-        noise -= bb * np.sum(noise * bb, axis=1, keepdims=True)
-        xyz = synth._bearing_f32(bb + noise)
-        vel = (bb - b_prev[pts]) / synth.KF_DT
-        vel[np.array([first_seen[i] == k for i in ids], dtype=bool)] = 0.0  # a new corner has no optical flow yet
-        u = 640.0 + 400.0 * np.arctan2(bb[:, 1], bb[:, 0]) / np.pi
-        v = 480.0 + 380.0 * np.cos(np.arccos(np.clip(bb[:, 2], -1, 1)))
+        if camera == "ocam":
+            px = synth.ocam_space_to_plane(bb) + rng.normal(0, pixel_noise, size=(len(pts), 2))
+            ray = synth.ocam_lift_projective(px)
+            xyz = synth._bearing_f32(ray / np.linalg.norm(ray, axis=1, keepdims=True))
+            now, prev = synth.ocam_lift_projective(synth.ocam_space_to_plane(bb)), synth.ocam_lift_projective(synth.ocam_space_to_plane(b_prev[pts]))
+            vel = (now / np.linalg.norm(now, axis=1, keepdims=True) - prev / np.linalg.norm(prev, axis=1, keepdims=True)) / fdt
+            u, v = px[:, 0], px[:, 1]
+        else:
+            noise = rng.normal(0, pixel_noise / 160.0, size=bb.shape)
+            noise -= bb * np.sum(noise * bb, axis=1, keepdims=True)
+            xyz = synth._bearing_f32(bb + noise)
+            vel = (bb - b_prev[pts]) / fdt
+            u = 640.0 + 400.0 * np.arctan2(bb[:, 1], bb[:, 0]) / np.pi
+            v = 480.0 + 380.0 * np.cos(np.arccos(np.clip(bb[:, 2], -1, 1)))
+        vel[seen_at[ids] == k] = 0.0  # a new corner has no optical flow yet
         stamp = t_img - synth.TD0
         w.features(stamp, ids, xyz, u, v, vel)
         P, R = cam_pose(t_img)

@@ -234,6 +234,32 @@ def test_replay_hip_stack_vs_oracle_stack(host, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_palvio_shaped_recording_ate_within_one_percent_of_the_cpu_stack(host, oracle, tmp_path):
+    """BASELINE configs[2] as far as a box without the PALVIO bag allows (what bench.py's `replay` record runs at 600 images): camera
+    15 Hz, IMU 200 Hz, every corner through the OCam polynomial with a pixel of noise, td and extrinsic estimated — the HIP stack and
+    the same host sources over the CPU oracle make the same keyframe decisions, and the ATE of the two trajectories against the
+    recording's truth differs by less than the north_star's 1 %."""
+    import ate
+    from lfvio.engine import Engine  # noqa: F401
+    from lfvio.host import HostEstimator
+
+    tp = str(tmp_path / "palvio_shaped.lfvt")
+    trace.make_stream(tp, seed=7, n_frames=120, frame_dt=1.0 / 15.0, camera="ocam")
+    res = []
+    for name, h in (("hip", host), ("oracle", HostEstimator(oracle.build_host_oracle()))):
+        h.clear_state()
+        h.set_min_parallax(10.0)
+        jp = str(tmp_path / f"traj_{name}.txt")
+        rc, st, ms = h.replay_timed(tp, jp)
+        assert rc == 0 and st["failures"] == 0, (name, st)
+        assert len(ms) == st["images"] and np.all(ms > 0)
+        res.append((st, ate.ate(jp, tp)["rmse"]))
+    (sa, ea), (sb, eb) = res
+    assert sa["poses"] >= 105 and (sa["poses"], sa["keyframes"], sa["non_keyframes"]) == (sb["poses"], sb["keyframes"], sb["non_keyframes"])
+    assert ea < 0.10 and abs(ea / eb - 1.0) < 0.01, (ea, eb)
+
+
+@pytest.mark.gpu
 def test_replay_recording_end_to_end(host, tmp_path):
     """60 images: 10 fill the window, the 11th bootstraps (device re-propagation of the window, triangulation,
     optimization), then one optimization() + slideWindow per image.  Trajectory file as pubOdometry writes it; ATE."""
