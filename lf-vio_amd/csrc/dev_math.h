@@ -213,6 +213,29 @@ DEV double sum8(double v) {  // over aligned groups of eight lanes; every lane o
   v += dpp_f64<0x141>(v);  // row_half_mirror
   return v;
 }
+// lane i of every row of 16 lanes <- lane J of its row (one v_mov_b64_dpp row_newbcast)
+template <int J>
+DEV double row_bcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
+template <int J>
+DEV int row_bcast_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
+DEV double row_bcast_k(double v, int k) {  // k: compile-time after unrolling
+  switch (k) {
+#define LFVIO_RB(K) case K: return row_bcast<K>(v);
+    LFVIO_RB(0) LFVIO_RB(1) LFVIO_RB(2) LFVIO_RB(3) LFVIO_RB(4) LFVIO_RB(5) LFVIO_RB(6) LFVIO_RB(7) LFVIO_RB(8) LFVIO_RB(9) LFVIO_RB(10)
+    LFVIO_RB(11) LFVIO_RB(12) LFVIO_RB(13) LFVIO_RB(14)
+#undef LFVIO_RB
+    default: return row_bcast<15>(v);
+  }
+}
+DEV int row_bcast_ik(int v, int k) {
+  switch (k) {
+#define LFVIO_RB(K) case K: return row_bcast_i<K>(v);
+    LFVIO_RB(0) LFVIO_RB(1) LFVIO_RB(2) LFVIO_RB(3) LFVIO_RB(4) LFVIO_RB(5) LFVIO_RB(6) LFVIO_RB(7) LFVIO_RB(8) LFVIO_RB(9) LFVIO_RB(10)
+    LFVIO_RB(11) LFVIO_RB(12) LFVIO_RB(13) LFVIO_RB(14)
+#undef LFVIO_RB
+    default: return row_bcast_i<15>(v);
+  }
+}
 // Workgroup barrier for data handed over through LDS only: waits for this wave's LDS (and scalar) operations, NOT for its global
 // loads and stores — __syncthreads() drains those too, and a kernel that has just stored a dozen per-landmark scalars pays their write
 // latency (1 - 2 us) at the next barrier although nobody in the workgroup reads them.

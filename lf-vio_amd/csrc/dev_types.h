@@ -227,7 +227,8 @@ struct Slot {
   int lm_half;                   // the landmark role of k_lin runs 8 lanes per track, 32 landmarks per workgroup (windows of at most SPEC_MAX_LM landmarks)
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
-  int spec_on, spec_pad_;        // 1: this is slot 0 of a context that keeps a shadow slot behind its last one — the marginalization may be run ahead
+  int spec_on, wt_clean;         // wt_clean: Slot::Wt is zero outside the landmarks' spans (k_setup cleared it, k_linw has swept since; 0 after every upload)
+                                 // 1: this is slot 0 of a context that keeps a shadow slot behind its last one — the marginalization may be run ahead
                                  // of the loop's end on a second stream (kernels_spec.h); set by the upload
   int dec_pending, mail_seq;     // dec holds a decision k_solve has not moved into the header yet; mail_seq: what the mailbox flags are set to (the upload's sequence number, never 0)
   // Early hand-over of the solution (lfvio_batch_optimize_begin): host memory the device writes directly — 0, or the

@@ -29,13 +29,18 @@ DEV int gidx20(int p, int q) { return p * 20 - (p * (p - 1)) / 2 + (q - p); }  /
 
 // ---------------------------------------------------------------------------
 // k_setup: grid (SETUP_WGS + ceil(N / 256), batch) x 256:
-//   [0] state, [1..10] IMU information roots, [11..26] prior normal matrix, [27..] inverse depths
+//   [0] state, [1] IMU information roots, [2..17] prior normal matrix, [18..] inverse depths
 // ---------------------------------------------------------------------------
 constexpr int SETUP_PRIOR_WGS = 16;
-constexpr int SETUP_WGS = 1 + LFVIO_WINDOW_SIZE + SETUP_PRIOR_WGS;
-__global__ __launch_bounds__(256, 5) void k_setup(char *base, size_t stride, int mode, int zero_wt) {  // (five waves per SIMD: what the workgroups of a resident batch ran at before build_tab learnt the off-sphere flavour)
+constexpr int SETUP_WGS = 2 + SETUP_PRIOR_WGS;  // [0] state, [1] the ten IMU information roots, [2 ..) prior normal matrix
+__global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int mode, int zero_wt) {  // (four waves per SIMD: the IMU role holds three 15-vectors per lane)
   Slot *S = SLOT(base, stride);
   const int tid = threadIdx.x;
+  // one workspace for the three roles that need one (the state's table, the IMU factors' transposition tiles, the prior's slab of J0):
+  // 19 KB, five workgroups of a resident batch per CU
+  constexpr int SETUP_PRIOR_SLAB = 2048, SETUP_LDS = LFVIO_WINDOW_SIZE * 15 * 16;
+  static_assert(SETUP_LDS >= SETUP_PRIOR_SLAB + LFVIO_MAX_PRIOR_DIM && SETUP_LDS >= 84 + TAB_SCRATCH, "k_setup's workspace");
+  __shared__ double sh_setup[SETUP_LDS];
   if (blockIdx.x == 0) {
     // state + trust-region init (TrustRegionMinimizer::Init, DoglegStrategy ctor)
     const double *src = (const double *)&S->x0;
@@ -66,91 +71,100 @@ __global__ __launch_bounds__(256, 5) void k_setup(char *base, size_t stride, int
       S->dec_pending = 0;
       if (mode >= MODE_MARG) t->mu = 0.0;
     }
-    __shared__ double bt[84 + TAB_SCRATCH];
+    double *bt = sh_setup;
     if (tid < 77) bt[tid] = (&S->x0.pose[0][0])[tid];
     else if (tid < 84) bt[tid] = S->x0.ex[tid - 77];
     __syncthreads();
     const unsigned offm = build_tab(bt, &S->tab[0], tid, bt + 84);
     if (tid == 0) S->ex_fixed_off = ((offm >> TAB_EX_BIT) & 1u) && !S->est_ex;  // (the candidates' tables inherit it: build_tab<false>)
     if (tid == 0 && S->spec_on) spec_arm(S);
-  } else if (blockIdx.x <= LFVIO_WINDOW_SIZE) {
-    // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64), hoisted out of the iteration loop:
-    // the reference recomputes it in every Evaluate().  One factor per workgroup: Gauss-Jordan with
-    // partial pivoting on [cov | I] in LDS, then a 15x15 column Cholesky of the inverse.
-    const int f = blockIdx.x - 1;
-    if (!S->imu_active[f]) return;
-    // The elimination ping-pongs between two copies of [cov | I]: every thread reads what it needs of the old matrix
-    // (pivot row p, its own source row with the swap applied by index), normalizes its pivot-row entry itself and writes
-    // the new entry into the other copy — the arithmetic of swap / scale / eliminate, one barrier per pivot instead of six.
-    __shared__ double Mb[2][15][31];
-    for (int e = tid; e < 225; e += 256) {
-      int r = e / 15, c = e % 15;
-      Mb[0][r][c] = S->imu[f].covariance[e];
-      Mb[0][r][15 + c] = (r == c) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    const int r1 = tid / 30, c1 = tid % 30;
-    const int t2 = tid + 256, r2 = t2 / 30, c2 = t2 % 30;
-    for (int k = 0; k < 15; k++) {
-      const double(*Mo)[31] = Mb[k & 1];
-      double(*Mn)[31] = Mb[(k & 1) ^ 1];
-      // the whole column in one batch of loads (a loop over r >= k waits for every load in turn)
-      double colk[15];
+  } else if (blockIdx.x == 1) {
+    // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64), hoisted out of the iteration loop: the reference recomputes it in every
+    // Evaluate().  All ten factors of the window in this workgroup, SIXTEEN LANES PER FACTOR (round 6; a workgroup of 256 per factor ran
+    // the elimination with one useful lane in a hundred: 92 k wave-instructions per window).  Gauss-Jordan with partial pivoting on
+    // [cov | I], 15 x 30, a lane holding COLUMNS l and l + 16 in registers: the pivot search of step k is lane k's own column, pivot and
+    // multiplier column reach the other lanes of the factor by DPP row broadcasts (the step is unrolled: the source lane is an
+    // immediate), the row swap is a select per register.  The arithmetic per entry is what it was — mk = M[p][c] / piv, entry =
+    // M[sr][c] - M[sr][k] mk on the swapped rows — and so are the bits.  Then the column Cholesky of the inverse, a lane per row.
+    const int grp = tid >> 4, l = tid & 15;
+    const int f = grp < LFVIO_WINDOW_SIZE ? grp : 0;  // (lanes beyond the tenth factor run along on the first one's numbers and store nothing)
+    const bool mine = grp < LFVIO_WINDOW_SIZE && S->imu_active[f];
+    const double *cov = S->imu[f].covariance;
+    double m0[15], m1[15];
 #pragma unroll
-      for (int r = 0; r < 15; r++) colk[r] = Mo[r][k];
+    for (int r = 0; r < 15; r++) {
+      m0[r] = l < 15 ? cov[r * 15 + l] : (r == 0 ? 1.0 : 0.0);  // column l of the covariance; lane 15: column 15 = the identity's first
+      m1[r] = r == l + 1 ? 1.0 : 0.0;                            // column 16 + l: the identity's column l + 1 (lanes 14, 15: nothing)
+    }
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+      // lane k's search of its column k (a chain of fifteen compares: a tournament over arrays of candidates was tried and spilled —
+      // 34 us against 14 for the kernel)
       int p = k;
       double best = -1.0, piv = 0.0;
 #pragma unroll
       for (int r = 0; r < 15; r++) {
-        const double v = fabs(colk[r]);
-        if (r >= k && v > best) best = v, p = r, piv = colk[r];
+        const double v = fabs(m0[r]);
+        if (r >= k && v > best) best = v, p = r, piv = m0[r];
       }
-      // row r of the swapped matrix is row src(r) of the old one
-      auto entry = [&](int r, int c) {
-        const double mk = Mo[p][c] / piv;
-        if (r == k) return mk;
-        const int sr = r == p ? k : r;
-        return Mo[sr][c] - Mo[sr][k] * mk;
-      };
-      if (tid < 450) Mn[r1][c1] = entry(r1, c1);
-      if (t2 < 450) Mn[r2][c2] = entry(r2, c2);
-      __syncthreads();
-    }
-    const double(*M)[31] = Mb[1];  // 15 pivots: the result is in copy 1
-    // Column Cholesky of the inverse in ONE wave, the rows in registers (lane i: row i): the entry of row j a step needs
-    // comes by v_readlane, so the thirty barriers of the LDS version are gone.  Same operations in the same order:
-    // t = m_ij - l_i0 l_j0 - l_i1 l_j1 ..., d = sqrt(t_jj), l_ij = t / d.
-    bool ok = true;
-    if (tid < 64) {
-      const int li = tid < 15 ? tid : 0;
-      double lrow[15], mrow[15];
+      p = row_bcast_ik(p, k), piv = row_bcast_k(piv, k);
+      double csr[15];                                      // M[src(r)][k]: column k with rows k and p exchanged
 #pragma unroll
-      for (int j = 0; j < 15; j++) mrow[j] = M[li][15 + j], lrow[j] = 0.0;
+      for (int r = 0; r < 15; r++) csr[r] = row_bcast_k(m0[r], k);
+      const double ck = csr[k];
 #pragma unroll
-      for (int j = 0; j < 15; j++) {
-        double t = mrow[j];
+      for (int r = 0; r < 15; r++) csr[r] = r == p ? ck : csr[r];
+      auto step = [&](double(&m)[15]) {
+        double Mp = m[0];
 #pragma unroll
-        for (int k = 0; k < j; k++) t -= lrow[k] * readlane_f64(lrow[k], j);
-        const double sj = readlane_f64(t, j);
-        if (!(sj > 0.0)) ok = false;
-        const double d = sqrt(sj);
-        lrow[j] = tid == j ? d : t / d;
-      }
-      if (tid < 15) {
+        for (int r = 1; r < 15; r++) Mp = p == r ? m[r] : Mp;
+        const double Mk = m[k], mk = Mp / piv;
 #pragma unroll
-        for (int i = 0; i < 15; i++) {
-          S->imu_sqrt[f][i * 15 + tid] = (tid >= i && ok) ? lrow[i] : 0.0;  // sqrt_info[i][j] = L[j][i], j >= i
+        for (int r = 0; r < 15; r++) {
+          const double Msr = r == p ? Mk : m[r];
+          m[r] = r == k ? mk : Msr - csr[r] * mk;
         }
-      }
+      };
+      step(m0), step(m1);
     }
-    if (!ok && tid == 0) S->imu_active[f] = 0;
+    // the inverse is columns 15 .. 29: column 15 + j sits in lane 15 (j = 0) or lane j - 1 (its second column); through LDS it becomes
+    // a row per lane, which is what the column Cholesky (and Eigen's LLT: the lower triangle) reads
+    double *T = sh_setup + f * (15 * 16);  // (the spare lanes write the first factor's numbers once more)
+#pragma unroll
+    for (int r = 0; r < 15; r++) {
+      if (l == 15) T[r * 16] = m0[r];
+      else if (l < 14) T[r * 16 + l + 1] = m1[r];
+    }
+    __syncthreads();
+    // Column Cholesky, lane i: row i.  Same operations in the same order: t = m_ij - l_i0 l_j0 - l_i1 l_j1 ..., d = sqrt(t_jj), l_ij = t / d.
+    const int li = l < 15 ? l : 0;
+    double lrow[15], mrow[15];
+#pragma unroll
+    for (int j = 0; j < 15; j++) mrow[j] = T[li * 16 + j], lrow[j] = 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 15; j++) {
+      double t = mrow[j];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= lrow[k] * row_bcast_k(lrow[k], j);
+      const double sj = row_bcast_k(t, j);
+      if (!(sj > 0.0)) ok = false;
+      const double d = sqrt(sj);
+      lrow[j] = l == j ? d : t / d;
+    }
+    if (mine && l < 15) {
+#pragma unroll
+      for (int i = 0; i < 15; i++) S->imu_sqrt[f][i * 15 + l] = (l >= i && ok) ? lrow[i] : 0.0;  // sqrt_info[i][j] = L[j][i], j >= i
+    }
+    if (mine && !ok && l == 0) S->imu_active[f] = 0;
   } else if (blockIdx.x >= SETUP_WGS) {
     // inverse depths of the window: 256 landmarks per workgroup
     const int l = (blockIdx.x - SETUP_WGS) * 256 + tid;
     if (l < S->N) S->lam[0][l] = S->lam0[l];
-    if (zero_wt) {
+    if (zero_wt && !S->wt_clean) {
       // k_linw writes the transposed rows (Slot::Wt) over the landmarks' own spans only: what lies outside is zero from here
-      // on (the spans do not change during a call)
+      // on (the spans do not change while the window is resident: k_linw marks the copy clean behind its first sweep, the next
+      // upload of the slot clears the mark — 189 KB per window that a batch re-solved where it lies does not write again)
       double2 *wt = (double2 *)(double *)S->Wt;
       const int nw = gridDim.x - SETUP_WGS, w = blockIdx.x - SETUP_WGS;
       for (int e = w * 256 + tid; e < WT_PAIRS * SPEC_MAX_LM; e += nw * 256) wt[e] = make_double2(0.0, 0.0);
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(256, 5) void k_setup(char *base, size_t stride, int
     // prior: A' = J0^T J0, b0 = J0^T r0 (constant over the solve), entries spread over SETUP_PRIOR_WGS workgroups
     if (!S->prior_valid) return;
     const int n = S->prior_n;
-    const int part = blockIdx.x - (LFVIO_WINDOW_SIZE + 1);
+    const int part = blockIdx.x - 2;
     // (a resident batch: as few of the SETUP_PRIOR_WGS workgroups as the entries need at PRIOR_EPT per thread — three for the usual
     // n = 76 —, because every one of them stages all of J0 and the batch pays that for every window; few windows: all of them,
     // 1.4 entries per thread — the latency of the call)
@@ -168,8 +182,8 @@ __global__ __launch_bounds__(256, 5) void k_setup(char *base, size_t stride, int
     if (part >= np) return;
     // J0 goes through LDS in slabs of rows (all of it for the usual n = 76): one batch of independent loads instead of
     // a dependent load per term.  A thread owns up to PRIOR_EPT entries of A' (n <= 172: 29 584 entries over 4 096 threads).
-    constexpr int PRIOR_SLAB = 2048;  // 16 KB: k_setup keeps 5 workgroups per CU for resident batches
-    __shared__ double Js[PRIOR_SLAB + LFVIO_MAX_PRIOR_DIM];
+    constexpr int PRIOR_SLAB = SETUP_PRIOR_SLAB;  // 16 KB
+    double *Js = sh_setup;
     const double *J = S->prior_J;
     const int rows_per = PRIOR_SLAB / n;
     double acc[PRIOR_EPT], accb = 0;

@@ -809,6 +809,8 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
 #pragma unroll
     for (int r = 0; r < 4; r++) ss[(wv + 4 * j) * 256 + r * 64 + lane] = acc[j][r];
   }
+  // every landmark's span of the transposed rows has been written: k_setup need not clear the copy again while this window is resident
+  if (tid == 0 && !marg && fl.do_lin) S->wt_clean = 1;
   WSTAMP(14);
 }
 template <bool OFFS = true>  // (see k_lin, kernels_lin.h)

@@ -30,9 +30,6 @@ __host__ __device__ constexpr int tile_a(int t) {
 __host__ __device__ constexpr int tile_b(int t) { return t - tile_id(tile_a(t), 0); }
 DEV int tsw(int r, int k) { return r * TLD + k; }
 DEV int lidx(int i, int j) { return tile_id(i >> 4, j >> 4) * TSZ + tsw(i & 15, j & 15); }  // entry (i, j), j <= i
-// lane i of every row of 16 lanes <- lane J of its row (one v_mov_b64_dpp row_newbcast)
-template <int J>
-DEV double row_bcast(double v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
 typedef double solve_d4 __attribute__((ext_vector_type(4)));
 // every lane <- the lane with the same row (lane & 15) in quarter T (lanes 16 T .. 16 T + 15): two gfx950 lane swaps per dword
 template <int T>
@@ -51,16 +48,6 @@ DEV double quarter_bcast(double x, int t) {  // t: compile-time after unrolling
     default: return __hiloint2double(quarter_bcast32<3>(hi), quarter_bcast32<3>(lo));
   }
 }
-DEV double row_bcast_k(double v, int k) {  // k: compile-time after unrolling
-  switch (k) {
-#define LFVIO_RB(K) case K: return row_bcast<K>(v);
-    LFVIO_RB(0) LFVIO_RB(1) LFVIO_RB(2) LFVIO_RB(3) LFVIO_RB(4) LFVIO_RB(5) LFVIO_RB(6) LFVIO_RB(7) LFVIO_RB(8) LFVIO_RB(9) LFVIO_RB(10)
-    LFVIO_RB(11) LFVIO_RB(12) LFVIO_RB(13) LFVIO_RB(14)
-#undef LFVIO_RB
-    default: return row_bcast<15>(v);
-  }
-}
-
 #define SOLVE_KEEP(v) asm volatile("" ::"v"(v))
 #define STAMP(S, k) do { if (threadIdx.x == 0) (S)->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 
