@@ -206,7 +206,7 @@ def window100k_record(device, flag, calls=10):
         ms = (time.perf_counter() - t0) / calls * 1e3
         sol, prior = e.batch_download(0, w.N)
         sweep = e.sweep_kernel(1)
-        name = {0: "k_lin<7>", 1: "k_linw", 2: "k_linb"}[sweep]
+        name = {0: "k_lin<7, false>", 1: "k_linw<false>", 2: "k_linb<false>"}[sweep]  # (the instantiation every sweep but a call's first runs: csrc/kernels_lin.h, OFFS)
         lin_ms = e.time_kernel({0: 0, 1: 12, 2: 15}[sweep], 1, 20)
         byts, flops = algorithmic_bytes(w.N, w.M), 2.0e3 * (w.M - w.N) + 1.6e3 * w.N
         traffic, src = pmc_traffic("window100k", [name])
@@ -619,7 +619,7 @@ def main():
     lin_ms = tk.time_kernel({0: 0, 1: 12, 2: 15}[sweep], batch, reps)
     bytes_per_launch = sum(algorithmic_bytes(w.N, w.M) for w in wins[:batch]) if not sharded else algorithmic_bytes(local_N, local_M)
     achieved = bytes_per_launch / (lin_ms * 1e-3) / 1e9
-    rows = ["k_linw"] if linw else ["k_linb"] if linb else (["k_lin<1>", "k_lin<2>", "k_lin<8>"] if batch >= 64 else ["k_lin<7>"])
+    rows = ["k_linw<false>"] if linw else ["k_linb<false>"] if linb else (["k_lin<1, false>", "k_lin<2, false>", "k_lin<8, false>"] if batch >= 64 else ["k_lin<7, false>"])
     traffic, traffic_src = pmc_traffic(workload if not stream_mode else "window300", rows)
     kernel_name = ("k_linw (window-resident sweep: IMU + prior factors, every observation once — residual, Jacobian basis, Gram SYRK —, "
                    "LDS accumulators of H_pp, Schur SYRK; one workgroup per window)") if linw else \
