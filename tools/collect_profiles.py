@@ -39,10 +39,26 @@ def short(name):
 WORKING_US = {}  # workload -> kernel -> mean duration of its working launches (us), from the kernel trace
 
 
+def load_working_us(tag):
+    """pmc-only mode: the durations of the working launches from the committed launch splits (profiles/<tag>/bench_*_launches.md)"""
+    for w in WORK:
+        f = os.path.join(ROOT, "profiles", tag, f"bench_{w}_launches.md")
+        if not os.path.exists(f):
+            continue
+        WORKING_US[w] = {}
+        for line in open(f):
+            c = [x.strip() for x in line.strip().strip("|").split("|")]
+            if len(c) == 6 and c[1].isdigit():
+                WORKING_US[w][c[0]] = float(c[3])
+
+
 def main():
     py = sys.executable
     bench = os.path.join(ROOT, "bench.py")
-    for w, args in WORK.items():
+    pmc_only = len(sys.argv) > 2 and sys.argv[2] == "pmc"
+    if pmc_only:
+        load_working_us(sys.argv[1])
+    for w, args in ({} if pmc_only else WORK).items():
         # 1. the bench line itself (full default length for the headline workload)
         r = sh([py, bench] + (args + ["--no-cpu-baseline"] if w != "window300" else []))
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -96,6 +112,9 @@ def main():
         agg = defaultdict(lambda: defaultdict(list))
         for i, ctrs in enumerate(PMC_PASSES):
             d = f"/tmp/pmc_{w}_{i}"
+            # (counter collection serializes kernels: a worker of csrc/kernels_spec.h waiting for the loop on another stream would sit out
+            # its 3 ms limit in front of every kernel of the loop — the passes are what the counters are about, the tail runs serially)
+            os.environ["LFVIO_DEBUG"] = "marg_ahead=0"
             sh(["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--", py, bench, "--no-cpu-baseline",
                                                  "--no-secondary", "--steps", "10" if w != "batch512" else "4", "--warmup", "2"] + (WORK[w][:2] if w != "window300" else []))
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
