@@ -28,6 +28,9 @@
 #include "kernels_lin.h"
 
 #ifdef LFVIO_LINW_PROFILE  // cycle stamps of window 0, wave 0 (tools/linw_clocks.py, a -DLFVIO_LINW_PROFILE build under variants/)
+#ifndef LFVIO_LINB_GROUP
+#define LFVIO_LINB_GROUP 0
+#endif
 #define WSTAMP(k) do { if (blockIdx.y == 0 && threadIdx.x == 0) S->dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
 #define WACC(k, t0) do { wacc[(k) - 24] += (long long)__builtin_readcyclecounter() - (t0); } while (0)
 #define WNOW() ((long long)__builtin_readcyclecounter())
@@ -451,6 +454,19 @@ DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off, int
   //   G  = Jw^T Jw                (32 x 32: tiles (0,0), (0,1), (1,1) x 4 steps) = [J^T J, J^T r; . , r^T r]
   const int kq = lane >> 4, ii = lane & 15;
   double *imu_out = (double *)((char *)S + imu_off);
+  // the weights of the wave's three factors in ONE round of loads (k_setup's sqrt_info: a memory round trip per factor otherwise)
+  double sa3[3][4];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int f = wv + 4 * q < LFVIO_WINDOW_SIZE ? wv + 4 * q : 0;
+    const double *Sq = S->imu_sqrt[f];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const int k = 4 * s4 + kq;
+      sa3[q][s4] = (ii < 15 && k < 15) ? Sq[ii * 15 + k] : 0.0;
+    }
+  }
+#pragma unroll
   for (int q = 0; q < 3; q++) {
     const int f = wv + 4 * q;
     if (f >= LFVIO_WINDOW_SIZE) break;
@@ -460,13 +476,7 @@ DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off, int
       continue;
     }
     const double(*Jr)[LW_JLD] = (const double(*)[LW_JLD])(Jr3 + 16 * LW_JLD * q);
-    const double *Sq = S->imu_sqrt[f];
-    double sa[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; s4++) {
-      const int k = 4 * s4 + kq;
-      sa[s4] = (ii < 15 && k < 15) ? Sq[ii * 15 + k] : 0.0;
-    }
+    const double(&sa)[4] = sa3[q];
     double4_t w0 = double4_t{0, 0, 0, 0}, w1 = w0;
 #pragma unroll
     for (int s4 = 0; s4 < 4; s4++) {
@@ -523,7 +533,25 @@ DEV void linw_prior(Slot *S, const LinView &lv, double *lw) {
   double *Js = lw, *dx = lw + LW_PRIOR_MAXN * LW_PRIOR_MAXN, *r = dx + KP, *part = r + KP;  // part: [2][KP]
   double *g = S->prior_g;
   const double *J = S->prior_J;
-  for (int e = tid; e < n * n; e += LW_THREADS) Js[e] = J[e];
+  {  // J0 into LDS in rounds of eight loads per thread (a loop of load - wait - store is a memory round trip per element: 23 of them;
+     // asking for it ahead of the IMU factors puts their own loads behind it in the queue: measured, no gain)
+    constexpr int PJ = 8, ROUNDS = (LW_PRIOR_MAXN * LW_PRIOR_MAXN + PJ * LW_THREADS - 1) / (PJ * LW_THREADS);
+    const int nn = n * n;
+#pragma unroll 1
+    for (int b = 0; b < ROUNDS && b * PJ * LW_THREADS < nn; b++) {
+      double v[PJ];
+#pragma unroll
+      for (int k = 0; k < PJ; k++) {
+        const int e = tid + LW_THREADS * (PJ * b + k);
+        v[k] = J[e < nn ? e : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < PJ; k++) {
+        const int e = tid + LW_THREADS * (PJ * b + k);
+        if (e < nn) Js[e] = v[k];
+      }
+    }
+  }
   for (int c = tid; c < KP + 4; c += LW_THREADS) g[c] = 0.0;
   if (tid < S->prior_nb) prior_block_dx(S, lv.x, tid, dx);
   __syncthreads();
@@ -798,6 +826,8 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
         }
       }
     };
+    // (skipping the tiles in front of a block's first start frame — zeros, the landmarks are sorted — was measured in round 6: the
+    // phase is not bound by the matrix pipe, 62 k -> 65 k cycles)
     if (__builtin_amdgcn_readfirstlane(wv) + 12 < NT) sweep(std::integral_constant<int, 4>{});
     else sweep(std::integral_constant<int, 3>{});
   }

@@ -759,7 +759,7 @@ DEV bool eig_tridiag(double *A, const double *b, int n, int tid, double *RV, dou
       else if ((k & 7) == 6) spec_poll_take(*sp);
     }
 #ifdef LFVIO_TRI_PROFILE
-#define TSTAMP(j) do { if (tid == 0 && k == LFVIO_TRI_PROFILE) dbg[16 + j] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TSTAMP(j) do { if (tid == 0 && k == LFVIO_TRI_PROFILE) dbg[3 + j] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define TSTAMP(j) do { } while (0)
 #endif
