@@ -192,8 +192,18 @@ __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int
     for (int k0 = 0; k0 < n; k0 += rows_per) {
       const int nk = min(rows_per, n - k0);
       __syncthreads();
-      for (int e = tid; e < nk * n; e += 256) Js[e] = J[k0 * n + e];
-      for (int e = tid; e < nk; e += 256) Js[PRIOR_SLAB + e] = S->prior_r[k0 + e];
+      {  // the slab in ONE round of loads (a loop of load - wait - store is a memory round trip per element: eight per slab)
+        static_assert(PRIOR_SLAB <= 8 * 256, "eight elements of a slab per thread");
+        double v[8];
+        const double *Jk = J + k0 * n;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = Jk[tid + 256 * q < nk * n ? tid + 256 * q : 0];
+        const double rv = S->prior_r[k0 + (tid < nk ? tid : 0)];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (tid + 256 * q < nk * n) Js[tid + 256 * q] = v[q];
+        if (tid < nk) Js[PRIOR_SLAB + tid] = rv;  // (nk <= PRIOR_SLAB / n < 256 rows)
+      }
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < PRIOR_EPT; q++) {

@@ -1142,12 +1142,23 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg_solve(char *base, size_t 
     if (a >= 0) perm[a] = c;
   }
   __syncthreads();
-  for (int e = tid; e < D * D; e += MARG_THREADS) {
-    const int r = perm[e / D], c = perm[e % D];
-    const int hi = max(r, c), lo = min(r, c);
-    double v = S->Hpp[hi * (hi + 1) / 2 + lo];
-    if (sub && hi < KC) v -= Sc[schur_index(lo, hi)];
-    A[e] = v;
+  {  // every entry of this thread in ONE round of loads (a loop of load - subtract - store is a memory round trip per entry: eleven of them)
+    constexpr int GR = (92 * 92 + MARG_THREADS - 1) / MARG_THREADS;
+    const double *Hp = &S->Hpp[0];
+    double hv[GR], sv[GR];
+#pragma unroll
+    for (int k = 0; k < GR; k++) {
+      const int e = tid + MARG_THREADS * k, ec = e < D * D ? e : 0;
+      const int r = perm[ec / D], c = perm[ec % D];
+      const int hi = max(r, c), lo = min(r, c);
+      hv[k] = Hp[hi * (hi + 1) / 2 + lo];
+      sv[k] = (sub && hi < KC) ? Sc[schur_index(lo, hi)] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < GR; k++) {
+      const int e = tid + MARG_THREADS * k;
+      if (e < D * D) A[e] = hv[k] - sv[k];
+    }
   }
   for (int a = tid; a < D; a += MARG_THREADS) {
     const int c = perm[a];

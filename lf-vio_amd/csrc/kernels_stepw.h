@@ -32,29 +32,78 @@ DEV void stepw_cost(Slot *S, int cur, double cg, double cn, double *ws) {
   if (n > 0 && tid < S->prior_nb) prior_block_dx(S, x, tid, dxs);
   // ---- the landmark part of the candidate and of the model: one lane per landmark
   double cost = 0, mlin = 0, mquad = 0, dn = 0, xn = 0;
-  for (int l = tid; l < N; l += nthr) {
-    const double s = S->scale_l[l];
-    const double dl = (cg * S->grad_l[l] + cn * S->gn_l[l]) / S->diag_l[l] * s;
-    const double lc = S->lam[cur][l] + dl;
-    lam_out[l] = lc, lcs[l] = lc;
-    dn += dl * dl, xn += lc * lc;
-    // model: -(delta.g) - 1/2 delta^T H delta, landmark rows / cols
-    const double wd = cg * S->d1[l] + cn * S->d2[l];  // w_l . delta_c
-    mlin += dl * S->b[l];
-    mquad += 2.0 * dl * wd + S->a[l] * dl * dl;
+  // (at most two trips — SPEC_MAX_LM landmarks over >= 256 threads — written as two guarded ones with every load of both in front
+  // of the first store: behind a store the compiler fetches the arrays' offsets again, and every fetch is a memory round trip)
+  {
+    const double *scale_l = &S->scale_l[0], *grad_l = &S->grad_l[0], *gn_l = &S->gn_l[0], *diag_l = &S->diag_l[0], *lam_cur = &S->lam[cur][0];
+    const double *d1a = &S->d1[0], *d2a = &S->d2[0], *ba = &S->b[0], *aa = &S->a[0];
+    double in[2][9];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int l = tid + nthr * t, lc = l < N ? l : 0;
+      in[t][0] = scale_l[lc], in[t][1] = grad_l[lc], in[t][2] = gn_l[lc], in[t][3] = diag_l[lc], in[t][4] = lam_cur[lc];
+      in[t][5] = d1a[lc], in[t][6] = d2a[lc], in[t][7] = ba[lc], in[t][8] = aa[lc];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int l = tid + nthr * t;
+      if (l < N) {
+        const double dl = (cg * in[t][1] + cn * in[t][2]) / in[t][3] * in[t][0];
+        const double lc = in[t][4] + dl;
+        lam_out[l] = lc, lcs[l] = lc;
+        dn += dl * dl, xn += lc * lc;
+        // model: -(delta.g) - 1/2 delta^T H delta, landmark rows / cols
+        const double wd = cg * in[t][5] + cn * in[t][6];  // w_l . delta_c
+        mlin += dl * in[t][7];
+        mquad += 2.0 * dl * wd + in[t][8] * dl * dl;
+      }
+    }
+    for (int l = tid + 2 * nthr; l < N; l += nthr) {  // (not with the launches this kernel has)
+      const double dl = (cg * grad_l[l] + cn * gn_l[l]) / diag_l[l] * scale_l[l];
+      const double lc = lam_cur[l] + dl;
+      lam_out[l] = lc, lcs[l] = lc;
+      dn += dl * dl, xn += lc * lc;
+      const double wd = cg * d1a[l] + cn * d2a[l];
+      mlin += dl * ba[l];
+      mquad += 2.0 * dl * wd + aa[l] * dl * dl;
+    }
   }
   __syncthreads();
   if (wv != imu_wave) {
     // ---- visual factors: one lane per OBSERVATION (pair-major: neighbours share the pair's table and sit on neighbouring landmarks)
     const double td = x->td, tor = S->tr_over_row, hr = S->half_row, si = S->sqrt_info;
-    for (int q = tid - vis0; q < NV; q += vis_n) {
-      const int l = S->pm_lm[q], pair = S->pm_pair[q];
-      ObsPair ob;
-      ob.pi = mk3(S->anc[0][l], S->anc[1][l], S->anc[2][l]), ob.vi = mk3(S->anc[3][l], S->anc[4][l], S->anc[5][l]);
-      ob.tdi = S->anc[6][l], ob.rowi = S->anc[7][l];
-      ob.pj = mk3(S->pmo[0][q], S->pmo[1][q], S->pmo[2][q]), ob.vj = mk3(S->pmo[3][q], S->pmo[4][q], S->pmo[5][q]);
-      ob.tdj = S->pmo[6][q], ob.rowj = S->pmo[7][q];
-      cost += 0.5 * visual_cost(ob, lcs[l], td, est_td, tor, hr, si, ldm(T->T[pair]), ld3(T->c[pair]));
+    // VB observations of a lane at a time: their indices in one round of loads, then everything the indices lead to in a second one
+    // (one observation per trip was two dependent memory round trips per trip, 7 to 8 trips a lane); summed in the same order
+    constexpr int VB = 2;
+    const int *pm_lm = &S->pm_lm[0];
+    const unsigned char *pm_pair = &S->pm_pair[0];
+    const double *anc[8], *pmo[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) anc[k] = &S->anc[k][0], pmo[k] = &S->pmo[k][0];
+    for (int q0 = tid - vis0; q0 < NV; q0 += VB * vis_n) {
+      int lq[VB], pq[VB];
+#pragma unroll
+      for (int b = 0; b < VB; b++) {
+        const int q = q0 + b * vis_n, qc = q < NV ? q : q0;
+        lq[b] = pm_lm[qc], pq[b] = pm_pair[qc];
+      }
+      ObsPair ob[VB];
+      m33 Tq[VB];
+      d3 cq[VB];
+      double lamq[VB];
+#pragma unroll
+      for (int b = 0; b < VB; b++) {
+        const int q = q0 + b * vis_n, qc = q < NV ? q : q0, l = lq[b];
+        ob[b].pi = mk3(anc[0][l], anc[1][l], anc[2][l]), ob[b].vi = mk3(anc[3][l], anc[4][l], anc[5][l]);
+        ob[b].tdi = anc[6][l], ob[b].rowi = anc[7][l];
+        ob[b].pj = mk3(pmo[0][qc], pmo[1][qc], pmo[2][qc]), ob[b].vj = mk3(pmo[3][qc], pmo[4][qc], pmo[5][qc]);
+        ob[b].tdj = pmo[6][qc], ob[b].rowj = pmo[7][qc];
+        Tq[b] = ldm(T->T[pq[b]]), cq[b] = ld3(T->c[pq[b]]);
+        lamq[b] = lcs[l];
+      }
+#pragma unroll
+      for (int b = 0; b < VB; b++)
+        if (q0 + b * vis_n < NV) cost += 0.5 * visual_cost(ob[b], lamq[b], td, est_td, tor, hr, si, Tq[b], cq[b]);
     }
   } else if (lane < LFVIO_WINDOW_SIZE) {
     // ---- IMU factors: one lane per factor (IntegrationBase::evaluate is a serial chain), on the fifth wave beside the visual ones
