@@ -416,41 +416,37 @@ DEV void linw_strips(Slot *S, const LinView &lv, const LinwArgs &A, int cur, int
 }
 
 // ---------------------------------------------------------------------------
-// phase 0: the pose-side factors.  IMUFactor::Evaluate's two serial jobs (residual and Jacobian of integration_base.h:160-186 /
-// imu_factor.h:88-196, a few thousand dependent instructions each) run one lane per factor and SIDE BY SIDE: the Jacobians of factors
-// 0 .. 4 / 5 .. 9 on five lanes of waves 0 / 1, the residuals on waves 2 / 3, straight into LDS (a wave that ran both for its own three
-// factors spent the sum of the two chains, on three lanes); one workgroup barrier, then wave w weights factors w, w + 4, w + 8 with
-// sqrt_info and forms J^T J, J^T r, the cost on the matrix pipe (what lin_imu_role does with a workgroup per factor).
+// phase 0: the pose-side factors.  IMU factor f = wave + 4 q is evaluated by lane q < 3 of the wave (IMUFactor::Evaluate's two
+// serial jobs — residual and Jacobian of integration_base.h:160-186 / imu_factor.h:88-196 — straight into LDS), then the wave
+// weights it with sqrt_info and forms J^T J, J^T r, the cost (what lin_imu_role does with a workgroup per factor).  No
+// workgroup barrier in here: a wave only reads what it wrote itself.
 // ---------------------------------------------------------------------------
 constexpr int LW_JLD = 33;                                   // 16 rows x (32 + 1 pad): columns 0 .. 29 the Jacobian, 30 the residual, row 15 zero
-constexpr int LW_IMU_JR = LFVIO_WINDOW_SIZE * 16 * LW_JLD;   // Jr of the ten factors
-constexpr int LW_IMU_WAVE = 16 * LW_JLD;                     // Jw of a wave
-static_assert(LW_IMU_JR + LINW_WAVES * LW_IMU_WAVE <= LW_LDS_P1, "phase 0 fits the phase-1 workspace");
+constexpr int LW_IMU_WAVE = 3 * 16 * LW_JLD + 16 * LW_JLD;   // Jr of the wave's three factors | Jw
+static_assert(LINW_WAVES * LW_IMU_WAVE <= LW_LDS_P1, "phase 0 fits the phase-1 workspace");
 DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off, int mode) {
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  double *Jr_all = lw;
-  double(*Jw)[LW_JLD] = (double(*)[LW_JLD])(lw + LW_IMU_JR + wv * LW_IMU_WAVE);
+  double *my = lw + wv * LW_IMU_WAVE;
+  double *Jr3 = my;
+  double(*Jw)[LW_JLD] = (double(*)[LW_JLD])(my + 3 * 16 * LW_JLD);
   const FrameState *x = lv.x;
   const bool pose_rank = !S->sharded || S->pose_side;
   // (the marginalization's sweep takes the factor between frames 0 and 1 only, and only if the plan says so)
   auto factor_on = [&](int f) { return S->imu_active[f] && pose_rank && (mode == MODE_SOLVE || (f == 0 && marg_plan(S, mode)->use_imu0)); };
-  for (int e = tid; e < LW_IMU_JR; e += LW_THREADS) Jr_all[e] = 0.0;
-  __syncthreads();
-  if (lane < 5) {
-    const int f = 5 * (wv & 1) + lane;
-    if (factor_on(f)) {
-      double *Jr = Jr_all + 16 * LW_JLD * f;
-      if (wv >= 2) {
-        double rr[15];
-        imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
+  for (int e = lane; e < 3 * 16 * LW_JLD; e += 64) my[e] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < 3) {
+    const int f = wv + 4 * lane;
+    if (f < LFVIO_WINDOW_SIZE && factor_on(f)) {
+      double rr[15];
+      imu_raw_residual(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], rr);
+      double *Jr = Jr3 + 16 * LW_JLD * lane;
 #pragma unroll
-        for (int k = 0; k < 15; k++) Jr[k * LW_JLD + 30] = rr[k];
-      } else {
-        imu_raw_jacobian(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], Jr, LW_JLD);
-      }
+      for (int k = 0; k < 15; k++) Jr[k * LW_JLD + 30] = rr[k];
+      imu_raw_jacobian(&S->imu[f], S->g, x->pose[f], x->sb[f], x->pose[f + 1], x->sb[f + 1], Jr, LW_JLD);
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   WSTAMP(29);
   // Both products on the FP64 matrix pipe.  Lane (kq, ii) = (lane >> 4, lane & 15) feeds A[ii][4 s + kq] and B[4 s + kq][ii]
   // of step s and holds D[kq + 4 r][ii], r = 0 .. 3, of a 16 x 16 result tile.
@@ -479,7 +475,7 @@ DEV void linw_imu(Slot *S, const LinView &lv, double *lw, long long imu_off, int
       for (int e = lane; e < IMU_OUT; e += 64) out[e] = 0.0;
       continue;
     }
-    const double(*Jr)[LW_JLD] = (const double(*)[LW_JLD])(Jr_all + 16 * LW_JLD * f);
+    const double(*Jr)[LW_JLD] = (const double(*)[LW_JLD])(Jr3 + 16 * LW_JLD * q);
     const double(&sa)[4] = sa3[q];
     double4_t w0 = double4_t{0, 0, 0, 0}, w1 = w0;
 #pragma unroll
