@@ -533,6 +533,9 @@ DEV void linw_prior(Slot *S, const LinView &lv, double *lw) {
   double *Js = lw, *dx = lw + LW_PRIOR_MAXN * LW_PRIOR_MAXN, *r = dx + KP, *part = r + KP;  // part: [2][KP]
   double *g = S->prior_g;
   const double *J = S->prior_J;
+  // (what the phases below take from memory one value at a time, requested with the first round of J0)
+  const double r0_row = (tid >> 1) < n ? S->prior_r[tid >> 1] : 0.0;
+  const int cmap_c = tid < n ? S->prior_cmap[tid] : 0;
   {  // J0 into LDS in rounds of eight loads per thread (a loop of load - wait - store is a memory round trip per element: 23 of them;
      // asking for it ahead of the IMU factors puts their own loads behind it in the queue: measured, no gain)
     constexpr int PJ = 8, ROUNDS = (LW_PRIOR_MAXN * LW_PRIOR_MAXN + PJ * LW_THREADS - 1) / (PJ * LW_THREADS);
@@ -566,7 +569,7 @@ DEV void linw_prior(Slot *S, const LinView &lv, double *lw) {
     }
     double sum = (s0 + s1) + (s2 + s3);
     sum += dpp_f64<0xB1>(sum);  // quad_perm [1,0,3,2]: the other half of the row
-    if (row < n && h == 0) r[row] = S->prior_r[row] + sum;
+    if (row < n && h == 0) r[row] = r0_row + sum;
   }
   __syncthreads();
   {  // g = J0^T r: column c, two halves of the rows
@@ -581,7 +584,8 @@ DEV void linw_prior(Slot *S, const LinView &lv, double *lw) {
     }
   }
   __syncthreads();
-  for (int c = tid; c < n; c += LW_THREADS) g[S->prior_cmap[c]] = part[c] + part[KP + c];
+  static_assert(LW_PRIOR_MAXN <= LW_THREADS, "one column per thread");
+  if (tid < n) g[cmap_c] = part[tid] + part[KP + tid];
   if (tid < 64) {
     double cs = 0;
     for (int row = tid; row < n; row += 64) cs += r[row] * r[row];
@@ -686,28 +690,48 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
       const double *imu_out = lw_at<const double>(S, A.imu_out);
       const double *prior_A = S->prior_A;
       const int prior_ok = S->prior_valid && (!S->sharded || S->pose_side), prior_n = S->prior_n;
-      for (int e = tid; e < PACKED; e += LW_THREADS) {
-        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-        while ((r + 1) * (r + 2) / 2 <= e) r++;
-        while (r * (r + 1) / 2 > e) r--;
-        const int c = e - r * (r + 1) / 2;
-        double val = r < KC ? lw[LW_HC + KC + e] : 0.0;
-        const int f0 = col_frame(r);
-        if (f0 >= 0) {
+      // eight entries of a thread per round: their indices, then the prior's column map, then the IMU and prior terms — every round of
+      // loads in front of the round's first store (one entry per trip was three dependent memory round trips per trip, 58 trips)
+      constexpr int MU = 8;
+      for (int e0 = tid; e0 < PACKED; e0 += MU * LW_THREADS) {
+        int rr[MU], cc[MU], pri[MU], pci[MU];
 #pragma unroll
-          for (int u = 0; u < 2; u++) {
-            const int f = f0 - 1 + u;
-            if (f >= 0 && f < LFVIO_WINDOW_SIZE) {
-              const int pl = imu_local(r, f), ql = imu_local(c, f);
-              if (pl >= 0 && ql >= 0) val += imu_out[(size_t)f * IMU_OUT + pl * 30 + ql];
-            }
+        for (int u = 0; u < MU; u++) {
+          const int e = e0 + u * LW_THREADS < PACKED ? e0 + u * LW_THREADS : PACKED - 1;
+          int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+          while ((r + 1) * (r + 2) / 2 <= e) r++;
+          while (r * (r + 1) / 2 > e) r--;
+          rr[u] = r, cc[u] = e - r * (r + 1) / 2;
+          pri[u] = prior_ok ? S->prior_inv[r] : -1, pci[u] = prior_ok ? S->prior_inv[cc[u]] : -1;
+        }
+        double val[MU], im[MU][2], pa[MU];
+        bool imok[MU][2];
+#pragma unroll
+        for (int u = 0; u < MU; u++) {
+          const int e = e0 + u * LW_THREADS < PACKED ? e0 + u * LW_THREADS : PACKED - 1, r = rr[u], c = cc[u];
+          val[u] = r < KC ? lw[LW_HC + KC + e] : 0.0;
+          const int f0 = col_frame(r);
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const int f = f0 - 1 + k;
+            const bool fin = f0 >= 0 && f >= 0 && f < LFVIO_WINDOW_SIZE;
+            const int pl = fin ? imu_local(r, f) : -1, ql = fin ? imu_local(c, f) : -1;
+            imok[u][k] = pl >= 0 && ql >= 0;
+            im[u][k] = imok[u][k] ? imu_out[(size_t)f * IMU_OUT + pl * 30 + ql] : 0.0;
+          }
+          pa[u] = (pri[u] >= 0 && pci[u] >= 0) ? prior_A[pri[u] * prior_n + pci[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < MU; u++) {
+          const int e = e0 + u * LW_THREADS;
+          if (e < PACKED) {
+            double v = val[u];
+            if (imok[u][0]) v += im[u][0];
+            if (imok[u][1]) v += im[u][1];
+            if (pri[u] >= 0 && pci[u] >= 0) v += pa[u];
+            Hpp[e] = v;
           }
         }
-        if (prior_ok) {
-          const int pr = S->prior_inv[r], pc = S->prior_inv[c];
-          if (pr >= 0 && pc >= 0) val += prior_A[pr * prior_n + pc];
-        }
-        Hpp[e] = val;
       }
       if (tid < KC) lw[tid] = lw[LW_HC + tid];
       __syncthreads();
