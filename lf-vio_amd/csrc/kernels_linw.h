@@ -627,6 +627,15 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
   LinView lv;
   lv.x = &S->x[fl.cur], lv.tab = &S->tab[fl.cur], lv.lam = lw_at<const double>(S, A.lam[fl.cur]), lv.mu = mu;
   WSTAMP(8);
+  // Phase 2 wants the first start frame of every block of 64 landmarks: two dependent loads (the array's offset, the entry) that a
+  // block would wait for between its barriers.  Thread b < 5 asks for block b's here and parks it in LDS behind the strips.
+  static_assert(SPEC_MAX_LM <= 5 * LM_BLOCK, "five blocks of landmarks per window");
+  __shared__ int blk_start[8];
+  const int my_start = tid < 5 ? S->lm_start[tid * LM_BLOCK < N ? tid * LM_BLOCK : 0] : 0;
+  if (!fl.do_lin) {
+    if (tid < 5) blk_start[tid] = my_start;
+    __syncthreads();
+  }
   if (fl.do_lin) {
     constexpr int P3_E = (SUM_VIS + LW_THREADS - 1) / LW_THREADS;
     int p3[P3_E];  // (phase 3's table entries: requested here, used a hundred microseconds later)
@@ -648,6 +657,7 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
                                P->nlm[tl] | (P->start[tl] << 8) | (P->kmax[tl] << 16));
     }
     WSTAMP(10);
+    if (tid < 5) blk_start[tid] = my_start;
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 5; k++) lw[LW_RED0 + 8 * wv + k] = part[k];
@@ -792,7 +802,7 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
     const int l = blk * LM_BLOCK + lane;
     // (landmarks are sorted by start frame: no row of the block has an entry in the columns of frames before its first
     // landmark's start — those pairs are zeros without a load)
-    const int pmin = 3 * rfl(S->lm_start[blk * LM_BLOCK]);
+    const int pmin = 3 * rfl(blk_start[blk]);
 #pragma unroll
     for (int k = 0; k < WPT; k++) {
       const int cp = wv + 4 * k;
