@@ -507,7 +507,12 @@ DEV void solve_body(Slot *S, double *smem, long long xch_off, long long imu_off,
         vis[k] = Hg[ec], vdst[k] = asm_tab[ec];
       }
       STAMP(S, 17);
-      for (int e = tid; e < TPACK; e += SOLVE_THREADS) Ht[e] = 0.0;
+      {  // (16-byte stores: half as many of them)
+        static_assert(TPACK % 2 == 0, "pairs");
+        double2 *Ht2 = (double2 *)Ht;
+#pragma unroll 5
+        for (int e = tid; e < TPACK / 2; e += SOLVE_THREADS) Ht2[e] = make_double2(0.0, 0.0);
+      }
       __syncthreads();
       STAMP(S, 18);
 #pragma unroll
