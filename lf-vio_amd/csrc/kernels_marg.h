@@ -280,17 +280,31 @@ __global__ __launch_bounds__(128) void k_spec_begin(char *base, size_t back) {
       for (int k = tid; k < LFVIO_WINDOW_SIZE * 225; k += 128) id[k] = is[k];
     }
     __syncthreads();
-    {
+    {  // the accepted state in ONE round of loads (a copy loop is a memory round trip per trip, and this kernel is on the call's critical
+      // path); the inverse depths take the setDepth / getDepthVector round trip of the gauge fix (gauge_landmarks) on the way
+      constexpr int XW = (int)(sizeof(FrameState) / 8), TW = (int)(sizeof(TRHead) / 8), XT = (XW + 127) / 128, LT = (SPEC_MAX_LM + 127) / 128;
+      static_assert(TW <= 128, "the trust-region header in one trip");
       const double *xs = (const double *)&S0->x[cur];
       double *xd = (double *)&S->x[0];
-      for (int k = tid; k < (int)(sizeof(FrameState) / 8); k += 128) xd[k] = xs[k];
       const double *ls = S0->lam[cur];
       double *ld = S->lam[0];
       const int N = S0->N;
-      for (int k = tid; k < N; k += 128) ld[k] = ls[k];
       const long long *ts = (const long long *)&S0->tr;
       long long *td = (long long *)&S->tr;
-      for (int k = tid; k < (int)(sizeof(TRHead) / 8); k += 128) td[k] = ts[k];
+      double xv[XT], lv[LT];
+#pragma unroll
+      for (int k = 0; k < XT; k++) xv[k] = xs[tid + 128 * k < XW ? tid + 128 * k : 0];
+#pragma unroll
+      for (int k = 0; k < LT; k++) lv[k] = ls[tid + 128 * k < N ? tid + 128 * k : 0];
+      const long long tv = ts[tid < TW ? tid : 0];
+#pragma unroll
+      for (int k = 0; k < XT; k++)
+        if (tid + 128 * k < XW) xd[tid + 128 * k] = xv[k];
+#pragma unroll
+      for (int k = 0; k < LT; k++)
+        if (tid + 128 * k < N) ld[tid + 128 * k] = 1.0 / (1.0 / lv[k]);
+      if (tid < TW) td[tid] = tv;
+      for (int k = tid + 128 * LT; k < N; k += 128) ld[k] = 1.0 / (1.0 / ls[k]);  // (no window with a shadow slot is that large)
     }
     __syncthreads();  // (every load of the copy has returned)
     if (tid == 0) {
@@ -315,8 +329,7 @@ __global__ __launch_bounds__(128) void k_spec_begin(char *base, size_t back) {
     __syncthreads();
     break;
   }
-  for (int l0 = 0; l0 < S->N; l0 += 128) gauge_landmarks(S, l0);
-  gauge_poses(S, 1, false);
+  gauge_poses(S, 1, false);  // (the landmarks' part of the gauge fix went with the copy)
 }
 
 // Inverse of a symmetric positive-definite m x m (m <= 15) matrix by ONE wave, everything in registers: lane i holds
