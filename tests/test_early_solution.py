@@ -434,3 +434,65 @@ def test_context_torn_down_or_reconfigured_with_the_tail_in_flight():
         same_solution(sol, ref_sol)
         same_prior(prior, ref_prior)
     eng.close()
+
+
+@pytest.mark.parametrize("n", [64, 300, 2000])
+def test_what_k_setup_derives_from_the_inputs_follows_the_upload(n):
+    """k_setup computes sqrt_info of the IMU factors and J0^T J0 of the prior once per upload (Slot::derived_clean): a resident
+    window solved again finds them, a new upload into the same slot — other pre-integrations, another prior, none at all — must not.
+    Every call against a fresh context's, bit for bit (300: the merged sequence with workers, 64: the same, 2000: the strip sweep of
+    a large window)."""
+    ser = serial()
+    mk = lambda x, f: ser.optimize(x, f)
+    wa = synth.make_window_with_prior(31, n, mk)[0]
+    wb = synth.make_window_with_prior(32, n, mk)[0]
+    wc = synth.make_window(33, n)  # no prior
+    eng = Engine(0)
+    eng.batch_reserve(1, max(wa.N, wb.N, wc.N), max(wa.M, wb.M, wc.M))
+    for w, flag, repeats in ((wa, abi.MARGIN_OLD, 3), (wb, abi.MARGIN_SECOND_NEW, 2), (wc, abi.MARGIN_OLD, 2), (wa, abi.MARGIN_OLD, 1)):
+        fresh = Engine(0)
+        want = whole(fresh, w, flag)
+        fresh.close()
+        eng.batch_upload(0, w)
+        for _ in range(repeats):
+            eng.batch_optimize(1, flag)
+            got = eng.batch_download(0, w.N)
+            same_solution(got[0], want[0])
+            same_prior(got[1], want[1])
+    eng.close()
+    ser.close()
+
+
+def test_derived_quantities_of_a_resident_batch_follow_the_uploads():
+    """The same over the window-resident sweep of a batch (k_linw sets the flag): four slots, two of them uploaded anew between sweeps."""
+    ser = serial()
+    mk = lambda x, f: ser.optimize(x, f)
+    first = [synth.make_window_with_prior(40 + s, 120, mk)[0] for s in range(4)]
+    second = [synth.make_window_with_prior(50 + s, 120, mk)[0] for s in range(4)]
+    ser.close()
+
+    def sweep(eng, wins):
+        eng.batch_optimize(len(wins), abi.MARGIN_OLD)
+        return [eng.batch_download(s, w.N) for s, w in enumerate(wins)]
+
+    eng = Engine(0)
+    eng.set_linw(2)
+    eng.batch_reserve(4, 320, max(w.M for w in first + second))
+    for s, w in enumerate(first):
+        eng.batch_upload(s, w)
+    sweep(eng, first)
+    mixed = [first[0], second[1], second[2], first[3]]
+    eng.batch_upload(1, second[1])
+    eng.batch_upload(2, second[2])
+    got = sweep(eng, mixed)
+    fresh = Engine(0)
+    fresh.set_linw(2)
+    fresh.batch_reserve(4, 320, max(w.M for w in first + second))
+    for s, w in enumerate(mixed):
+        fresh.batch_upload(s, w)
+    want = sweep(fresh, mixed)
+    for g, w in zip(got, want):
+        same_solution(g[0], w[0])
+        same_prior(g[1], w[1])
+    eng.close()
+    fresh.close()
