@@ -38,22 +38,40 @@ DEV void publish_solution(Slot *S) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const TRState *ts = &S->tr;
   const int cur = ts->cur, N = S->N;
+  // (every load of the three copies in front of the first store to the host: a copy loop is a device-memory round trip per trip)
   {
-    const double *src = (const double *)&S->x[cur];
-    double *dst = (double *)(m + MAIL_X + (size_t)cur * sizeof(FrameState));
-    for (int k = tid; k < (int)(sizeof(FrameState) / 8); k += nthr) dst[k] = src[k];
-  }
-  {
-    const long long *src = (const long long *)ts;
-    long long *dst = (long long *)(m + MAIL_TR);
+    constexpr int XW = (int)(sizeof(FrameState) / 8), XT = (XW + 63) / 64, LT = (SPEC_MAX_LM + 63) / 64, TT = 8;
+    const double *xs = (const double *)&S->x[cur];
+    double *xd = (double *)(m + MAIL_X + (size_t)cur * sizeof(FrameState));
+    const long long *tsrc = (const long long *)ts;
+    long long *tdst = (long long *)(m + MAIL_TR);
     const int tl = ts->trace_len < LFVIO_MAX_TRACE ? ts->trace_len : LFVIO_MAX_TRACE;
     const int words = (int)((offsetof(TRState, trace) + (size_t)(tl > 0 ? tl : 0) * sizeof(LfvioIterationSummary)) / 8);
-    for (int k = tid; k < words; k += nthr) dst[k] = src[k];
-  }
-  {
-    const double *src = S->lam[cur];
-    double *dst = (double *)(m + MAIL_LAM + (size_t)cur * MAIL_LAM_STRIDE);
-    for (int k = tid; k < N; k += nthr) dst[k] = src[k];
+    const double *ls = S->lam[cur];
+    double *ld = (double *)(m + MAIL_LAM + (size_t)cur * MAIL_LAM_STRIDE);
+    if (nthr >= 64 && XW <= XT * nthr && N <= LT * nthr && words <= TT * nthr) {
+      double xv[XT], lv[LT];
+      long long tv[TT];
+#pragma unroll
+      for (int k = 0; k < XT; k++) xv[k] = xs[tid + nthr * k < XW ? tid + nthr * k : 0];
+#pragma unroll
+      for (int k = 0; k < LT; k++) lv[k] = ls[tid + nthr * k < N ? tid + nthr * k : 0];
+#pragma unroll
+      for (int k = 0; k < TT; k++) tv[k] = tsrc[tid + nthr * k < words ? tid + nthr * k : 0];
+#pragma unroll
+      for (int k = 0; k < XT; k++)
+        if (tid + nthr * k < XW) xd[tid + nthr * k] = xv[k];
+#pragma unroll
+      for (int k = 0; k < TT; k++)
+        if (tid + nthr * k < words) tdst[tid + nthr * k] = tv[k];
+#pragma unroll
+      for (int k = 0; k < LT; k++)
+        if (tid + nthr * k < N) ld[tid + nthr * k] = lv[k];
+    } else {
+      for (int k = tid; k < XW; k += nthr) xd[k] = xs[k];
+      for (int k = tid; k < words; k += nthr) tdst[k] = tsrc[k];
+      for (int k = tid; k < N; k += nthr) ld[k] = ls[k];
+    }
   }
   if (tid == 0) ((int *)m)[4] = S->passes_used, ((int *)m)[5] = S->chain_err;  // (final: the loop is closed; k_prior_chain's verdict on the prior this window ran with)
   __threadfence_system();
@@ -153,7 +171,18 @@ __global__ __launch_bounds__(128) void k_decide_gauge(char *base, size_t stride,
     if (threadIdx.x == 0) spec_closing(S);
     __syncthreads();
   }
-  for (int l0 = 0; l0 < S->N; l0 += 128) gauge_landmarks(S, l0);
+  {  // gauge_landmarks for every landmark of the window (at most MAIL_MAX_LM with this kernel), the loads of all trips in one round
+    constexpr int LT = (SPEC_MAX_LM + 127) / 128;
+    double *lam = S->lam[S->tr.cur];
+    const int N = S->N, tid = threadIdx.x;
+    double lv[LT];
+#pragma unroll
+    for (int k = 0; k < LT; k++) lv[k] = lam[tid + 128 * k < N ? tid + 128 * k : 0];
+#pragma unroll
+    for (int k = 0; k < LT; k++)
+      if (tid + 128 * k < N) lam[tid + 128 * k] = 1.0 / (1.0 / lv[k]);
+    for (int l0 = 128 * LT; l0 < N; l0 += 128) gauge_landmarks(S, l0);
+  }
   gauge_poses(S, 1, publish != 0);  // publish: this call hands its state over early (lfvio_batch_optimize_begin)
   if (spec && threadIdx.x == 0) spec_settle(S);  // (behind the state's way out: the prior's owner is the marginalization's business)
 }
