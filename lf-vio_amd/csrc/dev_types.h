@@ -228,9 +228,6 @@ struct Slot {
   int schur_lm, sharded;         // sharded: this slot holds only a landmark range of the window (multi-GPU)
   int pose_side, pre_gram;       // sharded: this rank adds the IMU + prior factors; pre_gram: gather lists index pairG
   int spec_on, wt_clean;         // wt_clean: Slot::Wt is zero outside the landmarks' spans (k_setup cleared it, k_linw has swept since; 0 after every upload)
-  int derived_clean;             // the quantities k_setup derives from the uploaded inputs alone — sqrt_info of the ten IMU factors (imu_sqrt,
-                                 // imu_active), J0^T J0 and J0^T r0 of the prior (prior_A, prior_b0) — are in place: set by the first sweep
-                                 // of a solve behind k_setup (never by k_setup itself: its workgroups read the flag), 0 after every upload
                                  // 1: this is slot 0 of a context that keeps a shadow slot behind its last one — the marginalization may be run ahead
                                  // of the loop's end on a second stream (kernels_spec.h); set by the upload
   int dec_pending, mail_seq;     // dec holds a decision k_solve has not moved into the header yet; mail_seq: what the mailbox flags are set to (the upload's sequence number, never 0)

@@ -79,7 +79,6 @@ __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int
     if (tid == 0) S->ex_fixed_off = ((offm >> TAB_EX_BIT) & 1u) && !S->est_ex;  // (the candidates' tables inherit it: build_tab<false>)
     if (tid == 0 && S->spec_on) spec_arm(S);
   } else if (blockIdx.x == 1) {
-    if (S->derived_clean && !(zero_wt & 2)) return;  // (computed for this upload by an earlier call: a resident window solved again; 2: the debug interface times the role)
     // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64), hoisted out of the iteration loop: the reference recomputes it in every
     // Evaluate().  All ten factors of the window in this workgroup, SIXTEEN LANES PER FACTOR (round 6; a workgroup of 256 per factor ran
     // the elimination with one useful lane in a hundred: 92 k wave-instructions per window).  Gauss-Jordan with partial pivoting on
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int
     // inverse depths of the window: 256 landmarks per workgroup
     const int l = (blockIdx.x - SETUP_WGS) * 256 + tid;
     if (l < S->N) S->lam[0][l] = S->lam0[l];
-    if ((zero_wt & 1) && !S->wt_clean) {
+    if (zero_wt && !S->wt_clean) {
       // k_linw writes the transposed rows (Slot::Wt) over the landmarks' own spans only: what lies outside is zero from here
       // on (the spans do not change while the window is resident: k_linw marks the copy clean behind its first sweep, the next
       // upload of the slot clears the mark — 189 KB per window that a batch re-solved where it lies does not write again)
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int
     }
   } else {
     // prior: A' = J0^T J0, b0 = J0^T r0 (constant over the solve), entries spread over SETUP_PRIOR_WGS workgroups
-    if (!S->prior_valid || (S->derived_clean && !(zero_wt & 2))) return;
+    if (!S->prior_valid) return;
     const int n = S->prior_n;
     const int part = blockIdx.x - 2;
     // (a resident batch: as few of the SETUP_PRIOR_WGS workgroups as the entries need at PRIOR_EPT per thread — three for the usual
@@ -856,7 +855,7 @@ __global__ __launch_bounds__(LIN_THREADS, ROLES == LIN_ROLE_GRAM ? 3 : (ROLES ==
     } else if (owner && threadIdx.x == 0 && mode == MODE_SOLVE && S->spec_on) spec_publish(S, num_succ, cur);  // (the header's own state: the first pass of a graph)
     // a pass that starts with the loop still open is a pass this slot needs (the synchronous drivers size the first
     // graph of the next call from this count)
-    if (mode == MODE_SOLVE && owner && !done && threadIdx.x == 0) S->passes_used++, S->derived_clean = 1;
+    if (mode == MODE_SOLVE && owner && !done && threadIdx.x == 0) S->passes_used++;
     if (done | (!do_lin & !do_schur)) return;
   }
   LinView lv;

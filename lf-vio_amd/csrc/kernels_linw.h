@@ -621,7 +621,7 @@ DEV void linw_body(Slot *S, double *lw, const LinwArgs &A, int mode_bits) {
     fl.do_lin = fl.do_schur = 1;
   } else {
     // a pass that starts with the loop still open is a pass this slot needs (k_lin's count)
-    if (!fl.done && tid == 0) S->passes_used++, S->derived_clean = 1;
+    if (!fl.done && tid == 0) S->passes_used++;
     if (fl.done | (!fl.do_lin & !fl.do_schur)) return;
   }
   LinView lv;
@@ -946,7 +946,7 @@ DEV void linb_body(Slot *S, double *lw, const LinwArgs &A) {
   const int ng = P->ng, g = blockIdx.x;
   if (g > ng) return;
   // a pass that starts with the loop still open is a pass this slot needs (k_lin's count)
-  if (g == 0 && tid == 0 && !fl.done) S->passes_used++, S->derived_clean = 1;
+  if (g == 0 && tid == 0 && !fl.done) S->passes_used++;
   if (fl.done | (!fl.do_lin & !fl.do_schur)) return;
   LinView lv;
   lv.x = &S->x[fl.cur], lv.tab = &S->tab[fl.cur], lv.lam = lw_at<const double>(S, A.lam[fl.cur]), lv.mu = mu;

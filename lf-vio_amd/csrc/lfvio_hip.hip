@@ -2305,7 +2305,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
       } break;
       case 4: case 5: case 6: case 7: {  // k_setup by role: state + table | + IMU sqrt_info | + prior J0^T J0 | + inverse depths
         const int gx = which == 4 ? 1 : which == 5 ? 2 : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
-        hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 2);  // (2: the input-only roles run although the upload's are in place)
+        hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
       } break;
       case 11: case 12: launch_linw(c, count, MODE_SOLVE, offs); break;  // the window-resident sweep of a batch (k_linw: pose-side factors, visual sweep, Schur)
       case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;

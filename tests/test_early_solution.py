@@ -438,10 +438,10 @@ def test_context_torn_down_or_reconfigured_with_the_tail_in_flight():
 
 @pytest.mark.parametrize("n", [64, 300, 2000])
 def test_what_k_setup_derives_from_the_inputs_follows_the_upload(n):
-    """k_setup computes sqrt_info of the IMU factors and J0^T J0 of the prior once per upload (Slot::derived_clean): a resident
-    window solved again finds them, a new upload into the same slot — other pre-integrations, another prior, none at all — must not.
-    Every call against a fresh context's, bit for bit (300: the merged sequence with workers, 64: the same, 2000: the strip sweep of
-    a large window)."""
+    """A slot is uploaded again and again — other pre-integrations, another prior, none at all — and solved several times where it
+    lies in between: whatever a call keeps on the device between calls (the cleared transposed rows, captured graphs, shadow slots,
+    what k_setup derives from the inputs) must follow the upload.  Every call against a fresh context's, bit for bit (300: the
+    merged sequence with workers, 64: the same, 2000: the strip sweep of a large window)."""
     ser = serial()
     mk = lambda x, f: ser.optimize(x, f)
     wa = synth.make_window_with_prior(31, n, mk)[0]
@@ -464,7 +464,7 @@ def test_what_k_setup_derives_from_the_inputs_follows_the_upload(n):
 
 
 def test_derived_quantities_of_a_resident_batch_follow_the_uploads():
-    """The same over the window-resident sweep of a batch (k_linw sets the flag): four slots, two of them uploaded anew between sweeps."""
+    """The same over the window-resident sweep of a batch: four slots, two of them uploaded anew between sweeps."""
     ser = serial()
     mk = lambda x, f: ser.optimize(x, f)
     first = [synth.make_window_with_prior(40 + s, 120, mk)[0] for s in range(4)]
