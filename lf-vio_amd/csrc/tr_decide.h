@@ -209,7 +209,19 @@ DEV void decision_to_header(TRState *tr, const TRDecision &d) {
 DEV void copy_accepted(Slot *S, int az, int cur, int nlm, int tid, int nthr) {
   const double *xs = (const double *)&S->xE[az - 1], *ts = (const double *)&S->tabE[az - 1], *ls = S->lamE[az - 1];
   double *xd = (double *)&S->x[cur], *td = (double *)&S->tab[cur], *ld = S->lam[cur];
-  for (int k = tid; k < (int)(sizeof(FrameState) / 8); k += nthr) xd[k] = xs[k];
-  for (int k = tid; k < (int)(sizeof(Tab) / 8); k += nthr) td[k] = ts[k];
-  for (int k = tid; k < nlm; k += nthr) ld[k] = ls[k];
+  // rounds of eight loads per thread in front of their stores (a copy loop is a memory round trip per trip: fourteen of them for the
+  // 22 KB table, the state and 300 inverse depths on 256 threads — and the workers of kernels_spec.h wait for this copy)
+  auto copy = [&](double *d, const double *s, int n) {
+    for (int k0 = tid; k0 < n; k0 += 8 * nthr) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = s[k0 + q * nthr < n ? k0 + q * nthr : 0];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (k0 + q * nthr < n) d[k0 + q * nthr] = v[q];
+    }
+  };
+  copy(xd, xs, (int)(sizeof(FrameState) / 8));
+  copy(td, ts, (int)(sizeof(Tab) / 8));
+  copy(ld, ls, nlm);
 }
