@@ -28,6 +28,19 @@ DEV void gauge_landmarks(Slot *S, int l0) {
   double *lam = S->lam[S->tr.cur];
   if (l < S->N) lam[l] = 1.0 / (1.0 / lam[l]);
 }
+// dst[0, n) = src[0, n) by the calling workgroup, eight loads of a thread in front of their stores (a copy loop with a run-time trip count
+// is a memory round trip per trip: the stores may alias the next load as far as the compiler knows)
+template <class T>
+DEV void copy_rounds(T *dst, const T *src, int n, int tid, int nthr) {
+  for (int k0 = tid; k0 < n; k0 += 8 * nthr) {
+    T v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = src[k0 + q * nthr < n ? k0 + q * nthr : 0];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (k0 + q * nthr < n) dst[k0 + q * nthr] = v[q];
+  }
+}
 DEV void gauge_poses(Slot *S, int gated, bool publish);
 // The finished state into the caller's mailbox (Slot::mail, dev_types.h): x[cur], the trust-region header with as much of
 // the trace as there is, lam[cur] — plain stores to host memory, a system-scope fence, then the flag.  Called by every
@@ -89,13 +102,9 @@ DEV void publish_prior(Slot *S) {
   const LfvioPrior *src = &S->prior_out;
   LfvioPrior *dst = (LfvioPrior *)(m + MAIL_PRIOR);
   const int n = src->valid == 1 ? src->n : 0;
-  {
-    const long long *a = (const long long *)src;
-    long long *b = (long long *)dst;
-    for (int k = tid; k < (int)(offsetof(LfvioPrior, linearized_jacobians) / 8); k += nthr) b[k] = a[k];
-  }
-  for (int k = tid; k < n * n; k += nthr) dst->linearized_jacobians[k] = src->linearized_jacobians[k];
-  for (int k = tid; k < n; k += nthr) dst->linearized_residuals[k] = src->linearized_residuals[k];
+  copy_rounds((long long *)dst, (const long long *)src, (int)(offsetof(LfvioPrior, linearized_jacobians) / 8), tid, nthr);
+  copy_rounds(dst->linearized_jacobians, src->linearized_jacobians, n * n, tid, nthr);
+  copy_rounds(dst->linearized_residuals, src->linearized_residuals, n, tid, nthr);
   if (tid == 0) ((int *)m)[2] = S->passes_used, ((int *)m)[3] = S->tr.iteration;  // (two words: max_num_iterations is the caller's, either count may pass 255)
   __threadfence_system();
   __syncthreads();
@@ -134,19 +143,26 @@ __global__ __launch_bounds__(256) void k_prior_chain(char *base, size_t stride) 
   __syncthreads();
   // the block structure the host promised (its own plan of that marginalization) against what the marginalization wrote: same blocks in
   // the same order at the same columns, not just as many of them
-  bool same = !late && src->valid == 1 && src->n == n && src->num_blocks == nb;
-  if (same)
-    for (int i = 0; i < nb; i++)
-      same = same && src->blocks[i].kind == S->prior_kind[i] && src->blocks[i].frame == S->prior_frame[i] && src->block_idx[i] == S->prior_idx[i];
+  // (a thread per block: one after the other behind `same &&` every block's six loads were a memory round trip of their own)
+  __shared__ int differs;
+  if (tid == 0) differs = 0;
+  __syncthreads();
+  const bool head = !late && src->valid == 1 && src->n == n && src->num_blocks == nb;
+  if (head && tid < nb && !(src->blocks[tid].kind == S->prior_kind[tid] && src->blocks[tid].frame == S->prior_frame[tid] && src->block_idx[tid] == S->prior_idx[tid]))
+    differs = 1;
+  for (int i = 256 + tid; head && i < nb; i += 256)  // (more blocks than threads: not with LFVIO_MAX_PRIOR_BLOCKS, kept for the bound's sake)
+    if (!(src->blocks[i].kind == S->prior_kind[i] && src->blocks[i].frame == S->prior_frame[i] && src->block_idx[i] == S->prior_idx[i])) differs = 1;
+  __syncthreads();
+  const bool same = head && !differs;
   if (!same) {
     // no prior where one was promised (the marginalization failed or produced another structure): the window runs without one and says so
     if (tid == 0) S->prior_valid = 0, S->chain_err = 1;
     return;
   }
   double *J = S->prior_J, *r = S->prior_r;
-  for (int e = tid; e < n * n; e += 256) J[e] = src->linearized_jacobians[e];
-  for (int e = tid; e < n; e += 256) r[e] = src->linearized_residuals[e];
-  for (int e = tid; e < nb * 9; e += 256) S->prior_x0[e / 9][e % 9] = src->block_x0[e / 9][e % 9];
+  copy_rounds(J, src->linearized_jacobians, n * n, tid, 256);
+  copy_rounds(r, src->linearized_residuals, n, tid, 256);
+  copy_rounds(&S->prior_x0[0][0], &src->block_x0[0][0], nb * 9, tid, 256);  // (both [blocks][9])
 }
 __global__ __launch_bounds__(128) void k_gauge(char *base, size_t stride, int gated) {
   Slot *S = SLOT(base, stride);
@@ -1099,13 +1115,10 @@ DEV void spec_deliver(Slot *S, Slot *S0, int my_word, bool publish) {
   const LfvioPrior *src = &S->prior_out;
   LfvioPrior *dst = &S0->prior_out;
   const int n = src->valid == 1 ? src->n : 0;
-  {
-    const long long *a = (const long long *)src;
-    long long *b = (long long *)dst;
-    for (int k = tid; k < (int)(offsetof(LfvioPrior, linearized_jacobians) / 8); k += nthr) b[k] = a[k];
-  }
-  for (int k = tid; k < n * n; k += nthr) dst->linearized_jacobians[k] = src->linearized_jacobians[k];
-  for (int k = tid; k < n; k += nthr) dst->linearized_residuals[k] = src->linearized_residuals[k];
+  // (the worker's last step, on the call's critical path: rounds of loads)
+  copy_rounds((long long *)dst, (const long long *)src, (int)(offsetof(LfvioPrior, linearized_jacobians) / 8), tid, nthr);
+  copy_rounds(dst->linearized_jacobians, src->linearized_jacobians, n * n, tid, nthr);
+  copy_rounds(dst->linearized_residuals, src->linearized_residuals, n, tid, nthr);
   // ONE release for both readers — the next kernel of stream 0 that looks at tail_state (device) and the host behind the echo
   // (system) — by ONE thread, behind a barrier that has waited for every thread's stores: 768 write-backs of the same cache, one after
   // the other, were a tenth of this kernel
