@@ -33,6 +33,7 @@ DEV int gidx20(int p, int q) { return p * 20 - (p * (p - 1)) / 2 + (q - p); }  /
 // ---------------------------------------------------------------------------
 constexpr int SETUP_PRIOR_WGS = 16;
 constexpr int SETUP_WGS = 2 + SETUP_PRIOR_WGS;  // [0] state, [1] the ten IMU information roots, [2 ..) prior normal matrix
+constexpr int SETUP_TILED_MAXN = 88;          // a prior of up to 88 rows is one workgroup's in the compact grid of a batch (bit 2 of k_setup's last argument)
 __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int mode, int zero_wt) {  // (four waves per SIMD: the IMU role holds three 15-vectors per lane)
   Slot *S = SLOT(base, stride);
   const int tid = threadIdx.x;
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int
   constexpr int SETUP_PRIOR_SLAB = 2048, SETUP_LDS = LFVIO_WINDOW_SIZE * 15 * 16;
   static_assert(SETUP_LDS >= SETUP_PRIOR_SLAB + LFVIO_MAX_PRIOR_DIM && SETUP_LDS >= 84 + TAB_SCRATCH, "k_setup's workspace");
   __shared__ double sh_setup[SETUP_LDS];
+  const int setup_wgs = (zero_wt & 4) ? 3 : SETUP_WGS;  // compact grid of a resident batch: [0] state [1] IMU roots [2] prior, then the inverse depths
   if (blockIdx.x == 0) {
     // state + trust-region init (TrustRegionMinimizer::Init, DoglegStrategy ctor)
     const double *src = (const double *)&S->x0;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int
     // multiplier column reach the other lanes of the factor by DPP row broadcasts (the step is unrolled: the source lane is an
     // immediate), the row swap is a select per register.  The arithmetic per entry is what it was — mk = M[p][c] / piv, entry =
     // M[sr][c] - M[sr][k] mk on the swapped rows — and so are the bits.  Then the column Cholesky of the inverse, a lane per row.
+    if (tid >= 16 * ((LFVIO_WINDOW_SIZE + 3) & ~3)) return;  // (the fourth wave holds no factor: it would issue the whole elimination for nothing; the barrier below counts the waves that are left)
     const int grp = tid >> 4, l = tid & 15;
     const int f = grp < LFVIO_WINDOW_SIZE ? grp : 0;  // (lanes beyond the tenth factor run along on the first one's numbers and store nothing)
     const bool mine = grp < LFVIO_WINDOW_SIZE && S->imu_active[f];
@@ -157,16 +160,16 @@ __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int
       for (int i = 0; i < 15; i++) S->imu_sqrt[f][i * 15 + l] = (l >= i && ok) ? lrow[i] : 0.0;  // sqrt_info[i][j] = L[j][i], j >= i
     }
     if (mine && !ok && l == 0) S->imu_active[f] = 0;
-  } else if (blockIdx.x >= SETUP_WGS) {
+  } else if (blockIdx.x >= setup_wgs) {
     // inverse depths of the window: 256 landmarks per workgroup
-    const int l = (blockIdx.x - SETUP_WGS) * 256 + tid;
+    const int l = (blockIdx.x - setup_wgs) * 256 + tid;
     if (l < S->N) S->lam[0][l] = S->lam0[l];
-    if (zero_wt && !S->wt_clean) {
+    if ((zero_wt & 1) && !S->wt_clean) {
       // k_linw writes the transposed rows (Slot::Wt) over the landmarks' own spans only: what lies outside is zero from here
       // on (the spans do not change while the window is resident: k_linw marks the copy clean behind its first sweep, the next
       // upload of the slot clears the mark — 189 KB per window that a batch re-solved where it lies does not write again)
       double2 *wt = (double2 *)(double *)S->Wt;
-      const int nw = gridDim.x - SETUP_WGS, w = blockIdx.x - SETUP_WGS;
+      const int nw = gridDim.x - setup_wgs, w = blockIdx.x - setup_wgs;
       for (int e = w * 256 + tid; e < WT_PAIRS * SPEC_MAX_LM; e += nw * 256) wt[e] = make_double2(0.0, 0.0);
     }
   } else {
@@ -178,7 +181,74 @@ __global__ __launch_bounds__(256, 4) void k_setup(char *base, size_t stride, int
     // n = 76 —, because every one of them stages all of J0 and the batch pays that for every window; few windows: all of them,
     // 1.4 entries per thread — the latency of the call)
     constexpr int PRIOR_EPT = 8;
-    const int np = gridDim.y >= 8 ? min(SETUP_PRIOR_WGS, (n * n + 256 * PRIOR_EPT - 1) / (256 * PRIOR_EPT)) : SETUP_PRIOR_WGS;
+    const int nb4 = (n + 3) >> 2, tiles = nb4 * (nb4 + 1) / 2;  // 4 x 4 blocks of the upper triangle of A': 190 for n = 76
+    static_assert(((SETUP_TILED_MAXN + 3) / 4) * ((SETUP_TILED_MAXN + 3) / 4 + 1) / 2 <= 256, "a thread per 4 x 4 block of the upper triangle");
+    if (zero_wt & 4) {  // (the host has looked at every resident prior: at most SETUP_TILED_MAXN rows, setup_launch)
+      // A resident batch: ONE workgroup per window, a thread per 4 x 4 block of the upper triangle (and its mirror image): eight LDS
+      // reads per sixteen products instead of two per product — the entry-per-thread form below is bound by exactly that traffic
+      // (7.5 MB of LDS reads per window, three workgroups staging all of J0 each).  Every entry is the same chain of fma over the
+      // rows in ascending order as below, and (c, r) the same products as (r, c): same bits.
+      if (part != 0) return;
+      constexpr int PRIOR_SLAB = SETUP_PRIOR_SLAB;
+      double *Js = sh_setup;
+      const double *J = S->prior_J;
+      const int rows_per = PRIOR_SLAB / n;
+      int br = 0, rem = tid < tiles ? tid : 0;
+      while (rem >= nb4 - br) rem -= nb4 - br, br++;
+      const int r0 = 4 * br, c0 = 4 * (br + rem);
+      double acc[4][4], accb = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+      for (int k0 = 0; k0 < n; k0 += rows_per) {
+        const int nk = min(rows_per, n - k0);
+        __syncthreads();
+        {
+          double v[8];
+          const double *Jk = J + k0 * n;
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = Jk[tid + 256 * q < nk * n ? tid + 256 * q : 0];
+          const double rv = S->prior_r[k0 + (tid < nk ? tid : 0)];
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (tid + 256 * q < nk * n) Js[tid + 256 * q] = v[q];
+          if (tid < nk) Js[PRIOR_SLAB + tid] = rv;
+        }
+        __syncthreads();
+        if (tid < tiles) {
+          // (a row's last block may reach up to three entries past the row: the next row's numbers — or, behind the slab, r0's —, which
+          // are multiplied and never stored)
+#pragma unroll 2
+          for (int k = 0; k < nk; k++) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = Js[k * n + r0 + i], b[i] = Js[k * n + c0 + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+              for (int j = 0; j < 4; j++) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+          }
+        }
+        if (tid < n)
+          for (int k = 0; k < nk; k++) accb = fma(Js[k * n + tid], Js[PRIOR_SLAB + k], accb);
+      }
+      if (tid < tiles) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int r = r0 + i, c = c0 + j;
+            if (r < n && c < n) {
+              S->prior_A[r * n + c] = acc[i][j];
+              if (c0 != r0) S->prior_A[c * n + r] = acc[i][j];
+            }
+          }
+      }
+      if (tid < n) S->prior_b0[tid] = accb;
+      return;
+    }
+    const int np = gridDim.y >= 8 ? min(SETUP_PRIOR_WGS, (n * n + 256 * PRIOR_EPT - 1) / (256 * PRIOR_EPT)) : SETUP_PRIOR_WGS;  // (a batch with a prior beyond SETUP_TILED_MAXN rows)
     if (part >= np) return;
     // J0 goes through LDS in slabs of rows (all of it for the usual n = 76): one batch of independent loads instead of
     // a dependent load per term.  A thread owns up to PRIOR_EPT entries of A' (n <= 172: 29 584 entries over 4 096 threads).

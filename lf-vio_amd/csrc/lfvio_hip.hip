@@ -133,6 +133,7 @@ struct SlotHostInfo {
   bool offs_first = false, offs_all = false;
   int N = 0, M = 0, gLm = 0, gLw = 0, gCh = 0, gSc = 0;  // gLm: landmark blocks of 64; gLw: landmark workgroups of k_lin
   int marg_n = 0;            // the largest prior (tangent rows) a marginalization of this window can produce
+  int prior_n = 0;           // rows of the uploaded window's input prior (0: none)
   int max_iter = 0;          // LfvioWindow::max_num_iterations of the uploaded window
   double max_seconds = -1.0;  // LfvioWindow::max_solver_time_in_seconds (<= 0: no cap)
   std::vector<int> perm;  // device order -> caller order
@@ -190,7 +191,8 @@ struct lfvio_ctx {
   bool predicted_early = false;     // lfvio_batch_optimize_begin has fed this call's pass count to predict() already (the join / finish that follows must not again)
   int predict_passes = 4;           // passes the first graph of the next call carries: the most any of the last four calls needed (predict()); tail[flag]: force-done + gated gauge fix + marginalization
   double pass_seconds = 2e-4;       // measured duration of one pass of a continuation chunk (sizes the first graph of a call with a wall-clock cap)
-  int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0, k_linw = 0, k_offs = 0;  // (k_offs: slots_offs of the captured launches)
+  int k_batch = 0, k_lm = 0, k_ch = 0, k_sc = 0, k_spec = 0, k_linw = 0, k_offs = 0;
+  int k_setup = -1;  // bits of k_setup's launch the graphs were captured with (setup_launch)  // (k_offs: slots_offs of the captured launches)
   int *d_pending = nullptr, *h_pending = nullptr;  // number of slots whose trust-region loop is not done
   // lfvio_batch_optimize_begin / _finish: the solution of slot 0 arrives in host memory the gated gauge fix writes directly
   // (Slot::mail, dev_types.h MAIL_*) while the marginalization of the same graph is still running; `inflight` from the moment
@@ -934,6 +936,7 @@ int upload_window(lfvio_ctx *c, int slot, const LfvioWindow *w, int sharded = 0,
   // ---- commit: from here on the device copy changes, and the slot's description with it
   info.resident = false;
   info.N = N, info.M = M;
+  info.prior_n = S->prior_valid ? S->prior_n : 0;
   info.max_iter = w->max_num_iterations, info.max_seconds = w->max_solver_time_in_seconds;
   info.perm.swap(perm);
   info.gLm = S->nLmBlocks, info.gLw = S->nSchurParts, info.gCh = nChunks, info.gSc = S->nSchurParts;
@@ -1168,6 +1171,19 @@ bool use_linw(lfvio_ctx *c, int count, const Grid &g, int mode) {
   return true;
 }
 
+// k_setup's launch: grid.x and the bits of its last argument.  A resident batch is bound by the number of workgroups the launch
+// dispatches (21 per window, 16 of them for a prior that ONE workgroup handles there: 10 752 workgroups for 512 windows, ~10 ns each),
+// so it goes out with the compact grid — state, IMU roots, one prior workgroup, inverse depths — when every resident prior fits
+// that workgroup's 4 x 4 tiling (n <= 88: kernels_lin.h).
+struct SetupLaunch {
+  int gx, bits;
+};
+SetupLaunch setup_launch(lfvio_ctx *c, int count, int lm, bool zero_wt) {
+  bool compact = count >= 8;
+  for (int s = 0; compact && s < count; s++) compact = c->info[s].prior_n <= SETUP_TILED_MAXN;
+  return {(compact ? 3 : SETUP_WGS) + (lm + 3) / 4, (zero_wt ? 1 : 0) | (compact ? 4 : 0)};
+}
+
 // A large single window that carries a group list is linearized group by group (k_linb + k_sumb) instead of role by role; the
 // marginalization's sweep of such a window stays with the roles (one launch per call).
 bool use_linb(lfvio_ctx *c, int count, const Grid &g, int mode) {
@@ -1313,9 +1329,10 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
     }
     const int lwk = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0);
     const int offs = slots_offs(c, count);
-    if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk || c->k_offs != offs) {
+    const int setup_bits = setup_launch(c, count, g.lm, lwk == 1).bits;  // (the compact grid of k_setup is part of the captured launch)
+    if (c->k_batch != count || c->k_lm != g.lm || c->k_ch != g.ch || c->k_sc != g.sc || c->k_spec != (int)speculate || c->k_linw != lwk || c->k_offs != offs || c->k_setup != setup_bits) {
       destroy_graph(c, c->k_batch == count && ((c->k_offs ^ offs) & 2) == 0);  // (the workers' graphs: per context, but for the fixed-extrinsic bit)
-      c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk, c->k_offs = offs;
+      c->k_batch = count, c->k_lm = g.lm, c->k_ch = g.ch, c->k_sc = g.sc, c->k_spec = (int)speculate, c->k_linw = lwk, c->k_offs = offs, c->k_setup = setup_bits;
     }
     if (tail_done) *tail_done = false;
     const bool fuse = fused_flag >= 0 && fused_flag < 2;
@@ -1337,7 +1354,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       CaptureGuard guard(c->stream);
       if (setup)
-        hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
+        { const SetupLaunch sl_ = setup_launch(c, count, g.lm, use_linw(c, count, g, MODE_SOLVE)); hipLaunchKernelGGL(k_setup, dim3(sl_.gx, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, sl_.bits); }
       bool gauged = false;
       // (the sweep behind k_setup linearizes at the uploaded state: the only point of a call that can hold a quaternion off the unit sphere,
       // a fixed extrinsic aside — slots_offs)
@@ -1467,7 +1484,7 @@ int enqueue_solve(lfvio_ctx *c, int count, int max_iter, bool adaptive, int fuse
       if (int rc = wait_side(c)) return rc;
     return LFVIO_OK;
   }
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, use_linw(c, count, g, MODE_SOLVE) ? 1 : 0);
+  { const SetupLaunch sl_ = setup_launch(c, count, grid_for(c, count).lm, use_linw(c, count, g, MODE_SOLVE)); hipLaunchKernelGGL(k_setup, dim3(sl_.gx, count), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, sl_.bits); }
   const int offs_s = slots_offs(c, count);  // (the pass behind k_setup sweeps at the uploaded state: launch_lin)
   if (c->use_graph) {
     const int lwg = (use_linw(c, count, g, MODE_SOLVE) ? 1 : use_linb(c, count, g, MODE_SOLVE) ? 2 + 4 * linb_grid(c, count) : 0);
@@ -1495,7 +1512,7 @@ int enqueue_marg(lfvio_ctx *c, int count, int flag, bool standalone, bool gated)
   const Grid g = grid_for(c, count);
   const int mode = (MODE_MARG + flag) | (gated ? MODE_GATED : 0);
   if (standalone)
-    hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode, use_linw(c, count, g, mode) ? 1 : 0);
+    { const SetupLaunch sl_ = setup_launch(c, count, grid_for(c, count).lm, use_linw(c, count, g, mode)); hipLaunchKernelGGL(k_setup, dim3(sl_.gx, count), dim3(256), 0, c->stream, c->d_base, c->L.total, mode, sl_.bits); }
   // (standalone: the sweep is at the uploaded state; gated: at the re-anchored solution, on the sphere but for a fixed extrinsic)
   launch_iteration(c, count, g, mode, false, true, true, false, standalone ? slots_offs(c, count) != 0 : (slots_offs(c, count) & 2) != 0);
   hipLaunchKernelGGL(k_marg_solve<false>, dim3(1, count), dim3(MARG_THREADS), MARG_LDS, c->stream, c->d_base, c->L.total,
@@ -2145,7 +2162,7 @@ int lfvio_debug_linearize(lfvio_ctx *c, const LfvioWindow *in, double *Hpp, doub
   if (rc) return rc;
   if ((rc = upload_window(c, 0, in))) return rc;
   const Grid g = grid_for(c, 1);
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, 1).lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, 0);
+  { const SetupLaunch sl_ = setup_launch(c, 1, grid_for(c, 1).lm, false); hipLaunchKernelGGL(k_setup, dim3(sl_.gx, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, sl_.bits); }
   launch_lin(c, 1, g, MODE_SOLVE);
   launch_sum(c, 1, g, MODE_SOLVE);
   launch_solve(c, 1);
@@ -2215,7 +2232,7 @@ int lfvio_debug_schur_repeat(lfvio_ctx *c, const LfvioWindow *in, double mu, dou
     HIPCHK(c, hipMemcpy(out.data(), d + c->L.xch + sizeof(double) * XOFF_S, sizeof(double) * SCHUR_LEN, hipMemcpyDeviceToHost));
     return LFVIO_OK;
   };
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, lw ? 1 : 0);
+  { const SetupLaunch sl_ = setup_launch(c, 1, g.lm, lw); hipLaunchKernelGGL(k_setup, dim3(sl_.gx, 1), dim3(256), 0, c->stream, c->d_base, c->L.total, MODE_SOLVE, sl_.bits); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<double> first, repeat, full;
   const double mu1 = mu;
@@ -2279,7 +2296,7 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
     (void)hipEventDestroy(e0);
     HIPCHK(c, e);
   }
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (grid_for(c, count).lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
+  { const SetupLaunch sl_ = setup_launch(c, count, grid_for(c, count).lm, lw); hipLaunchKernelGGL(k_setup, dim3(sl_.gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, sl_.bits); }
   // one full linearization so that every kernel has valid inputs
   if (lw) {
     launch_linw(c, count, MODE_SOLVE, offs);
@@ -2304,8 +2321,9 @@ int lfvio_debug_time_kernel(lfvio_ctx *c, int which, int count, int reps, double
                            which == 9 ? gram_wgs : 0);
       } break;
       case 4: case 5: case 6: case 7: {  // k_setup by role: state + table | + IMU sqrt_info | + prior J0^T J0 | + inverse depths
-        const int gx = which == 4 ? 1 : which == 5 ? 2 : which == 6 ? SETUP_WGS : SETUP_WGS + (g.lm + 3) / 4;
-        hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, 0);
+        const SetupLaunch sl = setup_launch(c, count, g.lm, false);  // (the grid the product launches: compact for a resident batch)
+        const int wgs = (sl.bits & 4) ? 3 : SETUP_WGS, gx = which == 4 ? 1 : which == 5 ? 2 : which == 6 ? wgs : sl.gx;
+        hipLaunchKernelGGL(k_setup, dim3(gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, sl.bits);
       } break;
       case 11: case 12: launch_linw(c, count, MODE_SOLVE, offs); break;  // the window-resident sweep of a batch (k_linw: pose-side factors, visual sweep, Schur)
       case 13: launch_solve(c, count, use_linw(c, count, g, MODE_SOLVE)); break;
@@ -2351,7 +2369,7 @@ int lfvio_debug_resident_pass(lfvio_ctx *c, int count, int slot, double *gp, dou
   const Grid g = grid_for(c, count);
   const size_t st = c->L.total;
   const bool lw = use_linw(c, count, g, MODE_SOLVE), lb = !lw && use_linb(c, count, g, MODE_SOLVE);
-  hipLaunchKernelGGL(k_setup, dim3(SETUP_WGS + (g.lm + 3) / 4, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, lw ? 1 : 0);
+  { const SetupLaunch sl_ = setup_launch(c, count, g.lm, lw); hipLaunchKernelGGL(k_setup, dim3(sl_.gx, count), dim3(256), 0, c->stream, c->d_base, st, MODE_SOLVE, sl_.bits); }
   if (lw) {
     launch_linw(c, count);
   } else if (lb) {
