@@ -524,6 +524,48 @@ def test_randomized_sweep_against_the_oracle(eng, oracle):
                 assert rel(gp.J().T @ gp.J(), Ar) < 1e-6, tag
 
 
+def test_randomized_sweep_of_400_with_the_outlier_rate_stated(eng, oracle):
+    """400 more draws of the same generator (another stream of it).  Iteration counts, terminations, poses, speeds / biases are held
+    to the bars above in EVERY case.  Inverse depths and the prior's information matrix are held to 1e-6 too, with the allowance the
+    20 000-case sweeps of rounds 5 and 6 measured (profiles/r06/fuzz.md: 26 of 20 000 = 0.13 % outside, every one of them an inverse depth
+    below 3e-5 or a prior A' below 2.1e-5 relative, on windows of 1 ... 65 landmarks — directions the data of such a window does not
+    fix, tests/test_robustness.py holds the three classes against bars measured on the oracle itself): at most 3 of the 400 may
+    leave the 1e-6 bar, none of them by more than 1e-4, none on a window of more than 65 landmarks."""
+    rng = np.random.default_rng(20260929)
+    outside = []
+    for case in range(400):
+        seed = int(rng.integers(0, 10_000))
+        n = int(rng.choice([1, 2, 5, 9, 17, 33, 64, 65, 128, 300]))
+        kw = dict(estimate_extrinsic=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)),
+                  tr=float(rng.choice([0.0, 0.02])), max_num_iterations=int(rng.choice([1, 3, 8, 12])))
+        flag = int(rng.choice([abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW]))
+        if rng.integers(0, 2):
+            w = synth.make_window_with_prior(seed, n, lambda x, f: oracle.optimize(x, f), **kw)[0]
+        else:
+            w = synth.make_window(seed, n, **kw)
+        rs, rp = oracle.optimize(w, flag)
+        gs, gp = eng.optimize(w, flag)
+        tag = (case, seed, n, kw, flag)
+        assert (gs.c.num_iterations, gs.c.termination) == (rs.c.num_iterations, rs.c.termination), tag
+        assert np.abs(gs.pose - rs.pose).max() < 1e-6 * max(1.0, np.abs(rs.pose).max()), tag
+        assert np.abs(gs.speed_bias - rs.speed_bias).max() < 1e-6, tag
+        dl = rel(gs.lam, rs.lam)
+        if dl >= 1e-6:
+            outside.append((tag, "lam", dl))
+        assert gp.valid == rp.valid, tag
+        if rp.valid == 1:
+            assert (gp.m, gp.n, gp.num_blocks) == (rp.m, rp.n, rp.num_blocks) and gp.block_list() == rp.block_list(), tag
+            Ar = rp.J().T @ rp.J()
+            if np.abs(Ar).max() > 1.0:
+                da = rel(gp.J().T @ gp.J(), Ar)
+                if da >= 1e-6:
+                    outside.append((tag, "prior A", da))
+    print("outside the 1e-6 bar:", outside)
+    assert len(outside) <= 3, outside
+    for tag, what, d in outside:
+        assert d < 1e-4 and tag[2] <= 65, (tag, what, d)
+
+
 def test_batched_windows_match_single(eng, oracle):
     wins = [synth.make_window(100 + s, 120 + 37 * s) for s in range(5)]
     eng.batch_reserve(5, max(w.N for w in wins), max(w.M for w in wins))
